@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- KITTI-shape frames/s through the MV3D hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic KITTI-shaped frames whose
+inputs are already resident in HBM:
+
+    proposal_layer_3d (decode + project + clip/filter + score sort + NMS + top-N)
+      -> RoiPool 7x7 on the BEV feature map (76x76x512) with rois_bv
+      -> RoiPool 7x7 on the RGB feature map (46x155x512) with rois_img
+    [--train adds anchor_target stage-1, and RoiPoolGrad on both views]
+
+i.e. BASELINE.json configs[1] (1 GPU, BEV RPN with 76x76x4 = 23 104 anchors + HIP NMS,
+batch 1) widened by the two RoiPool views the reference has; the VGG16 trunks are not part
+of the path.  One process per GPU; frames shard across ranks with no
+data-path collective ("weak" scaling: per-GPU work fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--cfg TEST|TRAIN]
+                    [--variant peaky|rand] [--no-graph] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel, measured live with HIP events on the launch stream) and `cpu_baseline` (the C
+oracle, single thread, bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+CFGS = {
+    # experiments/cfgs/faster_rcnn_end2end.yml:15-20 (what experiments/scripts/mv3d.sh tests with)
+    "TEST": dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5),
+    # lib/fast_rcnn/config.py:126-148
+    "TRAIN": dict(RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5),
+}
+BEV_MAP = (76, 76, 512)      # conv5_3 of the 608x608 BEV, stride 8
+RGB_MAP = (46, 155, 512)     # conv5_3 of the 375x1242 image, stride 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--cfg", default="TEST", choices=list(CFGS))
+    ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class Frames:
+    """Per-rank device-resident inputs and the step closure."""
+
+    def __init__(self, args, rank):
+        from mv3d_tf_amd import ops, synth
+        self.ops, self.args = ops, args
+        B = args.batch
+        heads = [synth.rpn_head(1000 + rank * 64 + b, 76, 76, args.variant) for b in range(B)]
+        self.host_frame0 = heads[0]
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+        self.prob = t(np.concatenate([h[0] for h in heads]))
+        self.pred = t(np.concatenate([h[1] for h in heads]))
+        self.info = t(np.concatenate([h[2] for h in heads]))
+        self.calib = t(np.stack([h[3] for h in heads]))
+        self.bev = t(synth.feature_map(7, *BEV_MAP[:2], BEV_MAP[2], B))
+        self.rgb = t(synth.feature_map(8, *RGB_MAP[:2], RGB_MAP[2], B))
+        self.params = ops.proposal_params(CFGS[args.cfg])
+        self.out = None
+        self.step()                                   # allocates outputs / workspace
+        torch.cuda.synchronize()
+
+    def step(self):
+        o = self.ops
+        self.out = o.proposal_3d(self.prob, self.pred, self.info, self.calib, self.params, out=self.out)
+        bv, img = self.out[0], self.out[1]
+        cap = bv.shape[1]
+        rois_bv = bv.view(-1, 5)                      # (B*cap, 5), column 0 = frame index
+        rois_img = img.view(-1, 5)
+        if not hasattr(self, "tops"):
+            R = rois_bv.shape[0]
+            mk = lambda c, dt: torch.empty((R, 7, 7, c), dtype=dt, device="cuda")
+            self.tops = (mk(BEV_MAP[2], torch.float32), mk(BEV_MAP[2], torch.int32),
+                         mk(RGB_MAP[2], torch.float32), mk(RGB_MAP[2], torch.int32))
+        self._roi(self.bev, rois_bv, self.tops[0], self.tops[1])
+        self._roi(self.rgb, rois_img, self.tops[2], self.tops[3])
+        return cap
+
+    def _roi(self, data, rois, top, argmax):
+        import ctypes as C
+        from mv3d_tf_amd._lib import check, lib
+        B, H, W, Cc = data.shape
+        rc = lib().mv3d_roi_pool_forward(C.c_void_p(data.data_ptr()), C.c_float(0.125), B, rois.shape[0], H, W, Cc,
+                                         7, 7, C.c_void_p(rois.data_ptr()), C.c_void_p(top.data_ptr()),
+                                         C.c_void_p(argmax.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        check(rc, "mv3d_roi_pool_forward")
+
+
+def time_kernel_events(fn, iters=50):
+    """average duration (ms) of fn()'s launches with HIP events on the current stream"""
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline(fr):
+    """Dominant kernel = RoiPool forward on the RGB view (largest algorithmic traffic per frame):
+    algorithmic bytes = feature map once + rois + (top f32 + argmax i32) outputs."""
+    B = fr.args.batch
+    R = fr.out[0].shape[0] * fr.out[0].shape[1]
+    H, W, C = RGB_MAP
+    alg = B * H * W * C * 4 + R * 20 + R * 49 * C * 8
+    rois = fr.out[1].view(-1, 5)
+    ms = time_kernel_events(lambda: fr._roi(fr.rgb, rois, fr.tops[2], fr.tops[3]))
+    gbs = alg / (ms * 1e-3) / 1e9
+    return {"kernel": "roi_pool_fwd_kernel<4> (RGB view, R=%d)" % R, "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(fr, seconds):
+    """The C oracle (single thread) on the same frame-0 workload, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from mv3d_tf_amd import synth
+    prob, pred, info, calib = fr.host_frame0
+    bev = synth.feature_map(7, *BEV_MAP[:2], BEV_MAP[2], 1)
+    rgb = synth.feature_map(8, *RGB_MAP[:2], RGB_MAP[2], 1)
+    cfg = {fr.args.cfg: CFGS[fr.args.cfg]}
+    n, t0 = 0, time.perf_counter()
+    while True:
+        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, fr.args.cfg, [8, ], cfg=cfg)
+        oracle.roi_pool(bev, bv, 7, 7, 0.125)
+        oracle.roi_pool(rgb, img, 7, 7, 0.125)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 400:
+            break
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload (frame 0, %s cfg, %s scores) in %.1f s; C restatement "
+                      "oracle/mv3d_oracle.c, gcc -O2, 1 thread; host has %d cores" % (n, fr.args.cfg, fr.args.variant, dt, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from mv3d_tf_amd import build
+    build.build()
+
+    fr = Frames(args, rank)
+    run = fr.step
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fr.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fr.step()
+        run = graph.replay
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        frames = args.steps * args.batch * world
+        res = {
+            "metric": "KITTI-shape frames/sec (RPN+ROI-pool+NMS hot path)",
+            "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] + RoiPool views: proposal_layer_3d (76x76x4=23104 BEV anchors, "
+                                   "%s cfg pre/post-NMS %d/%d, NMS 0.7) -> RoiPool 7x7 BEV 76x76x512 + RGB 46x155x512, "
+                                   "R=%d rows/frame; %s scores" % (args.cfg, CFGS[args.cfg]["RPN_PRE_NMS_TOP_N"],
+                                                                   CFGS[args.cfg]["RPN_POST_NMS_TOP_N"],
+                                                                   fr.out[0].shape[1], args.variant),
+                       "batch_per_gpu": args.batch, "hipgraph": graph is not None, "parallelism": "frames/%d" % world},
+            "kept_rois_frame0": int(fr.out[3][0].item()),
+        }
+        res["roofline"] = roofline(fr)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

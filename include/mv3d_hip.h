@@ -1,0 +1,167 @@
+/*
+ * mv3d_hip.h -- C-ABI of libmv3d_hip.so, the MI355X (gfx950) implementation of the
+ * MV3D RPN -> ROI-pool -> NMS hot path.
+ *
+ * Drop-in boundary: every entry point below replaces one native or
+ * numpy interface of the reference (cited per function, paths relative to the upstream
+ * repository root).  Plain C: raw device pointers, sizes, an opaque stream handle
+ * (a hipStream_t passed as void*; NULL = the null stream).  No torch types, no
+ * exceptions, no exit(): every call returns an mv3d_status.  Hot calls never allocate:
+ * the caller owns outputs and a workspace whose size the *_workspace_bytes() queries
+ * return.  All calls are asynchronous on `stream` unless stated otherwise and are
+ * re-entrant per (stream, workspace).
+ *
+ * Frames are an outer, independent dimension (`batch`): the reference asserts batch==1
+ * in its RPN layers (lib/rpn_msr/proposal_layer_tf.py:48-49); here frame b of a batch
+ * gives exactly what the reference gives for that frame alone, with ROI column 0 = b.
+ */
+#ifndef MV3D_HIP_H
+#define MV3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MV3D_OK = 0,
+    MV3D_ERR_INVALID_ARG = 1,   /* bad shape / NULL pointer / unsupported size */
+    MV3D_ERR_WORKSPACE = 2,     /* workspace too small or misaligned (256 B) */
+    MV3D_ERR_HIP = 3,           /* a HIP runtime call or launch failed */
+    MV3D_ERR_ZERO_DIVISION = 4  /* host entries only: the reference's ZeroDivisionError */
+} mv3d_status;
+
+int mv3d_version(void);                      /* 100 * major + minor */
+const char *mv3d_status_string(int status);
+
+/* ------------------------------------------------------------------ NMS
+ * Replaces: lib/nms/cpu_nms.pyx:17-68 (== lib/utils/nms.pyx:17-68), dispatcher
+ * lib/fast_rcnn/nms_wrapper.py:13-21, and the CUDA path lib/nms/nms_kernel.cu:34-144 /
+ * lib/nms/gpu_nms.hpp:1-2.
+ *
+ * Semantics (CPU path = the parity target): f32 IoU with the +1 pixel convention,
+ * separate IEEE f32 operations, box j suppressed by an earlier kept box iff
+ * (double)IoU >= thresh.  The device-status word receives bit 0 = "a union was 0"
+ * (the reference raises ZeroDivisionError there; the pair is treated as not
+ * suppressing and the flag is raised). */
+
+/* Device entry: dets_dev (n,5) f32 [x1,y1,x2,y2,score], ALREADY in processing order
+ * (descending score).  keep_dev receives positions 0..n-1 of the kept boxes in order,
+ * at most max_keep of them (max_keep <= 0: no cap; the result equals the reference's
+ * keep[:max_keep]); num_keep_dev[0] the count; status_dev[0] flag bits (may be NULL). */
+size_t mv3d_nms_workspace_bytes(int max_boxes);
+int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep,
+                    int32_t *keep_dev, int32_t *num_keep_dev, int32_t *status_dev,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Host entry with cpu_nms(dets, thresh) semantics: host pointers, dets unsorted;
+ * sorts on the device (descending score, ties by descending index -- the reference
+ * leaves ties to numpy's unstable argsort), runs the NMS, returns indices into dets in
+ * processing order.  Synchronous; allocates and frees its own device buffers (like
+ * _nms below).  Returns MV3D_ERR_ZERO_DIVISION where the reference raises. */
+int mv3d_nms_host(int32_t *keep_out, int32_t *num_out, const float *dets_host, int n,
+                  double thresh, int device_id);
+
+/* Symbol-compatible replacement for lib/nms/gpu_nms.hpp:1-2 (bound by gpu_nms.pyx:13-14):
+ * host pointers, boxes pre-sorted by the caller, synchronous, selects device_id.  Keeps
+ * the CUDA path's own rule (nms_kernel.cu:71): suppressed iff IoU > thresh compared in
+ * f32 -- NOT identical to the CPU path; parity of this entry is
+ * unpinned (no CUDA device to run the original on). */
+void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num,
+          int boxes_dim, float nms_overlap_thresh, int device_id);
+
+/* ------------------------------------------------------------------ proposal_layer_3d
+ * Replaces the numpy py_func body lib/rpn_msr/proposal_layer_tf.py:25-202 and all it
+ * calls (bv_anchor_to_lidar, bbox_transform_inv_3d, lidar_3d_to_bv, lidar_3d_to_corners,
+ * lidar_cnr_to_img, clip_boxes, _filter_boxes, _filter_img_boxes, argsort top-N, nms).
+ *   prob_dev    (batch,H,W,8)  f32  rpn_cls_prob_reshape, channel 2a = bg, 2a+1 = fg
+ *   pred_dev    (batch,H,W,24) f32  rpn_bbox_pred, channels 6a..6a+5
+ *   im_info_dev (batch,3)      f32  [H_bev, W_bev, scale]
+ *   calib_dev   (batch,4,12)   f32  rows P2, P3, R0(9)+000, Tr_velo_to_cam
+ * Outputs, row capacity cap = mv3d_proposal_3d_capacity(): blob_bv (batch,cap,5),
+ * blob_img (batch,cap,5), blob_3d (batch,cap,7), rows >= num_out[b] zero-filled;
+ * num_out_dev (batch) i32; status_dev (batch) i32 flag bits as for the NMS (may be NULL). */
+typedef struct {
+    int32_t feat_stride;     /* 8: lib/networks/MV3D_train.py:5 */
+    int32_t pre_nms_topN;    /* cfg[key].RPN_PRE_NMS_TOP_N  (<=0: keep all) */
+    int32_t post_nms_topN;   /* cfg[key].RPN_POST_NMS_TOP_N (<=0: keep all) */
+    int32_t img_height;      /* 375  hard-coded at proposal_layer_tf.py:147 */
+    int32_t img_width;       /* 1242 */
+    int32_t img_padding;     /* 50: proposal_layer_tf.py:345 */
+    double nms_thresh;       /* cfg[key].RPN_NMS_THRESH */
+    double min_size;         /* cfg[key].RPN_MIN_SIZE   */
+} mv3d_proposal_params;
+
+int mv3d_proposal_3d_capacity(int H, int W, const mv3d_proposal_params *p);
+size_t mv3d_proposal_3d_workspace_bytes(int batch, int H, int W, const mv3d_proposal_params *p);
+int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, int batch, int H, int W,
+                     const float *im_info_dev, const float *calib_dev,
+                     const mv3d_proposal_params *p,
+                     float *blob_bv_dev, float *blob_img_dev, float *blob_3d_dev,
+                     int32_t *num_out_dev, int32_t *status_dev,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ RoiPool / RoiPoolGrad
+ * Replace lib/roi_pooling_layer/roi_pooling_op_gpu.h:18-27 (ROIPoolForwardLaucher /
+ * ROIPoolBackwardLaucher, bodies roi_pooling_op_gpu.cu.cc:20-110,113-215) and the CPU
+ * kernels roi_pooling_op.cc:74-190,319-452: same argument order, a stream handle where
+ * the reference takes `const Eigen::GpuDevice&`, a status instead of exit(-1).
+ * NHWC f32 data, rois (R,5) [batch_idx,x1,y1,x2,y2], argmax = flat index inside the
+ * frame (h*W+w)*C+c or -1; argmax_data may be NULL on forward.  `batch_size` lets the
+ * kernel refuse out-of-range batch indices (outputs 0 / -1) instead of reading out of
+ * bounds as the reference would.  Backward is the reference's deterministic gather
+ * (ROIs ascending, then ph, pw ascending): bit-identical f32 sums, no atomics. */
+int mv3d_roi_pool_forward(const float *bottom_data, float spatial_scale, int batch_size,
+                          int num_rois, int height, int width, int channels,
+                          int pooled_height, int pooled_width, const float *bottom_rois,
+                          float *top_data, int32_t *argmax_data, void *stream);
+int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale, int batch_size,
+                           int num_rois, int height, int width, int channels,
+                           int pooled_height, int pooled_width, const float *bottom_rois,
+                           float *bottom_diff, const int32_t *argmax_data, void *stream);
+
+/* ------------------------------------------------------------------ anchor_target_layer
+ * Replaces the deterministic part of lib/rpn_msr/anchor_target_layer_tf.py:21-250 plus
+ * lib/utils/bbox.pyx:15-55 and lib/fast_rcnn/bbox_transform.py:32-58 (one frame):
+ * stage1 = inside filter, f64 IoU vs gt_boxes_bv, argmax / max, gt-argmax flood, labels
+ * before any random subsampling, 6-d targets; it also compacts the three candidate
+ * lists the reference subsamples from.  The draws themselves come from the caller's
+ * numpy RNG (draw-for-draw parity needs the host's MT19937 stream): the caller reads
+ * counts_dev, draws the permutations, and stage2 applies them.
+ *   gt_bv_dev (G,5) f32, gt_3d_dev (G,7) f32, im_info_dev (3) f32.
+ *   labels_dev (N) f32 in {-1,0,1}; targets_dev (N,6) f32; N = H*W*4, anchor order (h,w,a).
+ *   counts_dev[8] i32: [0] n_inside, [1] n_fg (labels==1 before subsampling),
+ *     [2] n_bg (labels==0 before subsampling), [3] n_low (max_overlap < NEGATIVE_OVERLAP
+ *     among inside anchors), rest reserved.
+ *   fg_hi_dev (N) u8: for the k-th fg candidate, 1 iff its max_overlap >= NEGATIVE_OVERLAP
+ *     (lets the host know how many positives survive step 9 of SURVEY A.1). */
+typedef struct {
+    int32_t feat_stride;
+    int32_t clobber_positives;   /* cfg.TRAIN.RPN_CLOBBER_POSITIVES */
+    double negative_overlap;     /* cfg.TRAIN.RPN_NEGATIVE_OVERLAP  */
+    double positive_overlap;     /* cfg.TRAIN.RPN_POSITIVE_OVERLAP  */
+} mv3d_anchor_target_params;
+
+size_t mv3d_anchor_target_workspace_bytes(int H, int W, int G);
+int mv3d_anchor_target_stage1(int H, int W, const float *im_info_dev, const float *gt_bv_dev,
+                              const float *gt_3d_dev, int G, const mv3d_anchor_target_params *p,
+                              float *labels_dev, float *targets_dev, int32_t *counts_dev,
+                              uint8_t *fg_hi_dev, void *workspace, size_t workspace_bytes,
+                              void *stream);
+/* stage2: disable_fg_dev[n_dis_fg] = positions in the fg candidate list to set to -1,
+ * disable_bg1_dev[n_dis_bg1] positions in the first bg list; then the debug outputs
+ * anchors_dev (<=cap,5) / anchors_3d_dev (<=cap,7) / n_anchors_dev are taken (labels != -1),
+ * labels[max_overlap < NEGATIVE_OVERLAP] = 0, and disable_bg2_dev[n_dis_bg2] positions in
+ * the second bg list are set to -1 (anchor_target_layer_tf.py:146-183). */
+int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
+                              const int32_t *disable_fg_dev, int n_dis_fg,
+                              const int32_t *disable_bg1_dev, int n_dis_bg1,
+                              const int32_t *disable_bg2_dev, int n_dis_bg2,
+                              float *labels_dev, float *anchors_dev, float *anchors_3d_dev,
+                              int32_t *n_anchors_dev, int anchors_cap,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MV3D_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libmv3d_hip.so (include/mv3d_hip.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared
+object is missing or cannot be loaded, importing any operator raises immediately.
+torch is imported first so that the one HIP runtime already loaded by torch
+(libamdhip64.so.7) also serves this library: device pointers and stream handles are
+shared with torch tensors, which are used purely as buffers.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: provides libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmv3d_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_WORKSPACE, ERR_HIP, ERR_ZERO_DIVISION = 0, 1, 2, 3, 4
+
+
+class ProposalParams(C.Structure):
+    """mv3d_proposal_params"""
+    _fields_ = [("feat_stride", C.c_int32), ("pre_nms_topN", C.c_int32), ("post_nms_topN", C.c_int32),
+                ("img_height", C.c_int32), ("img_width", C.c_int32), ("img_padding", C.c_int32),
+                ("nms_thresh", C.c_double), ("min_size", C.c_double)]
+
+
+class AnchorTargetParams(C.Structure):
+    """mv3d_anchor_target_params"""
+    _fields_ = [("feat_stride", C.c_int32), ("clobber_positives", C.c_int32),
+                ("negative_overlap", C.c_double), ("positive_overlap", C.c_double)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "mv3d_version": (C.c_int, []),
+    "mv3d_status_string": (C.c_char_p, [C.c_int]),
+    "mv3d_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mv3d_nms_device": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_nms_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int]),
+    "_nms": (None, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "mv3d_proposal_3d_capacity": (C.c_int, [C.c_int, C.c_int, C.POINTER(ProposalParams)]),
+    "mv3d_proposal_3d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(ProposalParams)]),
+    "mv3d_proposal_3d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.POINTER(ProposalParams),
+                                   _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_roi_pool_forward": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, _P, _P, _P, _P]),
+    "mv3d_roi_pool_backward": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, _P, _P, _P, _P]),
+    "mv3d_anchor_target_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mv3d_anchor_target_stage1": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, C.POINTER(AnchorTargetParams),
+                                            _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_anchor_target_stage2": (C.c_int, [C.c_int, C.c_int, C.POINTER(AnchorTargetParams), _P, C.c_int, _P,
+                                            C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the product and has no fallback. "
+                "Build it with `python -m mv3d_tf_amd.build` (or __graft_entry__.build()).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)       # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+class Mv3dError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        super().__init__(f"{where}: {lib().mv3d_status_string(status).decode()} (status {status})")
+
+
+def check(status, where):
+    if status == ERR_ZERO_DIVISION:
+        raise ZeroDivisionError("float division")     # what lib/nms/cpu_nms.pyx:64 raises
+    if status != OK:
+        raise Mv3dError(status, where)

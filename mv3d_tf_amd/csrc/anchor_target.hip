@@ -1,0 +1,349 @@
+// anchor_target_layer for gfx950 (one frame): lib/rpn_msr/anchor_target_layer_tf.py:21-250
+// with lib/utils/bbox.pyx:15-55 (IoU, f64) and lib/fast_rcnn/bbox_transform.py:32-58 fused in;
+// the N x G overlap matrix is never materialised.
+//
+//  at_overlap_kernel   per anchor: inside test, f64 IoU against the G ground-truth boxes staged
+//                      in LDS, first-argmax / max per anchor, per-GT column maximum (u64 atomicMax
+//                      on the bit pattern of the non-negative f64, LDS first, then global).
+//  at_label_kernel     labels before any random subsampling (incl. the "every anchor tying a
+//                      GT's column max" flood) and the 6-d targets, written straight
+//                      into the full-grid (unmapped) outputs: -1 / 0 fill for outside anchors.
+//  at_compact_kernel   one workgroup: ordered (ascending anchor index) compaction of the three
+//                      lists the reference subsamples from + their counts.
+//  stage 2             applies the host-drawn permutations (numpy MT19937 draws stay on the host:
+//                      draw-for-draw parity) and emits the debug anchor lists.
+#include <math.h>
+#include "common.h"
+
+__constant__ int c_at_base[16] = {-19, -8, 20, 8, -5, -2, 5, 3, -8, -19, 8, 20, -2, -5, 3, 5};
+#define AT_MAX_GT 1024
+
+// Defined natural log (f64): x = m 2^k, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
+// log m = 2 s sum_{d odd <= 39} s^(d-1)/d, Horner with explicit fma; same sequence of IEEE
+// operations as oracle/mv3d_oracle.c:mv3d_ref_log.  Targets are rounded to f32 afterwards.
+__device__ __forceinline__ double mv3d_log(double x)
+{
+    if (x != x || x < 0) return NAN;
+    if (x == 0) return -INFINITY;
+    if (isinf(x)) return x;
+    int k;
+    double m = frexp(x, &k);
+    if (m < 0.70710678118654752440) { m *= 2.0; k -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 39;
+#pragma unroll
+    for (int d = 37; d >= 1; d -= 2) p = fma(p, z, 1.0 / d);
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double lm = 2.0 * s * p;
+    return fma((double)k, LN2_HI, fma((double)k, LN2_LO, lm));
+}
+
+// bbox.pyx:33-54 for one (anchor, gt) pair
+__device__ __forceinline__ double iou_f64(double b0, double b1, double b2, double b3, double q0, double q1, double q2,
+                                          double q3)
+{
+    const double iw = fmin(b2, q2) - fmax(b0, q0) + 1;
+    if (iw > 0) {
+        const double ih = fmin(b3, q3) - fmax(b1, q1) + 1;
+        if (ih > 0) {
+            const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
+            const double ua = (b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih;
+            return iw * ih / ua;
+        }
+    }
+    return 0.0;
+}
+
+struct AtDev {
+    int H, W, N, G, stride, clobber;
+    double neg_ov, pos_ov;
+    const float *im_info, *gt_bv, *gt_3d;
+    double *max_ov;                  // (N)  -1 for anchors outside the image
+    int32_t *argmax;                 // (N)
+    unsigned long long *gtmax;       // (G)  bit pattern of the column max (>= 0)
+    float *labels, *targets;
+};
+
+__device__ __forceinline__ void anchor_coords(const AtDev &d, int n, int &x1, int &y1, int &x2, int &y2)
+{
+    const int a = n & 3, cell = n >> 2, w = cell % d.W, h = cell / d.W;
+    const int sx = w * d.stride, sy = h * d.stride;
+    x1 = c_at_base[4 * a] + sx; y1 = c_at_base[4 * a + 1] + sy;
+    x2 = c_at_base[4 * a + 2] + sx; y2 = c_at_base[4 * a + 3] + sy;
+}
+
+__device__ __forceinline__ bool anchor_box(const AtDev &d, int n, int &x1, int &y1, int &x2, int &y2)
+{
+    anchor_coords(d, n, x1, y1, x2, y2);
+    // anchor_target_layer_tf.py:93-98 (_allowed_border = 0)
+    return x1 >= 0 && y1 >= 0 && (double)x2 < (double)d.im_info[1] && (double)y2 < (double)d.im_info[0];
+}
+
+__global__ __launch_bounds__(256) void at_overlap_kernel(AtDev d)
+{
+    __shared__ float s_gt[AT_MAX_GT * 4];
+    __shared__ unsigned long long s_max[AT_MAX_GT];
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
+        s_gt[4 * g + 0] = d.gt_bv[5 * g + 0]; s_gt[4 * g + 1] = d.gt_bv[5 * g + 1];
+        s_gt[4 * g + 2] = d.gt_bv[5 * g + 2]; s_gt[4 * g + 3] = d.gt_bv[5 * g + 3];
+        s_max[g] = 0ull;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < d.N) {
+        int x1, y1, x2, y2;
+        const bool inside = anchor_box(d, n, x1, y1, x2, y2);
+        double mx = -1.0;
+        int am = 0;
+        if (inside) {
+            for (int g = 0; g < d.G; ++g) {
+                const double o = iou_f64(x1, y1, x2, y2, s_gt[4 * g], s_gt[4 * g + 1], s_gt[4 * g + 2], s_gt[4 * g + 3]);
+                if (o > mx) { mx = o; am = g; }           // :118 argmax = first maximum
+                if (o > 0.0) atomicMax(&s_max[g], (unsigned long long)__double_as_longlong(o));
+            }
+        }
+        d.max_ov[n] = mx;
+        d.argmax[n] = am;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x)
+        if (s_max[g]) atomicMax(&d.gtmax[g], s_max[g]);
+}
+
+__global__ __launch_bounds__(256) void at_label_kernel(AtDev d)
+{
+    __shared__ float s_gt[AT_MAX_GT * 4];
+    __shared__ double s_max[AT_MAX_GT];
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
+        s_gt[4 * g + 0] = d.gt_bv[5 * g + 0]; s_gt[4 * g + 1] = d.gt_bv[5 * g + 1];
+        s_gt[4 * g + 2] = d.gt_bv[5 * g + 2]; s_gt[4 * g + 3] = d.gt_bv[5 * g + 3];
+        s_max[g] = __longlong_as_double((long long)d.gtmax[g]);
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= d.N) return;
+    int x1, y1, x2, y2;
+    const bool inside = anchor_box(d, n, x1, y1, x2, y2);
+    float lab = -1.0f;                                            // :110-111 / _unmap fill
+    float T[6] = {0, 0, 0, 0, 0, 0};
+    if (inside) {
+        const double mx = d.max_ov[n];
+        if (!d.clobber && 0 < mx && mx < d.neg_ov) lab = 0.0f;   // :125-130
+        for (int g = 0; g < d.G; ++g) {                            // :123,:133 every anchor tying a column max
+            const double o = iou_f64(x1, y1, x2, y2, s_gt[4 * g], s_gt[4 * g + 1], s_gt[4 * g + 2], s_gt[4 * g + 3]);
+            if (o == s_max[g]) { lab = 1.0f; break; }
+        }
+        if (mx >= d.pos_ov) lab = 1.0f;                            // :139
+        if (d.clobber && mx < d.neg_ov) lab = 0.0f;                // :141-143
+        if (d.G > 0) {
+            // transform.py:89-111 (f64) and bbox_transform.py:32-58 (f64) then astype(f32)
+            const double ex_len = (double)(y2 - y1) * 0.1, ex_wid = (double)(x2 - x1) * 0.1;
+            const double cx = (double)(x1 + x2) / 2.0, cy = (double)(y1 + y2) / 2.0;
+            const double ey = 600 * 0.1 - (cx + 0.5) * 0.1 + (-30.0);
+            const double ex = 600 * 0.1 - (cy + 0.5) * 0.1 + 0.0;
+            const double ez = (double)(float)(-(1.73 - 1.56 / 2.0)), eh = (double)(float)1.56;
+            const float *gt = d.gt_3d + 7 * d.argmax[n];
+            T[0] = (float)(((double)gt[0] - ex) / ex_wid);         // dx / ex_widths  (sic)
+            T[1] = (float)(((double)gt[1] - ey) / ex_len);         // dy / ex_lengths (sic)
+            T[2] = (float)(((double)gt[2] - ez) / eh);
+            T[3] = (float)mv3d_log((double)gt[3] / ex_len);
+            T[4] = (float)mv3d_log((double)gt[4] / ex_wid);
+            T[5] = (float)mv3d_log((double)gt[5] / eh);
+        }
+    }
+    d.labels[n] = lab;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d.targets[6 * (long long)n + j] = T[j];
+}
+
+// ---- ordered compaction in one workgroup (1024 threads, contiguous chunk per thread) ----------
+__device__ __forceinline__ int4 block_exclusive_scan4(int4 v, int4 &total)
+{
+    __shared__ int4 s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int4 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int4 t;
+        t.x = __shfl_up(inc.x, o); t.y = __shfl_up(inc.y, o); t.z = __shfl_up(inc.z, o); t.w = __shfl_up(inc.w, o);
+        if (lane >= o) { inc.x += t.x; inc.y += t.y; inc.z += t.z; inc.w += t.w; }
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int4 base = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
+    for (int k = 0; k < 16; ++k) {
+        const int4 s = s_wave[k];
+        if (k < wave) { base.x += s.x; base.y += s.y; base.z += s.z; base.w += s.w; }
+        tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w;
+    }
+    __syncthreads();
+    total = tot;
+    return make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+}
+
+struct AtLists {
+    int32_t *fg, *bg, *low;          // (N) each: anchor indices, ascending
+};
+
+__global__ __launch_bounds__(1024) void at_compact_kernel(const float *labels, const double *max_ov, int N, double neg_ov,
+                                                          AtLists L, int32_t *counts, uint8_t *fg_hi)
+{
+    const int per = (N + 1023) / 1024;
+    const int s = threadIdx.x * per, e = min(N, s + per);
+    int4 c = make_int4(0, 0, 0, 0);                  // inside, fg, bg, low
+    for (int n = s; n < e; ++n) {
+        const double mx = max_ov[n];
+        if (mx >= 0.0) {                             // inside anchors carry max_ov >= 0
+            const float lab = labels[n];
+            c.x += 1; c.y += (lab == 1.0f); c.z += (lab == 0.0f); c.w += (mx < neg_ov);
+        }
+    }
+    int4 tot;
+    int4 o = block_exclusive_scan4(c, tot);
+    for (int n = s; n < e; ++n) {
+        const double mx = max_ov[n];
+        if (mx >= 0.0) {
+            const float lab = labels[n];
+            if (lab == 1.0f) { L.fg[o.y] = n; fg_hi[o.y] = (mx >= neg_ov) ? 1 : 0; ++o.y; }
+            if (lab == 0.0f) L.bg[o.z++] = n;
+            if (mx < neg_ov) L.low[o.w++] = n;
+        }
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = tot.x; counts[1] = tot.y; counts[2] = tot.z; counts[3] = tot.w;
+        counts[4] = counts[5] = counts[6] = counts[7] = 0;
+    }
+}
+
+__global__ void at_disable_kernel(float *labels, const int32_t *list, const int32_t *pos, int n)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) labels[list[pos[t]]] = -1.0f;
+}
+
+// anchor_target_layer_tf.py:170-174: rows of (0, anchor) and (0, anchor_3d) for labels != -1
+__global__ __launch_bounds__(1024) void at_emit_anchors_kernel(AtDev d, float *anchors, float *anchors_3d, int32_t *n_out,
+                                                               int cap)
+{
+    const int per = (d.N + 1023) / 1024;
+    const int s = threadIdx.x * per, e = min(d.N, s + per);
+    int4 c = make_int4(0, 0, 0, 0);
+    for (int n = s; n < e; ++n) c.x += (d.max_ov[n] >= 0.0 && d.labels[n] != -1.0f);
+    int4 tot;
+    int4 o = block_exclusive_scan4(c, tot);
+    for (int n = s; n < e; ++n) {
+        if (d.max_ov[n] >= 0.0 && d.labels[n] != -1.0f) {
+            const int r = o.x++;
+            if (r < cap) {
+                int x1, y1, x2, y2;
+                anchor_coords(d, n, x1, y1, x2, y2);
+                float *A = anchors + 5 * (long long)r, *B = anchors_3d + 7 * (long long)r;
+                A[0] = 0.0f; A[1] = (float)x1; A[2] = (float)y1; A[3] = (float)x2; A[4] = (float)y2;
+                const double ex_len = (double)(y2 - y1) * 0.1, ex_wid = (double)(x2 - x1) * 0.1;
+                const double cx = (double)(x1 + x2) / 2.0, cy = (double)(y1 + y2) / 2.0;
+                B[0] = 0.0f;
+                B[1] = (float)(600 * 0.1 - (cy + 0.5) * 0.1 + 0.0);
+                B[2] = (float)(600 * 0.1 - (cx + 0.5) * 0.1 + (-30.0));
+                B[3] = (float)(-(1.73 - 1.56 / 2.0));
+                B[4] = (float)ex_len; B[5] = (float)ex_wid; B[6] = (float)1.56;
+            }
+        }
+    }
+    if (threadIdx.x == 0) n_out[0] = tot.x;
+}
+
+// anchor_target_layer_tf.py:176: labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0 (inside anchors)
+__global__ void at_relabel_low_kernel(float *labels, const double *max_ov, int N, double neg_ov)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+        const double mx = max_ov[n];
+        if (mx >= 0.0 && mx < neg_ov) labels[n] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------ workspace / C-ABI
+struct AtLayout { size_t o_maxov, o_argmax, o_gtmax, o_fg, o_bg, o_low, total; int N; };
+
+static bool at_layout(int H, int W, int G, AtLayout &L)
+{
+    if (H <= 0 || W <= 0 || G < 0 || G > AT_MAX_GT) return false;
+    const long long N = (long long)H * W * 4;
+    if (N > (1 << 22)) return false;
+    L.N = (int)N;
+    size_t o = 0;
+    L.o_maxov = o; o += mv3d_align_up((size_t)N * 8);
+    L.o_argmax = o; o += mv3d_align_up((size_t)N * 4);
+    L.o_gtmax = o; o += mv3d_align_up((size_t)AT_MAX_GT * 8);
+    L.o_fg = o; o += mv3d_align_up((size_t)N * 4);
+    L.o_bg = o; o += mv3d_align_up((size_t)N * 4);
+    L.o_low = o; o += mv3d_align_up((size_t)N * 4);
+    L.total = o;
+    return true;
+}
+
+extern "C" size_t mv3d_anchor_target_workspace_bytes(int H, int W, int G)
+{
+    AtLayout L;
+    return at_layout(H, W, G, L) ? L.total : 0;
+}
+
+static void at_fill(AtDev &d, const AtLayout &L, int H, int W, int G, const mv3d_anchor_target_params *p, char *ws)
+{
+    d.H = H; d.W = W; d.N = L.N; d.G = G; d.stride = p->feat_stride; d.clobber = p->clobber_positives;
+    d.neg_ov = p->negative_overlap; d.pos_ov = p->positive_overlap;
+    d.max_ov = (double *)(ws + L.o_maxov); d.argmax = (int32_t *)(ws + L.o_argmax);
+    d.gtmax = (unsigned long long *)(ws + L.o_gtmax);
+}
+
+extern "C" int mv3d_anchor_target_stage1(int H, int W, const float *im_info_dev, const float *gt_bv_dev,
+                                         const float *gt_3d_dev, int G, const mv3d_anchor_target_params *p,
+                                         float *labels_dev, float *targets_dev, int32_t *counts_dev, uint8_t *fg_hi_dev,
+                                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    AtLayout L;
+    if (!p || !at_layout(H, W, G, L) || p->feat_stride <= 0) return MV3D_ERR_INVALID_ARG;
+    if (!im_info_dev || !labels_dev || !targets_dev || !counts_dev || !fg_hi_dev || (G > 0 && (!gt_bv_dev || !gt_3d_dev)))
+        return MV3D_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    AtDev d;
+    at_fill(d, L, H, W, G, p, ws);
+    d.im_info = im_info_dev; d.gt_bv = gt_bv_dev; d.gt_3d = gt_3d_dev; d.labels = labels_dev; d.targets = targets_dev;
+    MV3D_HIP_TRY(hipMemsetAsync(d.gtmax, 0, (size_t)AT_MAX_GT * 8, s));
+    const int blocks = (L.N + 255) / 256;
+    hipLaunchKernelGGL(at_overlap_kernel, dim3(blocks), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(at_label_kernel, dim3(blocks), dim3(256), 0, s, d);
+    AtLists lists = {(int32_t *)(ws + L.o_fg), (int32_t *)(ws + L.o_bg), (int32_t *)(ws + L.o_low)};
+    hipLaunchKernelGGL(at_compact_kernel, dim3(1), dim3(1024), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov, lists,
+                       counts_dev, fg_hi_dev);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
+                                         const int32_t *disable_fg_dev, int n_dis_fg, const int32_t *disable_bg1_dev,
+                                         int n_dis_bg1, const int32_t *disable_bg2_dev, int n_dis_bg2, float *labels_dev,
+                                         float *anchors_dev, float *anchors_3d_dev, int32_t *n_anchors_dev,
+                                         int anchors_cap, void *workspace, size_t workspace_bytes, void *stream)
+{
+    AtLayout L;
+    if (!p || !at_layout(H, W, 0, L) || !labels_dev || n_dis_fg < 0 || n_dis_bg1 < 0 || n_dis_bg2 < 0)
+        return MV3D_ERR_INVALID_ARG;
+    if ((n_dis_fg && !disable_fg_dev) || (n_dis_bg1 && !disable_bg1_dev) || (n_dis_bg2 && !disable_bg2_dev))
+        return MV3D_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    AtDev d;
+    at_fill(d, L, H, W, 0, p, ws);
+    d.im_info = nullptr; d.gt_bv = nullptr; d.gt_3d = nullptr; d.labels = labels_dev; d.targets = nullptr;
+    int32_t *fg = (int32_t *)(ws + L.o_fg), *bg = (int32_t *)(ws + L.o_bg), *low = (int32_t *)(ws + L.o_low);
+    if (n_dis_fg) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_fg + 255) / 256), dim3(256), 0, s, labels_dev, fg, disable_fg_dev, n_dis_fg);
+    if (n_dis_bg1) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg1 + 255) / 256), dim3(256), 0, s, labels_dev, bg, disable_bg1_dev, n_dis_bg1);
+    if (anchors_dev && anchors_3d_dev && n_anchors_dev)
+        hipLaunchKernelGGL(at_emit_anchors_kernel, dim3(1), dim3(1024), 0, s, d, anchors_dev, anchors_3d_dev, n_anchors_dev, anchors_cap);
+    hipLaunchKernelGGL(at_relabel_low_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov);
+    if (n_dis_bg2) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg2 + 255) / 256), dim3(256), 0, s, labels_dev, low, disable_bg2_dev, n_dis_bg2);
+    return mv3d_launch_status();
+}

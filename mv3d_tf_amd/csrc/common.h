@@ -1,0 +1,48 @@
+// Shared host/device helpers for libmv3d_hip.so (gfx950 only; wave = 64 lanes).
+// Build flags that matter for parity: -ffp-contract=off (every *, + is one IEEE
+// rounding unless __fmaf_rn / fma is written out), no fast-math, IEEE f32 divide
+// (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt), denormals preserved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/mv3d_hip.h"
+
+#define MV3D_WAVE 64
+#define MV3D_ALIGN 256
+#define MV3D_FLAG_ZERO_DIVISION 1
+
+#define MV3D_HIP_TRY(expr)                           \
+    do {                                             \
+        if ((expr) != hipSuccess) return MV3D_ERR_HIP; \
+    } while (0)
+
+static inline int mv3d_launch_status() { return hipGetLastError() == hipSuccess ? MV3D_OK : MV3D_ERR_HIP; }
+static inline size_t mv3d_align_up(size_t v) { return (v + MV3D_ALIGN - 1) / MV3D_ALIGN * MV3D_ALIGN; }
+
+// Score -> order-preserving u32 key, larger key = processed earlier.  NaN first (numpy's
+// ascending argsort puts NaN last; the reference reverses it).  Valid keys are >= 1, so
+// 0 can mark "not a candidate".
+__host__ __device__ static inline uint32_t mv3d_score_key(float s)
+{
+    union { float f; uint32_t u; } c;
+    c.f = s;
+    if (s != s) return 0xFFFFFFFFu;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+
+// Cython inline float32 max / min of lib/nms/cpu_nms.pyx:11-15
+__device__ static inline float cy_max(float a, float b) { return a >= b ? a : b; }
+__device__ static inline float cy_min(float a, float b) { return a <= b ? a : b; }
+// numpy minimum / maximum: NaN in the first operand propagates
+__device__ static inline float np_min32(float a, float b) { return (a < b || a != a) ? a : b; }
+__device__ static inline float np_max32(float a, float b) { return (a >= b || a != a) ? a : b; }
+
+// smallest f32 >= t : (double)ovr >= t  <=>  ovr >= ceil_f32(t) for every non-NaN f32 ovr
+// (the Python-float compare of lib/nms/cpu_nms.pyx:65 without leaving f32 on the device)
+static inline float mv3d_ceil_f32(double t)
+{
+    float f = (float)t;
+    if ((double)f < t) f = nextafterf(f, INFINITY);
+    return f;
+}

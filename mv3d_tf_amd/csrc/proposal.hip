@@ -1,0 +1,361 @@
+// proposal_layer_3d for gfx950: lib/rpn_msr/proposal_layer_tf.py:25-202 behind one C-ABI call.
+//
+//   proposal_decode_kernel  one thread per anchor (h,w,a): anchor -> 3D anchor (f64,
+//        lib/utils/transform.py:89-111) -> decoded 3D box (f32, numpy's f32 exp restated;
+//        lib/fast_rcnn/bbox_transform.py:108-155) -> BEV pixel box (f64 floor-divide,
+//        transform.py:113-142) -> 8 corners (transform.py:290-315) -> image box (f32 matrix,
+//        f64 product, trunc to i32; transform.py:483-500,369-386) -> clip + both filters
+//        (bbox_transform.py:178-191, proposal_layer_tf.py:336-352).  Nothing but the final
+//        candidate record (BEV box, image box, 3D box, score key) is written: the ~25 numpy
+//        temporaries of the reference never exist.  Reads are the two NHWC head tensors,
+//        consecutive anchors = consecutive addresses.
+//   rank_kernel (rank.hip)   argsort()[::-1][:pre_nms_topN]
+//   nms_mask/reduce (nms.hip) greedy NMS on the sorted candidates, capped at post_nms_topN
+//   proposal_emit_kernel     gathers the three ROI blobs, zero-fills the unused rows.
+//
+// All shapes are static given (H, W, params); data-dependent counts stay on the device, so
+// the whole call is capturable in a hipGraph.
+#include <math.h>
+#include "kernels.h"
+
+// ---- constants of lib/utils/transform.py:3-11 and lib/rpn_msr/generate_anchors.py:37-51 ----
+// Xn = Yn = int((60 - 0) // 0.1) + 1 = 600 (Python float floor-division gives 599.0).
+#define BV_XN 600
+#define BV_YN 600
+#define BV_RES 0.1
+#define TOP_Y_MIN_D (-30.0)
+#define TOP_X_MIN_D 0.0
+__constant__ int c_base_anchors[16] = {-19, -8, 20, 8, -5, -2, 5, 3, -8, -19, 8, 20, -2, -5, 3, 5};
+
+// numpy f32 exp (simd_exp_FLOAT), see oracle/mv3d_oracle.c:mv3d_ref_expf for the provenance.
+__device__ __forceinline__ float np_expf(float x)
+{
+    if (x != x) return x;
+    if (x >= 88.72283935546875f) return INFINITY;
+    if (x <= -103.97208404541015625f) return 0.0f;
+    const float LOG2E = 1.44269504088896341f, MAGIC = 0x1.8p+23f;
+    const float C1 = -6.93145752e-1f, C2 = -1.42860677e-6f;
+    const float P0 = 9.999999999980870924916e-01f, P1 = 7.257664613233124478488e-01f,
+                P2 = 2.473615434895520810817e-01f, P3 = 5.114512081637298353406e-02f,
+                P4 = 6.757896990527504603057e-03f, P5 = 5.082762527590693718096e-04f;
+    const float Q0 = 1.0f, Q1 = -2.742335390411667452936e-01f, Q2 = 2.159509375685829852307e-02f;
+    const float k = __fsub_rn(__fadd_rn(__fmul_rn(x, LOG2E), MAGIC), MAGIC);
+    float r = __fmaf_rn(k, C1, x);
+    r = __fmaf_rn(k, C2, r);
+    float num = __fmaf_rn(P5, r, P4);
+    num = __fmaf_rn(num, r, P3);
+    num = __fmaf_rn(num, r, P2);
+    num = __fmaf_rn(num, r, P1);
+    num = __fmaf_rn(num, r, P0);
+    float den = __fmaf_rn(Q2, r, Q1);
+    den = __fmaf_rn(den, r, Q0);
+    return ldexpf(__fdiv_rn(num, den), (int)k);
+}
+
+// numpy npy_divmod -> floor_divide for f64 (what `//` does in transform.py:17-18)
+__device__ __forceinline__ double np_floor_divide(double a, double b)
+{
+    if (b == 0.0) return a / b;
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0) {
+        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
+    }
+    double fd;
+    if (div != 0.0) {
+        fd = floor(div);
+        if (div - fd > 0.5) fd += 1.0;
+    } else {
+        fd = copysign(0.0, a / b);
+    }
+    return fd;
+}
+
+// ndarray.astype(np.int32) of an f64 on x86-64 (cvttsd2si): trunc; NaN / out of range -> INT32_MIN
+__device__ __forceinline__ int32_t f64_to_i32(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+    return (int32_t)v;
+}
+
+// transform.py:369-386: (P2 . R0) . Tr in f32, k ascending, fused multiply-add from a zero
+// accumulator (what the build container's OpenBLAS sgemm does; pinned in tests/golden/proj_matrix.npz)
+__device__ __forceinline__ void proj_matrix(const float *__restrict__ calib, float M[12])
+{
+    const float *P2 = calib, *R0 = calib + 24, *Tr = calib + 36;
+    float m1[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = __fmaf_rn(P2[i * 4 + k], R0[k * 3 + j], acc);
+            m1[i * 3 + j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc = __fmaf_rn(m1[i * 3 + k], Tr[k * 4 + j], acc);
+            M[i * 4 + j] = acc;
+        }
+}
+
+// transform.py:89-111 + :81-87 for one integer BEV anchor box; f64, then .astype(f32)
+// (bbox_transform.py:112).  z and h are f32 constants in the reference.
+__device__ __forceinline__ void anchor_to_lidar(int x1, int y1, int x2, int y2, float o[6])
+{
+    const double ex_len = (double)(y2 - y1) * BV_RES;
+    const double ex_wid = (double)(x2 - x1) * BV_RES;
+    const double cx = (double)(x1 + x2) / 2.0;
+    const double cy = (double)(y1 + y2) / 2.0;
+    const double y = BV_XN * BV_RES - (cx + 0.5) * BV_RES + TOP_Y_MIN_D;
+    const double x = BV_YN * BV_RES - (cy + 0.5) * BV_RES + TOP_X_MIN_D;
+    o[0] = (float)x; o[1] = (float)y;
+    o[2] = (float)(-(1.73 - 1.56 / 2.0));     // -(LIDAR_HEIGHT - CAR_HEIGHT/2.)
+    o[3] = (float)ex_len; o[4] = (float)ex_wid;
+    o[5] = (float)1.56;                       // CAR_HEIGHT
+}
+
+// transform.py:483-500 for one box given its 6 decoded numbers
+__device__ __forceinline__ void image_box(const float M[12], const float P[6], int32_t out[4])
+{
+    const float hl = P[3] / 2.0f, hw = P[4] / 2.0f, hh = P[5] / 2.0f;   // transform.py:296-313
+    double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+    bool nanx = false, nany = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // corner signs x:[+,+,-,-,+,+,-,-] y:[+,-,-,+,+,-,-,+] z:[-,-,-,-,+,+,+,+]
+        const float sx = (k & 2) ? -hl : hl;
+        const float sy = ((k + 1) & 2) ? -hw : hw;
+        const float sz = (k & 4) ? hh : -hh;
+        const double cx = (double)(sx + P[0]), cy = (double)(sy + P[1]), cz = (double)(sz + P[2]);
+        double v[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+            acc = fma((double)M[r * 4 + 0], cx, acc);
+            acc = fma((double)M[r * 4 + 1], cy, acc);
+            acc = fma((double)M[r * 4 + 2], cz, acc);
+            acc = fma((double)M[r * 4 + 3], 0.0, acc);   // homogeneous w = 0 (sic)
+            v[r] = acc;
+        }
+        const double px = v[0] / v[2], py = v[1] / v[2];
+        nanx |= (px != px);
+        nany |= (py != py);
+        if (k == 0) { xmin = xmax = px; ymin = ymax = py; }
+        else {
+            if (px < xmin) xmin = px;
+            if (px > xmax) xmax = px;
+            if (py < ymin) ymin = py;
+            if (py > ymax) ymax = py;
+        }
+    }
+    if (nanx) xmin = xmax = NAN;
+    if (nany) ymin = ymax = NAN;
+    out[0] = f64_to_i32(xmin); out[1] = f64_to_i32(ymin);
+    out[2] = f64_to_i32(xmax); out[3] = f64_to_i32(ymax);
+}
+
+struct ProposalDev {
+    const float *prob, *pred, *im_info, *calib;
+    int H, W, N;
+    int feat_stride, img_h, img_w, img_pad;
+    float min_size;
+    // candidate records, (batch, N)
+    float4 *bv;
+    int4 *img;
+    float *p3;          // (batch, N, 6)
+    uint32_t *key;
+    int32_t *nvalid;    // (batch)
+};
+
+// grid (ceil(N/256), batch)
+__global__ __launch_bounds__(256) void proposal_decode_kernel(ProposalDev d)
+{
+    const int f = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    if (n < d.N) {
+        const int a = n & 3, cell = n >> 2, w = cell % d.W, h = cell / d.W;
+        const float *info = d.im_info + 3 * f;
+        float M[12];
+        proj_matrix(d.calib + 48 * f, M);
+        const int sx = w * d.feat_stride, sy = h * d.feat_stride;                 // proposal_layer_tf.py:79-95
+        float A[6];
+        anchor_to_lidar(c_base_anchors[4 * a] + sx, c_base_anchors[4 * a + 1] + sy,
+                        c_base_anchors[4 * a + 2] + sx, c_base_anchors[4 * a + 3] + sy, A);
+        const float *dl = d.pred + ((long long)f * d.H * d.W + cell) * 24 + 6 * a;   // :105
+        float P[6];
+        P[0] = __fadd_rn(__fmul_rn(dl[0], A[3]), A[0]);                            // bbox_transform.py:130-135
+        P[1] = __fadd_rn(__fmul_rn(dl[1], A[4]), A[1]);
+        P[2] = __fadd_rn(__fmul_rn(dl[2], A[5]), A[2]);
+        P[3] = __fmul_rn(np_expf(dl[3]), A[3]);
+        P[4] = __fmul_rn(np_expf(dl[4]), A[4]);
+        P[5] = __fmul_rn(np_expf(dl[5]), A[5]);
+        // transform.py:131-137
+        const double r0 = (double)__fadd_rn(P[0], __fmul_rn(P[3], 0.5f));
+        const double r1 = (double)__fadd_rn(P[1], __fmul_rn(P[4], 0.5f));
+        const double r2 = (double)__fsub_rn(P[0], __fmul_rn(P[3], 0.5f));
+        const double r3 = (double)__fsub_rn(P[1], __fmul_rn(P[4], 0.5f));
+        float B0 = (float)(BV_YN - np_floor_divide(r1 - TOP_Y_MIN_D, BV_RES));
+        float B1 = (float)(BV_XN - np_floor_divide(r0 - TOP_X_MIN_D, BV_RES));
+        float B2 = (float)(BV_YN - np_floor_divide(r3 - TOP_Y_MIN_D, BV_RES));
+        float B3 = (float)(BV_XN - np_floor_divide(r2 - TOP_X_MIN_D, BV_RES));
+        int32_t I[4];
+        image_box(M, P, I);
+        const float xmaxc = info[1] - 1.0f, ymaxc = info[0] - 1.0f;                // bbox_transform.py:184-190
+        B0 = np_max32(np_min32(B0, xmaxc), 0.0f);
+        B1 = np_max32(np_min32(B1, ymaxc), 0.0f);
+        B2 = np_max32(np_min32(B2, xmaxc), 0.0f);
+        B3 = np_max32(np_min32(B3, ymaxc), 0.0f);
+        const float ws = (B2 - B0) + 1.0f, hs = (B3 - B1) + 1.0f;                 // :336-341
+        const float min_size = d.min_size * info[2];
+        ok = (ws >= min_size) && (hs >= min_size);
+        ok = ok && (-d.img_pad <= I[0]) && (I[2] <= d.img_w + d.img_pad) &&       // :343-352
+             (-d.img_pad <= I[1]) && (I[3] <= d.img_h + d.img_pad);
+        const long long o = (long long)f * d.N + n;
+        d.bv[o] = make_float4(B0, B1, B2, B3);
+        d.img[o] = make_int4(I[0], I[1], I[2], I[3]);
+        float *q = d.p3 + o * 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q[j] = P[j];
+        const float score = d.prob[((long long)f * d.H * d.W + cell) * 8 + 2 * a + 1];   // :63
+        d.key[o] = ok ? mv3d_score_key(score) : 0u;
+    }
+    const unsigned long long bal = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&d.nvalid[f], __popcll(bal));
+}
+
+struct EmitDev {
+    const float4 *bv;
+    const int4 *img;
+    const float *p3;
+    const int32_t *order, *keep, *num_keep;
+    int N, order_cap, cap;
+    float *blob_bv, *blob_img, *blob_3d;
+    int32_t *num_out;
+};
+
+// grid (ceil(cap/256), batch): proposal_layer_tf.py:188-191 (batch column = frame index)
+__global__ __launch_bounds__(256) void proposal_emit_kernel(EmitDev e)
+{
+    const int f = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= e.cap) return;
+    const int nk = e.num_keep[f];
+    if (r == 0) e.num_out[f] = nk;
+    float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
+    float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
+    float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
+    if (r < nk) {
+        const int n = e.order[(long long)f * e.order_cap + e.keep[(long long)f * e.order_cap + r]];
+        const long long o = (long long)f * e.N + n;
+        const float4 b = e.bv[o];
+        const int4 im = e.img[o];
+        const float bi = (float)f;
+        obv[0] = bi; obv[1] = b.x; obv[2] = b.y; obv[3] = b.z; obv[4] = b.w;
+        oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
+        o3[0] = bi;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o3[1 + j] = e.p3[o * 6 + j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------ workspace
+struct ProposalLayout {
+    int N, order_cap, cap;
+    size_t o_bv, o_img, o_p3, o_key, o_order, o_keep, o_cnt, o_nms, total;
+};
+
+static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params *p, ProposalLayout &L)
+{
+    if (batch <= 0 || H <= 0 || W <= 0 || !p) return false;
+    const long long N = (long long)H * W * 4;
+    if (N > 16384 * 4) return false;
+    L.N = (int)N;
+    L.order_cap = (p->pre_nms_topN > 0 && p->pre_nms_topN < L.N) ? p->pre_nms_topN : L.N;
+    if ((L.order_cap + 63) / 64 > 256) return false;        // NMS bitmap limit (16384 boxes)
+    L.cap = (p->post_nms_topN > 0 && p->post_nms_topN < L.order_cap) ? p->post_nms_topN : L.order_cap;
+    size_t o = 0;
+    const size_t b = (size_t)batch;
+    L.o_bv = o; o += mv3d_align_up(b * L.N * 16);
+    L.o_img = o; o += mv3d_align_up(b * L.N * 16);
+    L.o_p3 = o; o += mv3d_align_up(b * L.N * 24);
+    L.o_key = o; o += mv3d_align_up(b * L.N * 4);
+    L.o_order = o; o += mv3d_align_up(b * L.order_cap * 4);
+    L.o_keep = o; o += mv3d_align_up(b * L.order_cap * 4);
+    L.o_cnt = o; o += mv3d_align_up(b * 2 * 4);              // nvalid[batch], num_keep[batch]
+    L.o_nms = o; o += mv3d_nms_ws_bytes(L.order_cap, batch);
+    L.total = o;
+    return true;
+}
+
+extern "C" int mv3d_proposal_3d_capacity(int H, int W, const mv3d_proposal_params *p)
+{
+    ProposalLayout L;
+    return proposal_layout(1, H, W, p, L) ? L.cap : -1;
+}
+
+extern "C" size_t mv3d_proposal_3d_workspace_bytes(int batch, int H, int W, const mv3d_proposal_params *p)
+{
+    ProposalLayout L;
+    return proposal_layout(batch, H, W, p, L) ? L.total : 0;
+}
+
+extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, int batch, int H, int W,
+                                const float *im_info_dev, const float *calib_dev, const mv3d_proposal_params *p,
+                                float *blob_bv_dev, float *blob_img_dev, float *blob_3d_dev, int32_t *num_out_dev,
+                                int32_t *status_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ProposalLayout L;
+    if (!proposal_layout(batch, H, W, p, L)) return MV3D_ERR_INVALID_ARG;
+    if (!prob_dev || !pred_dev || !im_info_dev || !calib_dev || !blob_bv_dev || !blob_img_dev || !blob_3d_dev ||
+        !num_out_dev || p->feat_stride <= 0)
+        return MV3D_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int32_t *cnt = (int32_t *)(ws + L.o_cnt);
+    MV3D_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * 2 * 4, s));
+    if (status_dev) MV3D_HIP_TRY(hipMemsetAsync(status_dev, 0, (size_t)batch * 4, s));
+
+    ProposalDev d;
+    d.prob = prob_dev; d.pred = pred_dev; d.im_info = im_info_dev; d.calib = calib_dev;
+    d.H = H; d.W = W; d.N = L.N; d.feat_stride = p->feat_stride;
+    d.img_h = p->img_height; d.img_w = p->img_width; d.img_pad = p->img_padding;
+    d.min_size = (float)p->min_size;
+    d.bv = (float4 *)(ws + L.o_bv); d.img = (int4 *)(ws + L.o_img); d.p3 = (float *)(ws + L.o_p3);
+    d.key = (uint32_t *)(ws + L.o_key); d.nvalid = cnt;
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3((L.N + 255) / 256, batch), dim3(256), 0, s, d);
+
+    int32_t *order = (int32_t *)(ws + L.o_order), *keep = (int32_t *)(ws + L.o_keep);
+    int rc = mv3d_launch_rank(d.key, L.N, batch, order, L.order_cap, s);
+    if (rc != MV3D_OK) return rc;
+
+    NmsLaunch nl = {};
+    nl.boxes = (const float *)d.bv; nl.box_stride = 4; nl.boxes_frame_stride = (long long)L.N * 4;
+    nl.idx = order; nl.idx_frame_stride = L.order_cap;
+    nl.n_dev = cnt; nl.n_cap = L.order_cap; nl.batch = batch;
+    nl.thresh_f32 = mv3d_ceil_f32(p->nms_thresh); nl.strict_gt = 0;
+    nl.max_keep = L.cap;
+    nl.keep = keep; nl.keep_frame_stride = L.order_cap; nl.num_keep = cnt + batch; nl.status = status_dev;
+    nl.workspace = ws + L.o_nms;
+    rc = mv3d_launch_nms(nl, s);
+    if (rc != MV3D_OK) return rc;
+
+    EmitDev e;
+    e.bv = d.bv; e.img = d.img; e.p3 = d.p3; e.order = order; e.keep = keep; e.num_keep = cnt + batch;
+    e.N = L.N; e.order_cap = L.order_cap; e.cap = L.cap;
+    e.blob_bv = blob_bv_dev; e.blob_img = blob_img_dev; e.blob_3d = blob_3d_dev; e.num_out = num_out_dev;
+    hipLaunchKernelGGL(proposal_emit_kernel, dim3((L.cap + 255) / 256, batch), dim3(256), 0, s, e);
+    return mv3d_launch_status();
+}

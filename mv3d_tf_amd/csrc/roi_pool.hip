@@ -1,0 +1,254 @@
+// RoiPool / RoiPoolGrad for gfx950, NHWC f32.
+// Replaces lib/roi_pooling_layer/roi_pooling_op_gpu.cu.cc:20-110 (forward) / :113-215
+// (backward) and the CPU kernels roi_pooling_op.cc:74-190 / :319-452; same arithmetic.
+//
+// Both kernels are HBM-bound streaming kernels:
+//  forward   one work item = (roi, ph, pw, 4 consecutive channels); 16-byte loads/stores,
+//            channel-fastest so a wave touches 1 KiB contiguous per pixel of the bin; the
+//            bin bounds are uniform per wave (C/4 is a multiple of 64 for C = 512) so the
+//            bin loops do not diverge.  Output (top + argmax, R*PH*PW*C*8 B) dominates.
+//  backward  the reference's deterministic gather, kept bit-identical (ROIs ascending, then
+//            ph, pw ascending, f32 adds in that order), but instead of every input element
+//            scanning all R ROIs (O(H*W*C*R)), one workgroup per input pixel finds the ROIs
+//            containing it once (wave 0: 64 ROIs per ballot, ascending compaction into LDS)
+//            and its C/4 lanes then walk only those ROIs' candidate bins with 16-byte
+//            loads.  No atomics, no dependence on scheduling.
+#include <float.h>
+#include <math.h>
+#include "common.h"
+
+struct RoiGeom { int rsw, rsh, rew, reh; };
+
+// roi_pooling_op.cc:139-143: round() (half away from zero) of the f32 product
+__device__ __forceinline__ RoiGeom roi_geom(const float *roi, float scale)
+{
+    RoiGeom g;
+    g.rsw = (int)roundf(__fmul_rn(roi[1], scale));
+    g.rsh = (int)roundf(__fmul_rn(roi[2], scale));
+    g.rew = (int)roundf(__fmul_rn(roi[3], scale));
+    g.reh = (int)roundf(__fmul_rn(roi[4], scale));
+    return g;
+}
+
+template <int VEC>
+struct VecT;
+template <> struct VecT<4> { typedef float4 F; typedef int4 I; };
+template <> struct VecT<1> { typedef float F; typedef int I; };
+
+__device__ __forceinline__ void upd(float v, int idx, float &mv, int &mi)
+{
+    if (v > mv) { mv = v; mi = idx; }          // strict >: first maximum wins, NaN never wins
+}
+
+// items = R*PH*PW*(C/VEC), grid-stride
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restrict__ data, float scale, int B, int R,
+                                                           int H, int W, int C, int PH, int PW,
+                                                           const float *__restrict__ rois, float *__restrict__ top,
+                                                           int *__restrict__ argmax)
+{
+    const int CV = C / VEC;
+    const long long items = (long long)R * PH * PW * CV;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % CV);
+        long long t = it / CV;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int n = (int)(t / PH);
+        const float *roi = rois + 5 * n;
+        const int bi = (int)roi[0];
+        const RoiGeom g = roi_geom(roi, scale);
+        const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);   // :146-147
+        const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;        // :148-151
+        int hs = (int)floorf(__fmul_rn((float)ph, bh)), ws = (int)floorf(__fmul_rn((float)pw, bw));
+        int he = (int)ceilf(__fmul_rn((float)(ph + 1), bh)), we = (int)ceilf(__fmul_rn((float)(pw + 1), bw));
+        hs = min(max(hs + g.rsh, 0), H); he = min(max(he + g.rsh, 0), H);          // :159-162
+        ws = min(max(ws + g.rsw, 0), W); we = min(max(we + g.rsw, 0), W);
+        const bool bad_batch = (bi < 0 || bi >= B);
+        const bool empty = (he <= hs) || (we <= ws) || bad_batch;
+        const int c0 = cv * VEC;
+        float mv[VEC];
+        int mi[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { mv[v] = empty ? 0.0f : -FLT_MAX; mi[v] = -1; }
+        if (!empty) {
+            const float *d = data + (long long)bi * H * W * C;
+            for (int h = hs; h < he; ++h)
+                for (int w = ws; w < we; ++w) {
+                    const int idx = (h * W + w) * C + c0;
+                    if (VEC == 4) {
+                        const float4 x = *reinterpret_cast<const float4 *>(d + idx);
+                        upd(x.x, idx + 0, mv[0], mi[0]);
+                        upd(x.y, idx + 1, mv[1 % VEC], mi[1 % VEC]);
+                        upd(x.z, idx + 2, mv[2 % VEC], mi[2 % VEC]);
+                        upd(x.w, idx + 3, mv[3 % VEC], mi[3 % VEC]);
+                    } else {
+                        upd(d[idx], idx, mv[0], mi[0]);
+                    }
+                }
+        }
+        const long long o = (((long long)n * PH + ph) * PW + pw) * C + c0;
+        if (VEC == 4) {
+            *reinterpret_cast<float4 *>(top + o) = make_float4(mv[0], mv[1 % VEC], mv[2 % VEC], mv[3 % VEC]);
+            if (argmax) *reinterpret_cast<int4 *>(argmax + o) = make_int4(mi[0], mi[1 % VEC], mi[2 % VEC], mi[3 % VEC]);
+        } else {
+            top[o] = mv[0];
+            if (argmax) argmax[o] = mi[0];
+        }
+    }
+}
+
+#define BWD_LIST 1024
+
+// grid = B*H*W workgroups (one input pixel each); block = min(256, roundup64(C/VEC)) threads
+template <int VEC>
+__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restrict__ top_diff, float scale, int B, int R,
+                                                           int H, int W, int C, int PH, int PW,
+                                                           const float *__restrict__ rois, float *__restrict__ bottom_diff,
+                                                           const int *__restrict__ argmax)
+{
+    __shared__ int s_roi[BWD_LIST];
+    __shared__ RoiGeom s_geom[BWD_LIST];
+    __shared__ int s_cnt;
+    const int pix = blockIdx.x;
+    const int w = pix % W, h = (pix / W) % H, n = pix / (W * H);
+    const int CV = C / VEC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NACC = 4;                               // channel groups per thread (C <= 256*VEC*NACC)
+    float acc[NACC][VEC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
+
+    for (int base = 0; base < R; base += BWD_LIST) {
+        __syncthreads();                              // previous chunk's list fully consumed
+        if (wave == 0) {
+            int cnt = 0;
+            const int lim = min(R, base + BWD_LIST);
+            for (int r0 = base; r0 < lim; r0 += 64) {
+                const int r = r0 + lane;
+                bool in = false;
+                RoiGeom g = {0, 0, 0, 0};
+                if (r < lim) {
+                    const float *roi = rois + 5 * r;
+                    g = roi_geom(roi, scale);
+                    // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
+                    in = (n == (int)roi[0]) && (w >= g.rsw && w <= g.rew && h >= g.rsh && h <= g.reh);
+                }
+                const unsigned long long bal = __ballot(in);
+                if (in) {
+                    const int p = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                    s_roi[p] = r;
+                    s_geom[p] = g;
+                }
+                cnt += __popcll(bal);
+            }
+            if (lane == 0) s_cnt = cnt;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int q = 0; q < cnt; ++q) {               // ascending ROI order
+            const RoiGeom g = s_geom[q];
+            const int r = s_roi[q];
+            const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);
+            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+            // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
+            int phs = (int)floorf((float)(h - g.rsh) / bh), phe = (int)ceilf((float)(h - g.rsh + 1) / bh);
+            int pws = (int)floorf((float)(w - g.rsw) / bw), pwe = (int)ceilf((float)(w - g.rsw + 1) / bw);
+            phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+            pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
+            const long long off = (long long)r * PH * PW * C;
+            for (int ph = phs; ph < phe; ++ph)
+                for (int pw = pws; pw < pwe; ++pw) {
+                    const long long o = off + ((long long)ph * PW + pw) * C;
+#pragma unroll
+                    for (int k = 0; k < NACC; ++k) {
+                        const int cv = threadIdx.x + k * blockDim.x;
+                        if (cv < CV) {
+                            const int c0 = cv * VEC;
+                            const int want = (h * W + w) * C + c0;
+                            if (VEC == 4) {
+                                const int4 am = *reinterpret_cast<const int4 *>(argmax + o + c0);
+                                const float4 td = *reinterpret_cast<const float4 *>(top_diff + o + c0);
+                                if (am.x == want + 0) acc[k][0] += td.x;
+                                if (am.y == want + 1) acc[k][1 % VEC] += td.y;
+                                if (am.z == want + 2) acc[k][2 % VEC] += td.z;
+                                if (am.w == want + 3) acc[k][3 % VEC] += td.w;
+                            } else {
+                                if (argmax[o + c0] == want) acc[k][0] += top_diff[o + c0];
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    float *out = bottom_diff + (long long)pix * C;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        const int cv = threadIdx.x + k * blockDim.x;
+        if (cv < CV) {
+            if (VEC == 4)
+                *reinterpret_cast<float4 *>(out + cv * 4) = make_float4(acc[k][0], acc[k][1 % VEC], acc[k][2 % VEC], acc[k][3 % VEC]);
+            else
+                out[cv] = acc[k][0];
+        }
+    }
+}
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int mv3d_roi_pool_forward(const float *bottom_data, float spatial_scale, int batch_size, int num_rois,
+                                     int height, int width, int channels, int pooled_height, int pooled_width,
+                                     const float *bottom_rois, float *top_data, int32_t *argmax_data, void *stream)
+{
+    if (batch_size <= 0 || num_rois < 0 || height <= 0 || width <= 0 || channels <= 0 || pooled_height <= 0 ||
+        pooled_width <= 0 || !bottom_data || !top_data || (num_rois > 0 && !bottom_rois))
+        return MV3D_ERR_INVALID_ARG;
+    if ((long long)height * width * channels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;   // argmax is i32
+    if (num_rois == 0) return MV3D_OK;
+    const bool v4 = (channels % 4 == 0) && aligned16(bottom_data) && aligned16(top_data) &&
+                    (!argmax_data || aligned16(argmax_data));
+    const long long items = (long long)num_rois * pooled_height * pooled_width * (channels / (v4 ? 4 : 1));
+    long long blocks = (items + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;            // grid-stride the rest
+    hipStream_t s = (hipStream_t)stream;
+    if (v4)
+        hipLaunchKernelGGL(roi_pool_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, bottom_data, spatial_scale,
+                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                           top_data, argmax_data);
+    else
+        hipLaunchKernelGGL(roi_pool_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, bottom_data, spatial_scale,
+                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                           top_data, argmax_data);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale, int batch_size, int num_rois,
+                                      int height, int width, int channels, int pooled_height, int pooled_width,
+                                      const float *bottom_rois, float *bottom_diff, const int32_t *argmax_data,
+                                      void *stream)
+{
+    if (batch_size <= 0 || num_rois < 0 || height <= 0 || width <= 0 || channels <= 0 || pooled_height <= 0 ||
+        pooled_width <= 0 || !bottom_diff || (num_rois > 0 && (!bottom_rois || !top_diff || !argmax_data)))
+        return MV3D_ERR_INVALID_ARG;
+    if ((long long)height * width * channels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
+    const long long pixels = (long long)batch_size * height * width;
+    if (pixels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
+    const bool v4 = (channels % 4 == 0) && aligned16(top_diff) && aligned16(bottom_diff) && aligned16(argmax_data);
+    const int cv = channels / (v4 ? 4 : 1);
+    if (cv > 256 * 4) return MV3D_ERR_INVALID_ARG;       // C <= 4096 (vectorised) / 1024 (scalar)
+    int threads = (cv + 63) / 64 * 64;
+    if (threads > 256) threads = 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (v4)
+        hipLaunchKernelGGL(roi_pool_bwd_kernel<4>, dim3((unsigned)pixels), dim3(threads), 0, s, top_diff, spatial_scale,
+                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                           bottom_diff, argmax_data);
+    else
+        hipLaunchKernelGGL(roi_pool_bwd_kernel<1>, dim3((unsigned)pixels), dim3(threads), 0, s, top_diff, spatial_scale,
+                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
+                           bottom_diff, argmax_data);
+    return mv3d_launch_status();
+}

@@ -1,0 +1,98 @@
+"""Global configuration object `cfg` with the keys the hot path reads.
+
+Mirror of the interface of lib/fast_rcnn/config.py (own implementation): attribute/dict
+access, `cfg_from_file(yaml)`, `cfg_from_list([k, v, ...])` with the reference's type
+checks.  Defaults are the reference's (config.py:26-243); `experiments/cfgs/
+faster_rcnn_end2end.yml` values are available as `apply_end2end_yml()`.
+"""
+import ast
+
+import numpy as np
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _section(**kw):
+    return AttrDict(**kw)
+
+
+cfg = AttrDict()
+cfg.TRAIN = _section(
+    IMS_PER_BATCH=2, BATCH_SIZE=128, FG_FRACTION=0.25, FG_THRESH=0.5, BG_THRESH_HI=0.5, BG_THRESH_LO=0.1,
+    RPN_POSITIVE_OVERLAP=0.7, RPN_NEGATIVE_OVERLAP=0.5, RPN_CLOBBER_POSITIVES=False, RPN_FG_FRACTION=0.25,
+    RPN_BATCHSIZE=128, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
+    HAS_RPN=False, BBOX_NORMALIZE_TARGETS_PRECOMPUTED=False, PROPOSAL_METHOD='selective_search',
+    DISPLAY=10, SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='VGGnet_fast_rcnn', SNAPSHOT_INFIX='', DEBUG_TIMELINE=False)
+cfg.TEST = _section(
+    NMS=0.5, HAS_RPN=True, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
+    DEBUG_TIMELINE=False)
+cfg.PIXEL_MEANS = np.array([[[95.8814, 98.7743, 93.8549]]])
+cfg.RNG_SEED = 3
+cfg.EPS = 1e-14
+cfg.EXP_DIR = 'default'
+# The reference keys this on `nvcc` being on PATH (config.py:235-242).  Here the device path
+# is the only implementation, so it is always on; GPU_ID selects the HIP device.
+cfg.USE_GPU_NMS = True
+cfg.GPU_ID = 0
+
+
+def _merge(a, b, path=""):
+    for k, v in a.items():
+        if k not in b:
+            raise KeyError('{} is not a valid config key'.format(path + k))
+        old = b[k]
+        if isinstance(old, dict):
+            if not isinstance(v, dict):
+                raise ValueError('Type mismatch for config key: {}'.format(path + k))
+            _merge(v, old, path + k + ".")
+            continue
+        if isinstance(old, np.ndarray):
+            v = np.array(v, dtype=old.dtype)
+        elif type(old) is not type(v) and not (isinstance(old, float) and isinstance(v, int)):
+            raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(old), type(v), path + k))
+        b[k] = type(old)(v) if isinstance(old, float) else v
+
+
+def cfg_from_file(filename):
+    """Merge a YAML file into `cfg` (lib/fast_rcnn/config.py:291-297)."""
+    import yaml
+    with open(filename) as f:
+        _merge(yaml.safe_load(f) or {}, cfg)
+
+
+def cfg_from_list(cfg_list):
+    """`--set K V K V ...` overrides (lib/fast_rcnn/config.py:299-319)."""
+    assert len(cfg_list) % 2 == 0
+    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
+        keys = k.split('.')
+        d = cfg
+        for sub in keys[:-1]:
+            assert sub in d
+            d = d[sub]
+        assert keys[-1] in d
+        try:
+            value = ast.literal_eval(v)
+        except Exception:
+            value = v
+        assert type(value) == type(d[keys[-1]]), 'type {} does not match original type {}'.format(
+            type(value), type(d[keys[-1]]))
+        d[keys[-1]] = value
+
+
+def apply_end2end_yml():
+    """experiments/cfgs/faster_rcnn_end2end.yml:1-20 (what experiments/scripts/mv3d.sh uses)."""
+    _merge({"EXP_DIR": "faster_rcnn_end2end",
+            "TRAIN": {"HAS_RPN": True, "IMS_PER_BATCH": 1, "BBOX_NORMALIZE_TARGETS_PRECOMPUTED": True,
+                      "RPN_POSITIVE_OVERLAP": 0.7, "RPN_BATCHSIZE": 128, "PROPOSAL_METHOD": "gt",
+                      "BG_THRESH_LO": 0.0, "BG_THRESH_HI": 0.5, "FG_THRESH": 0.7,
+                      "RPN_PRE_NMS_TOP_N": 12000, "RPN_POST_NMS_TOP_N": 2000},
+            "TEST": {"RPN_PRE_NMS_TOP_N": 6000, "RPN_POST_NMS_TOP_N": 300, "HAS_RPN": True, "NMS": 0.1}}, cfg)

@@ -1,0 +1,170 @@
+"""Tensor-level calls into libmv3d_hip.so.
+
+torch CUDA(ROCm) tensors are used only as device buffers: every function passes
+`tensor.data_ptr()` and the current stream handle through the C-ABI and returns tensors
+holding the results.  Nothing here synchronises with the host unless it says so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AnchorTargetParams, ProposalParams, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(t, dtype=torch.float32, device=None):
+    """numpy / tensor -> contiguous device tensor of dtype (the placeholder cast of the graph)."""
+    if isinstance(t, torch.Tensor):
+        return t.to(device=device or (t.device if t.is_cuda else "cuda"), dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(t), dtype=dtype).to(device or "cuda")
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Reused per (device, stream, tag) so hot calls never allocate (buffers are 256-B aligned)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ proposal_layer_3d
+def proposal_params(cfg_section, feat_stride=8, img_height=375, img_width=1242, img_padding=50):
+    """cfg[cfg_key] section (lib/rpn_msr/proposal_layer_tf.py:52-55) -> mv3d_proposal_params"""
+    return ProposalParams(int(feat_stride), int(cfg_section["RPN_PRE_NMS_TOP_N"]),
+                          int(cfg_section["RPN_POST_NMS_TOP_N"]), int(img_height), int(img_width),
+                          int(img_padding), float(cfg_section["RPN_NMS_THRESH"]),
+                          float(cfg_section["RPN_MIN_SIZE"]))
+
+
+def proposal_3d(prob, pred, im_info, calib, params, out=None):
+    """prob (B,H,W,8), pred (B,H,W,24), im_info (B,3), calib (B,4,12) device f32 tensors.
+    Returns (blob_bv (B,cap,5), blob_img (B,cap,5), blob_3d (B,cap,7), num_out (B) i32,
+    status (B) i32); rows >= num_out[b] are zero.  Asynchronous."""
+    B, H, W, _ = prob.shape
+    dev = prob.device
+    cap = lib().mv3d_proposal_3d_capacity(H, W, C.byref(params))
+    if cap < 0:
+        check(_lib.ERR_INVALID_ARG, "mv3d_proposal_3d_capacity")
+    nbytes = lib().mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(params))
+    ws = _workspace(nbytes, dev, "proposal")
+    if out is None:
+        out = (torch.empty((B, cap, 5), dtype=torch.float32, device=dev),
+               torch.empty((B, cap, 5), dtype=torch.float32, device=dev),
+               torch.empty((B, cap, 7), dtype=torch.float32, device=dev),
+               torch.empty((B,), dtype=torch.int32, device=dev),
+               torch.empty((B,), dtype=torch.int32, device=dev))
+    bv, img, b3, num, status = out
+    rc = lib().mv3d_proposal_3d(_ptr(prob), _ptr(pred), B, H, W, _ptr(im_info), _ptr(calib), C.byref(params),
+                                _ptr(bv), _ptr(img), _ptr(b3), _ptr(num), _ptr(status), _ptr(ws), ws.numel(),
+                                _stream())
+    check(rc, "mv3d_proposal_3d")
+    return out
+
+
+# ------------------------------------------------------------------ NMS
+def nms_device(dets, thresh, max_keep=0):
+    """dets (n,5) device f32 in processing order -> (keep (n) i32, num_keep (1) i32, status (1) i32)."""
+    n = dets.shape[0]
+    dev = dets.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib().mv3d_nms_workspace_bytes(n), dev, "nms")
+    rc = lib().mv3d_nms_device(_ptr(dets), n, float(thresh), int(max_keep), _ptr(keep), _ptr(cnt[0:1]),
+                               _ptr(cnt[1:2]), _ptr(ws), ws.numel(), _stream())
+    check(rc, "mv3d_nms_device")
+    return keep, cnt[0:1], cnt[1:2]
+
+
+def nms_host(dets, thresh, device_id=0):
+    """numpy (n,5) f32, unsorted -> list of kept indices (cpu_nms semantics, computed on the GPU)."""
+    d = np.ascontiguousarray(dets, dtype=np.float32)
+    n = d.shape[0]
+    keep = np.zeros(max(n, 1), np.int32)
+    num = C.c_int32(0)
+    rc = lib().mv3d_nms_host(keep.ctypes.data_as(C.c_void_p), C.byref(num), d.ctypes.data_as(C.c_void_p), n,
+                             float(thresh), int(device_id))
+    check(rc, "mv3d_nms_host")
+    return [int(i) for i in keep[:num.value]]
+
+
+def nms_gpu_rule_host(sorted_dets, thresh, device_id=0):
+    """_nms of lib/nms/gpu_nms.hpp: host pointers, pre-sorted boxes, IoU > thresh in f32."""
+    d = np.ascontiguousarray(sorted_dets, dtype=np.float32)
+    n = d.shape[0]
+    keep = np.zeros(max(n, 1), np.int32)
+    num = C.c_int(0)
+    lib()._nms(keep.ctypes.data_as(C.c_void_p), C.byref(num), d.ctypes.data_as(C.c_void_p), n, d.shape[1],
+               C.c_float(thresh), int(device_id))
+    return keep[:num.value]
+
+
+# ------------------------------------------------------------------ RoiPool
+def roi_pool_forward(data, rois, pooled_height, pooled_width, spatial_scale, want_argmax=True):
+    B, H, W, Cc = data.shape
+    R = rois.shape[0]
+    top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.float32, device=data.device)
+    argmax = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device) if want_argmax else None
+    rc = lib().mv3d_roi_pool_forward(_ptr(data), C.c_float(spatial_scale), B, R, H, W, Cc, pooled_height,
+                                     pooled_width, _ptr(rois), _ptr(top), _ptr(argmax), _stream())
+    check(rc, "mv3d_roi_pool_forward")
+    return top, argmax
+
+
+def roi_pool_backward(top_diff, rois, argmax, data_shape, pooled_height, pooled_width, spatial_scale):
+    B, H, W, Cc = data_shape
+    R = rois.shape[0]
+    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=top_diff.device)
+    rc = lib().mv3d_roi_pool_backward(_ptr(top_diff), C.c_float(spatial_scale), B, R, H, W, Cc, pooled_height,
+                                      pooled_width, _ptr(rois), _ptr(out), _ptr(argmax), _stream())
+    check(rc, "mv3d_roi_pool_backward")
+    return out
+
+
+# ------------------------------------------------------------------ anchor_target_layer
+def anchor_target_stage1(H, W, im_info, gt_bv, gt_3d, params):
+    dev = gt_bv.device
+    N = H * W * 4
+    G = gt_bv.shape[0]
+    labels = torch.empty((N,), dtype=torch.float32, device=dev)
+    targets = torch.empty((N, 6), dtype=torch.float32, device=dev)
+    counts = torch.empty((8,), dtype=torch.int32, device=dev)
+    fg_hi = torch.empty((N,), dtype=torch.uint8, device=dev)
+    ws = _workspace(lib().mv3d_anchor_target_workspace_bytes(H, W, G), dev, "anchor_target")
+    rc = lib().mv3d_anchor_target_stage1(H, W, _ptr(im_info), _ptr(gt_bv), _ptr(gt_3d), G, C.byref(params),
+                                         _ptr(labels), _ptr(targets), _ptr(counts), _ptr(fg_hi), _ptr(ws),
+                                         ws.numel(), _stream())
+    check(rc, "mv3d_anchor_target_stage1")
+    return labels, targets, counts, fg_hi, ws
+
+
+def anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, anchors_cap):
+    dev = labels.device
+
+    def up(a):
+        return None if a is None or len(a) == 0 else torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(dev)
+
+    t_fg, t_b1, t_b2 = up(dis_fg), up(dis_bg1), up(dis_bg2)
+    anchors = torch.empty((anchors_cap, 5), dtype=torch.float32, device=dev)
+    anchors_3d = torch.empty((anchors_cap, 7), dtype=torch.float32, device=dev)
+    n_anchors = torch.empty((1,), dtype=torch.int32, device=dev)
+    rc = lib().mv3d_anchor_target_stage2(H, W, C.byref(params), _ptr(t_fg), 0 if t_fg is None else t_fg.numel(),
+                                         _ptr(t_b1), 0 if t_b1 is None else t_b1.numel(),
+                                         _ptr(t_b2), 0 if t_b2 is None else t_b2.numel(),
+                                         _ptr(labels), _ptr(anchors), _ptr(anchors_3d), _ptr(n_anchors),
+                                         anchors_cap, _ptr(ws), ws.numel(), _stream())
+    check(rc, "mv3d_anchor_target_stage2")
+    return anchors, anchors_3d, n_anchors

@@ -1,0 +1,45 @@
+"""`proposal_layer_3d`: the callable that lib/networks/network.py:221-234 wraps in
+tf.py_func, same name / arguments / return tuple as lib/rpn_msr/proposal_layer_tf.py:25.
+
+Inputs may be numpy arrays (the py_func contract: host arrays in, fresh host arrays out,
+one frame) or torch device tensors (no host round trip, any batch).  All arithmetic runs
+in libmv3d_hip.so (csrc/proposal.hip)."""
+import numpy as np
+import torch
+
+from .. import ops
+from ..fast_rcnn.config import cfg
+
+
+def proposal_layer_3d(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, calib, cfg_key, _feat_stride=[8, ],
+                      anchor_scales=[1.0, 1.0]):
+    """Returns (blob_bv (R,5), blob_img (R,5), blob_3d (R,7)), f32, R <= RPN_POST_NMS_TOP_N.
+    Column 0 is the frame index.  Raises like the reference on batch != 1 for numpy input."""
+    if isinstance(cfg_key, bytes):
+        cfg_key = cfg_key.decode()
+    as_numpy = not isinstance(rpn_cls_prob_reshape, torch.Tensor)
+    if as_numpy:
+        assert rpn_cls_prob_reshape.shape[0] == 1, 'Only single item batches are supported'
+    prob = ops._dev(rpn_cls_prob_reshape)
+    pred = ops._dev(rpn_bbox_pred, device=prob.device)
+    B = prob.shape[0]
+    info = ops._dev(im_info, device=prob.device).reshape(-1, 3)
+    cal = ops._dev(calib, device=prob.device).reshape(-1, 4, 12)
+    if info.shape[0] == 1 and B > 1:
+        info = info.expand(B, 3).contiguous()
+    if cal.shape[0] == 1 and B > 1:
+        cal = cal.expand(B, 4, 12).contiguous()
+    stride = int(np.asarray(_feat_stride).reshape(-1)[0])
+    params = ops.proposal_params(cfg[cfg_key], feat_stride=stride)
+    bv, img, b3, num, status = ops.proposal_3d(prob, pred, info, cal, params)
+    counts = num.cpu().numpy()                     # the only host sync: ROI counts
+    if int(status.max().item()) & 1:
+        raise ZeroDivisionError("float division")
+    if B == 1:
+        r = int(counts[0])
+        outs = (bv[0, :r], img[0, :r], b3[0, :r])
+    else:
+        outs = tuple(torch.cat([t[b, :int(counts[b])] for b in range(B)], 0) for t in (bv, img, b3))
+    if as_numpy:
+        return tuple(o.cpu().numpy() for o in outs)
+    return outs

@@ -1,0 +1,70 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/mv3d_hip.h declares; argument validation paths that never
+touch a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    from mv3d_tf_amd import build
+    build.build()
+    from mv3d_tf_amd import _lib
+    return _lib
+
+
+def test_header_symbols_are_exported(hiplib):
+    hdr = open(os.path.join(ROOT, "include", "mv3d_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mv3d_[a-z0-9_]+|_nms)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    handle = hiplib.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/mv3d_hip.h but not exported"
+    assert declared == set(hiplib.EXPORTS)
+
+
+def test_version_and_status_strings(hiplib):
+    L = hiplib.lib()
+    assert L.mv3d_version() >= 100
+    assert L.mv3d_status_string(0) == b"ok"
+    assert b"division" in L.mv3d_status_string(hiplib.ERR_ZERO_DIVISION)
+
+
+def test_workspace_queries_and_argument_validation(hiplib):
+    L = hiplib.lib()
+    p = hiplib.ProposalParams(8, 12000, 2000, 375, 1242, 50, 0.7, 5.0)
+    assert L.mv3d_proposal_3d_capacity(76, 76, C.byref(p)) == 2000
+    assert L.mv3d_proposal_3d_workspace_bytes(1, 76, 76, C.byref(p)) > 12000 * 188 * 8
+    p2 = hiplib.ProposalParams(8, 6000, 300, 375, 1242, 50, 0.7, 5.0)
+    assert L.mv3d_proposal_3d_capacity(76, 76, C.byref(p2)) == 300
+    assert L.mv3d_proposal_3d_capacity(4, 4, C.byref(p2)) == 64        # fewer anchors than top-N
+    assert L.mv3d_nms_workspace_bytes(6000) >= 6016 * 94 * 8
+    assert L.mv3d_nms_workspace_bytes(10 ** 6) == 0                      # above the bitmap limit
+    assert L.mv3d_anchor_target_workspace_bytes(76, 76, 8) > 0
+    # NULL pointers are refused before any HIP call
+    assert L.mv3d_proposal_3d(None, None, 1, 76, 76, None, None, C.byref(p), None, None, None, None, None, None, 0,
+                              None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_roi_pool_forward(None, 0.125, 1, 4, 8, 8, 16, 7, 7, None, None, None, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_nms_device(None, 10, 0.7, 0, None, None, None, None, 0, None) == hiplib.ERR_INVALID_ARG
+
+
+def test_missing_library_fails_loudly(hiplib, monkeypatch, tmp_path):
+    monkeypatch.setattr(hiplib, "_lib", None)
+    monkeypatch.setattr(hiplib, "LIB_PATH", str(tmp_path / "libmv3d_hip.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        hiplib.lib()
+
+
+def test_config_mirror():
+    from mv3d_tf_amd.fast_rcnn import config
+    c = config.cfg
+    assert c.TRAIN.RPN_PRE_NMS_TOP_N == 12000 and c.TEST.RPN_POST_NMS_TOP_N in (2000, 300)
+    assert c.TRAIN.RPN_MIN_SIZE == 5 and c.TRAIN.RPN_NMS_THRESH == 0.7 and c.RNG_SEED == 3
+    with pytest.raises(KeyError):
+        config._merge({"TRAIN": {"NOT_A_KEY": 1}}, c)

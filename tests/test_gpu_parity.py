@@ -1,0 +1,269 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C-ABI (ctypes), against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on the same
+seeded inputs.  Integer / index / byte results must be bit-exact; the f32 regressions are
+asked to be within 1e-4 by BASELINE.json and are in fact required to be equal here."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from mv3d_tf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ops(torch_cuda):
+    from mv3d_tf_amd import build
+    build.build()
+    from mv3d_tf_amd import ops as o
+    return o
+
+
+def dev(t, torch, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(t), dtype=dtype).cuda()
+
+
+# ------------------------------------------------------------------ NMS
+from test_oracle_golden import NMS_CASES, nms_case, PROPOSAL_CASES, proposal_case, AT_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", NMS_CASES)
+def test_nms_host_matches_reference(ops, name):
+    g, dets = nms_case(name)
+    assert ops.nms_host(dets, float(g["thresh"])) == g["keep"].tolist()
+
+
+@pytest.mark.parametrize("name", NMS_CASES)
+def test_nms_device_presorted_matches_reference(ops, torch_cuda, name):
+    g, dets = nms_case(name)
+    order = np.argsort(-dets[:, 4], kind="stable")
+    keep, num, status = ops.nms_device(dev(dets[order], torch_cuda), float(g["thresh"]))
+    n = int(num.item())
+    assert keep[:n].cpu().numpy().tolist() == g["keep_presorted"].tolist()
+    assert int(status.item()) == 0
+    # cap = the reference's keep[:max_keep]
+    for cap in (1, 7, 300):
+        keep, num, _ = ops.nms_device(dev(dets[order], torch_cuda), float(g["thresh"]), max_keep=cap)
+        m = int(num.item())
+        assert m == min(cap, len(g["keep_presorted"]))
+        assert keep[:m].cpu().numpy().tolist() == g["keep_presorted"][:cap].tolist()
+
+
+def test_nms_exact_iou_double_compare(ops):
+    g = golden("nms_exact_iou")
+    for i in range(4):
+        assert ops.nms_host(g[f"dets{i}"], float(g[f"thresh{i}"])) == g[f"keep{i}"].tolist()
+
+
+def test_nms_degenerate_and_empty(ops):
+    d = golden("nms_degenerate")
+    with pytest.raises(ZeroDivisionError):
+        ops.nms_host(d["dets"], float(d["thresh"]))
+    assert ops.nms_host(np.zeros((0, 5), np.float32), 0.7) == []
+    from mv3d_tf_amd.fast_rcnn.nms_wrapper import nms
+    assert nms(np.zeros((0, 5), np.float32), 0.7) == []
+
+
+@pytest.mark.parametrize("seed,n,thr", [(101, 777, 0.3), (102, 4097, 0.5), (103, 64, 0.7), (104, 129, 0.9)])
+def test_nms_fractional_boxes_and_ties_vs_oracle(ops, oracle, seed, n, thr):
+    """non-integer coordinates (every IoU needs the IEEE divide) and tied scores (tie rule:
+    descending index) against the oracle."""
+    dets = synth.nms_dets(seed, n, "clustered", integer=False)
+    m = len(dets[1::3])
+    dets[0:3 * m:3, 4] = dets[1::3, 4]                      # inject ties
+    assert ops.nms_host(dets, thr) == oracle.cpu_nms(dets, thr)
+
+
+def test_nms_wrapper_and_idempotence_full_size(ops):
+    """size-independent property at the largest pre-NMS size: NMS of the kept set keeps all."""
+    from mv3d_tf_amd.fast_rcnn.nms_wrapper import nms
+    dets = synth.nms_dets(7, 12000, "clustered")
+    keep = nms(dets, 0.7)
+    assert len(keep) == len(set(keep)) and all(0 <= k < 12000 for k in keep)
+    s = dets[keep, 4]
+    assert np.all(s[:-1] >= s[1:])                             # processing order = descending score
+    again = nms(np.ascontiguousarray(dets[keep]), 0.7)
+    assert again == list(range(len(keep)))
+
+
+def test_gpu_nms_cuda_rule(ops):
+    """_nms keeps the CUDA kernel's `>` rule: the exact-IoU pair at thresh 0.5 is NOT suppressed."""
+    from mv3d_tf_amd.nms.gpu_nms import gpu_nms
+    d = np.array([[0, 0, 9, 9, .9], [0, 0, 9, 4, .8]], np.float32)    # IoU exactly 0.5
+    assert gpu_nms(d, 0.5) == [0, 1]
+    assert ops.nms_host(d, 0.5) == [0]                                 # cpu rule: >=
+
+
+# ------------------------------------------------------------------ proposal_layer_3d
+@pytest.mark.parametrize("name", PROPOSAL_CASES)
+def test_proposal_layer_3d_matches_reference(ops, name):
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
+    g, inp, c = proposal_case(name)
+    key = str(g["cfg_key"])
+    saved = dict(cfg[key])
+    cfg[key].update(c[key])
+    try:
+        bv, img, b3 = proposal_layer_3d(*inp, key, [8, ], [1.0, 1.0])
+    finally:
+        cfg[key].update(saved)
+    assert bv.shape == g["blob_bv"].shape
+    assert np.array_equal(bv, g["blob_bv"])          # ROI order (NMS keep) + BEV boxes bit-exact
+    assert np.array_equal(img, g["blob_img"])        # image boxes bit-exact
+    assert np.array_equal(b3, g["blob_3d"])          # 3D regressions: asked 1e-4, equal
+
+
+def test_proposal_3d_batch_is_per_frame(ops, torch_cuda, oracle):
+    """frames are independent: batch of 3 == three single-frame oracle runs, ROI column 0 = frame."""
+    torch = torch_cuda
+    frames = [synth.rpn_head(s, 76, 76, v) for s, v in ((11, "rand"), (12, "peaky"), (13, "peaky"))]
+    prob = dev(np.concatenate([f[0] for f in frames]), torch)
+    pred = dev(np.concatenate([f[1] for f in frames]), torch)
+    info = dev(np.concatenate([f[2] for f in frames]), torch)
+    cal = dev(np.stack([f[3] for f in frames]), torch)
+    sec = dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)
+    bv, img, b3, num, status = ops.proposal_3d(prob, pred, info, cal, ops.proposal_params(sec))
+    num = num.cpu().numpy()
+    for b, f in enumerate(frames):
+        o_bv, o_img, o_3d = oracle.proposal_layer_3d(*f, "TEST", [8, ], cfg={"TEST": sec})
+        r = int(num[b])
+        assert r == o_bv.shape[0]
+        o_bv[:, 0] = b; o_img[:, 0] = b; o_3d[:, 0] = b
+        assert np.array_equal(bv[b, :r].cpu().numpy(), o_bv)
+        assert np.array_equal(img[b, :r].cpu().numpy(), o_img)
+        assert np.array_equal(b3[b, :r].cpu().numpy(), o_3d)
+        assert not bv[b, r:].any() and not b3[b, r:].any()          # unused rows zero-filled
+    assert int(status.max().item()) == 0
+
+
+@pytest.mark.parametrize("H,W,seed", [(1, 1, 1), (3, 5, 2), (16, 16, 3), (17, 33, 4)])
+def test_proposal_3d_small_and_ragged_grids_vs_oracle(ops, oracle, H, W, seed):
+    from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
+    prob, pred, _, calib = synth.rpn_head(seed, max(H, W), max(H, W), "rand")
+    prob, pred = np.ascontiguousarray(prob[:, :H, :W]), np.ascontiguousarray(pred[:, :H, :W])
+    info = np.array([[H * 8, W * 8, 1.0]], np.float32)
+    got = proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ])
+    want = oracle.proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ])
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_proposal_3d_all_filtered(ops, oracle):
+    """min_size larger than the map: every anchor filtered -> zero ROIs, like nms_wrapper's empty case."""
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
+    prob, pred, info, calib = synth.rpn_head(5, 20, 20, "rand")
+    saved = cfg.TRAIN.RPN_MIN_SIZE
+    cfg.TRAIN.RPN_MIN_SIZE = 5000
+    try:
+        bv, img, b3 = proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ])
+    finally:
+        cfg.TRAIN.RPN_MIN_SIZE = saved
+    assert bv.shape == (0, 5) and img.shape == (0, 5) and b3.shape == (0, 7)
+
+
+# ------------------------------------------------------------------ RoiPool / RoiPoolGrad
+def roi_cases(seed, R, H, W, B):
+    rng = np.random.RandomState(seed)
+    x1 = rng.uniform(-20, W * 8, R); y1 = rng.uniform(-20, H * 8, R)
+    w = rng.uniform(0, W * 5, R); h = rng.uniform(0, H * 5, R)
+    rois = np.stack([rng.randint(0, B, R), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    rois[0, 1:] = [0, 0, 0, 0]                       # 1x1 roi
+    rois[1, 1:] = [W * 8 + 50, H * 8 + 50, W * 8 + 90, H * 8 + 90]   # fully outside -> empty bins
+    rois[2, 1:] = [30, 30, 10, 10]                   # malformed (end < start) -> forced 1x1
+    rois[3, 1:] = [-100, -100, W * 8 + 100, H * 8 + 100]             # larger than the map
+    rois[4, 1:] = [11.5, 3.5, 51.5, 43.5]            # .5 * 0.125 -> rounding half away
+    return rois
+
+
+@pytest.mark.parametrize("B,H,W,C,R,seed", [(1, 12, 9, 16, 24, 1), (2, 10, 14, 64, 40, 2), (1, 76, 76, 512, 128, 3),
+                                            (1, 9, 7, 6, 16, 4), (3, 8, 8, 20, 70, 5)])
+def test_roi_pool_forward_backward_vs_oracle(ops, torch_cuda, oracle, B, H, W, C, R, seed):
+    torch = torch_cuda
+    data = synth.feature_map(seed, H, W, C, B)
+    data[0, 0, 0, :] = 1.5; data[0, 0, 1 % W, :] = 1.5              # ties: first maximum must win
+    rois = roi_cases(seed, R, H, W, B)
+    top, am = ops.roi_pool_forward(dev(data, torch), dev(rois, torch), 7, 7, 0.125)
+    o_top, o_am = oracle.roi_pool(data, rois, 7, 7, 0.125)
+    assert np.array_equal(top.cpu().numpy(), o_top)
+    assert np.array_equal(am.cpu().numpy(), o_am)
+    grad = np.random.RandomState(seed + 100).uniform(-1, 1, o_top.shape).astype(np.float32)
+    bd = ops.roi_pool_backward(dev(grad, torch), dev(rois, torch), am, data.shape, 7, 7, 0.125)
+    o_bd = oracle.roi_pool_grad(data, rois, o_am, grad, 7, 7, 0.125)
+    assert np.array_equal(bd.cpu().numpy(), o_bd)                    # same f32 summation order
+    # forward without argmax (the reference allows argmax_data == nullptr)
+    top2, none = ops.roi_pool_forward(dev(data, torch), dev(rois, torch), 7, 7, 0.125, want_argmax=False)
+    assert none is None and np.array_equal(top2.cpu().numpy(), o_top)
+
+
+def test_roi_pool_other_pool_sizes_and_scales(ops, torch_cuda, oracle):
+    torch = torch_cuda
+    data = synth.feature_map(9, 20, 30, 8, 1)
+    rois = roi_cases(9, 12, 20, 30, 1)
+    for (ph, pw, sc) in ((6, 6, 1.0 / 3), (1, 1, 0.125), (3, 5, 0.0625)):   # roi_pooling_op_test.py uses 6,6,1/3
+        top, am = ops.roi_pool_forward(dev(data, torch), dev(rois, torch), ph, pw, sc)
+        o_top, o_am = oracle.roi_pool(data, rois, ph, pw, np.float32(sc))
+        assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am)
+
+
+def test_roi_pool_autograd_function(ops, torch_cuda, oracle):
+    torch = torch_cuda
+    from mv3d_tf_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
+    data = synth.feature_map(21, 10, 12, 32, 2)
+    rois = roi_cases(21, 20, 10, 12, 2)
+    x = dev(data, torch).requires_grad_(True)
+    top, am = roi_pool(x, dev(rois, torch), 7, 7, 0.125)
+    w = dev(np.random.RandomState(5).uniform(-1, 1, tuple(top.shape)).astype(np.float32), torch)
+    (top * w).sum().backward()
+    o_top, o_am = oracle.roi_pool(data, rois, 7, 7, 0.125)
+    assert np.array_equal(x.grad.cpu().numpy(), oracle.roi_pool_grad(data, rois, o_am, w.cpu().numpy(), 7, 7, 0.125))
+    # numpy-in / numpy-out face
+    t2, a2 = roi_pool(data, rois, 7, 7, 0.125)
+    assert np.array_equal(t2, o_top) and np.array_equal(a2, o_am)
+    g2 = roi_pool_grad(data, rois, a2, w.cpu().numpy(), 7, 7, 0.125)
+    assert np.array_equal(g2, x.grad.cpu().numpy())
+    # conservation: every non-empty bin's gradient lands somewhere
+    assert np.isclose(g2.sum(), (w.cpu().numpy() * (o_am >= 0)).sum(), rtol=1e-4)
+    with pytest.raises(ValueError):
+        roi_pool(data[0], rois, 7, 7, 0.125)
+
+
+# ------------------------------------------------------------------ anchor_target_layer
+@pytest.mark.parametrize("name", AT_CASES)
+def test_anchor_target_layer_matches_reference(ops, name):
+    from mv3d_tf_amd.rpn_msr.anchor_target_layer_tf import anchor_target_layer
+    g = golden(name)
+    H = int(g["H"])
+    np.random.seed(int(g["np_seed"]))
+    lab, tg, anc, anc3 = anchor_target_layer(np.zeros((1, H, H, 8), np.float32), g["gt_bv"], g["gt_3d"], g["im_info"],
+                                             [8, ], [1.0, 1.0])
+    assert np.array_equal(lab.astype(np.int8), g["labels"])                 # bit-exact anchor indices
+    assert np.array_equal(tg[g["target_rows"]], g["targets"])
+    assert np.array_equal(np.where(np.any(tg != 0, 1))[0], g["targets_nonzero_rows"])
+    assert np.array_equal(anc, g["anchors"])
+    assert np.array_equal(anc3, g["anchors_3d"])
+
+
+def test_anchor_target_rng_stream_position(ops, oracle):
+    """draw-for-draw: after the call the global numpy RNG is where the oracle leaves it."""
+    from mv3d_tf_amd.rpn_msr.anchor_target_layer_tf import anchor_target_layer
+    r = np.random.RandomState(77)
+    gtbv, gt3d, _ = synth.gt_cars(r, 5)
+    info = np.array([[608, 608, 1]], np.float32)
+    score = np.zeros((1, 76, 76, 8), np.float32)
+    np.random.seed(9)
+    a = anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+    after_dev = np.random.randint(1 << 30)
+    np.random.seed(9)
+    b = oracle.anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+    after_ora = np.random.randint(1 << 30)
+    assert after_dev == after_ora
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
