@@ -229,8 +229,14 @@ def test_roi_pool_autograd_function(ops, torch_cuda, oracle):
     assert np.array_equal(t2, o_top) and np.array_equal(a2, o_am)
     g2 = roi_pool_grad(data, rois, a2, w.cpu().numpy(), 7, 7, 0.125)
     assert np.array_equal(g2, x.grad.cpu().numpy())
-    # conservation: every non-empty bin's gradient lands somewhere
-    assert np.isclose(g2.sum(), (w.cpu().numpy() * (o_am >= 0)).sum(), rtol=1e-4)
+    # conservation on well-formed in-map ROIs: every non-empty bin's gradient lands somewhere
+    # (malformed / out-of-map ROIs lose gradient in the reference too: its containment test
+    # uses the unclamped rounded ROI, roi_pooling_op.cc:401-402)
+    good = np.array([[0, 8, 8, 60, 50], [1, 0, 0, 95, 79], [0, 16, 24, 16, 24]], np.float32)
+    gt_, ga_ = roi_pool(data, good, 7, 7, 0.125)
+    gw = np.random.RandomState(6).uniform(0.5, 1, gt_.shape).astype(np.float32)
+    gg = roi_pool_grad(data, good, ga_, gw, 7, 7, 0.125)
+    assert (ga_ >= 0).all() and np.isclose(gg.sum(dtype=np.float64), gw.sum(dtype=np.float64), rtol=1e-5)
     with pytest.raises(ValueError):
         roi_pool(data[0], rois, 7, 7, 0.125)
 
