@@ -54,6 +54,14 @@ int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep,
                     int32_t *keep_dev, int32_t *num_keep_dev, int32_t *status_dev,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Diagnostics: mv3d_nms_device plus a per-64-box-block trace of the greedy chain,
+ * trace_dev[4*b + 0..3] = {cycle at block start, cycle after waiting for the bulk workers,
+ * cycle after the diagonal fixed point, (iterations << 32) | kept-in-block}.  Used by
+ * tools/ and profiles/ only. */
+int mv3d_nms_device_trace(const float *dets_dev, int n, double thresh, int max_keep,
+                          int32_t *keep_dev, int32_t *num_keep_dev, int32_t *status_dev,
+                          void *workspace, size_t workspace_bytes, void *stream, int64_t *trace_dev);
+
 /* Host entry with cpu_nms(dets, thresh) semantics: host pointers, dets unsorted;
  * sorts on the device (descending score, ties by descending index -- the reference
  * leaves ties to numpy's unstable argsort), runs the NMS, returns indices into dets in

@@ -36,6 +36,7 @@ _SIGS = {
     "mv3d_status_string": (C.c_char_p, [C.c_int]),
     "mv3d_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mv3d_nms_device": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_nms_device_trace": (C.c_int, [_P, C.c_int, C.c_double, C.c_int, _P, _P, _P, _P, C.c_size_t, _P, _P]),
     "mv3d_nms_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_int]),
     "_nms": (None, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "mv3d_proposal_3d_capacity": (C.c_int, [C.c_int, C.c_int, C.POINTER(ProposalParams)]),

@@ -2,6 +2,19 @@
 #pragma once
 #include "common.h"
 
+// ---- ROI blob emission fused into the tail of the NMS reduce kernel -----------------
+// Row r < num_keep of frame f takes candidate n = order[keep[r]]; rows up to cap are zeroed.
+struct EmitDev {
+    int enabled;
+    int N, order_cap, cap;
+    const float4 *bv;           // (batch, N) clipped BEV boxes
+    const int4 *img;            // (batch, N) image boxes
+    const float *p3;            // (batch, N, 6) decoded 3D boxes
+    const int32_t *order;       // (batch, order_cap)
+    float *blob_bv, *blob_img, *blob_3d;   // (batch, cap, 5|5|7)
+    int32_t *num_out;           // (batch)
+};
+
 // ---- greedy NMS over boxes already in processing order (nms.hip) -------------------
 // Box p of frame f lives at boxes + f*boxes_frame_stride + q*box_stride (4 floats
 // x1,y1,x2,y2) with q = idx ? idx[f*idx_frame_stride + p] : p.
@@ -22,13 +35,21 @@ struct NmsLaunch {
     int32_t *num_keep;          // (batch)
     int32_t *status;            // (batch) flag bits, may be NULL; must be zeroed by the caller
     void *workspace;            // mv3d_nms_ws_bytes(n_cap, batch)
+    EmitDev emit;               // optional fused ROI-blob emission (proposal_layer_tf.py:188-191)
+    long long *trace;           // diagnostics (mv3d_nms_device_trace), may be NULL
 };
 size_t mv3d_nms_ws_bytes(int n_cap, int batch);
 int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream);
 
 // ---- rank by counting (rank.hip) -----------------------------------------------------
-// keys (batch, N) u32, 0 = not a candidate.  order[f*cap + r] = i for the candidate i of
+// keys (batch, key_stride) u32, 0 = not a candidate; key_stride = mv3d_rank_key_stride(N) and the
+// tail keys[N..key_stride) of every frame must be 0.  order[f*cap + r] = i for the candidate i of
 // frame f whose rank r (number of candidates that precede it: larger key, ties by larger
 // index) is < cap.  Entries r >= number of candidates are left untouched.
-int mv3d_launch_rank(const uint32_t *keys, int N, int batch, int32_t *order, int cap,
+// part_counts (batch, n_parts): per-producer-workgroup candidate counts; their per-frame
+// sum is written to n_valid (batch).  Both may be NULL.  workspace: mv3d_rank_ws_bytes().
+size_t mv3d_rank_ws_bytes(int N, int batch);
+int mv3d_rank_key_stride(int N);
+int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int32_t *order, int cap,
+                     const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace,
                      hipStream_t stream);

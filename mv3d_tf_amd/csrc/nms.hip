@@ -3,33 +3,50 @@
 // Replaces lib/nms/cpu_nms.pyx:17-68 (== lib/utils/nms.pyx:17-68) and the CUDA path
 // lib/nms/nms_kernel.cu:34-144.  Two kernels:
 //
-//  nms_mask_kernel    all CUs.  One wavefront <-> one 64x64 tile of the upper triangle of
-//                     the suppression matrix: lane = row box (registers), 64 column boxes
-//                     staged in LDS and read as broadcasts; one u64 mask word per lane.
-//                     For diagonal tiles the wave ballot of each column's predicate is the
-//                     TRANSPOSED word (who suppresses column j), which is what the greedy
-//                     pass wants, so only that form is stored for them.
-//  nms_reduce_kernel  one workgroup per frame: the greedy dependency chain.  `removed`
-//                     bitmap in LDS; per 64-box block wave 0 resolves the diagonal tile by
-//                     fixed-point iteration on ballots (converges in chain-depth steps to
-//                     the unique greedy solution), then all 16 waves OR the rows of the
-//                     kept boxes into `removed` (only kept rows are ever read).  Stops as
-//                     soon as max_keep boxes are kept (= the reference's keep[:post_nms_topN]).
+//  nms_mask_kernel    all CUs, one single-wave workgroup per 64x64 tile of the UPPER TRIANGLE of
+//                     the suppression matrix (tiles enumerated column-block-major so the launch is
+//                     balanced and the tiles past the live box count fall off the end): lane = row
+//                     box (registers), the 64 column boxes staged in LDS and read back as
+//                     broadcasts.  Tiles within NMS_BAND blocks of the diagonal are stored in COLUMN
+//                     form (lane j gets the ballot of column j's predicate = "which rows of the
+//                     row block suppress box j"); far tiles in ROW form (one u64 per row).
+//  nms_reduce_kernel  one workgroup per frame = the greedy dependency chain, software-pipelined by
+//                     wave specialisation:
+//                       wave 0 (chain)   per 64-box block: removed bits -> fixed-point iteration on
+//                                        ballots over the diagonal tile (converges to the unique
+//                                        greedy set) -> kept mask K_b; then the near-band column
+//                                        tiles turn K_b into removed bits of the next NMS_BAND-1
+//                                        blocks with one AND + one wave compare each.  All its
+//                                        global addresses are static, so its loads run 4 blocks
+//                                        ahead: the per-block critical path is ALU only.
+//                       waves 1-15       trail the chain: OR the ROW-form words of kept rows into
+//                                        the LDS bitmap for blocks >= NMS_BAND ahead (only kept rows
+//                                        are ever read).  LDS flags (chain position / per-worker
+//                                        progress) order the two roles; no global synchronisation.
+//                     Stops as soon as max_keep boxes are kept (= the reference's
+//                     keep[:post_nms_topN]) and, for proposal_layer_3d, gathers the ROI blobs.
 //
 // Arithmetic is the reference's, operation for operation (see pair_suppresses()).
 #include <math.h>
 #include "kernels.h"
 
 #define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
+#define NMS_BAND 8          // diagonal + 7 following column blocks are kept in column form
+#define NMS_WORKERS 15
+#define NMS_GROUPS 3            // worker groups; group g owns the blocks b = g (mod NMS_GROUPS)
+#define NMS_GW 5                // workers per group
+#define NMS_ROWS_PER_WORKER 13  // ceil(64 / NMS_GW)
+#define NMS_PF 4            // chain-wave prefetch depth (blocks)
 
 // lib/nms/cpu_nms.pyx:55-65 for one (kept box i, later box j) pair.  f32, separate IEEE
 // ops.  Cython emits ((xx2 - xx1) + 1.0) with a double literal and narrows to f32; for
 // f32 operands that equals the f32 add (the f64 sum is exact or rounds identically), so
 // the f32 form below is bit-identical.  `tf` is ceil_f32(thresh): (double)ovr >= thresh
-// <=> ovr >= tf.
+// <=> ovr >= tf.  The CUDA rule `ovr > thresh` (nms_kernel.cu:71) is served by the same
+// compare with tf = nextafter(thresh, +inf).
 __device__ __forceinline__ bool pair_suppresses(float ix1, float iy1, float ix2, float iy2, float iarea,
                                                 float jx1, float jy1, float jx2, float jy2, float jarea,
-                                                float tf, int strict_gt, bool &zero_den)
+                                                float tf, bool &zero_den)
 {
     const float xx1 = cy_max(ix1, jx1);
     const float yy1 = cy_max(iy1, jy1);
@@ -41,7 +58,7 @@ __device__ __forceinline__ bool pair_suppresses(float ix1, float iy1, float ix2,
     const float den = (iarea + jarea) - inter;
     zero_den = (den == 0.0f);
     const float ovr = inter / den;
-    return strict_gt ? (ovr > tf) : (ovr >= tf);
+    return ovr >= tf;
 }
 
 struct NmsDev {
@@ -52,16 +69,18 @@ struct NmsDev {
     long long idx_frame_stride;
     const int32_t *n_dev;
     int n_cap;
-    int nbw;                 // mask words per row = ceil(n_cap/64)
+    int nbw;                     // blocks of 64 boxes per frame (capacity)
+    int nbs;                     // row-form words per row = nbw rounded up to even (16-byte rows)
     float tf;
-    int strict_gt;
     int max_keep;
-    unsigned long long *mask;    // (batch, nbw*64, nbw)
-    unsigned long long *diagT;   // (batch, nbw*64)
+    unsigned long long *mask;    // (batch, nbw*64, nbw)        row form, far tiles
+    unsigned long long *band;    // (batch, nbw, NMS_BAND, 64)  column form, near tiles
     int32_t *keep;
     long long keep_frame_stride;
     int32_t *num_keep;
     int32_t *status;
+    EmitDev emit;
+    long long *trace;            // diagnostics: 4 x i64 per block (frame 0 only), may be NULL
 };
 
 __device__ __forceinline__ int frame_n(const NmsDev &d, int f)
@@ -78,127 +97,295 @@ __device__ __forceinline__ float4 load_box(const NmsDev &d, int f, int p)
     return make_float4(b[0], b[1], b[2], b[3]);
 }
 
-// grid: (nbw, ceil(nbw/4), batch); block 256 = 4 waves; wave w owns row block 4*blockIdx.y+w.
-__global__ __launch_bounds__(256) void nms_mask_kernel(NmsDev d)
+// Single-instruction max / min for the NaN-free fast path (fmaxf/fminf would add input
+// canonicalisation: two extra v_max per call under IEEE mode).
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// "tame": finite and small enough that no intermediate of pair_suppresses() can overflow or be
+// NaN.  For tame boxes cy_max/cy_min (a>=b?a:b) and v_max/v_min agree except for the sign of a
+// zero, which cannot change any later result (it only feeds x - y + 1 and w * h).
+__device__ __forceinline__ bool tame(float4 b)
+{
+    const float L = 0x1p60f;
+    return fabsf(b.x) < L && fabsf(b.y) < L && fabsf(b.z) < L && fabsf(b.w) < L;
+}
+
+// One 64x64 tile, every column valid, all boxes tame: straight-line, constant shifts.
+// COLFORM: the result is the column word of lane's own column (ballot over the rows);
+// otherwise the row word.  DIAG: rows only count against later columns of the same block.
+template <bool COLFORM, bool DIAG>
+__device__ __forceinline__ unsigned long long tile_fast(const float4 rbx, const float rarea, const float4 *s_box,
+                                                        const float *s_area, const float tf, const int lane,
+                                                        float &min_den)
+{
+    unsigned lo = 0, hi = 0;
+    unsigned long long mycol = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float4 c = s_box[j];
+        const float xx1 = vmax(rbx.x, c.x), yy1 = vmax(rbx.y, c.y);
+        const float xx2 = vmin(rbx.z, c.z), yy2 = vmin(rbx.w, c.w);
+        const float w = vmax(0.0f, (xx2 - xx1) + 1.0f);
+        const float h = vmax(0.0f, (yy2 - yy1) + 1.0f);
+        const float inter = w * h;
+        const float den = (rarea + s_area[j]) - inter;
+        min_den = vmin(min_den, fabsf(den));
+        const float ovr = inter / den;
+        bool p = (ovr >= tf);
+        if (DIAG) p = p && (lane < j);
+        if (COLFORM) {
+            const unsigned long long bal = __ballot(p);   // rows that suppress column j
+            if (lane == j) mycol = bal;
+        } else {
+            if (j < 32) lo |= p ? (1u << j) : 0u;
+            else hi |= p ? (1u << (j - 32)) : 0u;
+        }
+    }
+    return COLFORM ? mycol : (((unsigned long long)hi << 32) | lo);
+}
+
+// grid: (nbw*(nbw+1)/2 tiles, 1, batch); block 64 = one wave per tile.
+__global__ __launch_bounds__(64) void nms_mask_kernel(NmsDev d)
 {
     __shared__ float4 s_box[64];
     __shared__ float s_area[64];
     const int f = blockIdx.z;
     const int n = frame_n(d, f);
-    const int cb = blockIdx.x;
-    if (cb * 64 >= n) return;                       // whole block: nothing in this column block
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.y * 4 + wave;
-    if (threadIdx.x < 64) {
-        const int c = cb * 64 + threadIdx.x;
-        float4 b = make_float4(NAN, NAN, NAN, NAN); // NaN box: every predicate false
-        if (c < n) b = load_box(d, f, c);
-        s_box[threadIdx.x] = b;
-        s_area[threadIdx.x] = ((b.z - b.x) + 1.0f) * ((b.w - b.y) + 1.0f);   // cpu_nms.pyx:24
-    }
+    // tile t -> (cb, rb <= cb), column-block-major: t = cb(cb+1)/2 + rb
+    const int t = blockIdx.x;
+    int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+    while (cb * (cb + 1) / 2 > t) --cb;
+    const int rb = t - cb * (cb + 1) / 2;
+    if (cb * 64 >= n) return;
+    const int lane = threadIdx.x;
+    const int c = cb * 64 + lane;
+    float4 cbx = make_float4(NAN, NAN, NAN, NAN);   // NaN box: every predicate false
+    if (c < n) cbx = load_box(d, f, c);
+    s_box[lane] = cbx;
+    s_area[lane] = ((cbx.z - cbx.x) + 1.0f) * ((cbx.w - cbx.y) + 1.0f);      // cpu_nms.pyx:24
+    const bool cols_tame = __all(tame(cbx));        // false if the tile is ragged (NaN padding)
     __syncthreads();
-    if (rb > cb) return;                            // lower triangle
     const int r = rb * 64 + lane;
-    float4 rbx = make_float4(NAN, NAN, NAN, NAN);
+    float4 rbx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (r < n) rbx = load_box(d, f, r);
     const float rarea = ((rbx.z - rbx.x) + 1.0f) * ((rbx.w - rbx.y) + 1.0f);
-    const bool diag = (rb == cb);
-    unsigned long long bits = 0, mycol = 0;
+    const int dist = cb - rb;
+    const bool diag = (dist == 0), colform = (dist < NMS_BAND);
+    unsigned long long word = 0;
     bool any_zero = false;
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) {
-        const float4 cbx = s_box[j];
-        bool zd;
-        bool p = pair_suppresses(rbx.x, rbx.y, rbx.z, rbx.w, rarea, cbx.x, cbx.y, cbx.z, cbx.w, s_area[j],
-                                 d.tf, d.strict_gt, zd);
-        const bool live = diag ? (lane < j) : true;   // within a tile only earlier rows count
-        p = p && live;
-        any_zero |= (zd && live && r < n && (cb * 64 + j) < n);
-        bits |= (unsigned long long)p << j;
-        if (diag) {
-            const unsigned long long bal = __ballot(p);   // rows that suppress column j
+    if (cols_tame && __all(tame(rbx))) {
+        float min_den = 1.0f;
+        if (diag) word = tile_fast<true, true>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
+        else if (colform) word = tile_fast<true, false>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
+        else word = tile_fast<false, false>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
+        any_zero = (min_den == 0.0f) && (r < n);
+    } else {
+        // generic path: ragged last tile, or NaN / huge coordinates (exact cy_max / cy_min semantics)
+        if (r >= n) rbx = make_float4(NAN, NAN, NAN, NAN);
+        const float ra = ((rbx.z - rbx.x) + 1.0f) * ((rbx.w - rbx.y) + 1.0f);
+        unsigned long long bits = 0, mycol = 0;
+        for (int j = 0; j < 64; ++j) {
+            const float4 q = s_box[j];
+            bool zd;
+            bool p = pair_suppresses(rbx.x, rbx.y, rbx.z, rbx.w, ra, q.x, q.y, q.z, q.w, s_area[j], d.tf, zd);
+            const bool live = diag ? (lane < j) : true;
+            p = p && live;
+            any_zero |= (zd && live && r < n && (cb * 64 + j) < n);
+            bits |= (unsigned long long)p << j;
+            const unsigned long long bal = __ballot(p);
             if (lane == j) mycol = bal;
         }
+        word = colform ? mycol : bits;
     }
-    unsigned long long *mask = d.mask + (long long)f * d.nbw * 64 * d.nbw;
-    if (diag) d.diagT[(long long)f * d.nbw * 64 + cb * 64 + lane] = mycol;
-    else if (r < n) mask[(long long)r * d.nbw + cb] = bits;
+    if (colform) d.band[(((long long)f * d.nbw + rb) * NMS_BAND + dist) * 64 + lane] = word;
+    else if (r < n) d.mask[((long long)f * d.nbw * 64 + r) * d.nbs + cb] = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
 }
 
-// grid: (batch); block 1024 = 16 waves.
+// LDS flags between the waves of one workgroup.  The fences are restricted to the LDS address
+// space ("local"): a plain workgroup release/acquire would also drain vmcnt and serialise the
+// chain wave behind its own global prefetches.
+__device__ __forceinline__ int lds_load_i32(const int *p)
+{
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return v;
+}
+__device__ __forceinline__ void lds_store_i32(int *p, int v)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// grid: (batch); block 1024 = 16 waves: wave 0 = chain, waves 1..15 = bulk workers.
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(NmsDev d)
 {
-    __shared__ unsigned long long s_removed[NMS_MAX_WORDS];
-    __shared__ unsigned long long s_kept;
+    __shared__ unsigned long long s_removed[NMS_MAX_WORDS];   // far-band contributions (workers, ds_or)
+    __shared__ unsigned long long s_kept[NMS_MAX_WORDS];      // K_b, valid once s_chain_pos > b
+    __shared__ int s_chain_pos, s_done, s_total;
+    __shared__ int s_wprog[NMS_WORKERS + 1];
     const int f = blockIdx.x;
     const int n = frame_n(d, f);
     const int nb = (n + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long *mask = d.mask + (long long)f * d.nbw * 64 * d.nbw;
-    const unsigned long long *diagT = d.diagT + (long long)f * d.nbw * 64;
+    const unsigned long long *mask = d.mask + (long long)f * d.nbw * 64 * d.nbs;
+    const unsigned long long *band = d.band + (long long)f * d.nbw * NMS_BAND * 64;
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
     for (int w = threadIdx.x; w < NMS_MAX_WORDS; w += blockDim.x) s_removed[w] = 0;
+    if (threadIdx.x < NMS_WORKERS + 1) s_wprog[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_chain_pos = 0; s_done = 0; s_total = 0; }
     __syncthreads();
-    int total = 0;
-    for (int b = 0; b < nb; ++b) {
-        if (wave == 0) {
-            const int p = b * 64 + lane;
-            const bool alive = (p < n) && !((s_removed[b] >> lane) & 1ull);
-            const unsigned long long col = diagT[p];        // earlier rows of this block that suppress me
-            unsigned long long K = __ballot(alive);
-            // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
-            // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
-            for (;;) {
-                const unsigned long long K2 = __ballot(alive && !(col & K));
-                if (K2 == K) break;
-                K = K2;
-            }
-            const bool kept = (K >> lane) & 1ull;
-            const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
-            if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
-            if (lane == 0) s_kept = K;
-        }
-        __syncthreads();
-        const unsigned long long K = s_kept;
-        total += __popcll(K);
-        if (d.max_keep > 0 && total >= d.max_keep) break;
-        if (b + 1 < nb && K) {
-            // OR the rows of kept boxes into removed[b+1 .. nb): lane <-> word, wave <-> every 16th kept row
-            unsigned long long acc[NMS_MAX_WORDS / 64] = {0, 0, 0, 0};
-            unsigned long long Kw = K;
-            int ord = 0;
-            while (Kw) {
-                const int i = __builtin_ctzll(Kw);
-                Kw &= Kw - 1;
-                if ((ord++ & 15) != wave) continue;
-                const unsigned long long *row = mask + (long long)(b * 64 + i) * d.nbw;
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ chain wave
+        __builtin_amdgcn_s_setprio(3);
+        unsigned long long ring[NMS_PF][NMS_BAND];
 #pragma unroll
-                for (int ps = 0; ps < NMS_MAX_WORDS / 64; ++ps) {
-                    const int w = b + 1 + ps * 64 + lane;
-                    if (w < nb) acc[ps] |= row[w];
+        for (int s = 0; s < NMS_PF; ++s)
+#pragma unroll
+            for (int k = 0; k < NMS_BAND; ++k)
+                ring[s][k] = band[((long long)min(s, d.nbw - 1) * NMS_BAND + k) * 64 + lane];
+        unsigned long long acc[NMS_BAND];             // acc[k]: near-band removed bits for block b+k
+#pragma unroll
+        for (int k = 0; k < NMS_BAND; ++k) acc[k] = 0ull;
+        int total = 0;
+        bool stop = false;
+        for (int b0 = 0; b0 < nb && !stop; b0 += NMS_PF) {
+#pragma unroll
+            for (int s = 0; s < NMS_PF; ++s) {
+                const int b = b0 + s;
+                if (b >= nb || stop) break;
+                const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+                // far-band words for this block come from rows of blocks <= b - NMS_BAND
+                if (b >= NMS_BAND) {
+                    const int need = b - NMS_BAND + 1;
+                    for (;;) {
+                        const int pr = (lane < NMS_WORKERS) ? lds_load_i32(&s_wprog[lane]) : need;
+                        if (__all(pr >= need)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const long long t_wait = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+                int iters = 0;
+                const unsigned long long rem = s_removed[b] | acc[0];
+                const int p = b * 64 + lane;
+                const bool alive = (p < n) && !((rem >> lane) & 1ull);
+                const unsigned long long col = ring[s][0];
+                unsigned long long K = __ballot(alive);
+                // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
+                // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
+                for (;;) {
+                    const unsigned long long K2 = __ballot(alive && !(col & K));
+                    ++iters;
+                    if (K2 == K) break;
+                    K = K2;
+                }
+                if (d.trace && f == 0 && lane == 0) {
+                    long long *tr = d.trace + 4 * b;
+                    tr[0] = t_begin; tr[1] = t_wait; tr[2] = (long long)__builtin_readcyclecounter();
+                    tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
+                }
+                const bool kept = (K >> lane) & 1ull;
+                const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
+                if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
+                total += __popcll(K);
+                if (lane == 0) s_kept[b] = K;
+                lds_store_i32(&s_chain_pos, b + 1);
+                if (d.max_keep > 0 && total >= d.max_keep) { stop = true; break; }
+                // near band: K_b -> removed bits of blocks b+1 .. b+NMS_BAND-1
+#pragma unroll
+                for (int k = 1; k < NMS_BAND; ++k) acc[k] |= __ballot((ring[s][k] & K) != 0ull);
+#pragma unroll
+                for (int k = 0; k < NMS_BAND - 1; ++k) acc[k] = acc[k + 1];
+                acc[NMS_BAND - 1] = 0ull;
+                // refill this ring slot for block b + NMS_PF (static addresses: runs ahead of the chain)
+                const int bn = b + NMS_PF;
+                if (bn < nb) {
+#pragma unroll
+                    for (int k = 0; k < NMS_BAND; ++k) ring[s][k] = band[((long long)bn * NMS_BAND + k) * 64 + lane];
                 }
             }
+        }
+        if (lane == 0) s_total = total;
+        lds_store_i32(&s_done, 1);
+    } else {
+        // ------------------------------------------------------------------ bulk workers
+        // Group g trails the chain on the blocks b = g (mod NMS_GROUPS); its NMS_GW waves split the
+        // 64 rows.  All loads of a (block, pass) are in flight together: 16 bytes = 2 words per lane,
+        // 128 words per pass.  s_wprog[me] = first block this wave has NOT finished its share of
+        // (blocks of other groups count as finished).
+        const int me = wave - 1, g = me / NMS_GW, lw = me % NMS_GW;
+        lds_store_i32(&s_wprog[me], g);
+        int b = g;
+        for (; b + NMS_BAND < nb; b += NMS_GROUPS) {
+            bool quit = false;
+            for (;;) {
+                if (lds_load_i32(&s_chain_pos) > b) break;
+                if (lds_load_i32(&s_done)) { quit = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (quit) break;
+            const unsigned long long K = s_kept[b];
+            const int w0 = b + NMS_BAND;               // first far word of this block's rows
+            for (int wb = (w0 & ~1); wb < nb; wb += 128) {
+                const int w = wb + 2 * lane;            // this lane's two words: w, w + 1
+                ulonglong2 a[NMS_ROWS_PER_WORKER];
 #pragma unroll
-            for (int ps = 0; ps < NMS_MAX_WORDS / 64; ++ps) {
-                const int w = b + 1 + ps * 64 + lane;
-                if (w < nb && acc[ps]) atomicOr(&s_removed[w], acc[ps]);
+                for (int r = 0; r < NMS_ROWS_PER_WORKER; ++r) {
+                    const int i = lw + NMS_GW * r;
+                    const bool on = (i < 64) && ((K >> (i & 63)) & 1ull) && (w < nb);
+                    const ulonglong2 *row = reinterpret_cast<const ulonglong2 *>(mask + (long long)(b * 64 + (i & 63)) * d.nbs + w);
+                    a[r] = on ? *row : make_ulonglong2(0ull, 0ull);
+                }
+                ulonglong2 v = make_ulonglong2(0ull, 0ull);
+#pragma unroll
+                for (int r = 0; r < NMS_ROWS_PER_WORKER; ++r) { v.x |= a[r].x; v.y |= a[r].y; }
+                if (w >= w0 && w < nb && v.x) atomicOr(&s_removed[w], v.x);        // w0 - 1 is a band slot: skip
+                if (w + 1 < nb && v.y) atomicOr(&s_removed[w + 1], v.y);
+            }
+            lds_store_i32(&s_wprog[me], b + NMS_GROUPS);
+        }
+        lds_store_i32(&s_wprog[me], NMS_MAX_WORDS * 2);   // nothing left that the chain could wait for
+    }
+    __syncthreads();
+    int nk = s_total;
+    if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
+    if (threadIdx.x == 0) d.num_keep[f] = nk;
+    if (d.emit.enabled) {
+        // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
+        const EmitDev &e = d.emit;
+        if (threadIdx.x == 0) e.num_out[f] = nk;
+        for (int r = threadIdx.x; r < e.cap; r += blockDim.x) {
+            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
+            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
+            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
+            if (r < nk) {
+                const int c = e.order[(long long)f * e.order_cap + keep[r]];
+                const long long o = (long long)f * e.N + c;
+                const float4 bx = e.bv[o];
+                const int4 im = e.img[o];
+                const float bi = (float)f;
+                obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
+                oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
+                o3[0] = bi;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o3[1 + j] = e.p3[o * 6 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
             }
         }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int nk = total;
-        if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
-        d.num_keep[f] = nk;
     }
 }
 
 size_t mv3d_nms_ws_bytes(int n_cap, int batch)
 {
-    const size_t nbw = (size_t)(n_cap + 63) / 64;
+    const size_t nbw = (size_t)(n_cap + 63) / 64, nbs = (nbw + 1) & ~(size_t)1;
     const size_t rows = nbw * 64;
-    return (size_t)batch * (mv3d_align_up(rows * nbw * 8) + mv3d_align_up(rows * 8));
+    return (size_t)batch * (mv3d_align_up(rows * nbs * 8) + mv3d_align_up(nbw * NMS_BAND * 64 * 8)) + MV3D_ALIGN;
 }
 
 int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
@@ -209,14 +396,16 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     NmsDev d;
     d.boxes = L.boxes; d.box_stride = L.box_stride; d.boxes_frame_stride = L.boxes_frame_stride;
     d.idx = L.idx; d.idx_frame_stride = L.idx_frame_stride; d.n_dev = L.n_dev; d.n_cap = L.n_cap;
-    d.nbw = nbw; d.tf = L.thresh_f32; d.strict_gt = L.strict_gt; d.max_keep = L.max_keep;
+    d.nbw = nbw; d.nbs = (nbw + 1) & ~1; d.tf = L.strict_gt ? nextafterf(L.thresh_f32, INFINITY) : L.thresh_f32; d.max_keep = L.max_keep;
     const size_t rows = (size_t)nbw * 64;
     d.mask = (unsigned long long *)L.workspace;
-    d.diagT = (unsigned long long *)((char *)L.workspace + (size_t)L.batch * mv3d_align_up(rows * nbw * 8));
+    d.band = (unsigned long long *)((char *)L.workspace + (size_t)L.batch * mv3d_align_up(rows * (size_t)d.nbs * 8));
     d.keep = L.keep; d.keep_frame_stride = L.keep_frame_stride; d.num_keep = L.num_keep; d.status = L.status;
+    d.emit = L.emit;
+    d.trace = L.trace;
     if (nbw > 0) {
-        dim3 grid(nbw, (nbw + 3) / 4, L.batch);
-        hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d);
+        dim3 grid(nbw * (nbw + 1) / 2, 1, L.batch);
+        hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, stream, d);
     }
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(L.batch), dim3(1024), 0, stream, d);
     return mv3d_launch_status();
@@ -243,9 +432,9 @@ extern "C" size_t mv3d_nms_workspace_bytes(int max_boxes)
     return mv3d_nms_ws_bytes(max_boxes, 1);
 }
 
-extern "C" int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep, int32_t *keep_dev,
-                               int32_t *num_keep_dev, int32_t *status_dev, void *workspace,
-                               size_t workspace_bytes, void *stream)
+static int nms_device_impl(const float *dets_dev, int n, double thresh, int max_keep, int32_t *keep_dev,
+                           int32_t *num_keep_dev, int32_t *status_dev, void *workspace, size_t workspace_bytes,
+                           void *stream, long long *trace)
 {
     if (n < 0 || !keep_dev || !num_keep_dev || (n > 0 && !dets_dev)) return MV3D_ERR_INVALID_ARG;
     if ((n + 63) / 64 > NMS_MAX_WORDS) return MV3D_ERR_INVALID_ARG;
@@ -258,14 +447,31 @@ extern "C" int mv3d_nms_device(const float *dets_dev, int n, double thresh, int 
     L.thresh_f32 = mv3d_ceil_f32(thresh); L.strict_gt = 0; L.max_keep = max_keep;
     L.keep = keep_dev; L.keep_frame_stride = n; L.num_keep = num_keep_dev; L.status = status_dev;
     L.workspace = workspace;
+    L.trace = trace;
     return mv3d_launch_nms(L, s);
 }
 
+extern "C" int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep, int32_t *keep_dev,
+                               int32_t *num_keep_dev, int32_t *status_dev, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    return nms_device_impl(dets_dev, n, thresh, max_keep, keep_dev, num_keep_dev, status_dev, workspace,
+                           workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mv3d_nms_device_trace(const float *dets_dev, int n, double thresh, int max_keep, int32_t *keep_dev,
+                                     int32_t *num_keep_dev, int32_t *status_dev, void *workspace,
+                                     size_t workspace_bytes, void *stream, int64_t *trace_dev)
+{
+    return nms_device_impl(dets_dev, n, thresh, max_keep, keep_dev, num_keep_dev, status_dev, workspace,
+                           workspace_bytes, stream, (long long *)trace_dev);
+}
+
 // keys of a (n,5) dets array for the device sort of mv3d_nms_host
-__global__ void nms_score_keys_kernel(const float *dets, int n, uint32_t *keys)
+__global__ void nms_score_keys_kernel(const float *dets, int n, int key_stride, uint32_t *keys)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = mv3d_score_key(dets[5 * i + 4]);
+    if (i < key_stride) keys[i] = (i < n) ? mv3d_score_key(dets[5 * i + 4]) : 0u;
 }
 __global__ void nms_map_keep_kernel(const int32_t *order, const int32_t *keep, const int32_t *num_keep, int32_t *out)
 {
@@ -282,9 +488,11 @@ static int nms_host_impl(int32_t *keep_out, int32_t *num_out, const float *dets_
     MV3D_HIP_TRY(hipSetDevice(device_id));
     const size_t ws_bytes = mv3d_nms_ws_bytes(n, 1);
     char *buf = nullptr;
-    const size_t o_dets = 0, o_keys = mv3d_align_up((size_t)n * 20), o_order = o_keys + mv3d_align_up((size_t)n * 4),
+    const int kstride = mv3d_rank_key_stride(n);
+    const size_t o_dets = 0, o_keys = mv3d_align_up((size_t)n * 20), o_order = o_keys + mv3d_align_up((size_t)kstride * 4),
                  o_keep = o_order + mv3d_align_up((size_t)n * 4), o_out = o_keep + mv3d_align_up((size_t)n * 4),
-                 o_cnt = o_out + mv3d_align_up((size_t)n * 4), o_ws = o_cnt + MV3D_ALIGN;
+                 o_cnt = o_out + mv3d_align_up((size_t)n * 4), o_rank = o_cnt + MV3D_ALIGN,
+                 o_ws = o_rank + (presorted ? 0 : mv3d_rank_ws_bytes(n, 1));
     MV3D_HIP_TRY(hipMalloc(&buf, o_ws + ws_bytes));
     int rc = MV3D_OK;
     hipStream_t s = nullptr;
@@ -301,8 +509,8 @@ static int nms_host_impl(int32_t *keep_out, int32_t *num_out, const float *dets_
         L.max_keep = 0; L.keep = keep; L.keep_frame_stride = n; L.num_keep = cnt; L.status = cnt + 1;
         L.workspace = buf + o_ws;
         if (!presorted) {
-            hipLaunchKernelGGL(nms_score_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dets, n, keys);
-            if ((rc = mv3d_launch_rank(keys, n, 1, order, n, s)) != MV3D_OK) break;
+            hipLaunchKernelGGL(nms_score_keys_kernel, dim3(kstride / 256), dim3(256), 0, s, dets, n, kstride, keys);
+            if ((rc = mv3d_launch_rank(keys, n, kstride, 1, order, n, nullptr, 0, nullptr, buf + o_rank, s)) != MV3D_OK) break;
             L.idx = order; L.idx_frame_stride = n;
         }
         if ((rc = mv3d_launch_nms(L, s)) != MV3D_OK) break;

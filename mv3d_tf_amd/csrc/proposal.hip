@@ -11,7 +11,7 @@
 //        consecutive anchors = consecutive addresses.
 //   rank_kernel (rank.hip)   argsort()[::-1][:pre_nms_topN]
 //   nms_mask/reduce (nms.hip) greedy NMS on the sorted candidates, capped at post_nms_topN
-//   proposal_emit_kernel     gathers the three ROI blobs, zero-fills the unused rows.
+//   (ROI blobs)              gathered by the tail of the NMS reduce kernel, unused rows zero-filled.
 //
 // All shapes are static given (H, W, params); data-dependent counts stay on the device, so
 // the whole call is capturable in a hipGraph.
@@ -162,7 +162,7 @@ __device__ __forceinline__ void image_box(const float M[12], const float P[6], i
 
 struct ProposalDev {
     const float *prob, *pred, *im_info, *calib;
-    int H, W, N;
+    int H, W, N, key_stride;
     int feat_stride, img_h, img_w, img_pad;
     float min_size;
     // candidate records, (batch, N)
@@ -170,7 +170,8 @@ struct ProposalDev {
     int4 *img;
     float *p3;          // (batch, N, 6)
     uint32_t *key;
-    int32_t *nvalid;    // (batch)
+    int32_t *blockcnt;  // (batch, gridDim.x) candidates per workgroup (summed by rank_scatter_kernel)
+    int32_t *status;    // (batch) flag word, zeroed here (may be NULL)
 };
 
 // grid (ceil(N/256), batch)
@@ -224,56 +225,25 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(ProposalDev d)
 #pragma unroll
         for (int j = 0; j < 6; ++j) q[j] = P[j];
         const float score = d.prob[((long long)f * d.H * d.W + cell) * 8 + 2 * a + 1];   // :63
-        d.key[o] = ok ? mv3d_score_key(score) : 0u;
+        d.key[(long long)f * d.key_stride + n] = ok ? mv3d_score_key(score) : 0u;
+    } else if (n < d.key_stride) {
+        d.key[(long long)f * d.key_stride + n] = 0u;          // padding the rank kernel relies on
     }
+    __shared__ int s_cnt[4];
     const unsigned long long bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&d.nvalid[f], __popcll(bal));
-}
-
-struct EmitDev {
-    const float4 *bv;
-    const int4 *img;
-    const float *p3;
-    const int32_t *order, *keep, *num_keep;
-    int N, order_cap, cap;
-    float *blob_bv, *blob_img, *blob_3d;
-    int32_t *num_out;
-};
-
-// grid (ceil(cap/256), batch): proposal_layer_tf.py:188-191 (batch column = frame index)
-__global__ __launch_bounds__(256) void proposal_emit_kernel(EmitDev e)
-{
-    const int f = blockIdx.y;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= e.cap) return;
-    const int nk = e.num_keep[f];
-    if (r == 0) e.num_out[f] = nk;
-    float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
-    float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
-    float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
-    if (r < nk) {
-        const int n = e.order[(long long)f * e.order_cap + e.keep[(long long)f * e.order_cap + r]];
-        const long long o = (long long)f * e.N + n;
-        const float4 b = e.bv[o];
-        const int4 im = e.img[o];
-        const float bi = (float)f;
-        obv[0] = bi; obv[1] = b.x; obv[2] = b.y; obv[3] = b.z; obv[4] = b.w;
-        oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
-        o3[0] = bi;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) o3[1 + j] = e.p3[o * 6 + j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
-#pragma unroll
-        for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d.blockcnt[(long long)f * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (blockIdx.x == 0 && d.status) d.status[f] = 0;
     }
 }
 
 // ------------------------------------------------------------------------ workspace
 struct ProposalLayout {
     int N, order_cap, cap;
-    size_t o_bv, o_img, o_p3, o_key, o_order, o_keep, o_cnt, o_nms, total;
+    int n_blocks, key_stride;
+    size_t o_bv, o_img, o_p3, o_key, o_order, o_keep, o_cnt, o_rank, o_nms, total;
 };
 
 static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params *p, ProposalLayout &L)
@@ -290,10 +260,13 @@ static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params 
     L.o_bv = o; o += mv3d_align_up(b * L.N * 16);
     L.o_img = o; o += mv3d_align_up(b * L.N * 16);
     L.o_p3 = o; o += mv3d_align_up(b * L.N * 24);
-    L.o_key = o; o += mv3d_align_up(b * L.N * 4);
+    L.key_stride = mv3d_rank_key_stride(L.N);
+    L.o_key = o; o += mv3d_align_up(b * L.key_stride * 4);
     L.o_order = o; o += mv3d_align_up(b * L.order_cap * 4);
     L.o_keep = o; o += mv3d_align_up(b * L.order_cap * 4);
-    L.o_cnt = o; o += mv3d_align_up(b * 2 * 4);              // nvalid[batch], num_keep[batch]
+    L.n_blocks = L.key_stride / 256;
+    L.o_cnt = o; o += mv3d_align_up(b * (2 + L.n_blocks) * 4);   // nvalid[batch], num_keep[batch], blockcnt[batch][n_blocks]
+    L.o_rank = o; o += mv3d_rank_ws_bytes(L.N, batch);
     L.o_nms = o; o += mv3d_nms_ws_bytes(L.order_cap, batch);
     L.total = o;
     return true;
@@ -324,21 +297,19 @@ extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, in
     if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    int32_t *cnt = (int32_t *)(ws + L.o_cnt);
-    MV3D_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)batch * 2 * 4, s));
-    if (status_dev) MV3D_HIP_TRY(hipMemsetAsync(status_dev, 0, (size_t)batch * 4, s));
+    int32_t *cnt = (int32_t *)(ws + L.o_cnt);          // no memset: every word is written before it is read
 
     ProposalDev d;
     d.prob = prob_dev; d.pred = pred_dev; d.im_info = im_info_dev; d.calib = calib_dev;
-    d.H = H; d.W = W; d.N = L.N; d.feat_stride = p->feat_stride;
+    d.H = H; d.W = W; d.N = L.N; d.key_stride = L.key_stride; d.feat_stride = p->feat_stride;
     d.img_h = p->img_height; d.img_w = p->img_width; d.img_pad = p->img_padding;
     d.min_size = (float)p->min_size;
     d.bv = (float4 *)(ws + L.o_bv); d.img = (int4 *)(ws + L.o_img); d.p3 = (float *)(ws + L.o_p3);
-    d.key = (uint32_t *)(ws + L.o_key); d.nvalid = cnt;
-    hipLaunchKernelGGL(proposal_decode_kernel, dim3((L.N + 255) / 256, batch), dim3(256), 0, s, d);
+    d.key = (uint32_t *)(ws + L.o_key); d.blockcnt = cnt + 2 * batch; d.status = status_dev;
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3(L.n_blocks, batch), dim3(256), 0, s, d);
 
     int32_t *order = (int32_t *)(ws + L.o_order), *keep = (int32_t *)(ws + L.o_keep);
-    int rc = mv3d_launch_rank(d.key, L.N, batch, order, L.order_cap, s);
+    int rc = mv3d_launch_rank(d.key, L.N, L.key_stride, batch, order, L.order_cap, d.blockcnt, L.n_blocks, cnt, ws + L.o_rank, s);
     if (rc != MV3D_OK) return rc;
 
     NmsLaunch nl = {};
@@ -349,13 +320,9 @@ extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, in
     nl.max_keep = L.cap;
     nl.keep = keep; nl.keep_frame_stride = L.order_cap; nl.num_keep = cnt + batch; nl.status = status_dev;
     nl.workspace = ws + L.o_nms;
-    rc = mv3d_launch_nms(nl, s);
-    if (rc != MV3D_OK) return rc;
-
-    EmitDev e;
-    e.bv = d.bv; e.img = d.img; e.p3 = d.p3; e.order = order; e.keep = keep; e.num_keep = cnt + batch;
-    e.N = L.N; e.order_cap = L.order_cap; e.cap = L.cap;
-    e.blob_bv = blob_bv_dev; e.blob_img = blob_img_dev; e.blob_3d = blob_3d_dev; e.num_out = num_out_dev;
-    hipLaunchKernelGGL(proposal_emit_kernel, dim3((L.cap + 255) / 256, batch), dim3(256), 0, s, e);
-    return mv3d_launch_status();
+    nl.emit.enabled = 1; nl.emit.N = L.N; nl.emit.order_cap = L.order_cap; nl.emit.cap = L.cap;
+    nl.emit.bv = d.bv; nl.emit.img = d.img; nl.emit.p3 = d.p3; nl.emit.order = order;
+    nl.emit.blob_bv = blob_bv_dev; nl.emit.blob_img = blob_img_dev; nl.emit.blob_3d = blob_3d_dev;
+    nl.emit.num_out = num_out_dev;
+    return mv3d_launch_nms(nl, s);
 }
