@@ -72,6 +72,8 @@ struct NmsDev {
     int nbw;                     // blocks of 64 boxes per frame (capacity)
     int nbs;                     // row-form words per row = nbw rounded up to even (16-byte rows)
     float tf;
+    float neg_h;                 // -(half the gap below tf), see tile_fast()
+    int fast_ok;                 // tf is a positive normal f32 in a range where tile_fast() is valid
     int max_keep;
     unsigned long long *mask;    // (batch, nbw*64, nbw)        row form, far tiles
     unsigned long long *band;    // (batch, nbw, NMS_BAND, 64)  column form, near tiles
@@ -101,47 +103,61 @@ __device__ __forceinline__ float4 load_box(const NmsDev &d, int f, int p)
 // canonicalisation: two extra v_max per call under IEEE mode).
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// "tame": finite and small enough that no intermediate of pair_suppresses() can overflow or be
-// NaN.  For tame boxes cy_max/cy_min (a>=b?a:b) and v_max/v_min agree except for the sign of a
-// zero, which cannot change any later result (it only feeds x - y + 1 and w * h).
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// "tame": finite and small enough (|coordinate| < 2^18) that no intermediate of
+// pair_suppresses() can overflow, be NaN or lose the exactness arguments below.  For tame
+// boxes cy_max/cy_min (a>=b?a:b) and v_max/v_min agree except for the sign of a zero, which
+// cannot change any later result (it only feeds x - y + 1 and w * h).
 __device__ __forceinline__ bool tame(float4 b)
 {
-    const float L = 0x1p60f;
+    const float L = 0x1p18f;
     return fabsf(b.x) < L && fabsf(b.y) < L && fabsf(b.z) < L && fabsf(b.w) < L;
 }
 
-// One 64x64 tile, every column valid, all boxes tame: straight-line, constant shifts.
-// COLFORM: the result is the column word of lane's own column (ballot over the rows);
-// otherwise the row word.  DIAG: rows only count against later columns of the same block.
-template <bool COLFORM, bool DIAG>
-__device__ __forceinline__ unsigned long long tile_fast(const float4 rbx, const float rarea, const float4 *s_box,
-                                                        const float *s_area, const float tf, const int lane,
-                                                        float &min_den)
+// Division-free exact form of  RN(inter / den) >= tf  for den > 0, inter >= 0 and a positive
+// normal tf:  let h = half the distance from tf to its f32 predecessor (a power of two) and
+// mid = tf - h.  RN(q) >= tf  <=>  q > mid, or q == mid and the tie rounds to tf.  With
+// e = fma(-tf, den, inter) (ONE rounding of inter - tf*den) and nc = -h*den (exact):
+//     e > nc  =>  inter - tf*den > -h*den  =>  q > mid            => suppressed
+//     e < nc  =>  q < mid                                         => not suppressed
+//     e == nc =>  undecided (q within a rounding of mid)          => the tile is redone exactly
+// (RN is monotone, so e > nc cannot come from an exact value <= nc).  Everything is f32 and
+// packed two columns per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+//
+// One 64x64 tile, all 128 boxes valid and tame.  `lb` is the lane's own box, `s_box/s_area` the
+// 64 boxes of the other side (LDS broadcasts).  Bit j of the result = predicate(lane box, box j).
+// DIAG_SWAPPED: the lane box is the COLUMN (later) box of a diagonal tile: only rows j < lane count.
+template <bool DIAG_SWAPPED>
+__device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const float larea, const float4 *s_box,
+                                                        const float *s_area, const float tf, const float neg_h,
+                                                        const int lane, float &min_den, bool &undecided)
 {
     unsigned lo = 0, hi = 0;
-    unsigned long long mycol = 0;
+    bool amb = false;
+    const f2 ntf = {-tf, -tf}, nh = {neg_h, neg_h}, one = {1.0f, 1.0f}, la = {larea, larea};
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float4 c = s_box[j];
-        const float xx1 = vmax(rbx.x, c.x), yy1 = vmax(rbx.y, c.y);
-        const float xx2 = vmin(rbx.z, c.z), yy2 = vmin(rbx.w, c.w);
-        const float w = vmax(0.0f, (xx2 - xx1) + 1.0f);
-        const float h = vmax(0.0f, (yy2 - yy1) + 1.0f);
-        const float inter = w * h;
-        const float den = (rarea + s_area[j]) - inter;
-        min_den = vmin(min_den, fabsf(den));
-        const float ovr = inter / den;
-        bool p = (ovr >= tf);
-        if (DIAG) p = p && (lane < j);
-        if (COLFORM) {
-            const unsigned long long bal = __ballot(p);   // rows that suppress column j
-            if (lane == j) mycol = bal;
-        } else {
-            if (j < 32) lo |= p ? (1u << j) : 0u;
-            else hi |= p ? (1u << (j - 32)) : 0u;
-        }
+    for (int j = 0; j < 64; j += 2) {
+        const float4 A = s_box[j], B = s_box[j + 1];
+        const f2 ca = *reinterpret_cast<const f2 *>(s_area + j);
+        const f2 xx1 = {vmax(lb.x, A.x), vmax(lb.x, B.x)}, yy1 = {vmax(lb.y, A.y), vmax(lb.y, B.y)};
+        const f2 xx2 = {vmin(lb.z, A.z), vmin(lb.z, B.z)}, yy2 = {vmin(lb.w, A.w), vmin(lb.w, B.w)};
+        const f2 dx = (xx2 - xx1) + one, dy = (yy2 - yy1) + one;
+        const f2 w = {vmax(0.0f, dx.x), vmax(0.0f, dx.y)}, h = {vmax(0.0f, dy.x), vmax(0.0f, dy.y)};
+        const f2 inter = w * h;
+        const f2 den = (la + ca) - inter;
+        min_den = vmin3(min_den, den.x, den.y);
+        const f2 e = __builtin_elementwise_fma(ntf, den, inter);
+        const f2 nc = den * nh;
+        bool p0 = e.x > nc.x, p1 = e.y > nc.y;
+        amb |= (e.x == nc.x) | (e.y == nc.y);
+        if (DIAG_SWAPPED) { p0 = p0 && (j < lane); p1 = p1 && (j + 1 < lane); }
+        if (j < 32) { lo |= p0 ? (1u << j) : 0u; lo |= p1 ? (2u << j) : 0u; }
+        else { hi |= p0 ? (1u << (j - 32)) : 0u; hi |= p1 ? (2u << (j - 32)) : 0u; }
     }
-    return COLFORM ? mycol : (((unsigned long long)hi << 32) | lo);
+    undecided = amb;
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // grid: (nbw*(nbw+1)/2 tiles, 1, batch); block 64 = one wave per tile.
@@ -159,53 +175,51 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsDev d)
     const int rb = t - cb * (cb + 1) / 2;
     if (cb * 64 >= n) return;
     const int lane = threadIdx.x;
-    const int c = cb * 64 + lane;
-    float4 cbx = make_float4(NAN, NAN, NAN, NAN);   // NaN box: every predicate false
-    if (c < n) cbx = load_box(d, f, c);
-    s_box[lane] = cbx;
-    s_area[lane] = ((cbx.z - cbx.x) + 1.0f) * ((cbx.w - cbx.y) + 1.0f);      // cpu_nms.pyx:24
-    const bool cols_tame = __all(tame(cbx));        // false if the tile is ragged (NaN padding)
-    __syncthreads();
-    const int r = rb * 64 + lane;
-    float4 rbx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (r < n) rbx = load_box(d, f, r);
-    const float rarea = ((rbx.z - rbx.x) + 1.0f) * ((rbx.w - rbx.y) + 1.0f);
     const int dist = cb - rb;
     const bool diag = (dist == 0), colform = (dist < NMS_BAND);
+    // Row form: lane = row box, LDS = column boxes, bit j = column j.  Column form (near band):
+    // the roles are swapped -- the predicate is symmetric in the two boxes (max/min/+/* commute) --
+    // so the lane's word is directly "which rows of block rb suppress my column".
+    const int lds_idx = (colform ? rb : cb) * 64 + lane, own_idx = (colform ? cb : rb) * 64 + lane;
+    float4 sb = make_float4(NAN, NAN, NAN, NAN);    // NaN box: every predicate false
+    if (lds_idx < n) sb = load_box(d, f, lds_idx);
+    s_box[lane] = sb;
+    s_area[lane] = ((sb.z - sb.x) + 1.0f) * ((sb.w - sb.y) + 1.0f);          // cpu_nms.pyx:24
+    const bool lds_tame = __all(tame(sb));          // false if the block is ragged (NaN padding)
+    __syncthreads();
+    float4 lb = make_float4(NAN, NAN, NAN, NAN);
+    if (own_idx < n) lb = load_box(d, f, own_idx);
+    const float larea = ((lb.z - lb.x) + 1.0f) * ((lb.w - lb.y) + 1.0f);
     unsigned long long word = 0;
-    bool any_zero = false;
-    if (cols_tame && __all(tame(rbx))) {
+    bool any_zero = false, done = false;
+    if (d.fast_ok && lds_tame && __all(tame(lb))) {
         float min_den = 1.0f;
-        if (diag) word = tile_fast<true, true>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
-        else if (colform) word = tile_fast<true, false>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
-        else word = tile_fast<false, false>(rbx, rarea, s_box, s_area, d.tf, lane, min_den);
-        any_zero = (min_den == 0.0f) && (r < n);
-    } else {
-        // generic path: ragged last tile, or NaN / huge coordinates (exact cy_max / cy_min semantics)
-        if (r >= n) rbx = make_float4(NAN, NAN, NAN, NAN);
-        const float ra = ((rbx.z - rbx.x) + 1.0f) * ((rbx.w - rbx.y) + 1.0f);
-        unsigned long long bits = 0, mycol = 0;
+        bool und;
+        if (diag) word = tile_fast<true>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und);
+        else word = tile_fast<false>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und);
+        // a denominator that is not safely positive, or an undecided compare: redo the tile exactly
+        done = !__any(und || !(min_den >= 0x1p-20f));
+    }
+    if (!done) {
+        // exact path: ragged blocks, NaN / huge coordinates, zero / negative unions, undecided compares
+        word = 0;
         for (int j = 0; j < 64; ++j) {
             const float4 q = s_box[j];
             bool zd;
-            bool p = pair_suppresses(rbx.x, rbx.y, rbx.z, rbx.w, ra, q.x, q.y, q.z, q.w, s_area[j], d.tf, zd);
-            const bool live = diag ? (lane < j) : true;
+            // arguments in (kept box i, later box j) order of cpu_nms.pyx: i = row side
+            bool p = colform ? pair_suppresses(q.x, q.y, q.z, q.w, s_area[j], lb.x, lb.y, lb.z, lb.w, larea, d.tf, zd)
+                             : pair_suppresses(lb.x, lb.y, lb.z, lb.w, larea, q.x, q.y, q.z, q.w, s_area[j], d.tf, zd);
+            const bool live = diag ? (j < lane) : true;                        // rows before my column
             p = p && live;
-            any_zero |= (zd && live && r < n && (cb * 64 + j) < n);
-            bits |= (unsigned long long)p << j;
-            const unsigned long long bal = __ballot(p);
-            if (lane == j) mycol = bal;
+            any_zero |= (zd && live && own_idx < n && ((colform ? rb : cb) * 64 + j) < n);
+            word |= (unsigned long long)p << j;
         }
-        word = colform ? mycol : bits;
     }
     if (colform) d.band[(((long long)f * d.nbw + rb) * NMS_BAND + dist) * 64 + lane] = word;
-    else if (r < n) d.mask[((long long)f * d.nbw * 64 + r) * d.nbs + cb] = word;
+    else if (own_idx < n) d.mask[((long long)f * d.nbw * 64 + own_idx) * d.nbs + cb] = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
 }
 
-// LDS flags between the waves of one workgroup.  The fences are restricted to the LDS address
-// space ("local"): a plain workgroup release/acquire would also drain vmcnt and serialise the
-// chain wave behind its own global prefetches.
 __device__ __forceinline__ int lds_load_i32(const int *p)
 {
     const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -397,6 +411,8 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     d.boxes = L.boxes; d.box_stride = L.box_stride; d.boxes_frame_stride = L.boxes_frame_stride;
     d.idx = L.idx; d.idx_frame_stride = L.idx_frame_stride; d.n_dev = L.n_dev; d.n_cap = L.n_cap;
     d.nbw = nbw; d.nbs = (nbw + 1) & ~1; d.tf = L.strict_gt ? nextafterf(L.thresh_f32, INFINITY) : L.thresh_f32; d.max_keep = L.max_keep;
+    d.fast_ok = (d.tf >= 0x1p-10f && d.tf <= 0x1p10f) ? 1 : 0;
+    d.neg_h = d.fast_ok ? -0.5f * (d.tf - nextafterf(d.tf, 0.0f)) : 0.0f;
     const size_t rows = (size_t)nbw * 64;
     d.mask = (unsigned long long *)L.workspace;
     d.band = (unsigned long long *)((char *)L.workspace + (size_t)L.batch * mv3d_align_up(rows * (size_t)d.nbs * 8));

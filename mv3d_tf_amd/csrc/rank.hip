@@ -1,20 +1,22 @@
 // Score sort of proposal_layer_3d (lib/rpn_msr/proposal_layer_tf.py:161-167:
-// scores.argsort()[::-1][:pre_nms_topN]) as rank-by-counting across the whole chip.
+// scores.argsort()[::-1][:pre_nms_topN]).  order[rank(i)] = i for rank(i) < cap with
 //
-// rank(i) = #{ j : key_j > key_i  or (key_j == key_i and j > i) }   (descending score,
-// ties by descending index = stable ascending sort reversed; the reference leaves ties to
-// numpy's unstable sort).  order[rank(i)] = i for rank(i) < cap.  No multi-pass sort and no
-// inter-workgroup dependency:
+//   rank(i) = #{ j : key_j > key_i  or (key_j == key_i and j > i) }
 //
-//   rank_partial_kernel  grid (N/256, N/1024, batch): workgroup (bi, s) owns 256 candidates i
-//        and the 1024 keys j of segment s, which are wave-uniform and arrive in SGPRs through
-//        scalar loads; 2 VALU ops per pair (v_cmp into VCC + add-with-carry), nothing else.  The
-//        index tie-break is folded into the choice between `>` and `>=` per 256-key sub-tile
-//        (uniform per workgroup), so only the workgroup's own sub-tile pays for the full rule.
-//        Writes partial[f][s][i].
-//   rank_scatter_kernel  sums the partial counts of a candidate and scatters its index; block 0
-//        also totals the per-workgroup candidate counts left by the producer (n_valid), so no
-//        atomics and no memset are needed anywhere on the path.
+// (descending score, ties by descending index = stable ascending sort reversed; the reference
+// leaves ties to numpy's unstable sort).  Two implementations, both exact and deterministic:
+//
+//  A. merge-rank (key_stride <= 24576 keys per frame, i.e. every KITTI-sized grid; 2 kernels)
+//     rank_local_kernel   sorts runs of 1024 keys by counting inside the run (keys wave-uniform
+//                         through scalar loads, 2 VALU per pair) and writes each run sorted.
+//     rank_merge_kernel   each workgroup stages ALL sorted runs of its frame in LDS (<= 96 KB of
+//                         the CU's 160 KB) and every thread binary-searches its key in each other
+//                         run: 11 LDS reads per run instead of 1024 compares.  Because runs own
+//                         disjoint index ranges, the tie-break reduces to searching with `>` in
+//                         runs of smaller index and `>=` in runs of larger index.  Scatters the
+//                         order and totals n_valid (no atomics, no memset).
+//  B. counting (any size; fallback): rank_partial_kernel + rank_scatter_kernel, O(N^2) pairs at two
+//     VALU instructions per pair.
 #include "kernels.h"
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
@@ -74,6 +76,125 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
     if (i < N) partial[((long long)f * S + s) * N + i] = cnt;
 }
 
+// ---------------------------------------------------------------------------- A. merge-rank
+#define RANK_LDS_KEYS 24576
+#define RANK_RUN 1024            // sorted run length (= RANK_SEG: one scalar-load segment)
+
+// grid (key_stride/256, batch).  Workgroup bi owns 256 keys of run R = bi/4 and ranks them inside
+// the run by counting over its 1024 keys (wave-uniform, scalar loads; `>` / `>=` per 256-key
+// sub-tile as in rank_partial_kernel).  Candidates are written to their run position:
+// sorted[f][R*1024 + r] = key, sidx = index inside the run.  Non-candidates (key 0) are not
+// written at all; cnt256[f][bi] = candidates of this workgroup lets the consumer treat the tail of
+// every run as zeros.
+__global__ __launch_bounds__(256) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
+                                                         uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
+                                                         int32_t *__restrict__ cnt256)
+{
+    __shared__ int s_wc[4];
+    const int f = blockIdx.y, t = threadIdx.x, bi = blockIdx.x;
+    const int run = bi >> 2, my_sub = bi & 3;
+    const uint32_t *__restrict__ k = keys + (long long)f * key_stride + run * RANK_RUN;
+    const uint32_t ki = k[my_sub * 256 + t];
+    const uint32_t kim1 = ki - 1u;                  // kj >= ki  <=>  kj > ki - 1   (ki >= 1 for candidates)
+    unsigned cnt = 0;
+    for (int sub = 0; sub < 4; ++sub) {
+        const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
+        if (sub < my_sub) {
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) count16<false>(cnt, ki, q[u]);
+        } else if (sub > my_sub) {
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) count16<true>(cnt, ki, q[u]);
+        } else {
+#pragma unroll 16
+            for (int j = 0; j < 256; ++j) {
+                const uint32_t kj = k[sub * 256 + j];           // wave-uniform: scalar load
+                const uint32_t thr = (j > t) ? kim1 : ki;       // the later index wins a tie
+                cnt += (kj > thr) ? 1u : 0u;
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(ki != 0u);
+    if ((t & 63) == 0) s_wc[t >> 6] = __popcll(bal);
+    __syncthreads();
+    if (t == 0) cnt256[(long long)f * gridDim.x + bi] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if (ki != 0u) {
+        const long long o = (long long)f * key_stride + run * RANK_RUN + cnt;
+        sorted[o] = ki;
+        sidx[o] = (uint16_t)(my_sub * 256 + t);
+    }
+}
+
+template <bool GE>
+__device__ __forceinline__ int count_before(const uint32_t *sb, const uint32_t ki)
+{
+    // sb: RANK_RUN keys in descending order; number of keys kj with kj > ki (GE: kj >= ki)
+    int pos = 0;
+#pragma unroll
+    for (int step = RANK_RUN / 2; step >= 1; step >>= 1) {
+        const uint32_t v = sb[pos + step - 1];
+        if (GE ? (v >= ki) : (v > ki)) pos += step;
+    }
+    const uint32_t v = sb[pos];                     // pos <= RANK_RUN - 1
+    if (GE ? (v >= ki) : (v > ki)) pos += 1;
+    return pos;
+}
+
+// grid (key_stride/256, batch), 256 threads: thread t of workgroup bi owns position
+// (bi&3)*256 + t of run bi/4.  All runs of the frame are staged in LDS (<= 96 KB).
+__global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restrict__ sorted,
+                                                         const uint16_t *__restrict__ sidx,
+                                                         const int32_t *__restrict__ cnt256, int N, int key_stride,
+                                                         int32_t *order, int cap, const int32_t *part_counts, int n_parts,
+                                                         int32_t *n_valid)
+{
+    __shared__ uint32_t s_keys[RANK_LDS_KEYS];
+    const int f = blockIdx.y, bi = blockIdx.x, t = threadIdx.x;
+    const int nrun = key_stride / RANK_RUN, nb256 = key_stride >> 8;
+    const uint32_t *__restrict__ src = sorted + (long long)f * key_stride;
+    const int32_t *__restrict__ c256 = cnt256 + (long long)f * nb256;
+    for (int q = t; q < key_stride / 4; q += 256) {
+        const int r = (q * 4) / RANK_RUN, p = (q * 4) % RANK_RUN;
+        const int nc = c256[4 * r] + c256[4 * r + 1] + c256[4 * r + 2] + c256[4 * r + 3];
+        uint4 v = reinterpret_cast<const uint4 *>(src)[q];
+        if (p + 0 >= nc) v.x = 0u;                   // slots past the run's candidates were never written
+        if (p + 1 >= nc) v.y = 0u;
+        if (p + 2 >= nc) v.z = 0u;
+        if (p + 3 >= nc) v.w = 0u;
+        reinterpret_cast<uint4 *>(s_keys)[q] = v;
+    }
+    __syncthreads();
+    const int R = bi >> 2, pos = (bi & 3) * 256 + t;
+    const uint32_t ki = s_keys[R * RANK_RUN + pos];
+    if (ki != 0u) {
+        int rank = pos;                              // position inside the own sorted run
+        int r2 = 0;
+        for (; r2 + 2 <= R; r2 += 2) {               // runs of smaller index: only strictly larger keys precede
+            const int c0 = count_before<false>(s_keys + (r2 + 0) * RANK_RUN, ki);
+            const int c1 = count_before<false>(s_keys + (r2 + 1) * RANK_RUN, ki);
+            rank += c0 + c1;
+        }
+        for (; r2 < R; ++r2) rank += count_before<false>(s_keys + r2 * RANK_RUN, ki);
+        r2 = R + 1;
+        for (; r2 + 2 <= nrun; r2 += 2) {            // runs of larger index: equal keys precede too
+            const int c0 = count_before<true>(s_keys + (r2 + 0) * RANK_RUN, ki);
+            const int c1 = count_before<true>(s_keys + (r2 + 1) * RANK_RUN, ki);
+            rank += c0 + c1;
+        }
+        for (; r2 < nrun; ++r2) rank += count_before<true>(s_keys + r2 * RANK_RUN, ki);
+        if (rank < cap)
+            order[(long long)f * cap + rank] = R * RANK_RUN + (int)sidx[(long long)f * key_stride + R * RANK_RUN + pos];
+    }
+    if (n_valid && bi == 0 && t < 64) {
+        int v = 0;
+        for (int p = t; p < n_parts; p += 64) v += part_counts[(long long)f * n_parts + p];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (t == 0) n_valid[f] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------- B. counting (scatter)
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__restrict__ keys, int N, int key_stride, int S,
                                                            const uint32_t *__restrict__ partial, int32_t *order, int cap,
                                                            const int32_t *part_counts, int n_parts, int32_t *n_valid)
@@ -97,18 +218,31 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__res
     }
 }
 
+int mv3d_rank_key_stride(int N) { return (N + RANK_SEG - 1) / RANK_SEG * RANK_SEG; }
+
 size_t mv3d_rank_ws_bytes(int N, int batch)
 {
-    const size_t S = (size_t)(N + RANK_SEG - 1) / RANK_SEG;
+    const size_t ks = (size_t)mv3d_rank_key_stride(N);
+    if (ks <= RANK_LDS_KEYS)
+        return mv3d_align_up((size_t)batch * ks * 4) + mv3d_align_up((size_t)batch * ks * 2) + mv3d_align_up((size_t)batch * (ks / 256) * 4);
+    const size_t S = ks / RANK_SEG;
     return mv3d_align_up((size_t)batch * S * N * 4);
 }
-
-int mv3d_rank_key_stride(int N) { return (N + RANK_SEG - 1) / RANK_SEG * RANK_SEG; }
 
 int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int32_t *order, int cap,
                      const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace, hipStream_t stream)
 {
     if (N <= 0 || batch <= 0 || cap <= 0 || !workspace || key_stride != mv3d_rank_key_stride(N)) return MV3D_ERR_INVALID_ARG;
+    if (key_stride <= RANK_LDS_KEYS) {
+        uint32_t *sorted = (uint32_t *)workspace;
+        uint16_t *sidx = (uint16_t *)((char *)workspace + mv3d_align_up((size_t)batch * key_stride * 4));
+        int32_t *cnt256 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
+        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 256, batch), dim3(256), 0, stream, keys, key_stride, sorted, sidx,
+                           cnt256);
+        hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 256, batch), dim3(256), 0, stream, sorted, sidx, cnt256, N,
+                           key_stride, order, cap, part_counts, n_parts, n_valid);
+        return mv3d_launch_status();
+    }
     const int S = key_stride / RANK_SEG, IB = (N + 255) / 256;
     uint32_t *partial = (uint32_t *)workspace;
     hipLaunchKernelGGL(rank_partial_kernel, dim3(IB, S, batch), dim3(256), 0, stream, keys, N, key_stride, S, partial);

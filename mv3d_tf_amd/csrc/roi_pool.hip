@@ -40,6 +40,14 @@ __device__ __forceinline__ void upd(float v, int idx, float &mv, int &mi)
     if (v > mv) { mv = v; mi = idx; }          // strict >: first maximum wins, NaN never wins
 }
 
+__device__ __forceinline__ void upd4(const float4 x, int idx, float4 &mv, int4 &mi)
+{
+    upd(x.x, idx + 0, mv.x, mi.x);
+    upd(x.y, idx + 1, mv.y, mi.y);
+    upd(x.z, idx + 2, mv.z, mi.z);
+    upd(x.w, idx + 3, mv.w, mi.w);
+}
+
 // items = R*PH*PW*(C/VEC), grid-stride
 template <int VEC>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restrict__ data, float scale, int B, int R,
@@ -95,6 +103,92 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
         } else {
             top[o] = mv[0];
             if (argmax) argmax[o] = mi[0];
+        }
+    }
+}
+
+// Fast forward for C/4 in {64,128,256} (C = 256, 512, 1024), XCD-aware.
+//
+// The 8 XCDs have private 4 MiB L2s and workgroup b is placed on XCD b % 8 (observed; only speed
+// depends on it).  A feature map (BEV 11.8 MB, RGB 14.6 MB) does not fit one L2, and with ROIs
+// spread over all XCDs every L2 would stream the whole map.  So the CHANNELS are split instead:
+// workgroup b handles channel slice b % 8 (C/8 channels = 256 B per pixel for C = 512) of bin
+// group b / 8 -- each XCD then only ever touches its own 1/8 of the map (<= 1.8 MB, L2 resident)
+// while the overlapping bins of neighbouring ROIs re-read it.  The bin geometry (f32 divides,
+// round / floor / ceil) is computed once per bin by the first lanes and broadcast through LDS.
+#define FWD_PASSES 2
+struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
+
+__global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__restrict__ data, float scale, int B, int R,
+                                                               int H, int W, int C, int PH, int PW,
+                                                               const float *__restrict__ rois, float *__restrict__ top,
+                                                               int *__restrict__ argmax, int tpb_shift)
+{
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
+    const int tpb = 1 << tpb_shift;                  // threads per bin = C/32 (8, 16 or 32 float4 lanes)
+    const int bpp = 256 >> tpb_shift;                // bins per pass (32, 16 or 8)
+    const int slice = blockIdx.x & 7;
+    const long long nbins = (long long)R * PH * PW;
+    const long long bin0 = (long long)(blockIdx.x >> 3) * (FWD_PASSES * bpp);
+    if (threadIdx.x < FWD_PASSES * bpp) {
+        BinGeom g;
+        g.hs = g.he = g.ws = g.we = 0; g.base = -1; g.pad0 = g.pad1 = g.pad2 = 0;
+        const long long bin = bin0 + threadIdx.x;
+        if (bin < nbins) {
+            const int pw = (int)(bin % PW);
+            const int ph = (int)((bin / PW) % PH);
+            const int n = (int)(bin / ((long long)PW * PH));
+            const float *roi = rois + 5 * n;
+            const int bi = (int)roi[0];
+            const RoiGeom q = roi_geom(roi, scale);
+            const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);   // roi_pooling_op.cc:146-147
+            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;        // :148-151
+            int hs = (int)floorf(__fmul_rn((float)ph, bh)), ws = (int)floorf(__fmul_rn((float)pw, bw));
+            int he = (int)ceilf(__fmul_rn((float)(ph + 1), bh)), we = (int)ceilf(__fmul_rn((float)(pw + 1), bw));
+            g.hs = min(max(hs + q.rsh, 0), H); g.he = min(max(he + q.rsh, 0), H);      // :159-162
+            g.ws = min(max(ws + q.rsw, 0), W); g.we = min(max(we + q.rsw, 0), W);
+            const bool empty = (g.he <= g.hs) || (g.we <= g.ws) || bi < 0 || bi >= B;
+            g.base = empty ? -1 : bi;
+        }
+        s_g[threadIdx.x] = g;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x >> tpb_shift;        // bin inside the pass
+    const int c0 = (slice * tpb + (threadIdx.x & (tpb - 1))) * 4;
+#pragma unroll
+    for (int pass = 0; pass < FWD_PASSES; ++pass) {
+        const int lb = pass * bpp + sub;
+        const long long bin = bin0 + lb;
+        if (bin < nbins) {
+            const BinGeom g = s_g[lb];
+            float4 mv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int4 mi = make_int4(-1, -1, -1, -1);
+            if (g.base >= 0) {
+                mv = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+                const float *d = data + (long long)g.base * H * W * C + c0;
+                for (int h = g.hs; h < g.he; ++h) {
+                    int w = g.ws;
+                    // four independent 16-byte loads in flight, consumed in scan order (first max wins)
+                    for (; w + 4 <= g.we; w += 4) {
+                        const int idx = (h * W + w) * C;
+                        const float4 x0 = *reinterpret_cast<const float4 *>(d + idx);
+                        const float4 x1 = *reinterpret_cast<const float4 *>(d + idx + C);
+                        const float4 x2 = *reinterpret_cast<const float4 *>(d + idx + 2 * C);
+                        const float4 x3 = *reinterpret_cast<const float4 *>(d + idx + 3 * C);
+                        upd4(x0, idx + c0, mv, mi);
+                        upd4(x1, idx + C + c0, mv, mi);
+                        upd4(x2, idx + 2 * C + c0, mv, mi);
+                        upd4(x3, idx + 3 * C + c0, mv, mi);
+                    }
+                    for (; w < g.we; ++w) {
+                        const int idx = (h * W + w) * C;
+                        upd4(*reinterpret_cast<const float4 *>(d + idx), idx + c0, mv, mi);
+                    }
+                }
+            }
+            const long long o = bin * C + c0;
+            *reinterpret_cast<float4 *>(top + o) = mv;
+            if (argmax) *reinterpret_cast<int4 *>(argmax + o) = mi;
         }
     }
 }
@@ -214,6 +308,17 @@ extern "C" int mv3d_roi_pool_forward(const float *bottom_data, float spatial_sca
     long long blocks = (items + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;            // grid-stride the rest
     hipStream_t s = (hipStream_t)stream;
+    const int cv4 = channels / 4;
+    if (v4 && (cv4 == 64 || cv4 == 128 || cv4 == 256)) {
+        const int tpb_shift = cv4 == 64 ? 3 : (cv4 == 128 ? 4 : 5);      // threads per bin = cv4 / 8
+        const long long nbins = (long long)num_rois * pooled_height * pooled_width;
+        const long long per_block = (long long)FWD_PASSES * (256 >> tpb_shift);
+        const long long groups = (nbins + per_block - 1) / per_block;
+        hipLaunchKernelGGL(roi_pool_fwd_xcd_kernel, dim3((unsigned)(groups * 8)), dim3(256), 0, s, bottom_data,
+                           spatial_scale, batch_size, num_rois, height, width, channels, pooled_height, pooled_width,
+                           bottom_rois, top_data, argmax_data, tpb_shift);
+        return mv3d_launch_status();
+    }
     if (v4)
         hipLaunchKernelGGL(roi_pool_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, bottom_data, spatial_scale,
                            batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,

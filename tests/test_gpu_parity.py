@@ -184,7 +184,8 @@ def roi_cases(seed, R, H, W, B):
 
 
 @pytest.mark.parametrize("B,H,W,C,R,seed", [(1, 12, 9, 16, 24, 1), (2, 10, 14, 64, 40, 2), (1, 76, 76, 512, 128, 3),
-                                            (1, 9, 7, 6, 16, 4), (3, 8, 8, 20, 70, 5)])
+                                            (1, 9, 7, 6, 16, 4), (3, 8, 8, 20, 70, 5), (1, 12, 9, 256, 24, 6),
+                                            (2, 6, 5, 1024, 10, 7), (1, 46, 155, 512, 300, 8)])
 def test_roi_pool_forward_backward_vs_oracle(ops, torch_cuda, oracle, B, H, W, C, R, seed):
     torch = torch_cuda
     data = synth.feature_map(seed, H, W, C, B)
