@@ -169,6 +169,37 @@ int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
                               int32_t *n_anchors_dev, int anchors_cap,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------ proposal_target_layer_3d
+ * Replaces lib/rpn_msr/proposal_target_layer_tf.py:19-94 with _sample_rois_3d (:227-298),
+ * _compute_targets_cnr (:211-225), _get_bbox_regression_labels_3d (:172-194) and the image
+ * projection (one frame).  stage1: candidate set = proposals followed by the GT boxes, f64 IoU
+ * vs gt_boxes_bv, first-argmax / max, ordered fg / bg candidate lists; counts_dev[4] =
+ * [n_candidates, n_fg (max_ov >= FG_THRESH), n_bg (LO <= max_ov < HI), 0].  The caller draws
+ * npr.permutation(n_fg)[:k_fg] and npr.permutation(n_bg)[:k_bg] (legacy RandomState.choice
+ * without replacement) and stage2 gathers the sampled ROIs: rois_bv (S,5), rois_img (S,5),
+ * labels (S) i32, bbox_targets (S, 24*num_classes), rois_3d (S,7), S = n_fg + n_bg rows, fg first. */
+typedef struct {
+    int32_t num_classes;         /* n_classes = 2: lib/networks/MV3D_train.py:4 */
+    int32_t reserved;
+    double fg_thresh;            /* cfg.TRAIN.FG_THRESH    */
+    double bg_thresh_hi;         /* cfg.TRAIN.BG_THRESH_HI */
+    double bg_thresh_lo;         /* cfg.TRAIN.BG_THRESH_LO */
+} mv3d_proposal_target_params;
+
+size_t mv3d_proposal_target_workspace_bytes(int num_rois, int G);
+int mv3d_proposal_target_stage1(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
+                                const float *gt_bv_dev, const float *gt_3d_dev, int G,
+                                const mv3d_proposal_target_params *p, int32_t *counts_dev,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
+                                const float *gt_bv_dev, const float *gt_3d_dev,
+                                const float *gt_corners_dev, int G, const float *calib_dev,
+                                const mv3d_proposal_target_params *p,
+                                const int32_t *fg_pick_dev, int n_fg, const int32_t *bg_pick_dev, int n_bg,
+                                float *rois_bv_out, float *rois_img_out, int32_t *labels_out,
+                                float *bbox_targets_out, float *rois_3d_out,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,12 @@ class AnchorTargetParams(C.Structure):
                 ("negative_overlap", C.c_double), ("positive_overlap", C.c_double)]
 
 
+class ProposalTargetParams(C.Structure):
+    """mv3d_proposal_target_params"""
+    _fields_ = [("num_classes", C.c_int32), ("reserved", C.c_int32), ("fg_thresh", C.c_double),
+                ("bg_thresh_hi", C.c_double), ("bg_thresh_lo", C.c_double)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "mv3d_version": (C.c_int, []),
@@ -52,6 +58,11 @@ _SIGS = {
                                             _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_anchor_target_stage2": (C.c_int, [C.c_int, C.c_int, C.POINTER(AnchorTargetParams), _P, C.c_int, _P,
                                             C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_proposal_target_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mv3d_proposal_target_stage1": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(ProposalTargetParams), _P, _P,
+                                              C.c_size_t, _P]),
+    "mv3d_proposal_target_stage2": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.POINTER(ProposalTargetParams),
+                                              _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

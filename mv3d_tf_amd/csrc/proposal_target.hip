@@ -1,0 +1,236 @@
+// proposal_target_layer_3d for gfx950 (one frame): lib/rpn_msr/proposal_target_layer_tf.py:19-94
+// with _sample_rois_3d (:227-298), lib/utils/bbox.pyx:15-55 (f64 IoU), lib/fast_rcnn/
+// bbox_transform.py:61-72 (corner targets), _get_bbox_regression_labels_3d (:172-194) and the image
+// projection (lib/utils/transform.py:483-500) fused in.
+//
+//  pt_overlap_kernel  per candidate ROI (proposals followed by the G ground-truth boxes, :38-44):
+//                     f64 IoU against the GT staged in LDS, first-argmax / max.
+//  pt_compact_kernel  one workgroup: ordered compaction of the fg (max_ov >= FG_THRESH) and bg
+//                     (LO <= max_ov < HI) candidate lists + counts.
+//  (host)             draws npr.permutation(n_fg) / (n_bg) from the numpy global RNG: draw-for-draw
+//                     parity with `npr.choice(inds, size=k, replace=False)`.
+//  pt_emit_kernel     one thread per sampled ROI: gathers the ROI, its 8 corners (f32), corner
+//                     targets (gt - roi) / ||gt_p0 - gt_p6|| in f32, class-slot expansion, image box.
+#include <math.h>
+#include "geometry.h"
+
+#define PT_MAX_GT 1024
+
+struct PtDev {
+    const float *rois_bv, *rois_3d;      // (R,5), (R,7)
+    const float *gt_bv, *gt_3d;          // (G,5), (G,7)
+    int R, G;
+    double fg_thresh, bg_hi, bg_lo;
+    double *max_ov;                      // (R+G)
+    int32_t *assign;                     // (R+G)
+    int32_t *fg_list, *bg_list;          // (R+G) each
+};
+
+// row r of the candidate set: proposals then ground truth with a 0 batch column (:38-44)
+__device__ __forceinline__ void cand_bv(const PtDev &d, int r, float o[5])
+{
+    if (r < d.R) { for (int j = 0; j < 5; ++j) o[j] = d.rois_bv[5 * r + j]; }
+    else { o[0] = 0.0f; for (int j = 0; j < 4; ++j) o[1 + j] = d.gt_bv[5 * (r - d.R) + j]; }
+}
+__device__ __forceinline__ void cand_3d(const PtDev &d, int r, float o[7])
+{
+    if (r < d.R) { for (int j = 0; j < 7; ++j) o[j] = d.rois_3d[7 * r + j]; }
+    else { o[0] = 0.0f; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - d.R) + j]; }
+}
+
+__global__ __launch_bounds__(256) void pt_overlap_kernel(PtDev d)
+{
+    __shared__ float s_gt[PT_MAX_GT * 4];
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x)
+        for (int j = 0; j < 4; ++j) s_gt[4 * g + j] = d.gt_bv[5 * g + j];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= d.R + d.G) return;
+    float b[5];
+    cand_bv(d, r, b);
+    const double b0 = b[1], b1 = b[2], b2 = b[3], b3 = b[4];
+    double mx = 0.0;
+    int am = 0;
+    // bbox.pyx:33-54; overlaps.argmax(axis=1) = first maximum, overlaps.max(axis=1) (:233-237)
+    for (int g = 0; g < d.G; ++g) {
+        const double q0 = s_gt[4 * g], q1 = s_gt[4 * g + 1], q2 = s_gt[4 * g + 2], q3 = s_gt[4 * g + 3];
+        double o = 0.0;
+        const double iw = fmin(b2, q2) - fmax(b0, q0) + 1;
+        if (iw > 0) {
+            const double ih = fmin(b3, q3) - fmax(b1, q1) + 1;
+            if (ih > 0) {
+                const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
+                const double ua = (b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih;
+                o = iw * ih / ua;
+            }
+        }
+        if (g == 0 || o > mx) { mx = o; am = g; }
+    }
+    d.max_ov[r] = mx;
+    d.assign[r] = am;
+}
+
+__global__ __launch_bounds__(1024) void pt_compact_kernel(PtDev d, int32_t *counts)
+{
+    __shared__ int s_wave[16][2];
+    const int n = d.R + d.G;
+    const int per = (n + 1023) / 1024;
+    const int s = threadIdx.x * per, e = min(n, s + per);
+    int cf = 0, cb = 0;
+    for (int r = s; r < e; ++r) {
+        const double mx = d.max_ov[r];
+        cf += (mx >= d.fg_thresh);                          // :246
+        cb += (mx < d.bg_hi) && (mx >= d.bg_lo);            // :259-260
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inf = cf, inb = cb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int tf_ = __shfl_up(inf, o), tb_ = __shfl_up(inb, o);
+        if (lane >= o) { inf += tf_; inb += tb_; }
+    }
+    if (lane == 63) { s_wave[wave][0] = inf; s_wave[wave][1] = inb; }
+    __syncthreads();
+    int bf = 0, bb = 0, tf_tot = 0, tb_tot = 0;
+    for (int k = 0; k < 16; ++k) {
+        if (k < wave) { bf += s_wave[k][0]; bb += s_wave[k][1]; }
+        tf_tot += s_wave[k][0]; tb_tot += s_wave[k][1];
+    }
+    int of = bf + inf - cf, ob = bb + inb - cb;
+    for (int r = s; r < e; ++r) {
+        const double mx = d.max_ov[r];
+        if (mx >= d.fg_thresh) d.fg_list[of++] = r;
+        if ((mx < d.bg_hi) && (mx >= d.bg_lo)) d.bg_list[ob++] = r;
+    }
+    if (threadIdx.x == 0) { counts[0] = n; counts[1] = tf_tot; counts[2] = tb_tot; counts[3] = 0; }
+}
+
+struct PtEmit {
+    const int32_t *fg_pick, *bg_pick;    // positions in the fg / bg lists
+    int n_fg, n_bg, num_classes;
+    const float *gt_corners, *calib;     // (G,25), (4,12)
+    float *rois_bv, *rois_img, *targets, *rois_3d;
+    int32_t *labels;
+};
+
+__global__ __launch_bounds__(128) void pt_emit_kernel(PtDev d, PtEmit e)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = e.n_fg + e.n_bg;
+    if (t >= S) return;
+    // keep_inds = append(fg_inds, bg_inds) (:272)
+    const int r = (t < e.n_fg) ? d.fg_list[e.fg_pick[t]] : d.bg_list[e.bg_pick[t - e.n_fg]];
+    const int g = d.assign[r];
+    // labels = gt_boxes_bv[gt_assignment, 4]; labels[fg_rois_per_this_image:] = 0 (:238, :276)
+    const float lab = (t < e.n_fg) ? d.gt_bv[5 * g + 4] : 0.0f;
+    float b[5], q[7];
+    cand_bv(d, r, b);
+    cand_3d(d, r, q);
+    for (int j = 0; j < 5; ++j) e.rois_bv[5 * t + j] = b[j];
+    for (int j = 0; j < 7; ++j) e.rois_3d[7 * t + j] = q[j];
+    e.labels[t] = (int32_t)lab;
+    // lidar_3d_to_corners (transform.py:290-315), f32
+    const float *P = q + 1;
+    const float hl = P[3] / 2.0f, hw = P[4] / 2.0f, hh = P[5] / 2.0f;
+    float c[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c[k] = ((k & 2) ? -hl : hl) + P[0];
+        c[8 + k] = (((k + 1) & 2) ? -hw : hw) + P[1];
+        c[16 + k] = ((k & 4) ? hh : -hh) + P[2];
+    }
+    // bbox_transform_cnr (bbox_transform.py:61-72): f32; diag = sqrt((d0^2 + d1^2) + d2^2)
+    const float *gc = e.gt_corners + 25 * g;
+    const float d0 = gc[0] - gc[6], d1 = gc[8] - gc[14], d2 = gc[16] - gc[22];
+    float ss = __fmul_rn(d0, d0);
+    ss = __fadd_rn(ss, __fmul_rn(d1, d1));
+    ss = __fadd_rn(ss, __fmul_rn(d2, d2));
+    const float diag = sqrtf(ss);   // IEEE (correctly rounded) sqrt; __fsqrt_rn is the native approximation in HIP
+    // _get_bbox_regression_labels_3d (:172-194): class slot, zeros elsewhere
+    const int nc = e.num_classes;
+    float *T = e.targets + (long long)t * 24 * nc;
+    for (int j = 0; j < 24 * nc; ++j) T[j] = 0.0f;
+    const int cls = (int)(unsigned short)lab;           // np.array(..., dtype=np.uint16)
+    if (cls > 0 && cls < nc)
+        for (int j = 0; j < 24; ++j) T[24 * cls + j] = __fdiv_rn(gc[j] - c[j], diag);
+    // lidar_cnr_to_img (transform.py:483-500); first column = the ROI's batch index (:76)
+    float M[12];
+    proj_matrix(e.calib, M);
+    int32_t I[4];
+    image_box(M, P, I);
+    e.rois_img[5 * t] = b[0];
+    for (int j = 0; j < 4; ++j) e.rois_img[5 * t + 1 + j] = (float)I[j];
+}
+
+struct PtLayout { size_t o_maxov, o_assign, o_fg, o_bg, total; };
+static bool pt_layout(int R, int G, PtLayout &L)
+{
+    if (R < 0 || G <= 0 || G > PT_MAX_GT || (long long)R + G > (1 << 22)) return false;
+    const size_t n = (size_t)R + G;
+    size_t o = 0;
+    L.o_maxov = o; o += mv3d_align_up(n * 8);
+    L.o_assign = o; o += mv3d_align_up(n * 4);
+    L.o_fg = o; o += mv3d_align_up(n * 4);
+    L.o_bg = o; o += mv3d_align_up(n * 4);
+    L.total = o;
+    return true;
+}
+
+static void pt_fill(PtDev &d, const PtLayout &L, char *ws, const float *rois_bv, const float *rois_3d, int R,
+                    const float *gt_bv, const float *gt_3d, int G, const mv3d_proposal_target_params *p)
+{
+    d.rois_bv = rois_bv; d.rois_3d = rois_3d; d.gt_bv = gt_bv; d.gt_3d = gt_3d; d.R = R; d.G = G;
+    d.fg_thresh = p->fg_thresh; d.bg_hi = p->bg_thresh_hi; d.bg_lo = p->bg_thresh_lo;
+    d.max_ov = (double *)(ws + L.o_maxov); d.assign = (int32_t *)(ws + L.o_assign);
+    d.fg_list = (int32_t *)(ws + L.o_fg); d.bg_list = (int32_t *)(ws + L.o_bg);
+}
+
+extern "C" size_t mv3d_proposal_target_workspace_bytes(int num_rois, int G)
+{
+    PtLayout L;
+    return pt_layout(num_rois, G, L) ? L.total : 0;
+}
+
+extern "C" int mv3d_proposal_target_stage1(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
+                                           const float *gt_bv_dev, const float *gt_3d_dev, int G,
+                                           const mv3d_proposal_target_params *p, int32_t *counts_dev, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    PtLayout L;
+    if (!p || !pt_layout(num_rois, G, L) || !gt_bv_dev || !gt_3d_dev || !counts_dev ||
+        (num_rois > 0 && (!rois_bv_dev || !rois_3d_dev)))
+        return MV3D_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    PtDev d;
+    pt_fill(d, L, (char *)workspace, rois_bv_dev, rois_3d_dev, num_rois, gt_bv_dev, gt_3d_dev, G, p);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pt_overlap_kernel, dim3((num_rois + G + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(pt_compact_kernel, dim3(1), dim3(1024), 0, s, d, counts_dev);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
+                                           const float *gt_bv_dev, const float *gt_3d_dev,
+                                           const float *gt_corners_dev, int G, const float *calib_dev,
+                                           const mv3d_proposal_target_params *p, const int32_t *fg_pick_dev, int n_fg,
+                                           const int32_t *bg_pick_dev, int n_bg, float *rois_bv_out, float *rois_img_out,
+                                           int32_t *labels_out, float *bbox_targets_out, float *rois_3d_out,
+                                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    PtLayout L;
+    if (!p || !pt_layout(num_rois, G, L) || n_fg < 0 || n_bg < 0 || p->num_classes <= 0) return MV3D_ERR_INVALID_ARG;
+    if (n_fg + n_bg == 0) return MV3D_OK;
+    if (!gt_bv_dev || !gt_3d_dev || !gt_corners_dev || !calib_dev || (n_fg && !fg_pick_dev) || (n_bg && !bg_pick_dev) ||
+        !rois_bv_out || !rois_img_out || !labels_out || !bbox_targets_out || !rois_3d_out)
+        return MV3D_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    PtDev d;
+    pt_fill(d, L, (char *)workspace, rois_bv_dev, rois_3d_dev, num_rois, gt_bv_dev, gt_3d_dev, G, p);
+    PtEmit e;
+    e.fg_pick = fg_pick_dev; e.bg_pick = bg_pick_dev; e.n_fg = n_fg; e.n_bg = n_bg; e.num_classes = p->num_classes;
+    e.gt_corners = gt_corners_dev; e.calib = calib_dev;
+    e.rois_bv = rois_bv_out; e.rois_img = rois_img_out; e.targets = bbox_targets_out; e.rois_3d = rois_3d_out;
+    e.labels = labels_out;
+    hipLaunchKernelGGL(pt_emit_kernel, dim3((n_fg + n_bg + 127) / 128), dim3(128), 0, (hipStream_t)stream, d, e);
+    return mv3d_launch_status();
+}

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AnchorTargetParams, ProposalParams, check, lib
+from ._lib import AnchorTargetParams, ProposalParams, ProposalTargetParams, check, lib
 
 
 def _stream():
@@ -168,3 +168,36 @@ def anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, anc
                                          anchors_cap, _ptr(ws), ws.numel(), _stream())
     check(rc, "mv3d_anchor_target_stage2")
     return anchors, anchors_3d, n_anchors
+
+
+# ------------------------------------------------------------------ proposal_target_layer_3d
+def proposal_target_stage1(rois_bv, rois_3d, gt_bv, gt_3d, params):
+    dev = gt_bv.device
+    R, G = rois_bv.shape[0], gt_bv.shape[0]
+    counts = torch.empty((4,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib().mv3d_proposal_target_workspace_bytes(R, G), dev, "proposal_target")
+    rc = lib().mv3d_proposal_target_stage1(_ptr(rois_bv), _ptr(rois_3d), R, _ptr(gt_bv), _ptr(gt_3d), G, C.byref(params),
+                                           _ptr(counts), _ptr(ws), ws.numel(), _stream())
+    check(rc, "mv3d_proposal_target_stage1")
+    return counts, ws
+
+
+def proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, calib, params, fg_pick, bg_pick, ws):
+    dev = gt_bv.device
+    R, G = rois_bv.shape[0], gt_bv.shape[0]
+
+    def up(a):
+        return None if len(a) == 0 else torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(dev)
+
+    t_fg, t_bg = up(fg_pick), up(bg_pick)
+    S = len(fg_pick) + len(bg_pick)
+    nc = params.num_classes
+    out = (torch.empty((S, 5), dtype=torch.float32, device=dev), torch.empty((S, 5), dtype=torch.float32, device=dev),
+           torch.empty((S, 1), dtype=torch.int32, device=dev), torch.empty((S, 24 * nc), dtype=torch.float32, device=dev),
+           torch.empty((S, 7), dtype=torch.float32, device=dev))
+    rc = lib().mv3d_proposal_target_stage2(_ptr(rois_bv), _ptr(rois_3d), R, _ptr(gt_bv), _ptr(gt_3d), _ptr(gt_cnr), G,
+                                           _ptr(calib), C.byref(params), _ptr(t_fg), len(fg_pick), _ptr(t_bg), len(bg_pick),
+                                           _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]),
+                                           _ptr(ws), ws.numel(), _stream())
+    check(rc, "mv3d_proposal_target_stage2")
+    return out

@@ -274,3 +274,40 @@ def test_anchor_target_rng_stream_position(ops, oracle):
     assert after_dev == after_ora
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ------------------------------------------------------------------ proposal_target_layer_3d
+@pytest.mark.parametrize("name", ["proposal_target_few", "proposal_target_many"])
+def test_proposal_target_layer_3d_matches_reference(ops, name):
+    from mv3d_tf_amd.rpn_msr.proposal_target_layer_tf import proposal_target_layer_3d
+    g = golden(name)
+    np.random.seed(int(g["np_seed"]))
+    out = proposal_target_layer_3d(g["rois_bv_in"], g["rois_3d_in"], g["gt_bv"], g["gt_3d"], g["gt_cnr"], g["calib"], 2)
+    assert np.array_equal(out[0], g["rois_bv"])
+    assert np.array_equal(out[1], g["rois_img"])
+    assert np.array_equal(out[2], g["labels"]) and out[2].dtype == np.int32
+    assert np.array_equal(out[3], g["bbox_targets"])          # asked 1e-4, equal
+    assert np.array_equal(out[4], g["rois_3d"])
+
+
+def test_proposal_target_yml_thresholds_vs_oracle(ops, oracle):
+    """end2end yml thresholds (FG 0.7, BG [0, 0.5)), 2000 proposals + GT: sampled set, targets and RNG
+    position identical to the oracle."""
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.rpn_msr.proposal_target_layer_tf import proposal_target_layer_3d
+    g = golden("proposal_target_many")
+    saved = (cfg.TRAIN.FG_THRESH, cfg.TRAIN.BG_THRESH_LO)
+    cfg.TRAIN.FG_THRESH, cfg.TRAIN.BG_THRESH_LO = 0.7, 0.0
+    tr = dict(oracle.TRAIN, FG_THRESH=0.7, BG_THRESH_LO=0.0)
+    try:
+        np.random.seed(5)
+        a = proposal_target_layer_3d(g["rois_bv_in"], g["rois_3d_in"], g["gt_bv"], g["gt_3d"], g["gt_cnr"], g["calib"], 2)
+        ra = np.random.randint(1 << 30)
+        np.random.seed(5)
+        b = oracle.proposal_target_layer_3d(g["rois_bv_in"], g["rois_3d_in"], g["gt_bv"], g["gt_3d"], g["gt_cnr"], g["calib"], 2, train=tr)
+        rb = np.random.randint(1 << 30)
+    finally:
+        cfg.TRAIN.FG_THRESH, cfg.TRAIN.BG_THRESH_LO = saved
+    assert ra == rb and a[0].shape[0] == 128
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
