@@ -121,9 +121,19 @@ def time_kernel_events(fn, iters=50):
     return e0.elapsed_time(e1) / iters
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh + tools/pmc_summary.py:
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes); None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return int(json.load(open(path))[kernel]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def roofline(fr):
-    """Dominant kernel = RoiPool forward on the RGB view (largest algorithmic traffic per frame):
-    algorithmic bytes = feature map once + rois + (top f32 + argmax i32) outputs."""
+    """Dominant kernel = RoiPool forward on the RGB view (largest share of the step and the largest
+    algorithmic traffic): bytes = feature map once + rois + (top f32 + argmax i32) outputs."""
     B = fr.args.batch
     R = fr.out[0].shape[0] * fr.out[0].shape[1]
     H, W, C = RGB_MAP
@@ -131,9 +141,12 @@ def roofline(fr):
     rois = fr.out[1].view(-1, 5)
     ms = time_kernel_events(lambda: fr._roi(fr.rgb, rois, fr.tops[2], fr.tops[3]))
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"kernel": "roi_pool_fwd_kernel<4> (RGB view, R=%d)" % R, "bound": "hbm", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "alg_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2)}
+    return {"kernel": "roi_pool_fwd_xcd_kernel (RGB view 46x155x512, R=%d)" % R, "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic("roi_pool_fwd_xcd_kernel"),
+            "alg_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2),
+            "note": "HIP events over 50 back-to-back launches on the launch stream; traffic = PMC FETCH_SIZE*2+WRITE_SIZE "
+                    "per launch (profiles/r01_pmc_traffic.txt); write-only fill ceiling on this box 5.8-6.0 TB/s (profiles/r01_hbm_probe.txt)"}
 
 
 def cpu_baseline(fr, seconds):
@@ -203,10 +216,8 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    from mv3d_tf_amd import sharding
+    dt = sharding.max_over_ranks(dt, dist, device="cuda")
 
     if rank == 0:
         frames = args.steps * args.batch * world
