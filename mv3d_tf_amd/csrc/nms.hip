@@ -1,42 +1,36 @@
-// Greedy IoU NMS for gfx950 (wave64).
+// Greedy IoU NMS for gfx950 (wave64), one fused launch.
 //
 // Replaces lib/nms/cpu_nms.pyx:17-68 (== lib/utils/nms.pyx:17-68) and the CUDA path
-// lib/nms/nms_kernel.cu:34-144.  Two kernels:
+// lib/nms/nms_kernel.cu:34-144.  The suppression matrix is cut into 64x64 tiles of its upper
+// triangle, enumerated column-block-major (tile (rb, cb) at cb(cb+1)/2 + rb), every tile stored in
+// COLUMN form: lane j of the tile holds the u64 "which rows of row block rb suppress box cb*64+j".
 //
-//  nms_mask_kernel    all CUs, one single-wave workgroup per 64x64 tile of the UPPER TRIANGLE of
-//                     the suppression matrix (tiles enumerated column-block-major so the launch is
-//                     balanced and the tiles past the live box count fall off the end): lane = row
-//                     box (registers), the 64 column boxes staged in LDS and read back as
-//                     broadcasts.  Tiles within NMS_BAND blocks of the diagonal are stored in COLUMN
-//                     form (lane j gets the ballot of column j's predicate = "which rows of the
-//                     row block suppress box j"); far tiles in ROW form (one u64 per row).
-//  nms_reduce_kernel  one workgroup per frame = the greedy dependency chain, software-pipelined by
-//                     wave specialisation:
-//                       wave 0 (chain)   per 64-box block: removed bits -> fixed-point iteration on
-//                                        ballots over the diagonal tile (converges to the unique
-//                                        greedy set) -> kept mask K_b; then the near-band column
-//                                        tiles turn K_b into removed bits of the next NMS_BAND-1
-//                                        blocks with one AND + one wave compare each.  All its
-//                                        global addresses are static, so its loads run 4 blocks
-//                                        ahead: the per-block critical path is ALU only.
-//                       waves 1-15       trail the chain: OR the ROW-form words of kept rows into
-//                                        the LDS bitmap for blocks >= NMS_BAND ahead (only kept rows
-//                                        are ever read).  LDS flags (chain position / per-worker
-//                                        progress) order the two roles; no global synchronisation.
-//                     Stops as soon as max_keep boxes are kept (= the reference's
-//                     keep[:post_nms_topN]) and, for proposal_layer_3d, gathers the ROI blobs.
+//  workgroups [batch, ...)  PRODUCERS, 4 waves = 4 tiles each, in tile order.  lane = column box
+//        (registers), the 64 row boxes staged in LDS and read back as broadcasts; packed-f32 math
+//        and a division-free exact compare (tile_fast()); the lane's word is a plain accumulation
+//        of predicate bits.  A finished tile is published with an agent-scope release and an
+//        atomic increment of ready[cb]; a producer that sees the frame's cancel flag exits at once.
+//  workgroup  f < batch     CHAIN of frame f, the greedy dependency itself, in "pull" form: for block
+//        b it needs exactly column block b (b+1 tiles, static addresses).  removed(j) =
+//        OR over row blocks rb < b of (tile(rb,b)[j] & K_rb) != 0 -- one AND + one wave compare per
+//        tile, spread over three pull waves -- then wave 0 resolves the diagonal tile by fixed-point
+//        iteration on ballots (converges to the unique greedy set) and publishes K_b in LDS.  The
+//        chain polls ready[] 2, 4, 8, then 16 column blocks at a time (one agent-scope acquire each),
+//        prefetches the next column block while it works, stops at max_keep kept boxes (= the
+//        reference's keep[:post_nms_topN]), raises the cancel flag so that the tiles nobody will read
+//        are never computed, and finally gathers the ROI blobs of proposal_layer_3d.
 //
+// Producers never wait, so the only inter-workgroup edge is producer -> chain (release/acquire at
+// agent scope, placement independent).  ready[] / cancel are zeroed before every launch (by the
+// preceding kernel of the stream on the proposal path, else by a memset node).
 // Arithmetic is the reference's, operation for operation (see pair_suppresses()).
 #include <math.h>
 #include "kernels.h"
 
 #define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
-#define NMS_BAND 8          // diagonal + 7 following column blocks are kept in column form
-#define NMS_WORKERS 15
-#define NMS_GROUPS 3            // worker groups; group g owns the blocks b = g (mod NMS_GROUPS)
-#define NMS_GW 5                // workers per group
-#define NMS_ROWS_PER_WORKER 13  // ceil(64 / NMS_GW)
-#define NMS_PF 4            // chain-wave prefetch depth (blocks)
+#define NMS_TPB 4           // tiles (waves) per producer workgroup
+#define NMS_CB 16           // column blocks acquired per poll (the first polls are shorter)
+#define NMS_PULL 3          // pull waves of the chain workgroup (waves 1..3; wave 0 = diagonal)
 
 // lib/nms/cpu_nms.pyx:55-65 for one (kept box i, later box j) pair.  f32, separate IEEE
 // ops.  Cython emits ((xx2 - xx1) + 1.0) with a double literal and narrows to f32; for
@@ -70,13 +64,15 @@ struct NmsDev {
     const int32_t *n_dev;
     int n_cap;
     int nbw;                     // blocks of 64 boxes per frame (capacity)
-    int nbs;                     // row-form words per row = nbw rounded up to even (16-byte rows)
+    int ntiles;                  // nbw (nbw + 1) / 2
+    int pblocks;                 // producer workgroups per frame
+    int batch;
     float tf;
     float neg_h;                 // -(half the gap below tf), see tile_fast()
     int fast_ok;                 // tf is a positive normal f32 in a range where tile_fast() is valid
     int max_keep;
-    unsigned long long *mask;    // (batch, nbw*64, nbw)        row form, far tiles
-    unsigned long long *band;    // (batch, nbw, NMS_BAND, 64)  column form, near tiles
+    unsigned long long *tiles;   // (batch, ntiles, 64) column form
+    int32_t *flags;              // (batch, nbw + 8): ready[nbw], then the cancel word
     int32_t *keep;
     long long keep_frame_stride;
     int32_t *num_keep;
@@ -134,62 +130,59 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
                                                         const float *s_area, const float tf, const float neg_h,
                                                         const int lane, float &min_den, bool &undecided)
 {
-    unsigned lo = 0, hi = 0;
+    unsigned long long word = 0;
     bool amb = false;
     const f2 ntf = {-tf, -tf}, nh = {neg_h, neg_h}, one = {1.0f, 1.0f}, la = {larea, larea};
+    // 4 chunks of 16 columns: the chunk body is straight-line (constant shifts, loads hoisted), the
+    // chunk loop is kept rolled so that the live set stays well inside 128 VGPRs
+#pragma unroll 1
+    for (int c = 0; c < 64; c += 16) {
+        unsigned bits = 0;
 #pragma unroll
-    for (int j = 0; j < 64; j += 2) {
-        const float4 A = s_box[j], B = s_box[j + 1];
-        const f2 ca = *reinterpret_cast<const f2 *>(s_area + j);
-        const f2 xx1 = {vmax(lb.x, A.x), vmax(lb.x, B.x)}, yy1 = {vmax(lb.y, A.y), vmax(lb.y, B.y)};
-        const f2 xx2 = {vmin(lb.z, A.z), vmin(lb.z, B.z)}, yy2 = {vmin(lb.w, A.w), vmin(lb.w, B.w)};
-        const f2 dx = (xx2 - xx1) + one, dy = (yy2 - yy1) + one;
-        const f2 w = {vmax(0.0f, dx.x), vmax(0.0f, dx.y)}, h = {vmax(0.0f, dy.x), vmax(0.0f, dy.y)};
-        const f2 inter = w * h;
-        const f2 den = (la + ca) - inter;
-        min_den = vmin3(min_den, den.x, den.y);
-        const f2 e = __builtin_elementwise_fma(ntf, den, inter);
-        const f2 nc = den * nh;
-        bool p0 = e.x > nc.x, p1 = e.y > nc.y;
-        amb |= (e.x == nc.x) | (e.y == nc.y);
-        if (DIAG_SWAPPED) { p0 = p0 && (j < lane); p1 = p1 && (j + 1 < lane); }
-        if (j < 32) { lo |= p0 ? (1u << j) : 0u; lo |= p1 ? (2u << j) : 0u; }
-        else { hi |= p0 ? (1u << (j - 32)) : 0u; hi |= p1 ? (2u << (j - 32)) : 0u; }
+        for (int u = 0; u < 16; u += 2) {
+            const int j = c + u;
+            const float4 A = s_box[j], B = s_box[j + 1];
+            const f2 ca = *reinterpret_cast<const f2 *>(s_area + j);
+            const f2 xx1 = {vmax(lb.x, A.x), vmax(lb.x, B.x)}, yy1 = {vmax(lb.y, A.y), vmax(lb.y, B.y)};
+            const f2 xx2 = {vmin(lb.z, A.z), vmin(lb.z, B.z)}, yy2 = {vmin(lb.w, A.w), vmin(lb.w, B.w)};
+            const f2 dx = (xx2 - xx1) + one, dy = (yy2 - yy1) + one;
+            const f2 w = {vmax(0.0f, dx.x), vmax(0.0f, dx.y)}, h = {vmax(0.0f, dy.x), vmax(0.0f, dy.y)};
+            const f2 inter = w * h;
+            const f2 den = (la + ca) - inter;
+            min_den = vmin3(min_den, den.x, den.y);
+            const f2 e = __builtin_elementwise_fma(ntf, den, inter);
+            const f2 nc = den * nh;
+            bool p0 = e.x > nc.x, p1 = e.y > nc.y;
+            amb |= (e.x == nc.x) | (e.y == nc.y);
+            if (DIAG_SWAPPED) { p0 = p0 && (j < lane); p1 = p1 && (j + 1 < lane); }
+            bits |= p0 ? (1u << u) : 0u;
+            bits |= p1 ? (2u << u) : 0u;
+        }
+        word |= (unsigned long long)bits << c;
     }
     undecided = amb;
-    return ((unsigned long long)hi << 32) | lo;
+    return word;
 }
 
-// grid: (nbw*(nbw+1)/2 tiles, 1, batch); block 64 = one wave per tile.
-__global__ __launch_bounds__(64) void nms_mask_kernel(NmsDev d)
+__device__ __forceinline__ int agent_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---------------------------------------------------------------------------------- producers
+__device__ __forceinline__ void produce_tile(const NmsDev &d, const int f, const int t, float4 *s_box, float *s_area,
+                                             const int lane, const int n, const bool active, const int cb, const int rb)
 {
-    __shared__ float4 s_box[64];
-    __shared__ float s_area[64];
-    const int f = blockIdx.z;
-    const int n = frame_n(d, f);
-    // tile t -> (cb, rb <= cb), column-block-major: t = cb(cb+1)/2 + rb
-    const int t = blockIdx.x;
-    int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
-    while (cb * (cb + 1) / 2 > t) --cb;
-    const int rb = t - cb * (cb + 1) / 2;
-    if (cb * 64 >= n) return;
-    const int lane = threadIdx.x;
-    const int dist = cb - rb;
-    const bool diag = (dist == 0), colform = (dist < NMS_BAND);
-    // Row form: lane = row box, LDS = column boxes, bit j = column j.  Column form (near band):
-    // the roles are swapped -- the predicate is symmetric in the two boxes (max/min/+/* commute) --
-    // so the lane's word is directly "which rows of block rb suppress my column".
-    const int lds_idx = (colform ? rb : cb) * 64 + lane, own_idx = (colform ? cb : rb) * 64 + lane;
-    float4 sb = make_float4(NAN, NAN, NAN, NAN);    // NaN box: every predicate false
-    if (lds_idx < n) sb = load_box(d, f, lds_idx);
+    // LDS side = the 64 ROW boxes of block rb; lane = COLUMN box cb*64 + lane
+    const int ridx = rb * 64 + lane, cidx = cb * 64 + lane;
+    float4 sb = make_float4(NAN, NAN, NAN, NAN);            // NaN box: every predicate false
+    if (active && ridx < n) sb = load_box(d, f, ridx);
     s_box[lane] = sb;
-    s_area[lane] = ((sb.z - sb.x) + 1.0f) * ((sb.w - sb.y) + 1.0f);          // cpu_nms.pyx:24
-    const bool lds_tame = __all(tame(sb));          // false if the block is ragged (NaN padding)
+    s_area[lane] = ((sb.z - sb.x) + 1.0f) * ((sb.w - sb.y) + 1.0f);         // cpu_nms.pyx:24
+    const bool lds_tame = __all(tame(sb));                  // false if the block is ragged (NaN padding)
     __syncthreads();
+    if (!active) return;
     float4 lb = make_float4(NAN, NAN, NAN, NAN);
-    if (own_idx < n) lb = load_box(d, f, own_idx);
+    if (cidx < n) lb = load_box(d, f, cidx);
     const float larea = ((lb.z - lb.x) + 1.0f) * ((lb.w - lb.y) + 1.0f);
+    const bool diag = (rb == cb);
     unsigned long long word = 0;
     bool any_zero = false, done = false;
     if (d.fast_ok && lds_tame && __all(tame(lb))) {
@@ -206,163 +199,129 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsDev d)
         for (int j = 0; j < 64; ++j) {
             const float4 q = s_box[j];
             bool zd;
-            // arguments in (kept box i, later box j) order of cpu_nms.pyx: i = row side
-            bool p = colform ? pair_suppresses(q.x, q.y, q.z, q.w, s_area[j], lb.x, lb.y, lb.z, lb.w, larea, d.tf, zd)
-                             : pair_suppresses(lb.x, lb.y, lb.z, lb.w, larea, q.x, q.y, q.z, q.w, s_area[j], d.tf, zd);
-            const bool live = diag ? (j < lane) : true;                        // rows before my column
+            // (kept box i = row j of the LDS side, later box = my column), the argument order of cpu_nms.pyx
+            bool p = pair_suppresses(q.x, q.y, q.z, q.w, s_area[j], lb.x, lb.y, lb.z, lb.w, larea, d.tf, zd);
+            const bool live = diag ? (j < lane) : true;                       // rows before my column
             p = p && live;
-            any_zero |= (zd && live && own_idx < n && ((colform ? rb : cb) * 64 + j) < n);
+            any_zero |= (zd && live && cidx < n && (rb * 64 + j) < n);
             word |= (unsigned long long)p << j;
         }
     }
-    if (colform) d.band[(((long long)f * d.nbw + rb) * NMS_BAND + dist) * 64 + lane] = word;
-    else if (own_idx < n) d.mask[((long long)f * d.nbw * 64 + own_idx) * d.nbs + cb] = word;
+    // publish (guide G16, form R1): the 8-byte payload goes out WRITE-THROUGH (agent-scope relaxed
+    // atomic store = global_store_dwordx2 sc1), so no L2 write-back fence per tile is needed; the
+    // wave drains its stores, then one lane moves the column block's counter.
+    __hip_atomic_store(&d.tiles[((long long)f * d.ntiles + t) * 64 + lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&d.flags[(long long)f * (d.nbw + 8) + cb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ int lds_load_i32(const int *p)
+// ---------------------------------------------------------------------------------- chain
+template <int KMAX>
+__device__ __forceinline__ void chain(const NmsDev &d, const int f)
 {
-    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    return v;
-}
-__device__ __forceinline__ void lds_store_i32(int *p, int v)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// grid: (batch); block 1024 = 16 waves: wave 0 = chain, waves 1..15 = bulk workers.
-__global__ __launch_bounds__(1024) void nms_reduce_kernel(NmsDev d)
-{
-    __shared__ unsigned long long s_removed[NMS_MAX_WORDS];   // far-band contributions (workers, ds_or)
-    __shared__ unsigned long long s_kept[NMS_MAX_WORDS];      // K_b, valid once s_chain_pos > b
-    __shared__ int s_chain_pos, s_done, s_total;
-    __shared__ int s_wprog[NMS_WORKERS + 1];
-    const int f = blockIdx.x;
+    __shared__ unsigned long long s_K[NMS_MAX_WORDS];        // kept mask of every finished block
+    __shared__ unsigned long long s_rem;                      // removed bits of the block in flight
+    __shared__ int s_total, s_stop;
     const int n = frame_n(d, f);
     const int nb = (n + 63) >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long *mask = d.mask + (long long)f * d.nbw * 64 * d.nbs;
-    const unsigned long long *band = d.band + (long long)f * d.nbw * NMS_BAND * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long *tiles = d.tiles + (long long)f * d.ntiles * 64;
+    int32_t *flags = d.flags + (long long)f * (d.nbw + 8);
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
-    for (int w = threadIdx.x; w < NMS_MAX_WORDS; w += blockDim.x) s_removed[w] = 0;
-    if (threadIdx.x < NMS_WORKERS + 1) s_wprog[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_chain_pos = 0; s_done = 0; s_total = 0; }
+    if (threadIdx.x == 0) { s_rem = 0ull; s_total = 0; s_stop = 0; }
     __syncthreads();
-
-    if (wave == 0) {
-        // ------------------------------------------------------------------ chain wave
-        __builtin_amdgcn_s_setprio(3);
-        unsigned long long ring[NMS_PF][NMS_BAND];
+    int total = 0;                                            // tracked by wave 0
+    for (int c0 = 0, c1 = 0; c0 < nb; c0 = c1) {
+        // batches of 2, 4, 8, then 16 column blocks: start early, then amortise the acquire
+        c1 = min(nb, c0 + (c0 == 0 ? 2 : (c0 < 6 ? 4 : (c0 < 14 ? 8 : NMS_CB))));
+        const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+        if (wave == 0) {
+            // column block c is complete when its c + 1 tiles have been published
+            const int c = c0 + lane;
+            for (;;) {
+                const bool ok = (c >= c1) || (agent_load(&flags[c]) >= c + 1);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const long long t_wait = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+        // Wave 0 owns the diagonal tiles (the serial part); waves 1..3 pull the off-diagonal tiles of
+        // column block b: row blocks rb = (wave - 1) + 3 k  (< b).  cur / dcur hold column b.
+        unsigned long long cur[KMAX], dcur = 0ull, dnxt = 0ull;
+        {
+            const long long base = (long long)c0 * (c0 + 1) / 2;
+            if (wave == 0) dcur = tiles[(base + c0) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < NMS_PF; ++s)
-#pragma unroll
-            for (int k = 0; k < NMS_BAND; ++k)
-                ring[s][k] = band[((long long)min(s, d.nbw - 1) * NMS_BAND + k) * 64 + lane];
-        unsigned long long acc[NMS_BAND];             // acc[k]: near-band removed bits for block b+k
-#pragma unroll
-        for (int k = 0; k < NMS_BAND; ++k) acc[k] = 0ull;
-        int total = 0;
+            for (int k = 0; k < KMAX; ++k) {
+                const int rb = wave - 1 + NMS_PULL * k;
+                cur[k] = (wave > 0 && rb < c0) ? tiles[(base + rb) * 64 + lane] : 0ull;
+            }
+        }
         bool stop = false;
-        for (int b0 = 0; b0 < nb && !stop; b0 += NMS_PF) {
+        for (int b = c0; b < c1; ++b) {
+            if (wave > 0) {
+                unsigned long long part = 0ull;
 #pragma unroll
-            for (int s = 0; s < NMS_PF; ++s) {
-                const int b = b0 + s;
-                if (b >= nb || stop) break;
-                const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-                // far-band words for this block come from rows of blocks <= b - NMS_BAND
-                if (b >= NMS_BAND) {
-                    const int need = b - NMS_BAND + 1;
-                    for (;;) {
-                        const int pr = (lane < NMS_WORKERS) ? lds_load_i32(&s_wprog[lane]) : need;
-                        if (__all(pr >= need)) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
+                for (int k = 0; k < KMAX; ++k) {
+                    const int rb = wave - 1 + NMS_PULL * k;
+                    if (rb < b) part |= __ballot((cur[k] & s_K[rb]) != 0ull);
                 }
-                const long long t_wait = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-                int iters = 0;
-                const unsigned long long rem = s_removed[b] | acc[0];
+                if (lane == 0 && part) atomicOr(&s_rem, part);
+            }
+            if (b + 1 < c1) {
+                // cur is dead: refill it with column b + 1 (already acquired); the loads fly under the
+                // two barriers and the diagonal step below
+                const long long base = (long long)(b + 1) * (b + 2) / 2;
+                if (wave == 0) dnxt = tiles[(base + b + 1) * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int rb = wave - 1 + NMS_PULL * k;
+                    cur[k] = (wave > 0 && rb < b + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const long long t0 = d.trace ? (long long)__builtin_readcyclecounter() : 0;
                 const int p = b * 64 + lane;
-                const bool alive = (p < n) && !((rem >> lane) & 1ull);
-                const unsigned long long col = ring[s][0];
+                const bool alive = (p < n) && !((s_rem >> lane) & 1ull);
                 unsigned long long K = __ballot(alive);
+                int iters = 0;
                 // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
                 // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
                 for (;;) {
-                    const unsigned long long K2 = __ballot(alive && !(col & K));
+                    const unsigned long long K2 = __ballot(alive && !(dcur & K));
                     ++iters;
                     if (K2 == K) break;
                     K = K2;
-                }
-                if (d.trace && f == 0 && lane == 0) {
-                    long long *tr = d.trace + 4 * b;
-                    tr[0] = t_begin; tr[1] = t_wait; tr[2] = (long long)__builtin_readcyclecounter();
-                    tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
                 }
                 const bool kept = (K >> lane) & 1ull;
                 const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
                 if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
                 total += __popcll(K);
-                if (lane == 0) s_kept[b] = K;
-                lds_store_i32(&s_chain_pos, b + 1);
-                if (d.max_keep > 0 && total >= d.max_keep) { stop = true; break; }
-                // near band: K_b -> removed bits of blocks b+1 .. b+NMS_BAND-1
-#pragma unroll
-                for (int k = 1; k < NMS_BAND; ++k) acc[k] |= __ballot((ring[s][k] & K) != 0ull);
-#pragma unroll
-                for (int k = 0; k < NMS_BAND - 1; ++k) acc[k] = acc[k + 1];
-                acc[NMS_BAND - 1] = 0ull;
-                // refill this ring slot for block b + NMS_PF (static addresses: runs ahead of the chain)
-                const int bn = b + NMS_PF;
-                if (bn < nb) {
-#pragma unroll
-                    for (int k = 0; k < NMS_BAND; ++k) ring[s][k] = band[((long long)bn * NMS_BAND + k) * 64 + lane];
+                if (lane == 0) {
+                    s_K[b] = K;
+                    s_rem = 0ull;
+                    s_total = total;
+                    if (d.max_keep > 0 && total >= d.max_keep) s_stop = 1;
+                    if (d.trace && f == 0) {
+                        long long *tr = d.trace + 4 * b;
+                        tr[0] = (b == c0) ? t_begin : t0; tr[1] = (b == c0) ? t_wait : t0;
+                        tr[2] = (long long)__builtin_readcyclecounter();
+                        tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
+                    }
                 }
+                dcur = dnxt;
             }
+            __syncthreads();
+            if (s_stop) { stop = true; break; }
         }
-        if (lane == 0) s_total = total;
-        lds_store_i32(&s_done, 1);
-    } else {
-        // ------------------------------------------------------------------ bulk workers
-        // Group g trails the chain on the blocks b = g (mod NMS_GROUPS); its NMS_GW waves split the
-        // 64 rows.  All loads of a (block, pass) are in flight together: 16 bytes = 2 words per lane,
-        // 128 words per pass.  s_wprog[me] = first block this wave has NOT finished its share of
-        // (blocks of other groups count as finished).
-        const int me = wave - 1, g = me / NMS_GW, lw = me % NMS_GW;
-        lds_store_i32(&s_wprog[me], g);
-        int b = g;
-        for (; b + NMS_BAND < nb; b += NMS_GROUPS) {
-            bool quit = false;
-            for (;;) {
-                if (lds_load_i32(&s_chain_pos) > b) break;
-                if (lds_load_i32(&s_done)) { quit = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (quit) break;
-            const unsigned long long K = s_kept[b];
-            const int w0 = b + NMS_BAND;               // first far word of this block's rows
-            for (int wb = (w0 & ~1); wb < nb; wb += 128) {
-                const int w = wb + 2 * lane;            // this lane's two words: w, w + 1
-                ulonglong2 a[NMS_ROWS_PER_WORKER];
-#pragma unroll
-                for (int r = 0; r < NMS_ROWS_PER_WORKER; ++r) {
-                    const int i = lw + NMS_GW * r;
-                    const bool on = (i < 64) && ((K >> (i & 63)) & 1ull) && (w < nb);
-                    const ulonglong2 *row = reinterpret_cast<const ulonglong2 *>(mask + (long long)(b * 64 + (i & 63)) * d.nbs + w);
-                    a[r] = on ? *row : make_ulonglong2(0ull, 0ull);
-                }
-                ulonglong2 v = make_ulonglong2(0ull, 0ull);
-#pragma unroll
-                for (int r = 0; r < NMS_ROWS_PER_WORKER; ++r) { v.x |= a[r].x; v.y |= a[r].y; }
-                if (w >= w0 && w < nb && v.x) atomicOr(&s_removed[w], v.x);        // w0 - 1 is a band slot: skip
-                if (w + 1 < nb && v.y) atomicOr(&s_removed[w + 1], v.y);
-            }
-            lds_store_i32(&s_wprog[me], b + NMS_GROUPS);
-        }
-        lds_store_i32(&s_wprog[me], NMS_MAX_WORDS * 2);   // nothing left that the chain could wait for
+        if (stop) break;
     }
-    __syncthreads();
+    // nobody will read the remaining tiles: let the producers that have not started skip them
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[d.nbw], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int nk = s_total;
     if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
     if (threadIdx.x == 0) d.num_keep[f] = nk;
@@ -395,11 +354,48 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(NmsDev d)
     }
 }
 
+// grid: batch chain workgroups, then batch * pblocks producer workgroups; block 256 = 4 waves.
+__global__ __launch_bounds__(256) void nms_fused_kernel(NmsDev d)
+{
+    if ((int)blockIdx.x < d.batch) {
+        // KMAX = ceil(nbw / NMS_PULL) tiles per pull wave and column
+        if (d.nbw <= 48) chain<16>(d, blockIdx.x);
+        else if (d.nbw <= 96) chain<32>(d, blockIdx.x);
+        else if (d.nbw <= 192) chain<64>(d, blockIdx.x);
+        else chain<86>(d, blockIdx.x);
+        return;
+    }
+    __shared__ float4 s_box[NMS_TPB][64];
+    __shared__ float s_area[NMS_TPB][64];
+    const int pb = blockIdx.x - d.batch;
+    const int f = pb / d.pblocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = (pb % d.pblocks) * NMS_TPB + wave;
+    const int n = frame_n(d, f);
+    // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
+    int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+    while (cb * (cb + 1) / 2 > t) --cb;
+    const int rb = t - cb * (cb + 1) / 2;
+    const bool cancelled = agent_load(&d.flags[(long long)f * (d.nbw + 8) + d.nbw]) != 0;
+    const bool active = (t < d.ntiles) && (cb * 64 < n) && !cancelled;
+    produce_tile(d, f, t, s_box[wave], s_area[wave], lane, n, active, cb, rb);
+}
+
 size_t mv3d_nms_ws_bytes(int n_cap, int batch)
 {
-    const size_t nbw = (size_t)(n_cap + 63) / 64, nbs = (nbw + 1) & ~(size_t)1;
-    const size_t rows = nbw * 64;
-    return (size_t)batch * (mv3d_align_up(rows * nbs * 8) + mv3d_align_up(nbw * NMS_BAND * 64 * 8)) + MV3D_ALIGN;
+    const size_t nbw = (size_t)(n_cap + 63) / 64;
+    const size_t ntiles = nbw * (nbw + 1) / 2;
+    return (size_t)batch * mv3d_align_up(ntiles * 64 * 8) + mv3d_align_up((size_t)batch * (nbw + 8) * 4);
+}
+
+// where the flag words (ready[] + cancel) of a launch live, so that a preceding kernel can zero them
+int32_t *mv3d_nms_flags(void *workspace, int n_cap, int batch, size_t *count)
+{
+    const size_t nbw = (size_t)(n_cap + 63) / 64;
+    const size_t ntiles = nbw * (nbw + 1) / 2;
+    if (count) *count = (size_t)batch * (nbw + 8);
+    return (int32_t *)((char *)workspace + (size_t)batch * mv3d_align_up(ntiles * 64 * 8));
 }
 
 int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
@@ -410,20 +406,18 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     NmsDev d;
     d.boxes = L.boxes; d.box_stride = L.box_stride; d.boxes_frame_stride = L.boxes_frame_stride;
     d.idx = L.idx; d.idx_frame_stride = L.idx_frame_stride; d.n_dev = L.n_dev; d.n_cap = L.n_cap;
-    d.nbw = nbw; d.nbs = (nbw + 1) & ~1; d.tf = L.strict_gt ? nextafterf(L.thresh_f32, INFINITY) : L.thresh_f32; d.max_keep = L.max_keep;
+    d.nbw = nbw; d.ntiles = nbw * (nbw + 1) / 2; d.pblocks = (d.ntiles + NMS_TPB - 1) / NMS_TPB; d.batch = L.batch;
+    d.tf = L.strict_gt ? nextafterf(L.thresh_f32, INFINITY) : L.thresh_f32; d.max_keep = L.max_keep;
     d.fast_ok = (d.tf >= 0x1p-10f && d.tf <= 0x1p10f) ? 1 : 0;
     d.neg_h = d.fast_ok ? -0.5f * (d.tf - nextafterf(d.tf, 0.0f)) : 0.0f;
-    const size_t rows = (size_t)nbw * 64;
-    d.mask = (unsigned long long *)L.workspace;
-    d.band = (unsigned long long *)((char *)L.workspace + (size_t)L.batch * mv3d_align_up(rows * (size_t)d.nbs * 8));
+    d.tiles = (unsigned long long *)L.workspace;
+    size_t nflags;
+    d.flags = mv3d_nms_flags(L.workspace, L.n_cap, L.batch, &nflags);
     d.keep = L.keep; d.keep_frame_stride = L.keep_frame_stride; d.num_keep = L.num_keep; d.status = L.status;
     d.emit = L.emit;
     d.trace = L.trace;
-    if (nbw > 0) {
-        dim3 grid(nbw * (nbw + 1) / 2, 1, L.batch);
-        hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, stream, d);
-    }
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(L.batch), dim3(1024), 0, stream, d);
+    if (!L.flags_zeroed) MV3D_HIP_TRY(hipMemsetAsync(d.flags, 0, nflags * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(nms_fused_kernel, dim3(L.batch + L.batch * d.pblocks), dim3(256), 0, stream, d);
     return mv3d_launch_status();
 }
 
