@@ -37,10 +37,8 @@ struct NmsLaunch {
     void *workspace;            // mv3d_nms_ws_bytes(n_cap, batch)
     EmitDev emit;               // optional fused ROI-blob emission (proposal_layer_tf.py:188-191)
     long long *trace;           // diagnostics (mv3d_nms_device_trace), may be NULL
-    int flags_zeroed;           // the caller's previous kernel zeroed mv3d_nms_flags(): no memset node
 };
 size_t mv3d_nms_ws_bytes(int n_cap, int batch);
-int32_t *mv3d_nms_flags(void *workspace, int n_cap, int batch, size_t *count);
 int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream);
 
 // ---- rank by counting (rank.hip) -----------------------------------------------------

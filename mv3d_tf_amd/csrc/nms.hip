@@ -1,36 +1,32 @@
-// Greedy IoU NMS for gfx950 (wave64), one fused launch.
+// Greedy IoU NMS for gfx950 (wave64).
 //
 // Replaces lib/nms/cpu_nms.pyx:17-68 (== lib/utils/nms.pyx:17-68) and the CUDA path
 // lib/nms/nms_kernel.cu:34-144.  The suppression matrix is cut into 64x64 tiles of its upper
 // triangle, enumerated column-block-major (tile (rb, cb) at cb(cb+1)/2 + rb), every tile stored in
 // COLUMN form: lane j of the tile holds the u64 "which rows of row block rb suppress box cb*64+j".
+// The work proceeds in ROUNDS over ranges of column blocks ([0,32), [32,nbw) -- three for > 8192 boxes):
+// the greedy pass almost always reaches post_nms_topN inside the first range, and a round whose
+// frame is already finished returns at once, so the tiles nobody will read are never computed
+// (a TEST-config frame needs ~15 of its 94 column blocks: 528 tiles instead of 4465).
 //
-//  workgroups [batch, ...)  PRODUCERS, 4 waves = 4 tiles each, in tile order.  lane = column box
-//        (registers), the 64 row boxes staged in LDS and read back as broadcasts; packed-f32 math
-//        and a division-free exact compare (tile_fast()); the lane's word is a plain accumulation
-//        of predicate bits.  A finished tile is published with an agent-scope release and an
-//        atomic increment of ready[cb]; a producer that sees the frame's cancel flag exits at once.
-//  workgroup  f < batch     CHAIN of frame f, the greedy dependency itself, in "pull" form: for block
-//        b it needs exactly column block b (b+1 tiles, static addresses).  removed(j) =
-//        OR over row blocks rb < b of (tile(rb,b)[j] & K_rb) != 0 -- one AND + one wave compare per
-//        tile, spread over three pull waves -- then wave 0 resolves the diagonal tile by fixed-point
-//        iteration on ballots (converges to the unique greedy set) and publishes K_b in LDS.  The
-//        chain polls ready[] 2, 4, 8, then 16 column blocks at a time (one agent-scope acquire each),
-//        prefetches the next column block while it works, stops at max_keep kept boxes (= the
-//        reference's keep[:post_nms_topN]), raises the cancel flag so that the tiles nobody will read
-//        are never computed, and finally gathers the ROI blobs of proposal_layer_3d.
+//  nms_tiles_kernel   all CUs, one single-wave workgroup per tile of the round.  lane = column box
+//        (registers), the 64 row boxes staged in LDS and read back as broadcasts; packed-f32 math and
+//        a division-free exact compare (tile_fast()); the lane's word is a plain accumulation of bits.
+//  nms_chain_kernel   one workgroup per frame: the greedy dependency in "pull" form.  For block b it
+//        needs exactly column block b (b+1 tiles, static addresses, prefetched one column ahead):
+//        removed(j) = OR over row blocks rb < b of (tile(rb,b)[j] & K_rb) != 0 -- one AND + one wave
+//        compare per tile, spread over 15 pull waves -- then wave 0 resolves the diagonal tile by
+//        fixed-point iteration on ballots (converges to the unique greedy set) and publishes K_b in
+//        LDS.  State (K_b, kept count, done flag) persists in the workspace between rounds.  The round
+//        that finishes the frame (max_keep kept boxes = the reference's keep[:post_nms_topN], or the
+//        last block) also gathers the ROI blobs of proposal_layer_3d.
 //
-// Producers never wait, so the only inter-workgroup edge is producer -> chain (release/acquire at
-// agent scope, placement independent).  ready[] / cancel are zeroed before every launch (by the
-// preceding kernel of the stream on the proposal path, else by a memset node).
 // Arithmetic is the reference's, operation for operation (see pair_suppresses()).
 #include <math.h>
 #include "kernels.h"
 
 #define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
-#define NMS_TPB 4           // tiles (waves) per producer workgroup
-#define NMS_CB 16           // column blocks acquired per poll (the first polls are shorter)
-#define NMS_PULL 3          // pull waves of the chain workgroup (waves 1..3; wave 0 = diagonal)
+#define NMS_PULL 15         // pull waves of the chain workgroup (waves 1..15; wave 0 = diagonal)
 
 // lib/nms/cpu_nms.pyx:55-65 for one (kept box i, later box j) pair.  f32, separate IEEE
 // ops.  Cython emits ((xx2 - xx1) + 1.0) with a double literal and narrows to f32; for
@@ -65,14 +61,15 @@ struct NmsDev {
     int n_cap;
     int nbw;                     // blocks of 64 boxes per frame (capacity)
     int ntiles;                  // nbw (nbw + 1) / 2
-    int pblocks;                 // producer workgroups per frame
-    int batch;
+    int b0, b1;                  // column-block range of this round
+    int first_round;
     float tf;
     float neg_h;                 // -(half the gap below tf), see tile_fast()
     int fast_ok;                 // tf is a positive normal f32 in a range where tile_fast() is valid
     int max_keep;
     unsigned long long *tiles;   // (batch, ntiles, 64) column form
-    int32_t *flags;              // (batch, nbw + 8): ready[nbw], then the cancel word
+    unsigned long long *kstate;  // (batch, nbw) kept masks of finished blocks
+    int32_t *cstate;             // (batch, 4): [0] kept so far, [1] done
     int32_t *keep;
     long long keep_frame_stride;
     int32_t *num_keep;
@@ -164,21 +161,31 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
     return word;
 }
 
-__device__ __forceinline__ int agent_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ---------------------------------------------------------------------------------- producers
-__device__ __forceinline__ void produce_tile(const NmsDev &d, const int f, const int t, float4 *s_box, float *s_area,
-                                             const int lane, const int n, const bool active, const int cb, const int rb)
+// grid: (tiles of the round, 1, batch); block 64 = one wave per tile.
+__global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
 {
-    // LDS side = the 64 ROW boxes of block rb; lane = COLUMN box cb*64 + lane
+    __shared__ float4 s_box[64];
+    __shared__ float s_area[64];
+    const int f = blockIdx.z;
+    if (!d.first_round && d.cstate[4 * f + 1]) return;       // frame already finished in an earlier round
+    const int n = frame_n(d, f);
+    // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
+    const int t = d.b0 * (d.b0 + 1) / 2 + blockIdx.x;
+    int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+    while (cb * (cb + 1) / 2 > t) --cb;
+    const int rb = t - cb * (cb + 1) / 2;
+    if (cb * 64 >= n) return;
+    const int lane = threadIdx.x;
+    // LDS side = the 64 ROW boxes of block rb; lane = COLUMN box cb*64 + lane.  The predicate is
+    // symmetric in the two boxes (max/min/+/* commute), so this is the transposed tile.
     const int ridx = rb * 64 + lane, cidx = cb * 64 + lane;
     float4 sb = make_float4(NAN, NAN, NAN, NAN);            // NaN box: every predicate false
-    if (active && ridx < n) sb = load_box(d, f, ridx);
+    if (ridx < n) sb = load_box(d, f, ridx);
     s_box[lane] = sb;
     s_area[lane] = ((sb.z - sb.x) + 1.0f) * ((sb.w - sb.y) + 1.0f);         // cpu_nms.pyx:24
     const bool lds_tame = __all(tame(sb));                  // false if the block is ragged (NaN padding)
     __syncthreads();
-    if (!active) return;
     float4 lb = make_float4(NAN, NAN, NAN, NAN);
     if (cidx < n) lb = load_box(d, f, cidx);
     const float larea = ((lb.z - lb.x) + 1.0f) * ((lb.w - lb.y) + 1.0f);
@@ -207,123 +214,103 @@ __device__ __forceinline__ void produce_tile(const NmsDev &d, const int f, const
             word |= (unsigned long long)p << j;
         }
     }
-    // publish (guide G16, form R1): the 8-byte payload goes out WRITE-THROUGH (agent-scope relaxed
-    // atomic store = global_store_dwordx2 sc1), so no L2 write-back fence per tile is needed; the
-    // wave drains its stores, then one lane moves the column block's counter.
-    __hip_atomic_store(&d.tiles[((long long)f * d.ntiles + t) * 64 + lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.tiles[((long long)f * d.ntiles + t) * 64 + lane] = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(&d.flags[(long long)f * (d.nbw + 8) + cb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---------------------------------------------------------------------------------- chain
+// grid: (batch); block 1024 = 16 waves: wave 0 = diagonal (serial part), waves 1..15 = pull.
 template <int KMAX>
-__device__ __forceinline__ void chain(const NmsDev &d, const int f)
+__device__ __forceinline__ void chain_round(const NmsDev &d, const int f)
 {
     __shared__ unsigned long long s_K[NMS_MAX_WORDS];        // kept mask of every finished block
     __shared__ unsigned long long s_rem;                      // removed bits of the block in flight
     __shared__ int s_total, s_stop;
     const int n = frame_n(d, f);
     const int nb = (n + 63) >> 6;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long *tiles = d.tiles + (long long)f * d.ntiles * 64;
-    int32_t *flags = d.flags + (long long)f * (d.nbw + 8);
+    unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
+    int32_t *cstate = d.cstate + 4 * f;
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
-    if (threadIdx.x == 0) { s_rem = 0ull; s_total = 0; s_stop = 0; }
+    const int b0 = d.b0, b1 = min(d.b1, nb);
+    for (int w = threadIdx.x; w < b0; w += blockDim.x) s_K[w] = kstate[w];   // earlier rounds
+    if (threadIdx.x == 0) { s_rem = 0ull; s_total = d.first_round ? 0 : cstate[0]; s_stop = 0; }
     __syncthreads();
-    int total = 0;                                            // tracked by wave 0
-    for (int c0 = 0, c1 = 0; c0 < nb; c0 = c1) {
-        // batches of 2, 4, 8, then 16 column blocks: start early, then amortise the acquire
-        c1 = min(nb, c0 + (c0 == 0 ? 2 : (c0 < 6 ? 4 : (c0 < 14 ? 8 : NMS_CB))));
-        const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-        if (wave == 0) {
-            // column block c is complete when its c + 1 tiles have been published
-            const int c = c0 + lane;
-            for (;;) {
-                const bool ok = (c >= c1) || (agent_load(&flags[c]) >= c + 1);
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int total = s_total;                                      // tracked by wave 0
+    // cur / dcur hold column b: pull wave w has the tiles of row blocks rb = (w - 1) + 15 k  (< b)
+    unsigned long long cur[KMAX], dcur = 0ull, dnxt = 0ull;
+    if (b0 < b1) {
+        const long long base = (long long)b0 * (b0 + 1) / 2;
+        if (wave == 0) dcur = tiles[(base + b0) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int rb = wave - 1 + NMS_PULL * k;
+            cur[k] = (wave > 0 && rb < b0) ? tiles[(base + rb) * 64 + lane] : 0ull;
         }
-        __syncthreads();
-        const long long t_wait = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-        // Wave 0 owns the diagonal tiles (the serial part); waves 1..3 pull the off-diagonal tiles of
-        // column block b: row blocks rb = (wave - 1) + 3 k  (< b).  cur / dcur hold column b.
-        unsigned long long cur[KMAX], dcur = 0ull, dnxt = 0ull;
-        {
-            const long long base = (long long)c0 * (c0 + 1) / 2;
-            if (wave == 0) dcur = tiles[(base + c0) * 64 + lane];
+    }
+    for (int b = b0; b < b1; ++b) {
+        const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+        if (wave > 0) {
+            unsigned long long part = 0ull;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 const int rb = wave - 1 + NMS_PULL * k;
-                cur[k] = (wave > 0 && rb < c0) ? tiles[(base + rb) * 64 + lane] : 0ull;
+                if (rb < b) part |= __ballot((cur[k] & s_K[rb]) != 0ull);
+            }
+            if (lane == 0 && part) atomicOr(&s_rem, part);
+        }
+        if (b + 1 < b1) {
+            // cur is dead: refill it with column b + 1; the loads fly under the two barriers and the
+            // diagonal step below (all addresses are static)
+            const long long base = (long long)(b + 1) * (b + 2) / 2;
+            if (wave == 0) dnxt = tiles[(base + b + 1) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int rb = wave - 1 + NMS_PULL * k;
+                cur[k] = (wave > 0 && rb < b + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
             }
         }
-        bool stop = false;
-        for (int b = c0; b < c1; ++b) {
-            if (wave > 0) {
-                unsigned long long part = 0ull;
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const int rb = wave - 1 + NMS_PULL * k;
-                    if (rb < b) part |= __ballot((cur[k] & s_K[rb]) != 0ull);
-                }
-                if (lane == 0 && part) atomicOr(&s_rem, part);
+        __syncthreads();
+        if (wave == 0) {
+            const long long t0 = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+            const int p = b * 64 + lane;
+            const bool alive = (p < n) && !((s_rem >> lane) & 1ull);
+            unsigned long long K = __ballot(alive);
+            int iters = 0;
+            // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
+            // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
+            for (;;) {
+                const unsigned long long K2 = __ballot(alive && !(dcur & K));
+                ++iters;
+                if (K2 == K) break;
+                K = K2;
             }
-            if (b + 1 < c1) {
-                // cur is dead: refill it with column b + 1 (already acquired); the loads fly under the
-                // two barriers and the diagonal step below
-                const long long base = (long long)(b + 1) * (b + 2) / 2;
-                if (wave == 0) dnxt = tiles[(base + b + 1) * 64 + lane];
-#pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    const int rb = wave - 1 + NMS_PULL * k;
-                    cur[k] = (wave > 0 && rb < b + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
+            const bool kept = (K >> lane) & 1ull;
+            const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
+            if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
+            total += __popcll(K);
+            if (lane == 0) {
+                s_K[b] = K;
+                kstate[b] = K;
+                s_rem = 0ull;
+                s_total = total;
+                if (d.max_keep > 0 && total >= d.max_keep) s_stop = 1;
+                if (d.trace && f == 0) {
+                    long long *tr = d.trace + 4 * b;
+                    tr[0] = t_begin; tr[1] = t0; tr[2] = (long long)__builtin_readcyclecounter();
+                    tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
                 }
             }
-            __syncthreads();
-            if (wave == 0) {
-                const long long t0 = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-                const int p = b * 64 + lane;
-                const bool alive = (p < n) && !((s_rem >> lane) & 1ull);
-                unsigned long long K = __ballot(alive);
-                int iters = 0;
-                // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
-                // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
-                for (;;) {
-                    const unsigned long long K2 = __ballot(alive && !(dcur & K));
-                    ++iters;
-                    if (K2 == K) break;
-                    K = K2;
-                }
-                const bool kept = (K >> lane) & 1ull;
-                const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
-                if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
-                total += __popcll(K);
-                if (lane == 0) {
-                    s_K[b] = K;
-                    s_rem = 0ull;
-                    s_total = total;
-                    if (d.max_keep > 0 && total >= d.max_keep) s_stop = 1;
-                    if (d.trace && f == 0) {
-                        long long *tr = d.trace + 4 * b;
-                        tr[0] = (b == c0) ? t_begin : t0; tr[1] = (b == c0) ? t_wait : t0;
-                        tr[2] = (long long)__builtin_readcyclecounter();
-                        tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
-                    }
-                }
-                dcur = dnxt;
-            }
-            __syncthreads();
-            if (s_stop) { stop = true; break; }
+            dcur = dnxt;
         }
-        if (stop) break;
+        __syncthreads();
+        if (s_stop) break;
     }
-    // nobody will read the remaining tiles: let the producers that have not started skip them
-    if (threadIdx.x == 0) __hip_atomic_store(&flags[d.nbw], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool finished = s_stop || (b1 >= nb);
     int nk = s_total;
     if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
+    if (threadIdx.x == 0) { cstate[0] = s_total; cstate[1] = finished ? 1 : 0; }
+    if (!finished) return;
     if (threadIdx.x == 0) d.num_keep[f] = nk;
     if (d.emit.enabled) {
         // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
@@ -354,48 +341,146 @@ __device__ __forceinline__ void chain(const NmsDev &d, const int f)
     }
 }
 
-// grid: batch chain workgroups, then batch * pblocks producer workgroups; block 256 = 4 waves.
-__global__ __launch_bounds__(256) void nms_fused_kernel(NmsDev d)
+template <int KMAX>
+__global__ __launch_bounds__(1024) void nms_chain_kernel(NmsDev d)
 {
-    if ((int)blockIdx.x < d.batch) {
-        // KMAX = ceil(nbw / NMS_PULL) tiles per pull wave and column
-        if (d.nbw <= 48) chain<16>(d, blockIdx.x);
-        else if (d.nbw <= 96) chain<32>(d, blockIdx.x);
-        else if (d.nbw <= 192) chain<64>(d, blockIdx.x);
-        else chain<86>(d, blockIdx.x);
-        return;
-    }
-    __shared__ float4 s_box[NMS_TPB][64];
-    __shared__ float s_area[NMS_TPB][64];
-    const int pb = blockIdx.x - d.batch;
-    const int f = pb / d.pblocks;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = (pb % d.pblocks) * NMS_TPB + wave;
+    const int f = blockIdx.x;
+    if (!d.first_round && d.cstate[4 * f + 1]) return;       // finished in an earlier round
+    chain_round<KMAX>(d, f);
+}
+
+// Single-wave form of the same round (grid: (batch); block 64), used while a column block has at
+// most KMAX row-block tiles: no barriers and no LDS atomics at all -- the wave pulls all b tiles of
+// column b itself (registers, refilled one column ahead) and then resolves the diagonal tile.  The
+// per-block critical path is ~25 cycles per tile plus the fixed point.
+template <int KMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
+{
+    __shared__ unsigned long long s_K[NMS_MAX_WORDS];
+    __shared__ int s_fin, s_nk;
+    const int f = blockIdx.x;
+    int32_t *cstate = d.cstate + 4 * f;
+    if (!d.first_round && cstate[1]) return;                  // finished in an earlier round (uniform)
     const int n = frame_n(d, f);
-    // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
-    int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
-    while (cb * (cb + 1) / 2 > t) --cb;
-    const int rb = t - cb * (cb + 1) / 2;
-    const bool cancelled = agent_load(&d.flags[(long long)f * (d.nbw + 8) + d.nbw]) != 0;
-    const bool active = (t < d.ntiles) && (cb * 64 < n) && !cancelled;
-    produce_tile(d, f, t, s_box[wave], s_area[wave], lane, n, active, cb, rb);
+    const int nb = (n + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+    const unsigned long long *tiles = d.tiles + (long long)f * d.ntiles * 64;
+    unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
+    int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
+    const int b0 = d.b0, b1 = min(d.b1, nb);
+    for (int w = lane; w < NMS_MAX_WORDS; w += 64) s_K[w] = (w < b0) ? kstate[w] : 0ull;   // earlier rounds
+    int total = d.first_round ? 0 : cstate[0];
+    bool stop = false;
+    unsigned long long cur[KMAX], dcur = 0ull;
+    if (b0 < b1) {
+        const long long base = (long long)b0 * (b0 + 1) / 2;
+        dcur = tiles[(base + b0) * 64 + lane];
+#pragma unroll
+        for (int rb = 0; rb < KMAX; ++rb) cur[rb] = (rb < b0) ? tiles[(base + rb) * 64 + lane] : 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // s_K visible to every lane's reads
+    for (int b = b0; b < b1; ++b) {
+        const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+        unsigned long long rem = 0ull;
+        const int bu = __builtin_amdgcn_readfirstlane(b);     // scalar: whole chunks of 8 tiles are branched over
+#pragma unroll
+        for (int c = 0; c < KMAX / 8; ++c) {
+            if (8 * c < bu) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rb = 8 * c + u;                 // cur[rb] == 0 for rb >= b (never refilled)
+                    rem |= __ballot((cur[rb] & s_K[rb]) != 0ull);
+                }
+            }
+        }
+        const unsigned long long dg = dcur;
+        if (bu + 1 < b1) {                                    // refill with column b + 1 (static addresses)
+            const long long base = (long long)(bu + 1) * (bu + 2) / 2;
+            dcur = tiles[(base + bu + 1) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < KMAX / 8; ++c) {
+                if (8 * c < bu + 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int rb = 8 * c + u;
+                        cur[rb] = (rb < bu + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
+                    }
+                }
+            }
+        }
+        const long long t0 = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+        const int p = b * 64 + lane;
+        const bool alive = (p < n) && !((rem >> lane) & 1ull);
+        unsigned long long K = __ballot(alive);
+        int iters = 0;
+        for (;;) {                                            // fixed point = greedy set (see chain_round)
+            const unsigned long long K2 = __ballot(alive && !(dg & K));
+            ++iters;
+            if (K2 == K) break;
+            K = K2;
+        }
+        const bool kept = (K >> lane) & 1ull;
+        const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
+        if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
+        total += __popcll(K);
+        if (lane == 0) { s_K[b] = K; kstate[b] = K; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (d.trace && f == 0 && lane == 0) {
+            long long *tr = d.trace + 4 * b;
+            tr[0] = t_begin; tr[1] = t0; tr[2] = (long long)__builtin_readcyclecounter();
+            tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
+        }
+        if (d.max_keep > 0 && total >= d.max_keep) { stop = true; break; }
+    }
+    const bool finished = stop || (b1 >= nb);
+    int nk = total;
+    if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
+    if (lane == 0) {
+        cstate[0] = total; cstate[1] = finished ? 1 : 0;
+        s_fin = finished ? 1 : 0; s_nk = nk;
+        if (finished) d.num_keep[f] = nk;
+    }
+    }   // wave 0
+    __syncthreads();                                          // also orders wave 0's keep[] stores for the readers
+    if (!s_fin) return;
+    const int nk = s_nk;
+    const int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
+    if (d.emit.enabled) {
+        // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
+        const EmitDev &e = d.emit;
+        if (threadIdx.x == 0) e.num_out[f] = nk;
+        for (int r = threadIdx.x; r < e.cap; r += blockDim.x) {
+            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
+            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
+            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
+            if (r < nk) {
+                const int c = e.order[(long long)f * e.order_cap + keep[r]];
+                const long long o = (long long)f * e.N + c;
+                const float4 bx = e.bv[o];
+                const int4 im = e.img[o];
+                const float bi = (float)f;
+                obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
+                oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
+                o3[0] = bi;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) o3[1 + j] = e.p3[o * 6 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
+            }
+        }
+    }
 }
 
 size_t mv3d_nms_ws_bytes(int n_cap, int batch)
 {
     const size_t nbw = (size_t)(n_cap + 63) / 64;
     const size_t ntiles = nbw * (nbw + 1) / 2;
-    return (size_t)batch * mv3d_align_up(ntiles * 64 * 8) + mv3d_align_up((size_t)batch * (nbw + 8) * 4);
-}
-
-// where the flag words (ready[] + cancel) of a launch live, so that a preceding kernel can zero them
-int32_t *mv3d_nms_flags(void *workspace, int n_cap, int batch, size_t *count)
-{
-    const size_t nbw = (size_t)(n_cap + 63) / 64;
-    const size_t ntiles = nbw * (nbw + 1) / 2;
-    if (count) *count = (size_t)batch * (nbw + 8);
-    return (int32_t *)((char *)workspace + (size_t)batch * mv3d_align_up(ntiles * 64 * 8));
+    return (size_t)batch * mv3d_align_up(ntiles * 64 * 8) + mv3d_align_up((size_t)batch * nbw * 8) +
+           mv3d_align_up((size_t)batch * 4 * 4);
 }
 
 int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
@@ -406,18 +491,35 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     NmsDev d;
     d.boxes = L.boxes; d.box_stride = L.box_stride; d.boxes_frame_stride = L.boxes_frame_stride;
     d.idx = L.idx; d.idx_frame_stride = L.idx_frame_stride; d.n_dev = L.n_dev; d.n_cap = L.n_cap;
-    d.nbw = nbw; d.ntiles = nbw * (nbw + 1) / 2; d.pblocks = (d.ntiles + NMS_TPB - 1) / NMS_TPB; d.batch = L.batch;
+    d.nbw = nbw; d.ntiles = nbw * (nbw + 1) / 2;
     d.tf = L.strict_gt ? nextafterf(L.thresh_f32, INFINITY) : L.thresh_f32; d.max_keep = L.max_keep;
     d.fast_ok = (d.tf >= 0x1p-10f && d.tf <= 0x1p10f) ? 1 : 0;
     d.neg_h = d.fast_ok ? -0.5f * (d.tf - nextafterf(d.tf, 0.0f)) : 0.0f;
-    d.tiles = (unsigned long long *)L.workspace;
-    size_t nflags;
-    d.flags = mv3d_nms_flags(L.workspace, L.n_cap, L.batch, &nflags);
+    char *ws = (char *)L.workspace;
+    d.tiles = (unsigned long long *)ws;
+    ws += (size_t)L.batch * mv3d_align_up((size_t)d.ntiles * 64 * 8);
+    d.kstate = (unsigned long long *)ws;
+    ws += mv3d_align_up((size_t)L.batch * nbw * 8);
+    d.cstate = (int32_t *)ws;
     d.keep = L.keep; d.keep_frame_stride = L.keep_frame_stride; d.num_keep = L.num_keep; d.status = L.status;
     d.emit = L.emit;
     d.trace = L.trace;
-    if (!L.flags_zeroed) MV3D_HIP_TRY(hipMemsetAsync(d.flags, 0, nflags * sizeof(int32_t), stream));
-    hipLaunchKernelGGL(nms_fused_kernel, dim3(L.batch + L.batch * d.pblocks), dim3(256), 0, stream, d);
+    // rounds over column-block ranges; every kernel of a later round returns at once for a frame that
+    // is already finished.  A frame with no boxes is finished by the first chain launch.
+    int bounds[5] = {0, 32, nbw, nbw, nbw};
+    if (nbw > 128) { bounds[2] = 96; bounds[3] = nbw; }
+    for (int r = 0; r < 4; ++r) {
+        d.b0 = bounds[r]; d.b1 = bounds[r + 1] < nbw ? bounds[r + 1] : nbw;
+        d.first_round = (r == 0);
+        if (r > 0 && d.b0 >= nbw) break;
+        const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
+        if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
+        // a column block of the round has at most b1 - 1 off-diagonal tiles
+        if (d.b1 <= 32) hipLaunchKernelGGL((nms_chain1_kernel<32, 512>), dim3(L.batch), dim3(512), 0, stream, d);
+        else if (d.b1 <= 64) hipLaunchKernelGGL((nms_chain1_kernel<64, 512>), dim3(L.batch), dim3(512), 0, stream, d);
+        else if (d.b1 <= 128) hipLaunchKernelGGL((nms_chain1_kernel<128, 256>), dim3(L.batch), dim3(256), 0, stream, d);
+        else hipLaunchKernelGGL(nms_chain_kernel<18>, dim3(L.batch), dim3(1024), 0, stream, d);
+    }
     return mv3d_launch_status();
 }
 
