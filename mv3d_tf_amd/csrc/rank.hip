@@ -25,18 +25,23 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 // instructions per pair (compare into VCC, add-with-carry); hipcc's own lowering of the C form
 // mixes in v_cndmask/v_add sequences.  No manual wait states are needed between a VALU write of
 // VCC and a VALU carry-in read (CDNA3/4 ISA, "manually inserted wait states").
-#define RANK_P(OP, I) "v_cmp_" OP "_u32 vcc, %" #I ", %1\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+// 4 compares into 4 different SGPR pairs, then 4 add-with-carry into two accumulators: the
+// VALU -> SGPR -> VALU carry path is ~8 cycles deep, so a single VCC chain (cmp, addc, cmp, addc ...)
+// runs at a third of the issue rate when a SIMD holds only one or two waves.
+#define RANK_C(OP, M, I) "v_cmp_" OP "_u32 %[" #M "], %" #I ", %[ki]\n\t"
+#define RANK_A(ACC, M) "v_addc_co_u32 %[" #ACC "], %[" #M "], 0, %[" #ACC "], %[" #M "]\n\t"
+#define RANK_G(OP, I0, I1, I2, I3)                                                         \
+    RANK_C(OP, m0, I0) RANK_C(OP, m1, I1) RANK_C(OP, m2, I2) RANK_C(OP, m3, I3)            \
+    RANK_A(a, m0) RANK_A(b, m1) RANK_A(a, m2) RANK_A(b, m3)
 #define RANK_16(OP)                                                                                        \
-    asm(RANK_P(OP, 2) RANK_P(OP, 3) RANK_P(OP, 4) RANK_P(OP, 5) RANK_P(OP, 6) RANK_P(OP, 7) RANK_P(OP, 8)   \
-        RANK_P(OP, 9) RANK_P(OP, 10) RANK_P(OP, 11) RANK_P(OP, 12) RANK_P(OP, 13) RANK_P(OP, 14)             \
-        RANK_P(OP, 15) RANK_P(OP, 16) RANK_P(OP, 17)                                                         \
-        : "+v"(cnt)                                                                                          \
-        : "v"(ki), "s"(v.s0), "s"(v.s1), "s"(v.s2), "s"(v.s3), "s"(v.s4), "s"(v.s5), "s"(v.s6), "s"(v.s7),   \
-          "s"(v.s8), "s"(v.s9), "s"(v.sa), "s"(v.sb), "s"(v.sc), "s"(v.sd), "s"(v.se), "s"(v.sf)             \
-        : "vcc")
+    asm(RANK_G(OP, 7, 8, 9, 10) RANK_G(OP, 11, 12, 13, 14) RANK_G(OP, 15, 16, 17, 18) RANK_G(OP, 19, 20, 21, 22) \
+        : [a] "+v"(cnt), [b] "+v"(cnt2), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)     \
+        : [ki] "v"(ki), "s"(v.s0), "s"(v.s1), "s"(v.s2), "s"(v.s3), "s"(v.s4), "s"(v.s5), "s"(v.s6), "s"(v.s7), \
+          "s"(v.s8), "s"(v.s9), "s"(v.sa), "s"(v.sb), "s"(v.sc), "s"(v.sd), "s"(v.se), "s"(v.sf))
 template <bool GE>
-__device__ __forceinline__ void count16(unsigned &cnt, const uint32_t ki, const u32x16 v)
+__device__ __forceinline__ void count16(unsigned &cnt, unsigned &cnt2, const uint32_t ki, const u32x16 v)
 {
+    unsigned long long m0, m1, m2, m3;
     if (GE) RANK_16("ge");
     else RANK_16("gt");
 }
@@ -55,16 +60,16 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
     const uint32_t ki = k[i];                       // i < key_stride always (grid covers the padding)
     const int my_sub = blockIdx.x;                  // 256-key sub-tile holding this block's own keys
     const int t0 = s * RANK_SEG;
-    unsigned cnt = 0;
+    unsigned cnt = 0, cnt2 = 0;
     for (int q4 = 0; q4 < RANK_SEG / 256; ++q4) {
         const int sub = t0 / 256 + q4;
         const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
         if (sub < my_sub) {                         // all j < i : only a strictly larger key precedes
 #pragma unroll 4
-            for (int u = 0; u < 16; ++u) count16<false>(cnt, ki, q[u]);
+            for (int u = 0; u < 16; ++u) count16<false>(cnt, cnt2, ki, q[u]);
         } else if (sub > my_sub) {                  // all j > i : an equal key precedes too
 #pragma unroll 4
-            for (int u = 0; u < 16; ++u) count16<true>(cnt, ki, q[u]);
+            for (int u = 0; u < 16; ++u) count16<true>(cnt, cnt2, ki, q[u]);
         } else {                                    // own sub-tile: full rule
             const int jb = sub * 256;
             for (int u = 0; u < 256; ++u) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
             }
         }
     }
-    if (i < N) partial[((long long)f * S + s) * N + i] = cnt;
+    if (i < N) partial[((long long)f * S + s) * N + i] = cnt + cnt2;
 }
 
 // ---------------------------------------------------------------------------- A. merge-rank
@@ -86,42 +91,63 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
 // sorted[f][R*1024 + r] = key, sidx = index inside the run.  Non-candidates (key 0) are not
 // written at all; cnt256[f][bi] = candidates of this workgroup lets the consumer treat the tail of
 // every run as zeros.
-__global__ __launch_bounds__(256) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
-                                                         uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
-                                                         int32_t *__restrict__ cnt256)
+__global__ __launch_bounds__(1024) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
+                                                          uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
+                                                          int32_t *__restrict__ cnt256)
 {
+    // 1024 threads = 256 keys x 4 sub-tiles of the run: thread (t, sub) counts its key against the 256
+    // keys of sub-tile `sub`; 16 waves per CU keep the scalar-load and carry latencies covered.
+    __shared__ unsigned s_part[4][256];
     __shared__ int s_wc[4];
-    const int f = blockIdx.y, t = threadIdx.x, bi = blockIdx.x;
+    const int f = blockIdx.y, bi = blockIdx.x;
+    const int t = threadIdx.x & 255, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     const int run = bi >> 2, my_sub = bi & 3;
     const uint32_t *__restrict__ k = keys + (long long)f * key_stride + run * RANK_RUN;
     const uint32_t ki = k[my_sub * 256 + t];
     const uint32_t kim1 = ki - 1u;                  // kj >= ki  <=>  kj > ki - 1   (ki >= 1 for candidates)
-    unsigned cnt = 0;
-    for (int sub = 0; sub < 4; ++sub) {
-        const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
-        if (sub < my_sub) {
+    unsigned cnt = 0, cnt2 = 0;
+    const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
+    if (sub < my_sub) {                             // all j < i : only a strictly larger key precedes
 #pragma unroll 4
-            for (int u = 0; u < 16; ++u) count16<false>(cnt, ki, q[u]);
-        } else if (sub > my_sub) {
+        for (int u = 0; u < 16; ++u) count16<false>(cnt, cnt2, ki, q[u]);
+    } else if (sub > my_sub) {                      // all j > i : an equal key precedes too
 #pragma unroll 4
-            for (int u = 0; u < 16; ++u) count16<true>(cnt, ki, q[u]);
-        } else {
+        for (int u = 0; u < 16; ++u) count16<true>(cnt, cnt2, ki, q[u]);
+    } else {
+        // own sub-tile: per 64-key quarter the rule is again uniform for a whole wave, except
+        // for the wave's own quarter, where the later index wins a tie lane by lane
+        const int wq = __builtin_amdgcn_readfirstlane(t >> 6);
+        for (int qq = 0; qq < 4; ++qq) {
+            if (qq < wq) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) count16<false>(cnt, cnt2, ki, q[qq * 4 + u]);
+            } else if (qq > wq) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) count16<true>(cnt, cnt2, ki, q[qq * 4 + u]);
+            } else {
 #pragma unroll 16
-            for (int j = 0; j < 256; ++j) {
-                const uint32_t kj = k[sub * 256 + j];           // wave-uniform: scalar load
-                const uint32_t thr = (j > t) ? kim1 : ki;       // the later index wins a tie
-                cnt += (kj > thr) ? 1u : 0u;
+                for (int j = qq * 64; j < qq * 64 + 64; ++j) {
+                    const uint32_t kj = k[sub * 256 + j];       // wave-uniform: scalar load
+                    const uint32_t thr = (j > t) ? kim1 : ki;   // kj >= ki  <=>  kj > ki - 1
+                    cnt += (kj > thr) ? 1u : 0u;
+                }
             }
         }
     }
-    const unsigned long long bal = __ballot(ki != 0u);
-    if ((t & 63) == 0) s_wc[t >> 6] = __popcll(bal);
+    s_part[sub][t] = cnt + cnt2;
+    if (sub == 0) {
+        const unsigned long long bal = __ballot(ki != 0u);
+        if ((t & 63) == 0) s_wc[t >> 6] = __popcll(bal);
+    }
     __syncthreads();
-    if (t == 0) cnt256[(long long)f * gridDim.x + bi] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-    if (ki != 0u) {
-        const long long o = (long long)f * key_stride + run * RANK_RUN + cnt;
-        sorted[o] = ki;
-        sidx[o] = (uint16_t)(my_sub * 256 + t);
+    if (sub == 0) {
+        if (t == 0) cnt256[(long long)f * gridDim.x + bi] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+        if (ki != 0u) {
+            const unsigned r = s_part[0][t] + s_part[1][t] + s_part[2][t] + s_part[3][t];
+            const long long o = (long long)f * key_stride + run * RANK_RUN + r;
+            sorted[o] = ki;
+            sidx[o] = (uint16_t)(my_sub * 256 + t);
+        }
     }
 }
 
@@ -237,7 +263,7 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
         uint32_t *sorted = (uint32_t *)workspace;
         uint16_t *sidx = (uint16_t *)((char *)workspace + mv3d_align_up((size_t)batch * key_stride * 4));
         int32_t *cnt256 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
-        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 256, batch), dim3(256), 0, stream, keys, key_stride, sorted, sidx,
+        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 256, batch), dim3(1024), 0, stream, keys, key_stride, sorted, sidx,
                            cnt256);
         hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 256, batch), dim3(256), 0, stream, sorted, sidx, cnt256, N,
                            key_stride, order, cap, part_counts, n_parts, n_valid);
