@@ -9,10 +9,10 @@
 //            bin loops do not diverge.  Output (top + argmax, R*PH*PW*C*8 B) dominates.
 //  backward  the reference's deterministic gather, kept bit-identical (ROIs ascending, then
 //            ph, pw ascending, f32 adds in that order), but instead of every input element
-//            scanning all R ROIs (O(H*W*C*R)), one workgroup per input pixel finds the ROIs
-//            containing it once (wave 0: 64 ROIs per ballot, ascending compaction into LDS)
-//            and its C/4 lanes then walk only those ROIs' candidate bins with 16-byte
-//            loads.  No atomics, no dependence on scheduling.
+//            scanning all R ROIs (O(H*W*C*R)), the rounded ROI geometry is tabled once per
+//            workgroup in LDS and every wave owns whole input pixels: 64 ROIs per ballot,
+//            then only the containing ROIs' candidate bins, 16-byte loads over the channels.
+//            No atomics, no dependence on scheduling.
 #include <float.h>
 #include <math.h>
 #include "common.h"
@@ -193,100 +193,130 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__re
     }
 }
 
-#define BWD_LIST 1024
+#define BWD_CHUNK 1024      // ROIs whose geometry is staged in LDS at a time
+#define BWD_PIX 4           // input pixels per workgroup (1 per wave)
 
-// grid = B*H*W workgroups (one input pixel each); block = min(256, roundup64(C/VEC)) threads
-template <int VEC>
+// grid = ceil(B*H*W / BWD_PIX) workgroups of 256 threads.  The rounded ROI geometry (the part with
+// the f32 multiplies / round()) is computed once per workgroup into LDS; every WAVE then owns whole
+// input pixels: it scans the table 64 ROIs per ballot (ascending, so the reference's summation order
+// roi -> ph -> pw is kept and the f32 sums are bit-identical), and its lanes walk only the
+// containing ROIs' candidate bins with 16-byte loads over the channels.  No atomics, no barriers
+// after the table is built, nothing depends on scheduling.
+template <int VEC, int NACC>
 __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restrict__ top_diff, float scale, int B, int R,
                                                            int H, int W, int C, int PH, int PW,
                                                            const float *__restrict__ rois, float *__restrict__ bottom_diff,
                                                            const int *__restrict__ argmax)
 {
-    __shared__ int s_roi[BWD_LIST];
-    __shared__ RoiGeom s_geom[BWD_LIST];
-    __shared__ int s_cnt;
-    const int pix = blockIdx.x;
-    const int w = pix % W, h = (pix / W) % H, n = pix / (W * H);
+    __shared__ int4 s_geom[BWD_CHUNK];
+    __shared__ int s_bi[BWD_CHUNK];
     const int CV = C / VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int NACC = 4;                               // channel groups per thread (C <= 256*VEC*NACC)
-    float acc[NACC][VEC];
+    const long long npix = (long long)B * H * W;
+    float acc[BWD_PIX / 4][NACC][VEC];
 #pragma unroll
-    for (int k = 0; k < NACC; ++k)
+    for (int q = 0; q < BWD_PIX / 4; ++q)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
+        for (int k = 0; k < NACC; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[q][k][v] = 0.0f;
 
-    for (int base = 0; base < R; base += BWD_LIST) {
-        __syncthreads();                              // previous chunk's list fully consumed
-        if (wave == 0) {
-            int cnt = 0;
-            const int lim = min(R, base + BWD_LIST);
-            for (int r0 = base; r0 < lim; r0 += 64) {
-                const int r = r0 + lane;
-                bool in = false;
-                RoiGeom g = {0, 0, 0, 0};
-                if (r < lim) {
-                    const float *roi = rois + 5 * r;
-                    g = roi_geom(roi, scale);
-                    // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
-                    in = (n == (int)roi[0]) && (w >= g.rsw && w <= g.rew && h >= g.rsh && h <= g.reh);
-                }
-                const unsigned long long bal = __ballot(in);
-                if (in) {
-                    const int p = cnt + __popcll(bal & ((1ull << lane) - 1ull));
-                    s_roi[p] = r;
-                    s_geom[p] = g;
-                }
-                cnt += __popcll(bal);
-            }
-            if (lane == 0) s_cnt = cnt;
+    for (int base = 0; base < R; base += BWD_CHUNK) {
+        const int cnt = min(R - base, BWD_CHUNK);
+        __syncthreads();                              // previous chunk fully consumed
+        for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
+            const float *roi = rois + 5 * (base + r);
+            const RoiGeom g = roi_geom(roi, scale);
+            s_geom[r] = make_int4(g.rsw, g.rsh, g.rew, g.reh);
+            s_bi[r] = (int)roi[0];
         }
         __syncthreads();
-        const int cnt = s_cnt;
-        for (int q = 0; q < cnt; ++q) {               // ascending ROI order
-            const RoiGeom g = s_geom[q];
-            const int r = s_roi[q];
-            const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);
-            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-            // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
-            int phs = (int)floorf((float)(h - g.rsh) / bh), phe = (int)ceilf((float)(h - g.rsh + 1) / bh);
-            int pws = (int)floorf((float)(w - g.rsw) / bw), pwe = (int)ceilf((float)(w - g.rsw + 1) / bw);
-            phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
-            pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
-            const long long off = (long long)r * PH * PW * C;
-            for (int ph = phs; ph < phe; ++ph)
-                for (int pw = pws; pw < pwe; ++pw) {
-                    const long long o = off + ((long long)ph * PW + pw) * C;
 #pragma unroll
-                    for (int k = 0; k < NACC; ++k) {
-                        const int cv = threadIdx.x + k * blockDim.x;
-                        if (cv < CV) {
-                            const int c0 = cv * VEC;
-                            const int want = (h * W + w) * C + c0;
-                            if (VEC == 4) {
-                                const int4 am = *reinterpret_cast<const int4 *>(argmax + o + c0);
-                                const float4 td = *reinterpret_cast<const float4 *>(top_diff + o + c0);
-                                if (am.x == want + 0) acc[k][0] += td.x;
-                                if (am.y == want + 1) acc[k][1 % VEC] += td.y;
-                                if (am.z == want + 2) acc[k][2 % VEC] += td.z;
-                                if (am.w == want + 3) acc[k][3 % VEC] += td.w;
-                            } else {
-                                if (argmax[o + c0] == want) acc[k][0] += top_diff[o + c0];
+        for (int q = 0; q < BWD_PIX / 4; ++q) {
+            const long long pix = (long long)blockIdx.x * BWD_PIX + q * 4 + wave;
+            if (pix >= npix) continue;                // wave-uniform
+            const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+            for (int r0 = 0; r0 < cnt; r0 += 64) {
+                const int r = r0 + lane;
+                bool in = false;
+                if (r < cnt) {
+                    const int4 g = s_geom[r];
+                    // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
+                    in = (n == s_bi[r]) && (w >= g.x && w <= g.z && h >= g.y && h <= g.w);
+                }
+                unsigned long long bal = __ballot(in);
+                while (bal) {                         // ascending ROI order
+                    const int rr = r0 + __builtin_ctzll(bal);
+                    bal &= bal - 1;
+                    const int4 g = s_geom[rr];
+                    const int rw = max(g.z - g.x + 1, 1), rh = max(g.w - g.y + 1, 1);
+                    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+                    // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
+                    int phs = (int)floorf((float)(h - g.y) / bh), phe = (int)ceilf((float)(h - g.y + 1) / bh);
+                    int pws = (int)floorf((float)(w - g.x) / bw), pwe = (int)ceilf((float)(w - g.x + 1) / bw);
+                    phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+                    pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
+                    const long long off = (long long)(base + rr) * PH * PW * C;
+                    // candidate bins in (ph, pw) order, four at a time: the 16-byte loads of a group are
+                    // all in flight before the first is consumed; the adds stay in reference order
+                    const int nw = pwe - pws, nbins = (phe - phs) * nw;
+                    for (int t0 = 0; t0 < nbins; t0 += 4) {
+#pragma unroll
+                        for (int k = 0; k < NACC; ++k) {
+                            const int cv = lane + 64 * k;
+                            if (cv < CV) {
+                                const int c0 = cv * VEC;
+                                const int want = (h * W + w) * C + c0;
+                                if (VEC == 4) {
+                                    int4 am[4];
+                                    float4 td[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const int t = min(t0 + u, nbins - 1);
+                                        const long long o = off + ((long long)(phs + t / nw) * PW + (pws + t % nw)) * C + c0;
+                                        am[u] = *reinterpret_cast<const int4 *>(argmax + o);
+                                        td[u] = *reinterpret_cast<const float4 *>(top_diff + o);
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        if (t0 + u < nbins) {
+                                            if (am[u].x == want + 0) acc[q][k][0] += td[u].x;
+                                            if (am[u].y == want + 1) acc[q][k][1 % VEC] += td[u].y;
+                                            if (am[u].z == want + 2) acc[q][k][2 % VEC] += td[u].z;
+                                            if (am[u].w == want + 3) acc[q][k][3 % VEC] += td[u].w;
+                                        }
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        if (t0 + u < nbins) {
+                                            const int t = t0 + u;
+                                            const long long o = off + ((long long)(phs + t / nw) * PW + (pws + t % nw)) * C + c0;
+                                            if (argmax[o] == want) acc[q][k][0] += top_diff[o];
+                                        }
+                                    }
+                                }
                             }
                         }
                     }
                 }
+            }
         }
     }
-    float *out = bottom_diff + (long long)pix * C;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-        const int cv = threadIdx.x + k * blockDim.x;
-        if (cv < CV) {
-            if (VEC == 4)
-                *reinterpret_cast<float4 *>(out + cv * 4) = make_float4(acc[k][0], acc[k][1 % VEC], acc[k][2 % VEC], acc[k][3 % VEC]);
-            else
-                out[cv] = acc[k][0];
+    for (int q = 0; q < BWD_PIX / 4; ++q) {
+        const long long pix = (long long)blockIdx.x * BWD_PIX + q * 4 + wave;
+        if (pix >= npix) continue;
+        float *out = bottom_diff + pix * C;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            const int cv = lane + 64 * k;
+            if (cv < CV) {
+                if (VEC == 4)
+                    *reinterpret_cast<float4 *>(out + cv * 4) = make_float4(acc[q][k][0], acc[q][k][1 % VEC], acc[q][k][2 % VEC], acc[q][k][3 % VEC]);
+                else
+                    out[cv] = acc[q][k][0];
+            }
         }
     }
 }
@@ -343,17 +373,21 @@ extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale
     if (pixels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
     const bool v4 = (channels % 4 == 0) && aligned16(top_diff) && aligned16(bottom_diff) && aligned16(argmax_data);
     const int cv = channels / (v4 ? 4 : 1);
-    if (cv > 256 * 4) return MV3D_ERR_INVALID_ARG;       // C <= 4096 (vectorised) / 1024 (scalar)
-    int threads = (cv + 63) / 64 * 64;
-    if (threads > 256) threads = 256;
+    if (cv > 64 * 16) return MV3D_ERR_INVALID_ARG;       // C <= 4096 (vectorised) / 1024 (scalar)
+    const int nacc = cv <= 64 ? 1 : (cv <= 128 ? 2 : (cv <= 256 ? 4 : (cv <= 512 ? 8 : 16)));
+    const unsigned blocks = (unsigned)((pixels + BWD_PIX - 1) / BWD_PIX);
     hipStream_t s = (hipStream_t)stream;
-    if (v4)
-        hipLaunchKernelGGL(roi_pool_bwd_kernel<4>, dim3((unsigned)pixels), dim3(threads), 0, s, top_diff, spatial_scale,
-                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
-                           bottom_diff, argmax_data);
-    else
-        hipLaunchKernelGGL(roi_pool_bwd_kernel<1>, dim3((unsigned)pixels), dim3(threads), 0, s, top_diff, spatial_scale,
-                           batch_size, num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois,
-                           bottom_diff, argmax_data);
+#define MV3D_BWD(V, N)                                                                                             \
+    hipLaunchKernelGGL((roi_pool_bwd_kernel<V, N>), dim3(blocks), dim3(256), 0, s, top_diff, spatial_scale, batch_size, \
+                       num_rois, height, width, channels, pooled_height, pooled_width, bottom_rois, bottom_diff,   \
+                       argmax_data)
+    if (v4) {
+        switch (nacc) { case 1: MV3D_BWD(4, 1); break; case 2: MV3D_BWD(4, 2); break; case 4: MV3D_BWD(4, 4); break;
+                        case 8: MV3D_BWD(4, 8); break; default: MV3D_BWD(4, 16); break; }
+    } else {
+        switch (nacc) { case 1: MV3D_BWD(1, 1); break; case 2: MV3D_BWD(1, 2); break; case 4: MV3D_BWD(1, 4); break;
+                        case 8: MV3D_BWD(1, 8); break; default: MV3D_BWD(1, 16); break; }
+    }
+#undef MV3D_BWD
     return mv3d_launch_status();
 }
