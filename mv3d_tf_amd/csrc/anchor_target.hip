@@ -157,31 +157,7 @@ __global__ __launch_bounds__(256) void at_label_kernel(AtDev d)
     for (int j = 0; j < 6; ++j) d.targets[6 * (long long)n + j] = T[j];
 }
 
-// ---- ordered compaction in one workgroup (1024 threads, contiguous chunk per thread) ----------
-__device__ __forceinline__ int4 block_exclusive_scan4(int4 v, int4 &total)
-{
-    __shared__ int4 s_wave[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int4 inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int4 t;
-        t.x = __shfl_up(inc.x, o); t.y = __shfl_up(inc.y, o); t.z = __shfl_up(inc.z, o); t.w = __shfl_up(inc.w, o);
-        if (lane >= o) { inc.x += t.x; inc.y += t.y; inc.z += t.z; inc.w += t.w; }
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int4 base = make_int4(0, 0, 0, 0), tot = make_int4(0, 0, 0, 0);
-    for (int k = 0; k < 16; ++k) {
-        const int4 s = s_wave[k];
-        if (k < wave) { base.x += s.x; base.y += s.y; base.z += s.z; base.w += s.w; }
-        tot.x += s.x; tot.y += s.y; tot.z += s.z; tot.w += s.w;
-    }
-    __syncthreads();
-    total = tot;
-    return make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
-}
-
+// ---- ordered compaction in one workgroup (mv3d_block_compact, common.h) ----------------------
 struct AtLists {
     int32_t *fg, *bg, *low;          // (N) each: anchor indices, ascending
 };
@@ -189,29 +165,23 @@ struct AtLists {
 __global__ __launch_bounds__(1024) void at_compact_kernel(const float *labels, const double *max_ov, int N, double neg_ov,
                                                           AtLists L, int32_t *counts, uint8_t *fg_hi)
 {
-    const int per = (N + 1023) / 1024;
-    const int s = threadIdx.x * per, e = min(N, s + per);
-    int4 c = make_int4(0, 0, 0, 0);                  // inside, fg, bg, low
-    for (int n = s; n < e; ++n) {
-        const double mx = max_ov[n];
-        if (mx >= 0.0) {                             // inside anchors carry max_ov >= 0
+    int tot[4];
+    mv3d_block_compact<4>(
+        N,
+        [&](int n, bool f[4]) {
+            const double mx = max_ov[n];
             const float lab = labels[n];
-            c.x += 1; c.y += (lab == 1.0f); c.z += (lab == 0.0f); c.w += (mx < neg_ov);
-        }
-    }
-    int4 tot;
-    int4 o = block_exclusive_scan4(c, tot);
-    for (int n = s; n < e; ++n) {
-        const double mx = max_ov[n];
-        if (mx >= 0.0) {
-            const float lab = labels[n];
-            if (lab == 1.0f) { L.fg[o.y] = n; fg_hi[o.y] = (mx >= neg_ov) ? 1 : 0; ++o.y; }
-            if (lab == 0.0f) L.bg[o.z++] = n;
-            if (mx < neg_ov) L.low[o.w++] = n;
-        }
-    }
+            const bool inside = (mx >= 0.0);                 // inside anchors carry max_ov >= 0
+            f[0] = inside; f[1] = inside && (lab == 1.0f); f[2] = inside && (lab == 0.0f); f[3] = inside && (mx < neg_ov);
+        },
+        [&](int k, int pos, int n) {
+            if (k == 1) { L.fg[pos] = n; fg_hi[pos] = (max_ov[n] >= neg_ov) ? 1 : 0; }
+            else if (k == 2) L.bg[pos] = n;
+            else if (k == 3) L.low[pos] = n;
+        },
+        tot);
     if (threadIdx.x == 0) {
-        counts[0] = tot.x; counts[1] = tot.y; counts[2] = tot.z; counts[3] = tot.w;
+        counts[0] = tot[0]; counts[1] = tot[1]; counts[2] = tot[2]; counts[3] = tot[3];
         counts[4] = counts[5] = counts[6] = counts[7] = 0;
     }
 }
@@ -225,31 +195,26 @@ __global__ void at_disable_kernel(float *labels, const int32_t *list, const int3
 __global__ __launch_bounds__(1024) void at_emit_anchors_kernel(AtDev d, float *anchors, float *anchors_3d, int32_t *n_out,
                                                                int cap)
 {
-    const int per = (d.N + 1023) / 1024;
-    const int s = threadIdx.x * per, e = min(d.N, s + per);
-    int4 c = make_int4(0, 0, 0, 0);
-    for (int n = s; n < e; ++n) c.x += (d.max_ov[n] >= 0.0 && d.labels[n] != -1.0f);
-    int4 tot;
-    int4 o = block_exclusive_scan4(c, tot);
-    for (int n = s; n < e; ++n) {
-        if (d.max_ov[n] >= 0.0 && d.labels[n] != -1.0f) {
-            const int r = o.x++;
-            if (r < cap) {
-                int x1, y1, x2, y2;
-                anchor_coords(d, n, x1, y1, x2, y2);
-                float *A = anchors + 5 * (long long)r, *B = anchors_3d + 7 * (long long)r;
-                A[0] = 0.0f; A[1] = (float)x1; A[2] = (float)y1; A[3] = (float)x2; A[4] = (float)y2;
-                const double ex_len = (double)(y2 - y1) * 0.1, ex_wid = (double)(x2 - x1) * 0.1;
-                const double cx = (double)(x1 + x2) / 2.0, cy = (double)(y1 + y2) / 2.0;
-                B[0] = 0.0f;
-                B[1] = (float)(600 * 0.1 - (cy + 0.5) * 0.1 + 0.0);
-                B[2] = (float)(600 * 0.1 - (cx + 0.5) * 0.1 + (-30.0));
-                B[3] = (float)(-(1.73 - 1.56 / 2.0));
-                B[4] = (float)ex_len; B[5] = (float)ex_wid; B[6] = (float)1.56;
-            }
-        }
-    }
-    if (threadIdx.x == 0) n_out[0] = tot.x;
+    int tot[1];
+    mv3d_block_compact<1>(
+        d.N,
+        [&](int n, bool f[1]) { f[0] = (d.max_ov[n] >= 0.0) && (d.labels[n] != -1.0f); },
+        [&](int, int r, int n) {
+            if (r >= cap) return;
+            int x1, y1, x2, y2;
+            anchor_coords(d, n, x1, y1, x2, y2);
+            float *A = anchors + 5 * (long long)r, *B = anchors_3d + 7 * (long long)r;
+            A[0] = 0.0f; A[1] = (float)x1; A[2] = (float)y1; A[3] = (float)x2; A[4] = (float)y2;
+            const double ex_len = (double)(y2 - y1) * 0.1, ex_wid = (double)(x2 - x1) * 0.1;
+            const double cx = (double)(x1 + x2) / 2.0, cy = (double)(y1 + y2) / 2.0;
+            B[0] = 0.0f;
+            B[1] = (float)(600 * 0.1 - (cy + 0.5) * 0.1 + 0.0);
+            B[2] = (float)(600 * 0.1 - (cx + 0.5) * 0.1 + (-30.0));
+            B[3] = (float)(-(1.73 - 1.56 / 2.0));
+            B[4] = (float)ex_len; B[5] = (float)ex_wid; B[6] = (float)1.56;
+        },
+        tot);
+    if (threadIdx.x == 0) n_out[0] = tot[0];
 }
 
 // anchor_target_layer_tf.py:176: labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0 (inside anchors)

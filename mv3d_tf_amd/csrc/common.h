@@ -46,3 +46,65 @@ static inline float mv3d_ceil_f32(double t)
     if ((double)f < t) f = nextafterf(f, INFINITY);
     return f;
 }
+
+// Ordered (ascending index) multi-list compaction of N items by ONE workgroup of 1024 threads.
+// Wave w owns the contiguous index range [w*chunk, (w+1)*chunk); lanes read consecutive items
+// (coalesced), four 64-item groups are loaded before any is consumed, list positions come from
+// wave ballots + a 16-entry scan of the wave totals in LDS.  pred(i, flags[NP]) classifies item i,
+// emit(k, pos, i) stores it at position pos of list k; totals[k] receives the list lengths.
+template <int NP, typename Pred, typename Emit>
+__device__ __forceinline__ void mv3d_block_compact(const int N, Pred pred, Emit emit, int totals[NP])
+{
+    __shared__ int s_cnt[16][NP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = (((N + 15) / 16) + 63) / 64 * 64;
+    const int beg = wave * chunk, end = min(N, beg + chunk);
+    int cnt[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) cnt[k] = 0;
+    for (int b = beg; b < end; b += 256) {
+        bool f[4][NP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = b + 64 * u + lane;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[u][k] = false;
+            if (i < end) pred(i, f[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) cnt[k] += __popcll(__ballot(f[u][k]));
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) s_cnt[wave][k] = cnt[k];
+    __syncthreads();
+    int off[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        int o = 0, t = 0;
+        for (int w = 0; w < 16; ++w) { const int c = s_cnt[w][k]; if (w < wave) o += c; t += c; }
+        off[k] = o; totals[k] = t;
+    }
+    for (int b = beg; b < end; b += 256) {
+        bool f[4][NP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = b + 64 * u + lane;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[u][k] = false;
+            if (i < end) pred(i, f[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = b + 64 * u + lane;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const unsigned long long bal = __ballot(f[u][k]);
+                if (f[u][k]) emit(k, off[k] + __popcll(bal & ((1ull << lane) - 1ull)), i);
+                off[k] += __popcll(bal);
+            }
+        }
+    }
+}

@@ -72,37 +72,18 @@ __global__ __launch_bounds__(256) void pt_overlap_kernel(PtDev d)
 
 __global__ __launch_bounds__(1024) void pt_compact_kernel(PtDev d, int32_t *counts)
 {
-    __shared__ int s_wave[16][2];
     const int n = d.R + d.G;
-    const int per = (n + 1023) / 1024;
-    const int s = threadIdx.x * per, e = min(n, s + per);
-    int cf = 0, cb = 0;
-    for (int r = s; r < e; ++r) {
-        const double mx = d.max_ov[r];
-        cf += (mx >= d.fg_thresh);                          // :246
-        cb += (mx < d.bg_hi) && (mx >= d.bg_lo);            // :259-260
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inf = cf, inb = cb;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int tf_ = __shfl_up(inf, o), tb_ = __shfl_up(inb, o);
-        if (lane >= o) { inf += tf_; inb += tb_; }
-    }
-    if (lane == 63) { s_wave[wave][0] = inf; s_wave[wave][1] = inb; }
-    __syncthreads();
-    int bf = 0, bb = 0, tf_tot = 0, tb_tot = 0;
-    for (int k = 0; k < 16; ++k) {
-        if (k < wave) { bf += s_wave[k][0]; bb += s_wave[k][1]; }
-        tf_tot += s_wave[k][0]; tb_tot += s_wave[k][1];
-    }
-    int of = bf + inf - cf, ob = bb + inb - cb;
-    for (int r = s; r < e; ++r) {
-        const double mx = d.max_ov[r];
-        if (mx >= d.fg_thresh) d.fg_list[of++] = r;
-        if ((mx < d.bg_hi) && (mx >= d.bg_lo)) d.bg_list[ob++] = r;
-    }
-    if (threadIdx.x == 0) { counts[0] = n; counts[1] = tf_tot; counts[2] = tb_tot; counts[3] = 0; }
+    int tot[2];
+    mv3d_block_compact<2>(
+        n,
+        [&](int r, bool f[2]) {
+            const double mx = d.max_ov[r];
+            f[0] = (mx >= d.fg_thresh);                          // :246
+            f[1] = (mx < d.bg_hi) && (mx >= d.bg_lo);            // :259-260
+        },
+        [&](int k, int pos, int r) { (k == 0 ? d.fg_list : d.bg_list)[pos] = r; },
+        tot);
+    if (threadIdx.x == 0) { counts[0] = n; counts[1] = tot[0]; counts[2] = tot[1]; counts[3] = 0; }
 }
 
 struct PtEmit {
