@@ -200,6 +200,22 @@ int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_d
                                 float *bbox_targets_out, float *rois_3d_out,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------ SURVEY §8(f) "next" rows
+ * BEV rasteriser: replaces point_cloud_2_top (lib/utils/read_lidar.py:10-115, called with
+ * res=0.1, zres=0.3, side_range=(-30,30), fwd_range=(0,60), height_range=(-2,0.4):
+ * tools/read_lidar.py:121-133).  points_dev (P,4) f32 [x,y,z,reflectance], 16-byte aligned;
+ * top_dev (601,601,9) f32: channels 0-7 = z + 2 of the last point of each height slice, channel
+ * 8 = reflectance of the last point of the highest slice (numpy fancy-assignment order). */
+int mv3d_point_cloud_2_top(const float *points_dev, int num_points, float *top_dev, void *stream);
+
+/* Test-time tail of box_detect (lib/fast_rcnn/test_mv.py:240-261): rois_3d_dev (R,7) = rois[2],
+ * bbox_pred_dev (R,24*nc) -> corners (R,24) [lidar_3d_to_corners], pred_cnr_r (R,24*nc)
+ * [bbox_transform_inv_cnr, lib/fast_rcnn/bbox_transform.py:157-176], pred_bv / pred_bv_r (R,4*nc)
+ * [corners_to_bv, lib/utils/transform.py:342-366, of the unregressed / regressed corners]. */
+int mv3d_box_detect_tail(const float *rois_3d_dev, const float *bbox_pred_dev, int num_rois, int num_classes,
+                         float *corners_dev, float *pred_cnr_r_dev, float *pred_bv_dev, float *pred_bv_r_dev,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,8 @@ _SIGS = {
                                               C.c_size_t, _P]),
     "mv3d_proposal_target_stage2": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.POINTER(ProposalTargetParams),
                                               _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_point_cloud_2_top": (C.c_int, [_P, C.c_int, _P, _P]),
+    "mv3d_box_detect_tail": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

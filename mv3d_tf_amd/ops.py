@@ -201,3 +201,24 @@ def proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, calib, params
                                            _ptr(ws), ws.numel(), _stream())
     check(rc, "mv3d_proposal_target_stage2")
     return out
+
+
+# ------------------------------------------------------------------ SURVEY §8(f) next rows
+def point_cloud_2_top(points):
+    """points (P,4) f32 device tensor -> top (601,601,9) f32 device tensor."""
+    pts = points.contiguous()
+    top = torch.empty((601, 601, 9), dtype=torch.float32, device=pts.device)
+    check(lib().mv3d_point_cloud_2_top(_ptr(pts), pts.shape[0], _ptr(top), _stream()), "mv3d_point_cloud_2_top")
+    return top
+
+
+def box_detect_tail(rois_3d, bbox_pred, num_classes):
+    R = rois_3d.shape[0]
+    dev = rois_3d.device
+    cnr = torch.empty((R, 24), dtype=torch.float32, device=dev)
+    pr = torch.empty((R, 24 * num_classes), dtype=torch.float32, device=dev)
+    bv = torch.empty((R, 4 * num_classes), dtype=torch.float32, device=dev)
+    bvr = torch.empty((R, 4 * num_classes), dtype=torch.float32, device=dev)
+    check(lib().mv3d_box_detect_tail(_ptr(rois_3d), _ptr(bbox_pred), R, num_classes, _ptr(cnr), _ptr(pr), _ptr(bv), _ptr(bvr),
+                                     _stream()), "mv3d_box_detect_tail")
+    return cnr, pr, bv, bvr

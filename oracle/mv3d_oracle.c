@@ -629,3 +629,94 @@ void mv3d_ref_roi_pool_backward(const float *top_diff, const int32_t *argmax,
                 }
             }
 }
+
+/* ------------------------------------------------------------------ §8(f) next rows */
+float mv3d_ref_floor_dividef(float a, float b)
+{
+    /* npy_divmodf, f32 throughout */
+    if (b == 0.0f) return a / b;
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.0f) {
+        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0f; }
+    }
+    float floordiv;
+    if (div != 0.0f) {
+        floordiv = floorf(div);
+        if (div - floordiv > 0.5f) floordiv += 1.0f;
+    } else {
+        floordiv = copysignf(0.0f, a / b);
+    }
+    return floordiv;
+}
+
+/* transform.py:342-357 for one box's 24 corner numbers -> (x1,y1,x2,y2) BEV, all f32:
+ * np.min/np.max over the 8 x / y corners, then _lidar_to_bv_coord with f32 arrays (RES becomes f32) */
+static void corners_to_bv_one(const float *c, float out[4])
+{
+    const int Xn = grid_n(TOP_X_MIN, TOP_X_MAX), Yn = grid_n(TOP_Y_MIN, TOP_Y_MAX);
+    float xmin = c[0], xmax = c[0], ymin = c[8], ymax = c[8];
+    int nx = c[0] != c[0], ny = c[8] != c[8];
+    for (int k = 1; k < 8; ++k) {
+        if (c[k] < xmin) xmin = c[k];
+        if (c[k] > xmax) xmax = c[k];
+        if (c[8 + k] < ymin) ymin = c[8 + k];
+        if (c[8 + k] > ymax) ymax = c[8 + k];
+        nx |= c[k] != c[k]; ny |= c[8 + k] != c[8 + k];
+    }
+    if (nx) xmin = xmax = NAN;
+    if (ny) ymin = ymax = NAN;
+    const float res = (float)RES;
+    out[0] = (float)Yn - mv3d_ref_floor_dividef(ymax - (float)TOP_Y_MIN, res);
+    out[1] = (float)Xn - mv3d_ref_floor_dividef(xmax - (float)TOP_X_MIN, res);
+    out[2] = (float)Yn - mv3d_ref_floor_dividef(ymin - (float)TOP_Y_MIN, res);
+    out[3] = (float)Xn - mv3d_ref_floor_dividef(xmin - (float)TOP_X_MIN, res);
+}
+
+void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc, float *corners,
+                       float *pred_cnr_r, float *bv, float *bv_r)
+{
+    for (int i = 0; i < R; ++i) {
+        float *c = corners + 24 * i;
+        corners_one(rois_3d + 7 * i + 1, c);                       /* test_mv.py:240-244 */
+        /* bbox_transform.py:157-176: diag = ||p0 - p6|| (f32), deltas * diag + boxes */
+        const float d0 = c[0] - c[6], d1 = c[8] - c[14], d2 = c[16] - c[22];
+        float ss = d0 * d0;
+        ss = ss + d1 * d1;
+        ss = ss + d2 * d2;
+        const float diag = sqrtf(ss);
+        for (int k = 0; k < nc; ++k) {
+            for (int j = 0; j < 24; ++j)
+                pred_cnr_r[(size_t)i * 24 * nc + 24 * k + j] = deltas[(size_t)i * 24 * nc + 24 * k + j] * diag + c[j];
+            corners_to_bv_one(c, bv + (size_t)i * 4 * nc + 4 * k);                 /* hstack((cnr, cnr)) */
+            corners_to_bv_one(pred_cnr_r + (size_t)i * 24 * nc + 24 * k, bv_r + (size_t)i * 4 * nc + 4 * k);
+        }
+    }
+}
+
+void mv3d_ref_point_cloud_2_top(const float *pts, int P, float *top)
+{
+    /* read_lidar.py:48-113 with side_range=(-30,30), fwd_range=(0,60), height_range=(-2,0.4), res=0.1, zres=0.3 */
+    const double side0 = -30.0, side1 = 30.0, fwd0 = 0.0, fwd1 = 60.0, h0 = -2.0, h1 = 0.4, res = 0.1, zres = 0.3;
+    const int x_max = (int)((side1 - side0) / res), y_max = (int)((fwd1 - fwd0) / res), z_max = (int)((h1 - h0) / zres);
+    const int Wd = x_max + 1, Hd = y_max + 1, Cd = z_max + 1;
+    memset(top, 0, sizeof(float) * (size_t)Wd * Hd * Cd);
+    const int xoff = (int)floor(side0 / res), yoff = (int)floor(fwd1 / res);
+    const int nslice = (int)ceil((h1 - h0) / zres);               /* len(np.arange(h0, h1, zres)) */
+    const float resf = (float)res;
+    for (int i = 0; i < nslice; ++i) {
+        const double height = h0 + i * zres;                       /* np.arange: start + i*step */
+        for (int p = 0; p < P; ++p) {
+            const float x = pts[4 * p], y = pts[4 * p + 1], z = pts[4 * p + 2], r = pts[4 * p + 3];
+            if (!((double)x > fwd0 && (double)x < fwd1)) continue;
+            if (!((double)y > -side1 && (double)y < -side0)) continue;
+            if (!((double)z >= height && (double)z < height + zres)) continue;
+            int x_img = (int)(-y / resf), y_img = (int)(-x / resf);   /* f32 divide, trunc */
+            x_img -= xoff; y_img += yoff;
+            /* numpy negative indices wrap; the ranges above keep both in [0, 600] */
+            float *cell = top + ((size_t)y_img * Wd + x_img) * Cd;
+            cell[i] = z - (float)h0;
+            cell[z_max] = r;
+        }
+    }
+}

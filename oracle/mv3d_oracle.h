@@ -111,6 +111,22 @@ void mv3d_ref_roi_pool_backward(const float *top_diff, const int32_t *argmax,
                                 int B, int H, int W, int C,
                                 const float *rois, int R, int PH, int PW, float scale,
                                 float *bottom_diff);
+/* ---- SURVEY §8(f) "next" rows ------------------------------------------------------------ */
+float mv3d_ref_floor_dividef(float a, float b);   /* numpy npy_divmodf -> floor_divide (f32) */
+
+/* Test-time tail of box_detect (lib/fast_rcnn/test_mv.py:240-261): rois_3d (R,7) [b,x,y,z,l,w,h],
+ * deltas (R,24*nc) -> corners (R,24) f32 (lib/utils/transform.py:290-315), pred_cnr_r (R,24*nc) f32
+ * (lib/fast_rcnn/bbox_transform.py:157-176), bv (R,4*nc) and bv_r (R,4*nc): corners_to_bv
+ * (lib/utils/transform.py:342-366, f32 arithmetic incl. f32 floor-divide) of hstack(corners x nc)
+ * and of pred_cnr_r. */
+void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc, float *corners,
+                       float *pred_cnr_r, float *bv, float *bv_r);
+
+/* BEV rasteriser (lib/utils/read_lidar.py:10-115 with the ranges of tools/read_lidar.py:121-123):
+ * points (P,4) f32 -> top (601,601,9) f32; later point (then later height slice, for the
+ * reflectance channel) wins a cell, as numpy fancy assignment does. */
+void mv3d_ref_point_cloud_2_top(const float *points, int P, float *top);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,3 +322,21 @@ def floor_divide(a, b):
 def log(x):
     return np.array([lib().mv3d_ref_log(float(v)) for v in np.asarray(x, np.float64).ravel()],
                     np.float64).reshape(np.shape(x))
+
+
+def box_tail(rois_3d, deltas, nc=2):
+    """(corners (R,24), pred_cnr (R,24*nc), pred_cnr_r, pred_bv (R,4*nc) f64, pred_bv_r) of
+    lib/fast_rcnn/test_mv.py:240-261."""
+    r3, dl = _f32(rois_3d), _f32(deltas)
+    R = r3.shape[0]
+    cnr = np.zeros((R, 24), np.float32); pr = np.zeros((R, 24 * nc), np.float32)
+    bv = np.zeros((R, 4 * nc), np.float32); bvr = np.zeros((R, 4 * nc), np.float32)
+    lib().mv3d_ref_box_tail(_p(r3), _p(dl), C.c_int(R), C.c_int(nc), _p(cnr), _p(pr), _p(bv), _p(bvr))
+    return cnr, np.hstack([cnr] * nc), pr, bv.astype(np.float64), bvr.astype(np.float64)
+
+
+def point_cloud_2_top(points):
+    p = _f32(points)
+    top = np.zeros((601, 601, 9), np.float32)
+    lib().mv3d_ref_point_cloud_2_top(_p(p), C.c_int(p.shape[0]), _p(top))
+    return top

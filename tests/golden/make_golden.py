@@ -84,6 +84,10 @@ def build_scratch(d):
     for f in ("bbox_transform", "config", "nms_wrapper"):
         shutil.copy(f"{REF}/fast_rcnn/{f}.py", f"{L}/fast_rcnn/")
     shutil.copy(f"{REF}/utils/transform.py", f"{L}/utils/")
+    shutil.copy(f"{REF}/utils/read_lidar.py", f"{L}/utils/")
+    os.makedirs(os.path.join(d, "shim", "matplotlib"))
+    open(f"{d}/shim/matplotlib/__init__.py", "w").close()
+    open(f"{d}/shim/matplotlib/pyplot.py", "w").close()
     for p in ("fast_rcnn", "utils", "nms"):
         open(f"{L}/{p}/__init__.py", "w").close()
     shutil.copy(f"{REF}/nms/cpu_nms.pyx", f"{L}/nms/cpu_nms.pyx")
@@ -277,6 +281,26 @@ def main():
         out = proposal_target_layer_3d(bv, b3, gtbv, gt3d, gtc, calib, 2)
         save(f"proposal_target_{name}", rois_bv_in=bv, rois_3d_in=b3, gt_bv=gtbv, gt_3d=gt3d, gt_cnr=gtc, calib=calib,
              np_seed=seed, rois_bv=out[0], rois_img=out[1], labels=out[2], bbox_targets=out[3], rois_3d=out[4])
+
+    # ---- §8(f) rank 2: test-time tail of box_detect (lib/fast_rcnn/test_mv.py:240-261)
+    r = np.random.RandomState(51)
+    b3 = np.stack([r.uniform(0, 60, 300), r.uniform(-30, 30, 300), r.uniform(-1.5, 0, 300), r.uniform(1, 5, 300),
+                   r.uniform(0.5, 2, 300), r.uniform(1, 2, 300)], 1).astype(np.float32)
+    b3[0] = [59.95, -29.95, -1, 4, 1.6, 1.5]; b3[1] = [0.05, 29.95, -1, 3.9, 1.6, 1.5]   # map corners
+    deltas = (r.uniform(-0.2, 0.2, (300, 48))).astype(np.float32)
+    cnr = T.lidar_3d_to_corners(b3)
+    pred_cnr = np.hstack((cnr, cnr))
+    save("box_tail", boxes_3d=b3, deltas=deltas, corners=cnr, pred_cnr_r=BT.bbox_transform_inv_cnr(cnr, deltas),
+         pred_bv=T.corners_to_bv(pred_cnr), pred_bv_r=T.corners_to_bv(BT.bbox_transform_inv_cnr(cnr, deltas)))
+
+    # ---- §8(f) rank 1: BEV rasteriser (lib/utils/read_lidar.py:10-115 == tools/read_lidar.py)
+    from utils.read_lidar import point_cloud_2_top
+    for name, seed, P in (("small", 61, 20000), ("kitti", 62, 120000)):
+        pts = synth.point_cloud(seed, P)
+        top = point_cloud_2_top(pts, res=0.1, zres=0.3, side_range=(-30., 30.), fwd_range=(0., 60), height_range=(-2, 0.4))
+        nz = np.flatnonzero(top)
+        save(f"point_cloud_top_{name}", seed=seed, P=P, sha_points=synth.sha256(pts), shape=np.array(top.shape),
+             nz_index=nz.astype(np.int32), nz_value=top.ravel()[nz], sha_top=synth.sha256(top))
 
     if args.keep_scratch:
         print("scratch kept at", d)

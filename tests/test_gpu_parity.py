@@ -311,3 +311,39 @@ def test_proposal_target_yml_thresholds_vs_oracle(ops, oracle):
     assert ra == rb and a[0].shape[0] == 128
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ------------------------------------------------------------------ SURVEY §8(f) next rows
+@pytest.mark.parametrize("name", ["point_cloud_top_small", "point_cloud_top_kitti"])
+def test_point_cloud_2_top_matches_reference(ops, name):
+    from mv3d_tf_amd.utils.read_lidar import point_cloud_2_top
+    g = golden(name)
+    pts = synth.point_cloud(int(g["seed"]), int(g["P"]))
+    top = point_cloud_2_top(pts, res=0.1, zres=0.3, side_range=(-30., 30.), fwd_range=(0., 60), height_range=(-2, 0.4))
+    assert top.shape == (601, 601, 9) and top.dtype == np.float32
+    nz = np.flatnonzero(top)
+    assert np.array_equal(nz, g["nz_index"]) and np.array_equal(top.ravel()[nz], g["nz_value"])
+    assert synth.sha256(top) == str(g["sha_top"])
+    with pytest.raises(NotImplementedError):
+        point_cloud_2_top(pts, side_range=(-10., 10.))
+
+
+def test_point_cloud_2_top_empty_and_repeat(ops, torch_cuda, oracle):
+    torch = torch_cuda
+    top = ops.point_cloud_2_top(torch.zeros((0, 4), device="cuda"))
+    assert not top.any()
+    pts = synth.point_cloud(7, 5000)
+    a = ops.point_cloud_2_top(dev(pts, torch)).cpu().numpy()
+    b = ops.point_cloud_2_top(dev(pts, torch)).cpu().numpy()       # scatter order must not matter
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.point_cloud_2_top(pts))
+
+
+def test_box_detect_tail_matches_reference(ops, torch_cuda):
+    torch = torch_cuda
+    g = golden("box_tail")
+    r3 = np.hstack([np.zeros((len(g["boxes_3d"]), 1), np.float32), g["boxes_3d"]])
+    cnr, pr, bv, bvr = ops.box_detect_tail(dev(r3, torch), dev(g["deltas"], torch), 2)
+    assert np.array_equal(cnr.cpu().numpy(), g["corners"])
+    assert np.array_equal(pr.cpu().numpy(), g["pred_cnr_r"])
+    assert np.array_equal(bv.cpu().numpy().astype(np.float64), g["pred_bv"])
+    assert np.array_equal(bvr.cpu().numpy().astype(np.float64), g["pred_bv_r"])

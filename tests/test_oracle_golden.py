@@ -149,3 +149,25 @@ def test_proposal_target_layer_3d(oracle, name):
     assert np.array_equal(out[2], g["labels"])
     assert np.array_equal(out[3], g["bbox_targets"])
     assert np.array_equal(out[4], g["rois_3d"])
+
+
+def test_box_tail(oracle):
+    g = golden("box_tail")
+    r3 = np.hstack([np.zeros((len(g["boxes_3d"]), 1), np.float32), g["boxes_3d"]])
+    cnr, pred, pred_r, bv, bv_r = oracle.box_tail(r3, g["deltas"], 2)
+    assert np.array_equal(cnr, g["corners"])
+    assert np.array_equal(pred_r, g["pred_cnr_r"])
+    assert np.array_equal(bv, g["pred_bv"]) and bv.dtype == g["pred_bv"].dtype
+    assert np.array_equal(bv_r, g["pred_bv_r"])
+
+
+@pytest.mark.parametrize("name", ["point_cloud_top_small", "point_cloud_top_kitti"])
+def test_point_cloud_2_top(oracle, name):
+    g = golden(name)
+    pts = synth.point_cloud(int(g["seed"]), int(g["P"]))
+    assert synth.sha256(pts) == str(g["sha_points"])
+    top = oracle.point_cloud_2_top(pts)
+    assert tuple(g["shape"]) == top.shape == (601, 601, 9)
+    nz = np.flatnonzero(top)
+    assert np.array_equal(nz, g["nz_index"]) and np.array_equal(top.ravel()[nz], g["nz_value"])
+    assert synth.sha256(top) == str(g["sha_top"])
