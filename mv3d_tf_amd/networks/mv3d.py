@@ -1,0 +1,169 @@
+"""MV3D graphs (lib/networks/MV3D_test.py:32-123, MV3D_train.py:42-182) as data tables run
+by a small executor, with the hot-path layers bound to libmv3d_hip.so:
+
+    proposal_layer_3d / anchor_target_layer / proposal_target_layer_3d   mv3d_tf_amd.rpn_msr.*
+    roi_pool (+ gradient)                                                 mv3d_tf_amd.roi_pooling_layer
+    proposal_transform                                                    tuple element 0 ('bv') / 1 ('img')
+
+Layer names, shapes and the plumbing of lib/networks/network.py:199-405 are kept (`layers`
+dict, `get_output(name)`, NHWC activations, fc on a 4-D input flattens in (c,h,w) order,
+`reshape_layer(d)` + pairwise softmax for the RPN scores, `load()` of the `.npy`
+{layer: {weights, biases}} dictionary with ignore_missing).  The VGG16 convolutions / fully
+connected layers are dense contractions outside this repository's parity contract: they run
+through torch (MIOpen / rocBLAS) purely so that the drop-in entry points are runnable end to end.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..fast_rcnn.config import cfg
+from ..roi_pooling_layer.roi_pooling_op import roi_pool
+from ..rpn_msr.anchor_target_layer_tf import anchor_target_layer
+from ..rpn_msr.proposal_layer_tf import proposal_layer_3d
+from ..rpn_msr.proposal_target_layer_tf import proposal_target_layer_3d
+
+n_classes = 2                 # lib/networks/MV3D_train.py:4
+_feat_stride = [8, 8]         # :5
+anchor_scales = [1.0, 1.0]    # :6 (only len() is used: A = 2 * 2)
+
+# conv name stem -> (out channels, followed by a 2x2/2 VALID max-pool?)   (no pool4: stride stays 8)
+_VGG = [("conv1_1", 64, False), ("conv1_2", 64, True), ("conv2_1", 128, False), ("conv2_2", 128, True),
+        ("conv3_1", 256, False), ("conv3_2", 256, False), ("conv3_3", 256, True),
+        ("conv4_1", 512, False), ("conv4_2", 512, False), ("conv4_3", 512, False),
+        ("conv5_1", 512, False), ("conv5_2", 512, False), ("conv5_3", 512, False)]
+_INPUTS = ("lidar_bv_data", "image_data", "im_info", "calib", "gt_boxes", "gt_boxes_bv", "gt_boxes_3d",
+           "gt_boxes_corners")
+
+
+class MV3D:
+    """One class for both graphs; `phase` is 'TEST' (MV3D_test) or 'TRAIN' (MV3D_train)."""
+
+    def __init__(self, phase="TEST", trainable=True, device=None, seed=0):
+        self.phase = phase
+        self.trainable = trainable
+        self.device = torch.device(device or ("cuda:%d" % cfg.GPU_ID))
+        self.layers = {}
+        self.keep_prob = 1.0 if phase == "TEST" else 0.5          # train_mv.py:167 / test_mv.py:183
+        self.params = {}
+        g = torch.Generator().manual_seed(seed)
+
+        def var(name, shape, std):
+            w = (torch.randn(shape, generator=g) * std).to(self.device).requires_grad_(trainable)
+            b = torch.zeros(shape[0], device=self.device, requires_grad=trainable)
+            self.params[name] = [w, b]
+
+        for suffix, cin in (("", 9), ("_2", 3)):                   # BEV trunk (9 ch), RGB trunk (3 ch)
+            c = cin
+            for stem, cout, _ in _VGG:
+                var(stem + suffix, (cout, c, 3, 3), 0.01)
+                c = cout
+        var("rpn_conv/3x3", (512, 512, 3, 3), 0.01)
+        var("rpn_cls_score", (len(anchor_scales) * 2 * 2, 512, 1, 1), 0.01)
+        var("rpn_bbox_pred", (len(anchor_scales) * 2 * 6, 512, 1, 1), 0.01)
+        for t in ("_1", "_2"):
+            var("fc6" + t, (2048, 7 * 7 * 512), 0.01)
+            var("fc7" + t, (2048, 2048), 0.01)
+        var("cls_score", (n_classes, 4096), 0.01)
+        var("bbox_pred", (n_classes * 24, 4096), 0.001)            # network.py:382-384
+
+    # ---- lib/networks/network.py plumbing
+    def get_output(self, layer):
+        try:
+            return self.layers[layer]
+        except KeyError:
+            raise KeyError("Unknown layer name fed: %s" % layer)
+
+    def parameters(self):
+        return [p for wb in self.params.values() for p in wb]
+
+    def load(self, data_path, session=None, saver=None, ignore_missing=False):
+        """`.npy` dict {layer: {'weights' (TF HWIO / [in,out]), 'biases'}} (network.py:45-64)."""
+        data = np.load(data_path, allow_pickle=True, encoding="latin1").item()
+        for key, sub in data.items():
+            if key not in self.params:
+                if not ignore_missing:
+                    raise ValueError("no variable scope %s" % key)
+                continue
+            w = torch.as_tensor(np.asarray(sub["weights"], np.float32))
+            w = w.permute(3, 2, 0, 1) if w.ndim == 4 else w.t()
+            with torch.no_grad():
+                self.params[key][0].copy_(w.reshape(self.params[key][0].shape))
+                self.params[key][1].copy_(torch.as_tensor(np.asarray(sub["biases"], np.float32)))
+
+    # ---- dense layers (torch; NHWC kept as channels_last NCHW views)
+    def _conv(self, x, name, relu=True, pad=1):
+        w, b = self.params[name]
+        y = F.conv2d(x, w, b, padding=pad)
+        return F.relu(y) if relu else y
+
+    def _trunk(self, x, suffix):
+        for stem, _, pool in _VGG:
+            x = self._conv(x, stem + suffix)
+            self.layers[stem + suffix] = x.permute(0, 2, 3, 1)      # NHWC view, as fetched by callers
+            if pool:
+                x = F.max_pool2d(x, 2, 2)
+        return x
+
+    def _fc(self, x, name, relu=True):
+        if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)
+            x = x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
+        w, b = self.params[name]
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+
+    # ---- the graph
+    def forward(self, feed):
+        """feed: dict with the reference's placeholder names (Appendix C of SURVEY.md); numpy or tensors."""
+        L = self.layers
+        L.clear()
+        dev = self.device
+        for k in _INPUTS:
+            if k in feed and feed[k] is not None:
+                L[k] = torch.as_tensor(np.asarray(feed[k], np.float32)).to(dev) if not isinstance(feed[k], torch.Tensor) else feed[k].to(dev)
+        keep_prob = float(feed.get("keep_prob", self.keep_prob))
+        to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        bev = self._trunk(to_nchw(L["lidar_bv_data"]), "")
+        rgb = self._trunk(to_nchw(L["image_data"]), "_2")
+        # RPN (MV3D_train.py:82-103)
+        rpn = self._conv(bev, "rpn_conv/3x3")
+        L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
+        score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).permute(0, 2, 3, 1).contiguous()
+        L["rpn_cls_score"] = score
+        L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).permute(0, 2, 3, 1).contiguous()
+        n, h, w, c = score.shape
+        L["rpn_cls_score_reshape"] = score.reshape(n, h, -1, 2)                       # reshape_layer(2) (network.py:333-341)
+        L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)   # :399-403
+        L["rpn_cls_prob_reshape"] = L["rpn_cls_prob"].reshape(n, h, w, c)
+        stride = _feat_stride[0]
+        if self.phase == "TRAIN":
+            L["rpn-data"] = anchor_target_layer(score.detach(), L["gt_boxes_bv"], L["gt_boxes_3d"], L["im_info"], [stride, ],
+                                                anchor_scales)
+        bv, img, b3 = proposal_layer_3d(L["rpn_cls_prob_reshape"].detach(), L["rpn_bbox_pred"].detach(), L["im_info"],
+                                        L["calib"], self.phase, [stride, ], anchor_scales)
+        rois = (bv, img, b3, b3)                                                      # network.py:234
+        L["rpn_rois" if self.phase == "TRAIN" else "rois"] = rois
+        if self.phase == "TRAIN":
+            data = proposal_target_layer_3d(rois[0], rois[3], L["gt_boxes_bv"], L["gt_boxes_3d"], L["gt_boxes_corners"],
+                                            L["calib"], n_classes)
+            L["roi_data_3d"] = data                                                   # (rois_bv, rois_img, labels, targets, rois_3d)
+            L["roi_data_bv"], L["roi_data_img"] = data[0], data[1]                    # proposal_transform (network.py:292-315)
+        else:
+            L["roi_data_bv"], L["roi_data_img"] = rois[0], rois[1]
+        # RoI pooling on both views + fusion head (MV3D_test.py:95-123)
+        L["pool_5"] = roi_pool(L["conv5_3"].contiguous(), L["roi_data_bv"].contiguous(), 7, 7, 1.0 / 8)[0]
+        L["pool_5_2"] = roi_pool(L["conv5_3_2"].contiguous(), L["roi_data_img"].contiguous(), 7, 7, 1.0 / 8)[0]
+        tower = []
+        for t, pool in (("_1", "pool_5"), ("_2", "pool_5_2")):
+            x = self._fc(L[pool], "fc6" + t)
+            if self.phase == "TRAIN":
+                x = F.dropout(x, 1.0 - keep_prob, training=True)
+            x = self._fc(x, "fc7" + t)
+            if self.phase == "TRAIN":
+                x = F.dropout(x, 1.0 - keep_prob, training=True)
+            L["fc7" + t] = x
+            tower.append(x)
+        fused = torch.cat(tower, dim=1)
+        L["cls_score"] = self._fc(fused, "cls_score", relu=False)
+        L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
+        L["bbox_pred"] = self._fc(fused, "bbox_pred", relu=False)
+        return L

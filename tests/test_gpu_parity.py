@@ -347,3 +347,76 @@ def test_box_detect_tail_matches_reference(ops, torch_cuda):
     assert np.array_equal(pr.cpu().numpy(), g["pred_cnr_r"])
     assert np.array_equal(bv.cpu().numpy().astype(np.float64), g["pred_bv"])
     assert np.array_equal(bvr.cpu().numpy().astype(np.float64), g["pred_bv_r"])
+
+
+# ------------------------------------------------------------------ graph glue / entry points
+def test_get_network_and_box_detect_end_to_end(ops, torch_cuda, oracle):
+    """drop-in entry points (factory.get_network, test_mv.box_detect): layer names and tuple plumbing of
+    network.py, and the hot-path layers inside the graph equal the oracle on the graph's own tensors."""
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.fast_rcnn.test_mv import box_detect
+    from mv3d_tf_amd.networks import get_network
+    torch = torch_cuda
+    net = get_network("MV3D_test")
+    rng = np.random.RandomState(0)
+    bv = (rng.random_sample((64, 72, 9)) * (rng.random_sample((64, 72, 9)) < 0.05)).astype(np.float32)
+    im = rng.randint(0, 255, (48, 160, 3)).astype(np.float32)
+    with torch.no_grad():                                    # spread the RPN scores a little (random init is flat)
+        net.params["rpn_cls_score"][0].mul_(40.0)
+        net.params["rpn_bbox_pred"][0].mul_(5.0)
+    saved = dict(cfg.TEST)
+    cfg.TEST.update(RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=50)
+    try:
+        scores, pred_bv, pred_cnr, pred_cnr_r = box_detect(None, net, im, bv, synth.KITTI_CALIB)
+    finally:
+        cfg.TEST.update(saved)
+    L = net.layers
+    R = scores.shape[0]
+    assert 0 < R <= 50 and scores.shape == (R, 2) and pred_bv.shape == (R, 8) and pred_cnr.shape == (R, 48)
+    for name in ("conv5_3", "conv5_3_2", "rpn_cls_score", "rpn_bbox_pred", "rpn_cls_prob", "rpn_cls_prob_reshape", "rois",
+                 "pool_5", "pool_5_2", "cls_score", "cls_prob", "bbox_pred"):
+        assert name in L
+    assert L["conv5_3"].shape[1:3] == (8, 9) and L["rpn_cls_prob_reshape"].shape == (1, 8, 9, 8)
+    assert isinstance(L["rois"], tuple) and len(L["rois"]) == 4 and L["rois"][2] is L["rois"][3]
+    # the proposal layer inside the graph == oracle on the same head tensors
+    sec = dict(RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=50, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)
+    o = oracle.proposal_layer_3d(L["rpn_cls_prob_reshape"].cpu().numpy(), L["rpn_bbox_pred"].cpu().numpy(),
+                                 np.array([[64, 72, 1]], np.float32), synth.KITTI_CALIB, "TEST", [8, ], cfg={"TEST": sec})
+    for a, b in zip(L["rois"][:3], o):
+        assert np.array_equal(a.cpu().numpy(), b)
+    # RoiPool inside the graph == oracle
+    o_top, _ = oracle.roi_pool(L["conv5_3"].cpu().numpy(), o[0], 7, 7, 0.125)
+    assert np.array_equal(L["pool_5"].cpu().numpy(), o_top)
+    # tail == oracle
+    cn, pc, pr, bvv, _ = oracle.box_tail(o[2], L["bbox_pred"].cpu().numpy(), 2)
+    assert np.array_equal(pred_cnr, pc) and np.array_equal(pred_cnr_r, pr) and np.array_equal(pred_bv, bvv)
+    with pytest.raises(KeyError):
+        get_network("VGGnet_test")
+
+
+def test_train_graph_backward_through_roi_pool(ops, torch_cuda):
+    """MV3D_train graph: anchor / proposal targets + RoiPoolGrad compose (roi_pooling_op_test.py's intent)."""
+    from mv3d_tf_amd.networks import get_network
+    torch = torch_cuda
+    net = get_network("MV3D_train")
+    rng = np.random.RandomState(1)
+    gtbv = np.array([[200, 150, 216, 189, 1], [300, 300, 316, 339, 1]], np.float32)
+    gt3d = np.array([[43.0, 9.2, -0.95, 3.9, 1.6, 1.56, 1], [28.0, -0.8, -0.95, 3.9, 1.6, 1.56, 1]], np.float32)
+    r = np.random.RandomState(2)
+    _, _, gtc = synth.gt_cars(r, 2)
+    np.random.seed(3)
+    with torch.no_grad():
+        net.params["rpn_cls_score"][0].mul_(40.0)
+    L = net.forward({"lidar_bv_data": (rng.random_sample((1, 608, 608, 9)) < 0.02).astype(np.float32),
+                     "image_data": rng.randint(0, 255, (1, 96, 320, 3)).astype(np.float32),
+                     "im_info": np.array([[608, 608, 1]], np.float32), "calib": synth.KITTI_CALIB,
+                     "gt_boxes_bv": gtbv, "gt_boxes_3d": gt3d, "gt_boxes_corners": gtc})
+    lab, tg, _, _ = L["rpn-data"]
+    assert lab.shape == (76 * 76 * 4,) and tg.shape == (76 * 76 * 4, 6)
+    rois_bv, rois_img, labels, targets, rois_3d = L["roi_data_3d"]
+    S = rois_bv.shape[0]
+    assert 0 < S <= 128 and labels.shape == (S, 1) and targets.shape == (S, 48) and L["cls_score"].shape == (S, 2)
+    loss = L["cls_score"].square().mean() + L["bbox_pred"].square().mean()
+    loss.backward()
+    g = net.params["conv5_3"][0].grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0      # gradient came through RoiPoolGrad
