@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests on one GPU)")
     return ap.parse_args()
 
 
@@ -179,12 +180,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    ndev = torch.cuda.device_count()
+    if local >= ndev and args.dist_backend == "nccl":
+        raise SystemExit("rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local, ndev))
+    local = local % ndev                               # gloo logic tests may share one GPU
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     from mv3d_tf_amd import build
     build.build()
 
@@ -217,7 +225,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     from mv3d_tf_amd import sharding
-    dt = sharding.max_over_ranks(dt, dist, device="cuda")
+    dt = sharding.max_over_ranks(dt, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
 
     if rank == 0:
         frames = args.steps * args.batch * world
