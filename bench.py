@@ -93,9 +93,14 @@ class Frames:
             mk = lambda c, dt: torch.empty((R, 7, 7, c), dtype=dt, device="cuda")
             self.tops = (mk(BEV_MAP[2], torch.float32), mk(BEV_MAP[2], torch.int32),
                          mk(RGB_MAP[2], torch.float32), mk(RGB_MAP[2], torch.int32))
-        self._roi(self.bev, rois_bv, self.tops[0], self.tops[1])
-        self._roi(self.rgb, rois_img, self.tops[2], self.tops[3])
+        self._roi_views(rois_bv, rois_img)
         return cap
+
+    def _roi_views(self, rois_bv, rois_img):
+        """both RoiPool layers of the step (MV3D_test.py:95-107) in one launch"""
+        from mv3d_tf_amd import ops as o
+        o.roi_pool_forward_views([(self.bev, rois_bv, 0.125), (self.rgb, rois_img, 0.125)], 7, 7,
+                                 outs=[(self.tops[0], self.tops[1]), (self.tops[2], self.tops[3])])
 
     def _roi(self, data, rois, top, argmax):
         import ctypes as C
@@ -133,18 +138,21 @@ def pmc_traffic(kernel):
 
 
 def roofline(fr):
-    """Dominant kernel = RoiPool forward on the RGB view (largest share of the step and the largest
-    algorithmic traffic): bytes = feature map once + rois + (top f32 + argmax i32) outputs."""
+    """Dominant kernel = the RoiPool forward launch (BEV + RGB views; largest share of the step and of
+    its traffic).  Algorithmic bytes per launch: each feature map once + rois + (top f32 +
+    argmax i32) outputs of both views."""
     B = fr.args.batch
     R = fr.out[0].shape[0] * fr.out[0].shape[1]
-    H, W, C = RGB_MAP
-    alg = B * H * W * C * 4 + R * 20 + R * 49 * C * 8
-    rois = fr.out[1].view(-1, 5)
-    ms = time_kernel_events(lambda: fr._roi(fr.rgb, rois, fr.tops[2], fr.tops[3]))
+    alg = 0
+    for (H, W, C) in (BEV_MAP, RGB_MAP):
+        alg += B * H * W * C * 4 + R * 20 + R * 49 * C * 8
+    rois_bv, rois_img = fr.out[0].view(-1, 5), fr.out[1].view(-1, 5)
+    ms = time_kernel_events(lambda: fr._roi_views(rois_bv, rois_img))
     gbs = alg / (ms * 1e-3) / 1e9
-    return {"kernel": "roi_pool_fwd_xcd_kernel (RGB view 46x155x512, R=%d)" % R, "bound": "hbm", "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("roi_pool_fwd_xcd_kernel"),
+    name = "roi_pool_fwd_xcd_multi_kernel"
+    return {"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 views, R=%d rows each)" % (name, R), "bound": "hbm",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(name),
             "alg_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2),
             "note": "HIP events over 50 back-to-back launches on the launch stream; traffic = PMC FETCH_SIZE*2+WRITE_SIZE "
                     "per launch (profiles/r01_pmc_traffic.txt); write-only fill ceiling on this box 5.8-6.0 TB/s (profiles/r01_hbm_probe.txt)"}

@@ -56,8 +56,9 @@ int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep,
 
 /* Diagnostics: mv3d_nms_device plus a per-64-box-block trace of the greedy chain,
  * trace_dev[4*b + 0..3] = {cycle at block start, cycle after waiting for the bulk workers,
- * cycle after the diagonal fixed point, (iterations << 32) | kept-in-block}.  Used by
- * tools/ and profiles/ only. */
+ * cycle after the diagonal fixed point, (iterations << 32) | kept-in-block}, followed by 8
+ * phase stamps of the first round's chain kernel {start, first tiles in LDS, chain done, end};
+ * trace_dev holds 4*ceil(n/64) + 8 entries.  Used by tools/ and profiles/ only. */
 int mv3d_nms_device_trace(const float *dets_dev, int n, double thresh, int max_keep,
                           int32_t *keep_dev, int32_t *num_keep_dev, int32_t *status_dev,
                           void *workspace, size_t workspace_bytes, void *stream, int64_t *trace_dev);
@@ -127,6 +128,20 @@ int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale, int batch
                            int num_rois, int height, int width, int channels,
                            int pooled_height, int pooled_width, const float *bottom_rois,
                            float *bottom_diff, const int32_t *argmax_data, void *stream);
+
+/* Several views in one launch (e.g. the BEV and RGB RoiPool layers of one step, MV3D_test.py:95-107):
+ * same results as one mv3d_roi_pool_forward per view. */
+#define MV3D_MAX_ROI_VIEWS 4
+typedef struct {
+    const float *bottom_data;    /* (batch_size, height, width, channels) NHWC */
+    const float *bottom_rois;    /* (num_rois, 5) */
+    float *top_data;             /* (num_rois, pooled_height, pooled_width, channels) */
+    int32_t *argmax_data;        /* same shape, may be NULL */
+    float spatial_scale;
+    int32_t batch_size, num_rois, height, width, channels;
+} mv3d_roi_view;
+int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                void *stream);
 
 /* ------------------------------------------------------------------ anchor_target_layer
  * Replaces the deterministic part of lib/rpn_msr/anchor_target_layer_tf.py:21-250 plus

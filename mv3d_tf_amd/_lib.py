@@ -30,6 +30,13 @@ class AnchorTargetParams(C.Structure):
                 ("negative_overlap", C.c_double), ("positive_overlap", C.c_double)]
 
 
+class RoiView(C.Structure):
+    """mv3d_roi_view"""
+    _fields_ = [("bottom_data", C.c_void_p), ("bottom_rois", C.c_void_p), ("top_data", C.c_void_p),
+                ("argmax_data", C.c_void_p), ("spatial_scale", C.c_float), ("batch_size", C.c_int32),
+                ("num_rois", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
+
+
 class ProposalTargetParams(C.Structure):
     """mv3d_proposal_target_params"""
     _fields_ = [("num_classes", C.c_int32), ("reserved", C.c_int32), ("fg_thresh", C.c_double),
@@ -65,6 +72,7 @@ _SIGS = {
                                               _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_point_cloud_2_top": (C.c_int, [_P, C.c_int, _P, _P]),
     "mv3d_box_detect_tail": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

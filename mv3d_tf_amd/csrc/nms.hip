@@ -475,6 +475,202 @@ __global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
     }
 }
 
+// Round-1 form of the chain (column blocks [0, b1 <= 32)): the tiles of the round are ONE contiguous
+// stream in consumption order (column-block-major), so waves 1..7 stream it into LDS as fast as a
+// single CU can pull it (16-B loads, two batches in flight) while wave 0 runs the greedy dependency
+// out of LDS: removed(j) = (OR_rb tile(rb,b)[j] & K_rb) != 0 -- two v_and_or per tile, one compare per
+// column -- and never sees a global-memory latency.  The stream is cut into epochs that fit the
+// LDS arena ([0,23) and [23,32)); the sorted `order` of the round's boxes and the kept positions
+// stay in LDS too, so the ROI-blob gather at the end is one dependent load deep.
+#define CHL_THREADS 512
+#define CHL_LOADERS 7                                   // waves 1..7
+#define CHL_ARENA 276                                   // tiles (columns 0..22)
+#define CHL_PER (CHL_LOADERS * 64)                      // 16-B units per load instruction of the loader group
+#define CHL_BATCH (4 * CHL_PER)                         // units per batch (56 tiles)
+#define CHL_BOXES 2048
+
+__global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
+{
+    __shared__ uint4 s_tiles[(CHL_ARENA + 8) * 32];      // 512 B per tile; 8 tiles of slack for the chunked pull
+    __shared__ unsigned long long s_K[32];
+    __shared__ int s_order[CHL_BOXES];
+    __shared__ unsigned short s_keep[CHL_BOXES];
+    __shared__ int s_prog[8];
+    __shared__ int s_halt, s_stop, s_fin, s_nk;
+    const int f = blockIdx.x;
+    const long long t_start = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+    long long t_first = 0;
+    int32_t *cstate = d.cstate + 4 * f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint4 *gsrc = reinterpret_cast<const uint4 *>(d.tiles + (long long)f * d.ntiles * 64);
+    int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
+    unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
+    // the loaders work from the static capacity (tiles beyond the frame's boxes are never consumed)
+    const int cols = min(d.b1, d.nbw);
+    if (threadIdx.x < 32) s_K[threadIdx.x] = 0ull;           // K of an unfinished block masks its tiles out
+    if (threadIdx.x == 0) s_stop = 0;
+    int n = 0, nb = 0, b1 = 0;
+    if (wave == 0) { n = frame_n(d, f); nb = (n + 63) >> 6; b1 = min(d.b1, nb); }
+    int total = 0;                                         // wave 0
+    bool stop = false;
+    int c0 = 0;
+    while (c0 < cols) {
+        // epoch = columns [c0, c1): as many whole columns as fit the arena
+        const int T0 = c0 * (c0 + 1) / 2;
+        int c1 = c0;
+        while (c1 < cols && (c1 + 1) * (c1 + 2) / 2 - T0 <= CHL_ARENA) ++c1;
+        const int units = ((c1 * (c1 + 1)) / 2 - T0) * 32;
+        if (threadIdx.x < 8) s_prog[threadIdx.x] = 0;
+        if (threadIdx.x == 8) s_halt = 0;
+        __syncthreads();
+        if (wave > 0) {
+            // ---- loaders: two batches of four 16-B loads in flight per thread; addresses are clamped so
+            // that every load is unconditional (no divergent control flow around the loads)
+            const int lt = threadIdx.x - 64;
+            const uint4 *src = gsrc + (long long)T0 * 32;
+            const int last = units - 1;
+            const int nbatch = (units + CHL_BATCH - 1) / CHL_BATCH;
+            uint4 a0 = src[min(lt, last)], a1 = src[min(lt + CHL_PER, last)];
+            uint4 a2 = src[min(lt + 2 * CHL_PER, last)], a3 = src[min(lt + 3 * CHL_PER, last)];
+            int o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+            const bool want_order = (c0 == 0) && d.emit.enabled;
+            if (want_order) {
+                const int32_t *ord = d.emit.order + (long long)f * d.emit.order_cap;
+                const int m = min(d.n_cap, CHL_BOXES) - 1;
+                o0 = ord[min(lt, m)]; o1 = ord[min(lt + CHL_PER, m)]; o2 = ord[min(lt + 2 * CHL_PER, m)];
+                o3 = ord[min(lt + 3 * CHL_PER, m)]; o4 = ord[min(lt + 4 * CHL_PER, m)];
+            }
+            for (int k = 0; k < nbatch; ++k) {
+                const int u = k * CHL_BATCH + lt, v = u + CHL_BATCH;
+                const uint4 n0 = src[min(v, last)], n1 = src[min(v + CHL_PER, last)];
+                const uint4 n2 = src[min(v + 2 * CHL_PER, last)], n3 = src[min(v + 3 * CHL_PER, last)];
+                if (u < units) s_tiles[u] = a0;
+                if (u + CHL_PER < units) s_tiles[u + CHL_PER] = a1;
+                if (u + 2 * CHL_PER < units) s_tiles[u + 2 * CHL_PER] = a2;
+                if (u + 3 * CHL_PER < units) s_tiles[u + 3 * CHL_PER] = a3;
+                if (k == 0 && want_order) {
+                    s_order[lt] = o0; s_order[lt + CHL_PER] = o1; s_order[lt + 2 * CHL_PER] = o2; s_order[lt + 3 * CHL_PER] = o3;
+                    if (lt + 4 * CHL_PER < CHL_BOXES) s_order[lt + 4 * CHL_PER] = o4;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&s_prog[wave], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+                if (__hip_atomic_load(&s_halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            }
+        } else {
+            // ---- wave 0: the greedy dependency
+            const unsigned long long *arena = reinterpret_cast<const unsigned long long *>(s_tiles);
+            int have = 0;                                          // batches known to be complete
+            const int ce = min(c1, b1);
+            for (int b = c0; b < ce; ++b) {
+                const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
+                const int tb = b * (b + 1) / 2 - T0;               // arena slot of tile (0, b)
+                const int need = ((tb + b + 1) * 32 + CHL_BATCH - 1) / CHL_BATCH;
+                while (have < need) {
+                    int v = (lane >= 1 && lane <= CHL_LOADERS)
+                                ? __hip_atomic_load(&s_prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
+#pragma unroll
+                    for (int m = 1; m < 8; m <<= 1) v = min(v, __shfl_xor(v, m));
+                    have = __builtin_amdgcn_readfirstlane(v);
+                    if (have < need) __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                if (d.trace && b == 0) t_first = (long long)__builtin_readcyclecounter();
+                const unsigned long long *col = arena + (long long)tb * 64 + lane;
+                unsigned long long acc = 0ull;
+                const int bu = __builtin_amdgcn_readfirstlane(b);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (8 * c < bu) {                              // s_K[rb] == 0 for rb >= b
+                        unsigned long long t[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) t[q] = col[(8 * c + q) * 64];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc |= t[q] & s_K[8 * c + q];
+                    }
+                }
+                const unsigned long long dg = col[b * 64];
+                const int p = b * 64 + lane;
+                const bool alive = (p < n) && (acc == 0ull);
+                unsigned long long K = __ballot(alive);
+                int iters = 0;
+                for (;;) {                                        // fixed point = greedy set (see chain_round)
+                    const unsigned long long K2 = __ballot(alive && !(dg & K));
+                    ++iters;
+                    if (K2 == K) break;
+                    K = K2;
+                }
+                const bool kept = (K >> lane) & 1ull;
+                const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
+                if (kept && (d.max_keep <= 0 || pos < d.max_keep)) { keep[pos] = p; s_keep[pos] = (unsigned short)p; }
+                total += __popcll(K);
+                if (lane == 0) { s_K[b] = K; kstate[b] = K; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (d.trace && f == 0 && lane == 0) {
+                    long long *tr = d.trace + 4 * b;
+                    tr[0] = t_begin; tr[1] = t_begin; tr[2] = t_begin;   // one stamp per block (a second costs ~200 cycles)
+                    tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
+                }
+                if (d.max_keep > 0 && total >= d.max_keep) { stop = true; break; }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&s_halt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (stop || ce >= b1) __hip_atomic_store(&s_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        c0 = c1;
+        if (s_stop) break;
+    }
+    if (d.trace && f == 0 && threadIdx.x == 0) {
+        long long *ph = d.trace + 4 * (long long)d.nbw;       // phase stamps after the per-block records
+        ph[0] = t_start; ph[1] = t_first; ph[2] = (long long)__builtin_readcyclecounter();
+    }
+    if (wave == 0 && lane == 0) {
+        const bool finished = stop || (b1 >= nb);
+        int nk = total;
+        if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
+        cstate[0] = total; cstate[1] = finished ? 1 : 0;
+        s_fin = finished ? 1 : 0; s_nk = nk;
+        if (finished) d.num_keep[f] = nk;
+    }
+    __syncthreads();
+    if (!s_fin) return;
+    const int nk = s_nk;
+    if (d.emit.enabled) {
+        // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
+        const EmitDev &e = d.emit;
+        if (threadIdx.x == 0) e.num_out[f] = nk;
+        for (int r = threadIdx.x; r < e.cap; r += blockDim.x) {
+            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
+            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
+            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
+            if (r < nk) {
+                const int c = s_order[s_keep[r]];
+                const long long o = (long long)f * e.N + c;
+                const float4 bx = e.bv[o];
+                const int4 im = e.img[o];
+                const float2 pa = *reinterpret_cast<const float2 *>(e.p3 + o * 6);
+                const float2 pb = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 2);
+                const float2 pc = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 4);
+                const float bi = (float)f;
+                obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
+                oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
+                o3[0] = bi; o3[1] = pa.x; o3[2] = pa.y; o3[3] = pb.x; o3[4] = pb.y; o3[5] = pc.x; o3[6] = pc.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
+            }
+        }
+    }
+    if (d.trace && f == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) d.trace[4 * (long long)d.nbw + 3] = (long long)__builtin_readcyclecounter();
+    }
+}
+
 size_t mv3d_nms_ws_bytes(int n_cap, int batch)
 {
     const size_t nbw = (size_t)(n_cap + 63) / 64;
@@ -515,7 +711,7 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
         const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
         if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
         // a column block of the round has at most b1 - 1 off-diagonal tiles
-        if (d.b1 <= 32) hipLaunchKernelGGL((nms_chain1_kernel<32, 512>), dim3(L.batch), dim3(512), 0, stream, d);
+        if (r == 0) hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
         else if (d.b1 <= 64) hipLaunchKernelGGL((nms_chain1_kernel<64, 512>), dim3(L.batch), dim3(512), 0, stream, d);
         else if (d.b1 <= 128) hipLaunchKernelGGL((nms_chain1_kernel<128, 256>), dim3(L.batch), dim3(256), 0, stream, d);
         else hipLaunchKernelGGL(nms_chain_kernel<18>, dim3(L.batch), dim3(1024), 0, stream, d);

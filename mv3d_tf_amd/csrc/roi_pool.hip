@@ -119,17 +119,17 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
 #define FWD_PASSES 2
 struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
 
-__global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__restrict__ data, float scale, int B, int R,
-                                                               int H, int W, int C, int PH, int PW,
-                                                               const float *__restrict__ rois, float *__restrict__ top,
-                                                               int *__restrict__ argmax, int tpb_shift)
+__device__ __forceinline__ void roi_pool_fwd_xcd_block(const unsigned block, const float *__restrict__ data, float scale,
+                                                        int B, int R, int H, int W, int C, int PH, int PW,
+                                                        const float *__restrict__ rois, float *__restrict__ top,
+                                                        int *__restrict__ argmax, int tpb_shift)
 {
     __shared__ BinGeom s_g[FWD_PASSES * 32];
     const int tpb = 1 << tpb_shift;                  // threads per bin = C/32 (8, 16 or 32 float4 lanes)
     const int bpp = 256 >> tpb_shift;                // bins per pass (32, 16 or 8)
-    const int slice = blockIdx.x & 7;
+    const int slice = block & 7;
     const long long nbins = (long long)R * PH * PW;
-    const long long bin0 = (long long)(blockIdx.x >> 3) * (FWD_PASSES * bpp);
+    const long long bin0 = (long long)(block >> 3) * (FWD_PASSES * bpp);
     if (threadIdx.x < FWD_PASSES * bpp) {
         BinGeom g;
         g.hs = g.he = g.ws = g.we = 0; g.base = -1; g.pad0 = g.pad1 = g.pad2 = 0;
@@ -191,6 +191,37 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__re
             if (argmax) *reinterpret_cast<int4 *>(argmax + o) = mi;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__restrict__ data, float scale, int B, int R,
+                                                               int H, int W, int C, int PH, int PW,
+                                                               const float *__restrict__ rois, float *__restrict__ top,
+                                                               int *__restrict__ argmax, int tpb_shift)
+{
+    roi_pool_fwd_xcd_block(blockIdx.x, data, scale, B, R, H, W, C, PH, PW, rois, top, argmax, tpb_shift);
+}
+
+// Several views (the BEV and RGB maps of one step) in ONE launch: the second view's workgroups fill the
+// machine while the first view drains, and one kernel boundary disappears.
+struct RoiViewDev {
+    const float *data, *rois;
+    float *top;
+    int *argmax;
+    float scale;
+    int B, R, H, W, C, tpb_shift;
+    unsigned first_block;        // first workgroup of this view
+};
+struct RoiViewPack { RoiViewDev v[MV3D_MAX_ROI_VIEWS]; int n, PH, PW; };
+
+__global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack p)
+{
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
+    const RoiViewDev &v = p.v[k];
+    roi_pool_fwd_xcd_block(blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                           v.argmax, v.tpb_shift);
 }
 
 #define BWD_CHUNK 1024      // ROIs whose geometry is staged in LDS at a time
@@ -389,5 +420,51 @@ extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale
                         case 8: MV3D_BWD(1, 8); break; default: MV3D_BWD(1, 16); break; }
     }
 #undef MV3D_BWD
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                           void *stream)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0)
+        return MV3D_ERR_INVALID_ARG;
+    bool fast = true;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_data ||
+            !w.top_data || (w.num_rois > 0 && !w.bottom_rois))
+            return MV3D_ERR_INVALID_ARG;
+        const int cv4 = w.channels / 4;
+        fast = fast && (w.channels % 4 == 0) && (cv4 == 64 || cv4 == 128 || cv4 == 256) && aligned16(w.bottom_data) &&
+               aligned16(w.top_data) && (!w.argmax_data || aligned16(w.argmax_data));
+    }
+    if (!fast) {                                          // generic shapes: one launch per view
+        for (int k = 0; k < num_views; ++k) {
+            const mv3d_roi_view &w = views[k];
+            const int rc = mv3d_roi_pool_forward(w.bottom_data, w.spatial_scale, w.batch_size, w.num_rois, w.height, w.width,
+                                                 w.channels, pooled_height, pooled_width, w.bottom_rois, w.top_data,
+                                                 w.argmax_data, stream);
+            if (rc != MV3D_OK) return rc;
+        }
+        return MV3D_OK;
+    }
+    RoiViewPack p;
+    p.n = num_views; p.PH = pooled_height; p.PW = pooled_width;
+    unsigned blocks = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        const int cv4 = w.channels / 4;
+        RoiViewDev &v = p.v[k];
+        v.data = w.bottom_data; v.rois = w.bottom_rois; v.top = w.top_data; v.argmax = w.argmax_data; v.scale = w.spatial_scale;
+        v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
+        v.tpb_shift = cv4 == 64 ? 3 : (cv4 == 128 ? 4 : 5);
+        v.first_block = blocks;
+        const long long nbins = (long long)w.num_rois * pooled_height * pooled_width;
+        const long long per_block = (long long)FWD_PASSES * (256 >> v.tpb_shift);
+        blocks += (unsigned)(((nbins + per_block - 1) / per_block) * 8);
+    }
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
+    if (blocks == 0) return MV3D_OK;
+    hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return mv3d_launch_status();
 }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AnchorTargetParams, ProposalParams, ProposalTargetParams, check, lib
+from ._lib import AnchorTargetParams, ProposalParams, ProposalTargetParams, RoiView, check, lib
 
 
 def _stream():
@@ -222,3 +222,23 @@ def box_detect_tail(rois_3d, bbox_pred, num_classes):
     check(lib().mv3d_box_detect_tail(_ptr(rois_3d), _ptr(bbox_pred), R, num_classes, _ptr(cnr), _ptr(pr), _ptr(bv), _ptr(bvr),
                                      _stream()), "mv3d_box_detect_tail")
     return cnr, pr, bv, bvr
+
+
+def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None):
+    """views: list of (data (B,H,W,C), rois (R,5), spatial_scale); one launch for all of them.
+    Returns [(top, argmax), ...]; pass `outs` (same structure) to reuse output tensors."""
+    arr = (RoiView * len(views))()
+    res = []
+    for k, (data, rois, scale) in enumerate(views):
+        B, H, W, Cc = data.shape
+        R = rois.shape[0]
+        if outs is not None:
+            top, am = outs[k]
+        else:
+            top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.float32, device=data.device)
+            am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device)
+        arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, R, H, W, Cc)
+        res.append((top, am))
+    check(lib().mv3d_roi_pool_forward_views(len(views), arr, pooled_height, pooled_width, _stream()),
+          "mv3d_roi_pool_forward_views")
+    return res

@@ -204,6 +204,21 @@ def test_roi_pool_forward_backward_vs_oracle(ops, torch_cuda, oracle, B, H, W, C
     assert none is None and np.array_equal(top2.cpu().numpy(), o_top)
 
 
+def test_roi_pool_forward_views_one_launch(ops, torch_cuda, oracle):
+    torch = torch_cuda
+    d1, d2 = synth.feature_map(31, 76, 76, 512, 1), synth.feature_map(32, 46, 155, 512, 2)
+    r1, r2 = roi_cases(31, 60, 76, 76, 1), roi_cases(32, 45, 46, 155, 2)
+    (t1, a1), (t2, a2) = ops.roi_pool_forward_views([(dev(d1, torch), dev(r1, torch), 0.125), (dev(d2, torch), dev(r2, torch), 0.125)], 7, 7)
+    for (t, a, d, r) in ((t1, a1, d1, r1), (t2, a2, d2, r2)):
+        o_top, o_am = oracle.roi_pool(d, r, 7, 7, 0.125)
+        assert np.array_equal(t.cpu().numpy(), o_top) and np.array_equal(a.cpu().numpy(), o_am)
+    # generic channel counts fall back to one launch per view, same results
+    d3 = synth.feature_map(33, 9, 7, 6, 1); r3 = roi_cases(33, 10, 9, 7, 1)
+    (t3, a3), = ops.roi_pool_forward_views([(dev(d3, torch), dev(r3, torch), 0.125)], 7, 7)
+    o_top, o_am = oracle.roi_pool(d3, r3, 7, 7, 0.125)
+    assert np.array_equal(t3.cpu().numpy(), o_top) and np.array_equal(a3.cpu().numpy(), o_am)
+
+
 def test_roi_pool_other_pool_sizes_and_scales(ops, torch_cuda, oracle):
     torch = torch_cuda
     data = synth.feature_map(9, 20, 30, 8, 1)
