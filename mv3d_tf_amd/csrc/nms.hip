@@ -475,28 +475,80 @@ __global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
     }
 }
 
-// Round-1 form of the chain (column blocks [0, b1 <= 32)): the tiles of the round are ONE contiguous
-// stream in consumption order (column-block-major), so waves 1..7 stream it into LDS as fast as a
-// single CU can pull it (16-B loads, two batches in flight) while wave 0 runs the greedy dependency
-// out of LDS: removed(j) = (OR_rb tile(rb,b)[j] & K_rb) != 0 -- two v_and_or per tile, one compare per
-// column -- and never sees a global-memory latency.  The stream is cut into epochs that fit the
-// LDS arena ([0,23) and [23,32)); the sorted `order` of the round's boxes and the kept positions
-// stay in LDS too, so the ROI-blob gather at the end is one dependent load deep.
+// Round-1 form of the chain (column blocks [0, b1 <= 32)).  A single wave executes ~1 instruction per
+// 8-10 cycles, so the serial part is cut to the bone and everything else runs beside it, in one
+// workgroup of 8 waves with three roles that talk through LDS only:
+//   loaders (waves 5..7)  the tiles of the round are ONE contiguous stream in consumption order
+//        (column-block-major): stream it into LDS, 16-B loads, two batches (48 KB) in flight.
+//   helpers (waves 1..4)  column c (c mod 4 = helper) : acc_c[j] = OR over row blocks rb <= c-3 of
+//        tile(rb,c)[j] & K_rb, consumed as the K_rb are published; parked in an 8-slot LDS ring.
+//   wave 0                the greedy dependency proper: acc_c | the two youngest tiles & K, one compare,
+//        the diagonal fixed point, publish K_c.  ~45 instructions per 64-box block.
+// The stream is cut into epochs that fit the LDS arena ([0,23) and [23,32)); kept positions are
+// expanded from the K words by all waves afterwards, and the sorted `order` of the round's boxes is
+// staged in LDS so that the ROI-blob gather at the end is one dependent load deep.
 #define CHL_THREADS 512
-#define CHL_LOADERS 7                                   // waves 1..7
+#define CHL_HELPERS 4                                   // waves 1..4
+#define CHL_LOADER0 5                                   // waves 5..7
+#define CHL_LOADERS 3
 #define CHL_ARENA 276                                   // tiles (columns 0..22)
 #define CHL_PER (CHL_LOADERS * 64)                      // 16-B units per load instruction of the loader group
-#define CHL_BATCH (4 * CHL_PER)                         // units per batch (56 tiles)
+#define CHL_LU 8                                        // loads per loader thread and batch
+#define CHL_BATCH (CHL_LU * CHL_PER)                    // units per batch (48 tiles, 24 KB)
 #define CHL_BOXES 2048
+
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+
+// units of the stream known to be in LDS (min over the loader waves), refreshed until >= need
+__device__ __forceinline__ bool chl_wait_units(int &have, const int need, const int *s_prog, const int *s_halt, const int lane,
+                                               const bool may_halt)
+{
+    while (have < need) {
+        int v = (lane < CHL_LOADERS) ? lds_ld(&s_prog[CHL_LOADER0 + lane]) : 0x7fffffff;
+        v = min(v, __shfl_xor(v, 1));
+        v = min(v, __shfl_xor(v, 2));
+        have = __builtin_amdgcn_readfirstlane(v);
+        if (have < need) {
+            if (may_halt && lds_ld(s_halt)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    LDS_ACQUIRE();
+    return true;
+}
+
+// epoch = columns [c0, c1): as many whole columns as fit the arena
+__device__ __forceinline__ int chl_epoch_end(const int c0, const int cols)
+{
+    const int T0 = c0 * (c0 + 1) / 2;
+    int c1 = c0;
+    while (c1 < cols && (c1 + 1) * (c1 + 2) / 2 - T0 <= CHL_ARENA) ++c1;
+    return c1;
+}
+
+#define CHL_REP(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define CHL_DECL(q) uint4 ra##q, rb##q;
+#define CHL_LDA0(q) ra##q = src[min(lt + q * CHL_PER, last)];
+#define CHL_LDB(q) rb##q = src[min(v + q * CHL_PER, last)];
+#define CHL_LDA(q) ra##q = src[min(v + q * CHL_PER, last)];
+#define CHL_STA(q) if (u + q * CHL_PER < units) tiles_lds[u + q * CHL_PER] = ra##q;
+#define CHL_STB(q) if (u + q * CHL_PER < units) tiles_lds[u + q * CHL_PER] = rb##q;
 
 __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
 {
-    __shared__ uint4 s_tiles[(CHL_ARENA + 8) * 32];      // 512 B per tile; 8 tiles of slack for the chunked pull
+    __shared__ uint4 s_tiles[(CHL_ARENA + 3) * 32];      // 512 B per tile
     __shared__ unsigned long long s_K[32];
+    __shared__ unsigned long long s_acc[8 * 64];          // helper results, ring over columns
+    __shared__ unsigned long long s_junk[64];             // where lanes 1..63 of a "lane 0 only" store go
+    __shared__ int s_accflag[32];
     __shared__ int s_order[CHL_BOXES];
     __shared__ unsigned short s_keep[CHL_BOXES];
+    __shared__ int s_pref[32];
     __shared__ int s_prog[8];
-    __shared__ int s_halt, s_stop, s_fin, s_nk;
+    __shared__ int s_ready, s_halt, s_stop, s_fin, s_nk;
     const int f = blockIdx.x;
     const long long t_start = d.trace ? (long long)__builtin_readcyclecounter() : 0;
     long long t_first = 0;
@@ -504,138 +556,211 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint4 *gsrc = reinterpret_cast<const uint4 *>(d.tiles + (long long)f * d.ntiles * 64);
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
-    unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
-    // the loaders work from the static capacity (tiles beyond the frame's boxes are never consumed)
+    // loaders and helpers work from the static capacity (tiles beyond the frame's boxes are never consumed)
     const int cols = min(d.b1, d.nbw);
-    if (threadIdx.x < 32) s_K[threadIdx.x] = 0ull;           // K of an unfinished block masks its tiles out
-    if (threadIdx.x == 0) s_stop = 0;
+    const bool loader = wave >= CHL_LOADER0;
+    const int lt = threadIdx.x - CHL_LOADER0 * 64;
+    int c0 = 0, c1 = chl_epoch_end(0, cols);
+    // the first batch of the first epoch (and the sorted order of the round's boxes) is requested before
+    // anything else happens in the workgroup
+    CHL_REP(CHL_DECL)
+    int o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0, o8 = 0, o9 = 0, o10 = 0;
+    const bool want_order = d.emit.enabled;
+    if (loader && cols > 0) {
+        const uint4 *src = gsrc;
+        const int last = (c1 * (c1 + 1) / 2) * 32 - 1;
+        CHL_REP(CHL_LDA0)
+        if (want_order) {
+            const int32_t *ord = d.emit.order + (long long)f * d.emit.order_cap;
+            const int m = min(d.n_cap, CHL_BOXES) - 1;
+            o0 = ord[min(lt, m)]; o1 = ord[min(lt + CHL_PER, m)]; o2 = ord[min(lt + 2 * CHL_PER, m)];
+            o3 = ord[min(lt + 3 * CHL_PER, m)]; o4 = ord[min(lt + 4 * CHL_PER, m)]; o5 = ord[min(lt + 5 * CHL_PER, m)];
+            o6 = ord[min(lt + 6 * CHL_PER, m)]; o7 = ord[min(lt + 7 * CHL_PER, m)]; o8 = ord[min(lt + 8 * CHL_PER, m)];
+            o9 = ord[min(lt + 9 * CHL_PER, m)]; o10 = ord[min(lt + 10 * CHL_PER, m)];
+        }
+    }
+    if (threadIdx.x < 32) { s_K[threadIdx.x] = 0ull; s_accflag[threadIdx.x] = 0; }
+    if (threadIdx.x >= 32 && threadIdx.x < 40) s_prog[threadIdx.x - 32] = 0;
+    if (threadIdx.x == 40) { s_stop = 0; s_ready = 0; s_halt = 0; }
+    __syncthreads();
     int n = 0, nb = 0, b1 = 0;
-    if (wave == 0) { n = frame_n(d, f); nb = (n + 63) >> 6; b1 = min(d.b1, nb); }
+    if (wave == 0) { n = __builtin_amdgcn_readfirstlane(frame_n(d, f)); nb = (n + 63) >> 6; b1 = min(d.b1, nb); }
+    // three tiles of front padding: the "three youngest row blocks" of columns 0..2 read (and mask out) what lies before
+    uint4 *const tiles_lds = s_tiles + 3 * 32;
+    const unsigned long long *arena = reinterpret_cast<const unsigned long long *>(tiles_lds);
     int total = 0;                                         // wave 0
+    unsigned long long Kp1 = 0ull, Kp2 = 0ull, Kp3 = 0ull; // K of blocks b-1, b-2, b-3 (wave 0)
     bool stop = false;
-    int c0 = 0;
     while (c0 < cols) {
-        // epoch = columns [c0, c1): as many whole columns as fit the arena
         const int T0 = c0 * (c0 + 1) / 2;
-        int c1 = c0;
-        while (c1 < cols && (c1 + 1) * (c1 + 2) / 2 - T0 <= CHL_ARENA) ++c1;
         const int units = ((c1 * (c1 + 1)) / 2 - T0) * 32;
-        if (threadIdx.x < 8) s_prog[threadIdx.x] = 0;
-        if (threadIdx.x == 8) s_halt = 0;
-        __syncthreads();
-        if (wave > 0) {
-            // ---- loaders: two batches of four 16-B loads in flight per thread; addresses are clamped so
+        if (loader) {
+            // ---- loaders: two batches of eight 16-B loads in flight per thread; addresses are clamped so
             // that every load is unconditional (no divergent control flow around the loads)
-            const int lt = threadIdx.x - 64;
             const uint4 *src = gsrc + (long long)T0 * 32;
             const int last = units - 1;
             const int nbatch = (units + CHL_BATCH - 1) / CHL_BATCH;
-            uint4 a0 = src[min(lt, last)], a1 = src[min(lt + CHL_PER, last)];
-            uint4 a2 = src[min(lt + 2 * CHL_PER, last)], a3 = src[min(lt + 3 * CHL_PER, last)];
-            int o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-            const bool want_order = (c0 == 0) && d.emit.enabled;
-            if (want_order) {
-                const int32_t *ord = d.emit.order + (long long)f * d.emit.order_cap;
-                const int m = min(d.n_cap, CHL_BOXES) - 1;
-                o0 = ord[min(lt, m)]; o1 = ord[min(lt + CHL_PER, m)]; o2 = ord[min(lt + 2 * CHL_PER, m)];
-                o3 = ord[min(lt + 3 * CHL_PER, m)]; o4 = ord[min(lt + 4 * CHL_PER, m)];
-            }
-            for (int k = 0; k < nbatch; ++k) {
-                const int u = k * CHL_BATCH + lt, v = u + CHL_BATCH;
-                const uint4 n0 = src[min(v, last)], n1 = src[min(v + CHL_PER, last)];
-                const uint4 n2 = src[min(v + 2 * CHL_PER, last)], n3 = src[min(v + 3 * CHL_PER, last)];
-                if (u < units) s_tiles[u] = a0;
-                if (u + CHL_PER < units) s_tiles[u + CHL_PER] = a1;
-                if (u + 2 * CHL_PER < units) s_tiles[u + 2 * CHL_PER] = a2;
-                if (u + 3 * CHL_PER < units) s_tiles[u + 3 * CHL_PER] = a3;
-                if (k == 0 && want_order) {
-                    s_order[lt] = o0; s_order[lt + CHL_PER] = o1; s_order[lt + 2 * CHL_PER] = o2; s_order[lt + 3 * CHL_PER] = o3;
-                    if (lt + 4 * CHL_PER < CHL_BOXES) s_order[lt + 4 * CHL_PER] = o4;
+            for (int k = 0; k < nbatch; k += 2) {
+                {   // batch k from A while batch k+1 flies into B
+                    const int u = k * CHL_BATCH + lt, v = u + CHL_BATCH;
+                    CHL_REP(CHL_LDB)
+                    CHL_REP(CHL_STA)
+                    LDS_RELEASE();
+                    if (lane == 0) lds_st(&s_prog[wave], (k + 1) * CHL_BATCH);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                if (lane == 0) __hip_atomic_store(&s_prog[wave], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-                if (__hip_atomic_load(&s_halt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                if (k == 0 && c0 == 0 && want_order) {
+                    s_order[lt] = o0; s_order[lt + CHL_PER] = o1; s_order[lt + 2 * CHL_PER] = o2; s_order[lt + 3 * CHL_PER] = o3;
+                    s_order[lt + 4 * CHL_PER] = o4; s_order[lt + 5 * CHL_PER] = o5; s_order[lt + 6 * CHL_PER] = o6;
+                    s_order[lt + 7 * CHL_PER] = o7; s_order[lt + 8 * CHL_PER] = o8; s_order[lt + 9 * CHL_PER] = o9;
+                    if (lt + 10 * CHL_PER < CHL_BOXES) s_order[lt + 10 * CHL_PER] = o10;
+                }
+                if (k + 1 >= nbatch || lds_ld(&s_halt)) break;
+                {   // batch k+1 from B while batch k+2 flies into A
+                    const int u = (k + 1) * CHL_BATCH + lt, v = u + CHL_BATCH;
+                    CHL_REP(CHL_LDA)
+                    CHL_REP(CHL_STB)
+                    LDS_RELEASE();
+                    if (lane == 0) lds_st(&s_prog[wave], (k + 2) * CHL_BATCH);
+                }
+                if (lds_ld(&s_halt)) break;
+            }
+            // the frame is finished: nothing below needs the loaders (a barrier counts surviving waves only)
+            if (lds_ld(&s_halt) && lds_ld(&s_stop)) return;
+        } else if (wave >= 1) {
+            // ---- helpers: rows 0 .. c-4 of every fourth column, as the K words appear
+            int have = 0;
+            for (int c = max(c0, 4) + ((wave - 1 - max(c0, 4)) & 3); c < c1; c += CHL_HELPERS) {
+                const int tb = c * (c + 1) / 2 - T0;
+                if (!chl_wait_units(have, (tb + c - 3) * 32, s_prog, &s_halt, lane, true)) break;
+                const unsigned long long *col = arena + (long long)tb * 64 + lane;
+                const int rows = c - 3;
+                unsigned long long acc = 0ull;
+                int done = 0;
+                bool halted = false;
+                while (done < rows) {
+                    const int r = min(lds_ld(&s_ready), rows);
+                    if (r > done) {
+                        LDS_ACQUIRE();
+#pragma unroll 4
+                        for (int rb = done; rb < r; ++rb) acc |= col[rb * 64] & s_K[rb];
+                        done = r;
+                    } else if (lds_ld(&s_halt)) { halted = true; break; }
+                }
+                if (halted) break;
+                s_acc[(c & 7) * 64 + lane] = acc;
+                LDS_RELEASE();
+                if (lane == 0) lds_st(&s_accflag[c], 1);
             }
         } else {
-            // ---- wave 0: the greedy dependency
-            const unsigned long long *arena = reinterpret_cast<const unsigned long long *>(s_tiles);
-            int have = 0;                                          // batches known to be complete
+            // ---- wave 0: the greedy dependency, software-pipelined: the LDS reads of block b+1 are issued
+            // before the bookkeeping of block b.  "lane 0 only" stores are made branch-free by sending the
+            // other lanes' copies to s_junk.
+            __builtin_amdgcn_s_setprio(3);
+            int have = 0;
             const int ce = min(c1, b1);
+            unsigned long long tA = 0ull, tB = 0ull, tC = 0ull, dg = 0ull, av = 0ull;
+            int fl = 0;
+            unsigned long long *const junk = &s_junk[lane];
+// `pd` = this lane's word of the diagonal tile of block bb; the three youngest row blocks sit right before it
+#define CHL_FETCH(bb)                                                                                      \
+    {                                                                                                      \
+        if (__builtin_expect(have < need_u, 0)) chl_wait_units(have, need_u, s_prog, &s_halt, lane, false); \
+        fl = lds_ld(&s_accflag[(bb)]);                   /* flag first, then the value (LDS is in order) */ \
+        av = __hip_atomic_load(&s_acc[((bb) & 7) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        tA = pd[-192]; tB = pd[-128]; tC = pd[-64]; dg = pd[0];                                            \
+    }
+            const unsigned long long *pd = arena + ((long long)(c0 * (c0 + 1) / 2 - T0 + c0)) * 64 + lane;
+            int need_u = (c0 * (c0 + 1) / 2 - T0 + c0 + 1) * 32;   // units up to and including the diagonal tile
+            if (c0 < ce) CHL_FETCH(c0)
+            if (d.trace && c0 == 0) t_first = (long long)__builtin_readcyclecounter();
             for (int b = c0; b < ce; ++b) {
                 const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-                const int tb = b * (b + 1) / 2 - T0;               // arena slot of tile (0, b)
-                const int need = ((tb + b + 1) * 32 + CHL_BATCH - 1) / CHL_BATCH;
-                while (have < need) {
-                    int v = (lane >= 1 && lane <= CHL_LOADERS)
-                                ? __hip_atomic_load(&s_prog[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0x7fffffff;
-#pragma unroll
-                    for (int m = 1; m < 8; m <<= 1) v = min(v, __shfl_xor(v, m));
-                    have = __builtin_amdgcn_readfirstlane(v);
-                    if (have < need) __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                if (d.trace && b == 0) t_first = (long long)__builtin_readcyclecounter();
-                const unsigned long long *col = arena + (long long)tb * 64 + lane;
-                unsigned long long acc = 0ull;
-                const int bu = __builtin_amdgcn_readfirstlane(b);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (8 * c < bu) {                              // s_K[rb] == 0 for rb >= b
-                        unsigned long long t[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) t[q] = col[(8 * c + q) * 64];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc |= t[q] & s_K[8 * c + q];
+                // the three youngest row blocks (K of a missing block is 0) + the helpers' part
+                unsigned long long acc = (tA & Kp3) | (tB & Kp2) | (tC & Kp1);
+                if (b >= 4) {
+                    while (__builtin_expect(!fl, 0)) {
+                        fl = lds_ld(&s_accflag[b]);
+                        av = __hip_atomic_load(&s_acc[(b & 7) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    acc |= av;
                 }
-                const unsigned long long dg = col[b * 64];
-                const int p = b * 64 + lane;
-                const bool alive = (p < n) && (acc == 0ull);
-                unsigned long long K = __ballot(alive);
+                const unsigned long long A = __ballot(acc == 0ull && (b * 64 + lane) < n);
+                const unsigned long long dgc = dg;
+                unsigned long long K = A;
                 int iters = 0;
                 for (;;) {                                        // fixed point = greedy set (see chain_round)
-                    const unsigned long long K2 = __ballot(alive && !(dg & K));
+                    const unsigned long long K2 = A & __ballot((dgc & K) == 0ull);
                     ++iters;
                     if (K2 == K) break;
                     K = K2;
                 }
-                const bool kept = (K >> lane) & 1ull;
-                const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
-                if (kept && (d.max_keep <= 0 || pos < d.max_keep)) { keep[pos] = p; s_keep[pos] = (unsigned short)p; }
+                // publish: K word, then the count of finished blocks (two LDS stores of one wave stay in order)
+                __hip_atomic_store(lane == 0 ? &s_K[b] : junk, K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(lane == 0 ? &s_ready : (int *)junk, b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                Kp3 = Kp2; Kp2 = Kp1; Kp1 = K;
                 total += __popcll(K);
-                if (lane == 0) { s_K[b] = K; kstate[b] = K; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                const bool last_one = (d.max_keep > 0 && total >= d.max_keep);
+                pd += (b + 2) * 64; need_u += (b + 2) * 32;        // diagonal tile of block b + 1
+                if (b + 1 < ce && !last_one) CHL_FETCH(b + 1)
                 if (d.trace && f == 0 && lane == 0) {
                     long long *tr = d.trace + 4 * b;
                     tr[0] = t_begin; tr[1] = t_begin; tr[2] = t_begin;   // one stamp per block (a second costs ~200 cycles)
                     tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
                 }
-                if (d.max_keep > 0 && total >= d.max_keep) { stop = true; break; }
+                if (last_one) { stop = true; break; }
             }
             if (lane == 0) {
-                __hip_atomic_store(&s_halt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (stop || ce >= b1) __hip_atomic_store(&s_stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (stop || ce >= b1) lds_st(&s_stop, 1);
+                lds_st(&s_halt, 1);
             }
         }
         __syncthreads();
         c0 = c1;
-        if (s_stop) break;
+        if (s_stop || c0 >= cols) break;
+        // next epoch: reset the progress words, request its first batch
+        c1 = chl_epoch_end(c0, cols);
+        if (threadIdx.x < 8) s_prog[threadIdx.x] = 0;
+        if (threadIdx.x == 8) s_halt = 0;
+        if (loader) {
+            const int T1 = c0 * (c0 + 1) / 2;
+            const uint4 *src = gsrc + (long long)T1 * 32;
+            const int last = ((c1 * (c1 + 1)) / 2 - T1) * 32 - 1;
+            CHL_REP(CHL_LDA0)
+        }
+        __syncthreads();
     }
     if (d.trace && f == 0 && threadIdx.x == 0) {
         long long *ph = d.trace + 4 * (long long)d.nbw;       // phase stamps after the per-block records
         ph[0] = t_start; ph[1] = t_first; ph[2] = (long long)__builtin_readcyclecounter();
     }
-    if (wave == 0 && lane == 0) {
-        const bool finished = stop || (b1 >= nb);
-        int nk = total;
-        if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
-        cstate[0] = total; cstate[1] = finished ? 1 : 0;
-        s_fin = finished ? 1 : 0; s_nk = nk;
-        if (finished) d.num_keep[f] = nk;
+    if (wave == 0) {
+        // exclusive prefix of the kept counts per block (blocks not run have K = 0)
+        const int cnt = (lane < 32) ? __popcll(s_K[lane]) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
+        if (lane < 32) s_pref[lane] = inc - cnt;
+        if (lane == 0) {
+            const bool finished = stop || (b1 >= nb);
+            int nk = total;
+            if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
+            cstate[0] = total; cstate[1] = finished ? 1 : 0;
+            s_fin = finished ? 1 : 0; s_nk = nk;
+            if (finished) d.num_keep[f] = nk;
+        }
     }
     __syncthreads();
+    // kept positions from the K words (cpu_nms.pyx:45 keep.append(i), in processing order)
+    if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = s_K[threadIdx.x];
+    for (int p = threadIdx.x; p < CHL_BOXES; p += CHL_THREADS) {
+        const unsigned long long K = s_K[p >> 6];
+        if ((K >> (p & 63)) & 1ull) {
+            const int pos = s_pref[p >> 6] + __popcll(K & ((1ull << (p & 63)) - 1ull));
+            if (d.max_keep <= 0 || pos < d.max_keep) { keep[pos] = p; s_keep[pos] = (unsigned short)p; }
+        }
+    }
     if (!s_fin) return;
+    __syncthreads();
     const int nk = s_nk;
     if (d.emit.enabled) {
         // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
