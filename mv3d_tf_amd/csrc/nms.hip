@@ -496,11 +496,21 @@ __global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
 #define CHL_LU 8                                        // loads per loader thread and batch
 #define CHL_BATCH (CHL_LU * CHL_PER)                    // units per batch (48 tiles, 24 KB)
 #define CHL_BOXES 2048
+#define CHL_POST ((1 + CHL_HELPERS) * 64)                // threads of the post-processing (waves 0..4)
 
 __device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+
+// barrier among the waves that outlive the loaders: arrive on an LDS counter, wait for `target` arrivals
+__device__ __forceinline__ void chl_sync(int *ctr, const int target, const int lane)
+{
+    LDS_RELEASE();
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (lds_ld(ctr) < target) {}
+    LDS_ACQUIRE();
+}
 
 // units of the stream known to be in LDS (min over the loader waves), refreshed until >= need
 __device__ __forceinline__ bool chl_wait_units(int &have, const int need, const int *s_prog, const int *s_halt, const int lane,
@@ -545,15 +555,13 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     __shared__ unsigned long long s_junk[64];             // where lanes 1..63 of a "lane 0 only" store go
     __shared__ int s_accflag[32];
     __shared__ int s_order[CHL_BOXES];
-    __shared__ unsigned short s_keep[CHL_BOXES];
-    __shared__ int s_pref[32];
     __shared__ int s_prog[8];
-    __shared__ int s_ready, s_halt, s_stop, s_fin, s_nk;
+    __shared__ int s_ready, s_halt, s_stop, s_sync;
     const int f = blockIdx.x;
     const long long t_start = d.trace ? (long long)__builtin_readcyclecounter() : 0;
     long long t_first = 0;
     int32_t *cstate = d.cstate + 4 * f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint4 *gsrc = reinterpret_cast<const uint4 *>(d.tiles + (long long)f * d.ntiles * 64);
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
     // loaders and helpers work from the static capacity (tiles beyond the frame's boxes are never consumed)
@@ -581,16 +589,16 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     }
     if (threadIdx.x < 32) { s_K[threadIdx.x] = 0ull; s_accflag[threadIdx.x] = 0; }
     if (threadIdx.x >= 32 && threadIdx.x < 40) s_prog[threadIdx.x - 32] = 0;
-    if (threadIdx.x == 40) { s_stop = 0; s_ready = 0; s_halt = 0; }
+    if (threadIdx.x == 40) { s_stop = 0; s_ready = 0; s_halt = 0; s_sync = 0; }
     __syncthreads();
-    int n = 0, nb = 0, b1 = 0;
-    if (wave == 0) { n = __builtin_amdgcn_readfirstlane(frame_n(d, f)); nb = (n + 63) >> 6; b1 = min(d.b1, nb); }
+    // (a scalar load: every wave may ask, only wave 0 uses it)
+    const int n = __builtin_amdgcn_readfirstlane(frame_n(d, f)), nb = (n + 63) >> 6, b1 = min(d.b1, nb);
     // three tiles of front padding: the "three youngest row blocks" of columns 0..2 read (and mask out) what lies before
     uint4 *const tiles_lds = s_tiles + 3 * 32;
     const unsigned long long *arena = reinterpret_cast<const unsigned long long *>(tiles_lds);
     int total = 0;                                         // wave 0
     unsigned long long Kp1 = 0ull, Kp2 = 0ull, Kp3 = 0ull; // K of blocks b-1, b-2, b-3 (wave 0)
-    bool stop = false;
+    bool stop = false, frame_done = false;
     while (c0 < cols) {
         const int T0 = c0 * (c0 + 1) / 2;
         const int units = ((c1 * (c1 + 1)) / 2 - T0) * 32;
@@ -624,8 +632,6 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
                 }
                 if (lds_ld(&s_halt)) break;
             }
-            // the frame is finished: nothing below needs the loaders (a barrier counts surviving waves only)
-            if (lds_ld(&s_halt) && lds_ld(&s_stop)) return;
         } else if (wave >= 1) {
             // ---- helpers: rows 0 .. c-4 of every fourth column, as the K words appear
             int have = 0;
@@ -709,14 +715,22 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
                 }
                 if (last_one) { stop = true; break; }
             }
+            frame_done = stop || ce >= b1;
             if (lane == 0) {
-                if (stop || ce >= b1) lds_st(&s_stop, 1);
+                if (frame_done) lds_st(&s_stop, 1);        // stop first, then halt (LDS keeps the order)
                 lds_st(&s_halt, 1);
             }
         }
+        if (wave != 0) {
+            while (!lds_ld(&s_halt)) __builtin_amdgcn_s_sleep(1);
+            frame_done = __builtin_amdgcn_readfirstlane(lds_ld(&s_stop)) != 0;
+        }
+        // a finished frame needs no more tiles: its loaders leave at once (their last batch may still be in
+        // flight) and the other five waves go on without a workgroup barrier
+        if (frame_done) break;
         __syncthreads();
         c0 = c1;
-        if (s_stop || c0 >= cols) break;
+        if (c0 >= cols) break;
         // next epoch: reset the progress words, request its first batch
         c1 = chl_epoch_end(c0, cols);
         if (threadIdx.x < 8) s_prog[threadIdx.x] = 0;
@@ -729,69 +743,73 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
         }
         __syncthreads();
     }
+    if (loader) return;
+    // ---- waves 0..4 (CHL_POST threads): kept positions from the K words (cpu_nms.pyx:45 keep.append(i), in
+    // processing order) and, for a finished frame, the ROI blobs (proposal_layer_tf.py:188-191) -- every
+    // wave derives the prefix of the kept counts itself, so nothing here waits for another wave
     if (d.trace && f == 0 && threadIdx.x == 0) {
         long long *ph = d.trace + 4 * (long long)d.nbw;       // phase stamps after the per-block records
         ph[0] = t_start; ph[1] = t_first; ph[2] = (long long)__builtin_readcyclecounter();
     }
-    if (wave == 0) {
-        // exclusive prefix of the kept counts per block (blocks not run have K = 0)
-        const int cnt = (lane < 32) ? __popcll(s_K[lane]) : 0;
-        int inc = cnt;
+    const unsigned long long Kl = (lane < 32) ? s_K[lane] : 0ull;   // blocks not run have K = 0
+    const int cnt = __popcll(Kl);
+    int inc = cnt;
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
-        if (lane < 32) s_pref[lane] = inc - cnt;
-        if (lane == 0) {
-            const bool finished = stop || (b1 >= nb);
-            int nk = total;
-            if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
-            cstate[0] = total; cstate[1] = finished ? 1 : 0;
-            s_fin = finished ? 1 : 0; s_nk = nk;
-            if (finished) d.num_keep[f] = nk;
-        }
+    for (int m = 1; m < 32; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
+    const int pref = inc - cnt;                                 // lane l < 32: kept before block l
+    const int ktotal = __shfl(inc, 31);
+    const bool finished = (d.max_keep > 0 && ktotal >= d.max_keep) || (b1 >= nb);
+    const int nk = (d.max_keep > 0 && ktotal > d.max_keep) ? d.max_keep : ktotal;
+    if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;
+    if (threadIdx.x == 0) {
+        cstate[0] = ktotal; cstate[1] = finished ? 1 : 0;
+        if (finished) d.num_keep[f] = nk;
     }
-    __syncthreads();
-    // kept positions from the K words (cpu_nms.pyx:45 keep.append(i), in processing order)
-    if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = s_K[threadIdx.x];
-    for (int p = threadIdx.x; p < CHL_BOXES; p += CHL_THREADS) {
-        const unsigned long long K = s_K[p >> 6];
-        if ((K >> (p & 63)) & 1ull) {
-            const int pos = s_pref[p >> 6] + __popcll(K & ((1ull << (p & 63)) - 1ull));
-            if (d.max_keep <= 0 || pos < d.max_keep) { keep[pos] = p; s_keep[pos] = (unsigned short)p; }
-        }
-    }
-    if (!s_fin) return;
-    __syncthreads();
-    const int nk = s_nk;
-    if (d.emit.enabled) {
-        // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
-        const EmitDev &e = d.emit;
-        if (threadIdx.x == 0) e.num_out[f] = nk;
-        for (int r = threadIdx.x; r < e.cap; r += blockDim.x) {
-            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
-            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
-            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
-            if (r < nk) {
-                const int c = s_order[s_keep[r]];
-                const long long o = (long long)f * e.N + c;
-                const float4 bx = e.bv[o];
-                const int4 im = e.img[o];
-                const float2 pa = *reinterpret_cast<const float2 *>(e.p3 + o * 6);
-                const float2 pb = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 2);
-                const float2 pc = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 4);
-                const float bi = (float)f;
-                obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
-                oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
-                o3[0] = bi; o3[1] = pa.x; o3[2] = pa.y; o3[3] = pb.x; o3[4] = pb.y; o3[5] = pc.x; o3[6] = pc.y;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
-#pragma unroll
-                for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
+    const bool emit = finished && d.emit.enabled;
+    const EmitDev &e = d.emit;
+    const int nrun = __builtin_amdgcn_readfirstlane(lds_ld(&s_ready));   // blocks the chain went through
+    for (int p0 = 0; p0 < nrun * 64; p0 += CHL_POST) {
+        const int p = p0 + threadIdx.x;                            // one block (64 boxes) per wave and pass
+        const int w = p >> 6;                                      // wave-uniform
+        const unsigned long long K = __shfl(Kl, w & 31);
+        const int base = __shfl(pref, w & 31);
+        if (w < nrun && ((K >> lane) & 1ull)) {
+            const int pos = base + __popcll(K & ((1ull << lane) - 1ull));
+            if (d.max_keep <= 0 || pos < d.max_keep) {
+                keep[pos] = p;
+                if (emit && pos < e.cap) {
+                    const int c = s_order[p];
+                    const long long o = (long long)f * e.N + c;
+                    const float4 bx = e.bv[o];
+                    const int4 im = e.img[o];
+                    const float2 pa = *reinterpret_cast<const float2 *>(e.p3 + o * 6);
+                    const float2 pb = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 2);
+                    const float2 pc = *reinterpret_cast<const float2 *>(e.p3 + o * 6 + 4);
+                    float *obv = e.blob_bv + ((long long)f * e.cap + pos) * 5;
+                    float *oim = e.blob_img + ((long long)f * e.cap + pos) * 5;
+                    float *o3 = e.blob_3d + ((long long)f * e.cap + pos) * 7;
+                    const float bi = (float)f;
+                    obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
+                    oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
+                    o3[0] = bi; o3[1] = pa.x; o3[2] = pa.y; o3[3] = pb.x; o3[4] = pb.y; o3[5] = pc.x; o3[6] = pc.y;
+                }
             }
         }
     }
+    if (emit) {
+        if (threadIdx.x == 0) e.num_out[f] = nk;
+        for (int r = nk + threadIdx.x; r < e.cap; r += CHL_POST) {   // rows past the kept boxes are zero
+            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
+            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
+            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { obv[q] = 0.0f; oim[q] = 0.0f; }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) o3[q] = 0.0f;
+        }
+    }
     if (d.trace && f == 0) {
-        __syncthreads();
+        chl_sync(&s_sync, CHL_POST / 64, lane);
         if (threadIdx.x == 0) d.trace[4 * (long long)d.nbw + 3] = (long long)__builtin_readcyclecounter();
     }
 }
