@@ -26,6 +26,8 @@
 #include "kernels.h"
 
 #define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
+#define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 #define NMS_PULL 15         // pull waves of the chain workgroup (waves 1..15; wave 0 = diagonal)
 
 // lib/nms/cpu_nms.pyx:55-65 for one (kept box i, later box j) pair.  f32, separate IEEE
@@ -161,22 +163,19 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
     return word;
 }
 
-// grid: (tiles of the round, 1, batch); block 64 = one wave per tile.
-__global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
+// One tile by one wave.  `s_box/s_area` are the wave's own 64-entry LDS staging arrays.  AGENT_STORE: the
+// word is written through at agent scope (read later in the SAME kernel by another workgroup).
+template <bool AGENT_STORE>
+__device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const int t, const int lane, float4 *s_box,
+                                             float *s_area)
 {
-    __shared__ float4 s_box[64];
-    __shared__ float s_area[64];
-    const int f = blockIdx.z;
-    if (!d.first_round && d.cstate[4 * f + 1]) return;       // frame already finished in an earlier round
     const int n = frame_n(d, f);
     // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
-    const int t = d.b0 * (d.b0 + 1) / 2 + blockIdx.x;
     int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
     while (cb * (cb + 1) / 2 > t) --cb;
     const int rb = t - cb * (cb + 1) / 2;
     if (cb * 64 >= n) return;
-    const int lane = threadIdx.x;
     // LDS side = the 64 ROW boxes of block rb; lane = COLUMN box cb*64 + lane.  The predicate is
     // symmetric in the two boxes (max/min/+/* commute), so this is the transposed tile.
     const int ridx = rb * 64 + lane, cidx = cb * 64 + lane;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
     s_box[lane] = sb;
     s_area[lane] = ((sb.z - sb.x) + 1.0f) * ((sb.w - sb.y) + 1.0f);         // cpu_nms.pyx:24
     const bool lds_tame = __all(tame(sb));                  // false if the block is ragged (NaN padding)
-    __syncthreads();
+    LDS_RELEASE();                                          // one wave: its LDS stores are in order
     float4 lb = make_float4(NAN, NAN, NAN, NAN);
     if (cidx < n) lb = load_box(d, f, cidx);
     const float larea = ((lb.z - lb.x) + 1.0f) * ((lb.w - lb.y) + 1.0f);
@@ -214,8 +213,20 @@ __global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
             word |= (unsigned long long)p << j;
         }
     }
-    d.tiles[((long long)f * d.ntiles + t) * 64 + lane] = word;
+    unsigned long long *dst = &d.tiles[((long long)f * d.ntiles + t) * 64 + lane];
+    if (AGENT_STORE) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
+}
+
+// grid: (tiles of the round, 1, batch); block 64 = one wave per tile.
+__global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
+{
+    __shared__ float4 s_box[64];
+    __shared__ float s_area[64];
+    const int f = blockIdx.z;
+    if (!d.first_round && d.cstate[4 * f + 1]) return;       // frame already finished in an earlier round
+    nms_one_tile<false>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x, s_box, s_area);
 }
 
 // grid: (batch); block 1024 = 16 waves: wave 0 = diagonal (serial part), waves 1..15 = pull.
@@ -354,13 +365,11 @@ __global__ __launch_bounds__(1024) void nms_chain_kernel(NmsDev d)
 // column b itself (registers, refilled one column ahead) and then resolves the diagonal tile.  The
 // per-block critical path is ~25 cycles per tile plus the fixed point.
 template <int KMAX, int THREADS>
-__global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
+__device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
 {
     __shared__ unsigned long long s_K[NMS_MAX_WORDS];
     __shared__ int s_fin, s_nk;
-    const int f = blockIdx.x;
     int32_t *cstate = d.cstate + 4 * f;
-    if (!d.first_round && cstate[1]) return;                  // finished in an earlier round (uniform)
     const int n = frame_n(d, f);
     const int nb = (n + 63) >> 6;
     const int lane = threadIdx.x & 63;
@@ -475,6 +484,36 @@ __global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
     }
 }
 
+// A later round in ONE launch (grid: (<= 256, 1, batch); block 256 = four tiles at a time, grid-stride):
+// a frame that is already finished costs one flag load per workgroup; otherwise the workgroup that
+// finishes last (ticket in cstate[2]) runs the round's chain.  The tile words are written through at
+// agent scope and complete (vmcnt 0) before the ticket is taken; the chain side starts with an
+// agent-scope acquire, so it reads what the other XCDs wrote.
+__global__ __launch_bounds__(256) void nms_round_kernel(NmsDev d)
+{
+    __shared__ float4 s_box[4][64];
+    __shared__ float s_area[4][64];
+    __shared__ int s_last;
+    const int f = blockIdx.z;
+    int32_t *cstate = d.cstate + 4 * f;
+    if (cstate[1]) return;                                   // finished in an earlier round
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
+    for (int tl = blockIdx.x * 4 + wave; tl < ntr; tl += gridDim.x * 4) {
+        nms_one_tile<true>(d, f, d.b0 * (d.b0 + 1) / 2 + tl, lane, s_box[wave], s_area[wave]);
+        LDS_RELEASE();                                        // the staging arrays are reused by the next tile
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's tile words have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = (__hip_atomic_fetch_add(&cstate[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) cstate[2] = 0;                      // ready for the next launch on this workspace
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    chain1_round<128, 256>(d, f);
+}
+
 // Round-1 form of the chain (column blocks [0, b1 <= 32)).  A single wave executes ~1 instruction per
 // 8-10 cycles, so the serial part is cut to the bone and everything else runs beside it, in one
 // workgroup of 8 waves with three roles that talk through LDS only:
@@ -500,8 +539,6 @@ __global__ __launch_bounds__(THREADS) void nms_chain1_kernel(NmsDev d)
 
 __device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
-#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 
 // barrier among the waves that outlive the loaders: arrive on an LDS counter, wait for `target` arrivals
 __device__ __forceinline__ void chl_sync(int *ctr, const int target, const int lane)
@@ -762,7 +799,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     const int nk = (d.max_keep > 0 && ktotal > d.max_keep) ? d.max_keep : ktotal;
     if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;
     if (threadIdx.x == 0) {
-        cstate[0] = ktotal; cstate[1] = finished ? 1 : 0;
+        cstate[0] = ktotal; cstate[1] = finished ? 1 : 0; cstate[2] = 0;
         if (finished) d.num_keep[f] = nk;
     }
     const bool emit = finished && d.emit.enabled;
@@ -852,11 +889,13 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
         d.first_round = (r == 0);
         if (r > 0 && d.b0 >= nbw) break;
         const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
+        if (r > 0 && d.b1 <= 128) {                           // a column block has at most b1 - 1 off-diagonal tiles
+            const int wgs = (ntr + 3) / 4 < 256 ? (ntr + 3) / 4 : 256;
+            hipLaunchKernelGGL(nms_round_kernel, dim3(wgs, 1, L.batch), dim3(256), 0, stream, d);
+            continue;
+        }
         if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
-        // a column block of the round has at most b1 - 1 off-diagonal tiles
         if (r == 0) hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
-        else if (d.b1 <= 64) hipLaunchKernelGGL((nms_chain1_kernel<64, 512>), dim3(L.batch), dim3(512), 0, stream, d);
-        else if (d.b1 <= 128) hipLaunchKernelGGL((nms_chain1_kernel<128, 256>), dim3(L.batch), dim3(256), 0, stream, d);
         else hipLaunchKernelGGL(nms_chain_kernel<18>, dim3(L.batch), dim3(1024), 0, stream, d);
     }
     return mv3d_launch_status();

@@ -166,8 +166,9 @@ __device__ __forceinline__ int count_before(const uint32_t *sb, const uint32_t k
     return pos;
 }
 
-// grid (key_stride/256, batch), 256 threads: thread t of workgroup bi owns position
-// (bi&3)*256 + t of run bi/4.  All runs of the frame are staged in LDS (<= 96 KB).
+// grid (key_stride/128, batch), 256 threads: the thread pair (t & 127, half t >> 7) of workgroup bi owns
+// position (bi&7)*128 + (t&127) of run bi/8 -- half h searches the runs of parity h -- so that the LDS
+// traffic of the searches spreads over twice as many CUs.  All runs of the frame are staged in LDS (<= 96 KB).
 __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restrict__ sorted,
                                                          const uint16_t *__restrict__ sidx,
                                                          const int32_t *__restrict__ cnt256, int N, int key_stride,
@@ -175,48 +176,72 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
                                                          int32_t *n_valid)
 {
     __shared__ uint32_t s_keys[RANK_LDS_KEYS];
+    __shared__ int s_half[128];
     const int f = blockIdx.y, bi = blockIdx.x, t = threadIdx.x;
     const int nrun = key_stride / RANK_RUN, nb256 = key_stride >> 8;
-    const uint32_t *__restrict__ src = sorted + (long long)f * key_stride;
+    const int R = bi >> 3, pos = (bi & 7) * 128 + (t & 127), h = __builtin_amdgcn_readfirstlane(t >> 7);
+    // the scatter index of the own key is requested first: its latency hides under everything else
+    const int own = (int)sidx[(long long)f * key_stride + R * RANK_RUN + pos];
+    const uint4 *__restrict__ src4 = reinterpret_cast<const uint4 *>(sorted + (long long)f * key_stride);
     const int32_t *__restrict__ c256 = cnt256 + (long long)f * nb256;
-    for (int q = t; q < key_stride / 4; q += 256) {
-        const int r = (q * 4) / RANK_RUN, p = (q * 4) % RANK_RUN;
-        const int nc = c256[4 * r] + c256[4 * r + 1] + c256[4 * r + 2] + c256[4 * r + 3];
-        uint4 v = reinterpret_cast<const uint4 *>(src)[q];
-        if (p + 0 >= nc) v.x = 0u;                   // slots past the run's candidates were never written
-        if (p + 1 >= nc) v.y = 0u;
-        if (p + 2 >= nc) v.z = 0u;
-        if (p + 3 >= nc) v.w = 0u;
-        reinterpret_cast<uint4 *>(s_keys)[q] = v;
+    // staging: thread t owns keys 4t..4t+3 of every run; all loads are issued before the first use
+    constexpr int MAXRUN = RANK_LDS_KEYS / RANK_RUN;
+    uint4 v[MAXRUN];
+#pragma unroll
+    for (int r = 0; r < MAXRUN; ++r) v[r] = src4[t + 256 * min(r, nrun - 1)];
+#pragma unroll
+    for (int r = 0; r < MAXRUN; ++r) {
+        if (r < nrun) {
+            const int nc = c256[4 * r] + c256[4 * r + 1] + c256[4 * r + 2] + c256[4 * r + 3] - 4 * t;   // wave-uniform sum
+            uint4 w = v[r];
+            if (nc <= 0) w.x = 0u;                   // slots past the run's candidates were never written
+            if (nc <= 1) w.y = 0u;
+            if (nc <= 2) w.z = 0u;
+            if (nc <= 3) w.w = 0u;
+            reinterpret_cast<uint4 *>(s_keys)[t + 256 * r] = w;
+        }
     }
     __syncthreads();
-    const int R = bi >> 2, pos = (bi & 3) * 256 + t;
     const uint32_t ki = s_keys[R * RANK_RUN + pos];
+    // count_r = #{keys of run r that precede ki}: runs of smaller index `>`; runs of larger index `>=`,
+    // i.e. `> ki - 1` (ki >= 1); the own run and the runs that do not exist get a threshold nothing
+    // exceeds.  The binary searches of all runs advance in lock-step, so every step is one batch of
+    // independent LDS reads instead of a chain of dependent ones.
+    constexpr int HR = MAXRUN / 2;
+    int part = 0;
     if (ki != 0u) {
-        int rank = pos;                              // position inside the own sorted run
-        int r2 = 0;
-        for (; r2 + 2 <= R; r2 += 2) {               // runs of smaller index: only strictly larger keys precede
-            const int c0 = count_before<false>(s_keys + (r2 + 0) * RANK_RUN, ki);
-            const int c1 = count_before<false>(s_keys + (r2 + 1) * RANK_RUN, ki);
-            rank += c0 + c1;
+        uint32_t thr[HR];
+        int cnt[HR];
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const int r = 2 * i + h;
+            thr[i] = (r == R || r >= nrun) ? 0xffffffffu : (r > R ? ki - 1u : ki);
+            cnt[i] = 0;
         }
-        for (; r2 < R; ++r2) rank += count_before<false>(s_keys + r2 * RANK_RUN, ki);
-        r2 = R + 1;
-        for (; r2 + 2 <= nrun; r2 += 2) {            // runs of larger index: equal keys precede too
-            const int c0 = count_before<true>(s_keys + (r2 + 0) * RANK_RUN, ki);
-            const int c1 = count_before<true>(s_keys + (r2 + 1) * RANK_RUN, ki);
-            rank += c0 + c1;
+        const uint32_t *base = s_keys + h * RANK_RUN;
+#pragma unroll
+        for (int step = RANK_RUN / 2; step >= 1; step >>= 1) {
+            uint32_t q[HR];
+#pragma unroll
+            for (int i = 0; i < HR; ++i) q[i] = base[2 * i * RANK_RUN + cnt[i] + step - 1];
+#pragma unroll
+            for (int i = 0; i < HR; ++i) cnt[i] += (q[i] > thr[i]) ? step : 0;
         }
-        for (; r2 < nrun; ++r2) rank += count_before<true>(s_keys + r2 * RANK_RUN, ki);
-        if (rank < cap)
-            order[(long long)f * cap + rank] = R * RANK_RUN + (int)sidx[(long long)f * key_stride + R * RANK_RUN + pos];
+#pragma unroll
+        for (int i = 0; i < HR; ++i) part += cnt[i] + ((base[2 * i * RANK_RUN + cnt[i]] > thr[i]) ? 1 : 0);
+    }
+    if (h == 1) s_half[t & 127] = part;
+    __syncthreads();
+    if (h == 0 && ki != 0u) {
+        const int rank = pos + part + s_half[t];    // pos = position inside the own sorted run
+        if (rank < cap) order[(long long)f * cap + rank] = R * RANK_RUN + own;
     }
     if (n_valid && bi == 0 && t < 64) {
-        int v = 0;
-        for (int p = t; p < n_parts; p += 64) v += part_counts[(long long)f * n_parts + p];
+        int nv = 0;
+        for (int p = t; p < n_parts; p += 64) nv += part_counts[(long long)f * n_parts + p];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if (t == 0) n_valid[f] = v;
+        for (int o = 32; o > 0; o >>= 1) nv += __shfl_down(nv, o);
+        if (t == 0) n_valid[f] = nv;
     }
 }
 
@@ -265,7 +290,7 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
         int32_t *cnt256 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
         hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 256, batch), dim3(1024), 0, stream, keys, key_stride, sorted, sidx,
                            cnt256);
-        hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 256, batch), dim3(256), 0, stream, sorted, sidx, cnt256, N,
+        hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 128, batch), dim3(256), 0, stream, sorted, sidx, cnt256, N,
                            key_stride, order, cap, part_counts, n_parts, n_valid);
         return mv3d_launch_status();
     }
