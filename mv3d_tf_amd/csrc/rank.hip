@@ -85,25 +85,29 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
 #define RANK_LDS_KEYS 24576
 #define RANK_RUN 1024            // sorted run length (= RANK_SEG: one scalar-load segment)
 
-// grid (key_stride/256, batch).  Workgroup bi owns 256 keys of run R = bi/4 and ranks them inside
+// grid (key_stride/128, batch).  Workgroup bi owns 128 keys of run R = bi/8 and ranks them inside
 // the run by counting over its 1024 keys (wave-uniform, scalar loads; `>` / `>=` per 256-key
 // sub-tile as in rank_partial_kernel).  Candidates are written to their run position:
 // sorted[f][R*1024 + r] = key, sidx = index inside the run.  Non-candidates (key 0) are not
-// written at all; cnt256[f][bi] = candidates of this workgroup lets the consumer treat the tail of
-// every run as zeros.
-__global__ __launch_bounds__(1024) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
-                                                          uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
-                                                          int32_t *__restrict__ cnt256)
+// written at all; cnt128[f][run] = candidates of the run (counted by the run's first workgroup) lets the
+// consumer treat the tail of every run as zeros.  (128 keys per workgroup: 184 workgroups for a KITTI frame, so the counting --
+// the kernel is VALU-bound -- spreads over most of the 256 CUs.)
+#define RANK_LK 128
+__global__ __launch_bounds__(4 * RANK_LK) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
+                                                                 uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
+                                                                 int32_t *__restrict__ cnt128)
 {
-    // 1024 threads = 256 keys x 4 sub-tiles of the run: thread (t, sub) counts its key against the 256
-    // keys of sub-tile `sub`; 16 waves per CU keep the scalar-load and carry latencies covered.
-    __shared__ unsigned s_part[4][256];
-    __shared__ int s_wc[4];
+    // 512 threads = 128 keys x 4 sub-tiles of the run: thread (t, sub) counts its key against the 256
+    // keys of sub-tile `sub`.
+    __shared__ unsigned s_part[4][RANK_LK];
+    __shared__ int s_wc[4 * RANK_LK / 64];
     const int f = blockIdx.y, bi = blockIdx.x;
-    const int t = threadIdx.x & 255, sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    const int run = bi >> 2, my_sub = bi & 3;
+    const int t = threadIdx.x & (RANK_LK - 1), sub = __builtin_amdgcn_readfirstlane(threadIdx.x / RANK_LK);
+    const int run = bi >> 3, kb = bi & 7;
+    const int i = kb * RANK_LK + t;                 // key index inside the run
+    const int my_sub = kb >> 1;                     // its 256-key sub-tile
     const uint32_t *__restrict__ k = keys + (long long)f * key_stride + run * RANK_RUN;
-    const uint32_t ki = k[my_sub * 256 + t];
+    const uint32_t ki = k[i];
     const uint32_t kim1 = ki - 1u;                  // kj >= ki  <=>  kj > ki - 1   (ki >= 1 for candidates)
     unsigned cnt = 0, cnt2 = 0;
     const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(1024) void rank_local_kernel(const uint32_t *__rest
     } else {
         // own sub-tile: per 64-key quarter the rule is again uniform for a whole wave, except
         // for the wave's own quarter, where the later index wins a tie lane by lane
-        const int wq = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int wq = __builtin_amdgcn_readfirstlane((i & 255) >> 6);
+        const int il = i & 255;                     // index inside the sub-tile
         for (int qq = 0; qq < 4; ++qq) {
             if (qq < wq) {
 #pragma unroll
@@ -128,25 +133,30 @@ __global__ __launch_bounds__(1024) void rank_local_kernel(const uint32_t *__rest
 #pragma unroll 16
                 for (int j = qq * 64; j < qq * 64 + 64; ++j) {
                     const uint32_t kj = k[sub * 256 + j];       // wave-uniform: scalar load
-                    const uint32_t thr = (j > t) ? kim1 : ki;   // kj >= ki  <=>  kj > ki - 1
+                    const uint32_t thr = (j > il) ? kim1 : ki;  // kj >= ki  <=>  kj > ki - 1
                     cnt += (kj > thr) ? 1u : 0u;
                 }
             }
         }
     }
     s_part[sub][t] = cnt + cnt2;
-    if (sub == 0) {
-        const unsigned long long bal = __ballot(ki != 0u);
-        if ((t & 63) == 0) s_wc[t >> 6] = __popcll(bal);
+    if (kb == 0) {                                  // candidates of the whole run: two keys per thread
+        const int c = __popcll(__ballot(k[threadIdx.x] != 0u)) + __popcll(__ballot(k[threadIdx.x + 4 * RANK_LK] != 0u));
+        if ((threadIdx.x & 63) == 0) s_wc[threadIdx.x >> 6] = c;
     }
     __syncthreads();
     if (sub == 0) {
-        if (t == 0) cnt256[(long long)f * gridDim.x + bi] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+        if (kb == 0 && t == 0) {
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < 4 * RANK_LK / 64; ++w) c += s_wc[w];
+            cnt128[(long long)f * (gridDim.x >> 3) + run] = c;
+        }
         if (ki != 0u) {
             const unsigned r = s_part[0][t] + s_part[1][t] + s_part[2][t] + s_part[3][t];
             const long long o = (long long)f * key_stride + run * RANK_RUN + r;
             sorted[o] = ki;
-            sidx[o] = (uint16_t)(my_sub * 256 + t);
+            sidx[o] = (uint16_t)i;
         }
     }
 }
@@ -171,19 +181,19 @@ __device__ __forceinline__ int count_before(const uint32_t *sb, const uint32_t k
 // traffic of the searches spreads over twice as many CUs.  All runs of the frame are staged in LDS (<= 96 KB).
 __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restrict__ sorted,
                                                          const uint16_t *__restrict__ sidx,
-                                                         const int32_t *__restrict__ cnt256, int N, int key_stride,
+                                                         const int32_t *__restrict__ cnt128, int N, int key_stride,
                                                          int32_t *order, int cap, const int32_t *part_counts, int n_parts,
                                                          int32_t *n_valid)
 {
     __shared__ uint32_t s_keys[RANK_LDS_KEYS];
     __shared__ int s_half[128];
     const int f = blockIdx.y, bi = blockIdx.x, t = threadIdx.x;
-    const int nrun = key_stride / RANK_RUN, nb256 = key_stride >> 8;
+    const int nrun = key_stride / RANK_RUN;
     const int R = bi >> 3, pos = (bi & 7) * 128 + (t & 127), h = __builtin_amdgcn_readfirstlane(t >> 7);
     // the scatter index of the own key is requested first: its latency hides under everything else
     const int own = (int)sidx[(long long)f * key_stride + R * RANK_RUN + pos];
     const uint4 *__restrict__ src4 = reinterpret_cast<const uint4 *>(sorted + (long long)f * key_stride);
-    const int32_t *__restrict__ c256 = cnt256 + (long long)f * nb256;
+    const int32_t *__restrict__ crun = cnt128 + (long long)f * nrun;
     // staging: thread t owns keys 4t..4t+3 of every run; all loads are issued before the first use
     constexpr int MAXRUN = RANK_LDS_KEYS / RANK_RUN;
     uint4 v[MAXRUN];
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
 #pragma unroll
     for (int r = 0; r < MAXRUN; ++r) {
         if (r < nrun) {
-            const int nc = c256[4 * r] + c256[4 * r + 1] + c256[4 * r + 2] + c256[4 * r + 3] - 4 * t;   // wave-uniform sum
+            const int nc = crun[r] - 4 * t;          // candidates of the run (wave-uniform load)
             uint4 w = v[r];
             if (nc <= 0) w.x = 0u;                   // slots past the run's candidates were never written
             if (nc <= 1) w.y = 0u;
@@ -275,7 +285,7 @@ size_t mv3d_rank_ws_bytes(int N, int batch)
 {
     const size_t ks = (size_t)mv3d_rank_key_stride(N);
     if (ks <= RANK_LDS_KEYS)
-        return mv3d_align_up((size_t)batch * ks * 4) + mv3d_align_up((size_t)batch * ks * 2) + mv3d_align_up((size_t)batch * (ks / 256) * 4);
+        return mv3d_align_up((size_t)batch * ks * 4) + mv3d_align_up((size_t)batch * ks * 2) + mv3d_align_up((size_t)batch * (ks / 128) * 4);
     const size_t S = ks / RANK_SEG;
     return mv3d_align_up((size_t)batch * S * N * 4);
 }
@@ -287,10 +297,10 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
     if (key_stride <= RANK_LDS_KEYS) {
         uint32_t *sorted = (uint32_t *)workspace;
         uint16_t *sidx = (uint16_t *)((char *)workspace + mv3d_align_up((size_t)batch * key_stride * 4));
-        int32_t *cnt256 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
-        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 256, batch), dim3(1024), 0, stream, keys, key_stride, sorted, sidx,
-                           cnt256);
-        hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 128, batch), dim3(256), 0, stream, sorted, sidx, cnt256, N,
+        int32_t *cnt128 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
+        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 128, batch), dim3(4 * RANK_LK), 0, stream, keys, key_stride, sorted, sidx,
+                           cnt128);
+        hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 128, batch), dim3(256), 0, stream, sorted, sidx, cnt128, N,
                            key_stride, order, cap, part_counts, n_parts, n_valid);
         return mv3d_launch_status();
     }
