@@ -48,8 +48,10 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream);
 // index) is < cap.  Entries r >= number of candidates are left untouched.
 // part_counts (batch, n_parts): per-producer-workgroup candidate counts; their per-frame
 // sum is written to n_valid (batch).  Both may be NULL.  workspace: mv3d_rank_ws_bytes().
+// gather_src (batch, N) / gather_dst (batch, cap), optional: gather_dst[f*cap + r] = gather_src[f*N + i]
+// alongside order (16-byte records in rank order for the consumer, e.g. the NMS boxes).
 size_t mv3d_rank_ws_bytes(int N, int batch);
 int mv3d_rank_key_stride(int N);
 int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int32_t *order, int cap,
                      const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace,
-                     hipStream_t stream);
+                     hipStream_t stream, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr);

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(ProposalDev d)
 struct ProposalLayout {
     int N, order_cap, cap;
     int n_blocks, key_stride;
-    size_t o_bv, o_img, o_p3, o_key, o_order, o_keep, o_cnt, o_rank, o_nms, total;
+    size_t o_bv, o_img, o_p3, o_key, o_order, o_sbox, o_keep, o_cnt, o_rank, o_nms, total;
 };
 
 static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params *p, ProposalLayout &L)
@@ -122,6 +122,7 @@ static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params 
     L.key_stride = mv3d_rank_key_stride(L.N);
     L.o_key = o; o += mv3d_align_up(b * L.key_stride * 4);
     L.o_order = o; o += mv3d_align_up(b * L.order_cap * 4);
+    L.o_sbox = o; o += mv3d_align_up(b * L.order_cap * 16);       // BEV boxes in score order (NMS input)
     L.o_keep = o; o += mv3d_align_up(b * L.order_cap * 4);
     L.n_blocks = L.key_stride / 256;
     L.o_cnt = o; o += mv3d_align_up(b * (2 + L.n_blocks) * 4);   // nvalid[batch], num_keep[batch], blockcnt[batch][n_blocks]
@@ -168,12 +169,14 @@ extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, in
     hipLaunchKernelGGL(proposal_decode_kernel, dim3(L.n_blocks, batch), dim3(256), 0, s, d);
 
     int32_t *order = (int32_t *)(ws + L.o_order), *keep = (int32_t *)(ws + L.o_keep);
-    int rc = mv3d_launch_rank(d.key, L.N, L.key_stride, batch, order, L.order_cap, d.blockcnt, L.n_blocks, cnt, ws + L.o_rank, s);
+    float4 *sbox = (float4 *)(ws + L.o_sbox);
+    int rc = mv3d_launch_rank(d.key, L.N, L.key_stride, batch, order, L.order_cap, d.blockcnt, L.n_blocks, cnt, ws + L.o_rank, s,
+                              d.bv, sbox);
     if (rc != MV3D_OK) return rc;
 
     NmsLaunch nl = {};
-    nl.boxes = (const float *)d.bv; nl.box_stride = 4; nl.boxes_frame_stride = (long long)L.N * 4;
-    nl.idx = order; nl.idx_frame_stride = L.order_cap;
+    nl.boxes = (const float *)sbox; nl.box_stride = 4; nl.boxes_frame_stride = (long long)L.order_cap * 4;
+    nl.idx = nullptr; nl.idx_frame_stride = 0;
     nl.n_dev = cnt; nl.n_cap = L.order_cap; nl.batch = batch;
     nl.thresh_f32 = mv3d_ceil_f32(p->nms_thresh); nl.strict_gt = 0;
     nl.max_keep = L.cap;

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
                                                          const uint16_t *__restrict__ sidx,
                                                          const int32_t *__restrict__ cnt128, int N, int key_stride,
                                                          int32_t *order, int cap, const int32_t *part_counts, int n_parts,
-                                                         int32_t *n_valid)
+                                                         int32_t *n_valid, const float4 *__restrict__ gsrc, float4 *gdst)
 {
     __shared__ uint32_t s_keys[RANK_LDS_KEYS];
     __shared__ int s_half[128];
@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
     const int R = bi >> 3, pos = (bi & 7) * 128 + (t & 127), h = __builtin_amdgcn_readfirstlane(t >> 7);
     // the scatter index of the own key is requested first: its latency hides under everything else
     const int own = (int)sidx[(long long)f * key_stride + R * RANK_RUN + pos];
+    // ... and, when the caller wants its records in rank order too, the record of the own key (a slot past the
+    // run's candidates holds a stale index: the address is clamped and the value unused)
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gsrc && h == 0) rec = gsrc[(long long)f * N + min(R * RANK_RUN + own, N - 1)];
     const uint4 *__restrict__ src4 = reinterpret_cast<const uint4 *>(sorted + (long long)f * key_stride);
     const int32_t *__restrict__ crun = cnt128 + (long long)f * nrun;
     // staging: thread t owns keys 4t..4t+3 of every run; all loads are issued before the first use
@@ -244,7 +248,10 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
     __syncthreads();
     if (h == 0 && ki != 0u) {
         const int rank = pos + part + s_half[t];    // pos = position inside the own sorted run
-        if (rank < cap) order[(long long)f * cap + rank] = R * RANK_RUN + own;
+        if (rank < cap) {
+            order[(long long)f * cap + rank] = R * RANK_RUN + own;
+            if (gdst) gdst[(long long)f * cap + rank] = rec;
+        }
     }
     if (n_valid && bi == 0 && t < 64) {
         int nv = 0;
@@ -258,7 +265,8 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const uint32_t *__restr
 // ---------------------------------------------------------------------------- B. counting (scatter)
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__restrict__ keys, int N, int key_stride, int S,
                                                            const uint32_t *__restrict__ partial, int32_t *order, int cap,
-                                                           const int32_t *part_counts, int n_parts, int32_t *n_valid)
+                                                           const int32_t *part_counts, int n_parts, int32_t *n_valid,
+                                                           const float4 *__restrict__ gsrc, float4 *gdst)
 {
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -267,7 +275,10 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__res
         if (ki != 0u) {
             unsigned cnt = 0;
             for (int s = 0; s < S; ++s) cnt += partial[((long long)f * S + s) * N + i];
-            if ((int)cnt < cap) order[(long long)f * cap + cnt] = i;
+            if ((int)cnt < cap) {
+                order[(long long)f * cap + cnt] = i;
+                if (gdst) gdst[(long long)f * cap + cnt] = gsrc[(long long)f * N + i];
+            }
         }
     }
     if (n_valid && blockIdx.x == 0 && threadIdx.x < 64) {
@@ -291,7 +302,8 @@ size_t mv3d_rank_ws_bytes(int N, int batch)
 }
 
 int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int32_t *order, int cap,
-                     const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace, hipStream_t stream)
+                     const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace, hipStream_t stream,
+                     const float4 *gather_src, float4 *gather_dst)
 {
     if (N <= 0 || batch <= 0 || cap <= 0 || !workspace || key_stride != mv3d_rank_key_stride(N)) return MV3D_ERR_INVALID_ARG;
     if (key_stride <= RANK_LDS_KEYS) {
@@ -301,13 +313,13 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
         hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 128, batch), dim3(4 * RANK_LK), 0, stream, keys, key_stride, sorted, sidx,
                            cnt128);
         hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 128, batch), dim3(256), 0, stream, sorted, sidx, cnt128, N,
-                           key_stride, order, cap, part_counts, n_parts, n_valid);
+                           key_stride, order, cap, part_counts, n_parts, n_valid, gather_src, gather_dst);
         return mv3d_launch_status();
     }
     const int S = key_stride / RANK_SEG, IB = (N + 255) / 256;
     uint32_t *partial = (uint32_t *)workspace;
     hipLaunchKernelGGL(rank_partial_kernel, dim3(IB, S, batch), dim3(256), 0, stream, keys, N, key_stride, S, partial);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(IB, batch), dim3(256), 0, stream, keys, N, key_stride, S, partial, order,
-                       cap, part_counts, n_parts, n_valid);
+                       cap, part_counts, n_parts, n_valid, gather_src, gather_dst);
     return mv3d_launch_status();
 }
