@@ -4,22 +4,23 @@
 // lib/nms/nms_kernel.cu:34-144.  The suppression matrix is cut into 64x64 tiles of its upper
 // triangle, enumerated column-block-major (tile (rb, cb) at cb(cb+1)/2 + rb), every tile stored in
 // COLUMN form: lane j of the tile holds the u64 "which rows of row block rb suppress box cb*64+j".
-// The work proceeds in ROUNDS over ranges of column blocks ([0,32), [32,nbw) -- three for > 8192 boxes):
+// The work proceeds in ROUNDS over ranges of column blocks ([0,32), [32,nbw), or narrower ones for a large max_keep):
 // the greedy pass almost always reaches post_nms_topN inside the first range, and a round whose
 // frame is already finished returns at once, so the tiles nobody will read are never computed
 // (a TEST-config frame needs ~15 of its 94 column blocks: 528 tiles instead of 4465).
 //
-//  nms_tiles_kernel   all CUs, one single-wave workgroup per tile of the round.  lane = column box
+//  nms_tiles_kernel     round 1, all CUs, one single-wave workgroup per tile.  lane = column box
 //        (registers), the 64 row boxes staged in LDS and read back as broadcasts; packed-f32 math and
 //        a division-free exact compare (tile_fast()); the lane's word is a plain accumulation of bits.
-//  nms_chain_kernel   one workgroup per frame: the greedy dependency in "pull" form.  For block b it
-//        needs exactly column block b (b+1 tiles, static addresses, prefetched one column ahead):
-//        removed(j) = OR over row blocks rb < b of (tile(rb,b)[j] & K_rb) != 0 -- one AND + one wave
-//        compare per tile, spread over 15 pull waves -- then wave 0 resolves the diagonal tile by
-//        fixed-point iteration on ballots (converges to the unique greedy set) and publishes K_b in
-//        LDS.  State (K_b, kept count, done flag) persists in the workspace between rounds.  The round
-//        that finishes the frame (max_keep kept boxes = the reference's keep[:post_nms_topN], or the
-//        last block) also gathers the ROI blobs of proposal_layer_3d.
+//  nms_chain_lds_kernel round 1, one workgroup per frame: the greedy dependency.  Loader waves stream the
+//        round's tiles (one contiguous run in consumption order) into LDS, helper waves fold the older
+//        row blocks as their K words appear, one wave runs the serial part (see the kernel).
+//  nms_round_kernel     a later round in one launch: tile phase on all CUs (tiles of row blocks that
+//        earlier rounds finished are reduced on the spot to "removed" bits, the round's own tiles are
+//        stored), then the workgroup that finishes last runs the round's chain (chain1_round()).
+// State (K_b, kept count, done flag) persists in the workspace between rounds.  The round that finishes
+// the frame (max_keep kept boxes = the reference's keep[:post_nms_topN], or the last block) also
+// gathers the ROI blobs of proposal_layer_3d.
 //
 // Arithmetic is the reference's, operation for operation (see pair_suppresses()).
 #include <math.h>
@@ -71,6 +72,7 @@ struct NmsDev {
     int max_keep;
     unsigned long long *tiles;   // (batch, ntiles, 64) column form
     unsigned long long *kstate;  // (batch, nbw) kept masks of finished blocks
+    unsigned long long *rem;     // (batch, nbw) boxes removed by blocks of EARLIER rounds (later rounds only)
     int32_t *cstate;             // (batch, 4): [0] kept so far, [1] done
     int32_t *keep;
     long long keep_frame_stride;
@@ -214,7 +216,13 @@ __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const
         }
     }
     unsigned long long *dst = &d.tiles[((long long)f * d.ntiles + t) * 64 + lane];
-    if (AGENT_STORE) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (AGENT_STORE && rb < d.b0) {
+        // the row block was finished in an earlier round: its K word is final, so the tile reduces on the
+        // spot to "which boxes of column block cb does it remove" and never travels to the chain
+        const unsigned long long K = d.kstate[(long long)f * d.nbw + rb];
+        const unsigned long long m = __ballot((word & K) != 0ull);
+        if (m && lane == 0) __hip_atomic_fetch_or(&d.rem[(long long)f * d.nbw + cb], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (AGENT_STORE) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *dst = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
 }
@@ -229,141 +237,14 @@ __global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
     nms_one_tile<false>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x, s_box, s_area);
 }
 
-// grid: (batch); block 1024 = 16 waves: wave 0 = diagonal (serial part), waves 1..15 = pull.
-template <int KMAX>
-__device__ __forceinline__ void chain_round(const NmsDev &d, const int f)
-{
-    __shared__ unsigned long long s_K[NMS_MAX_WORDS];        // kept mask of every finished block
-    __shared__ unsigned long long s_rem;                      // removed bits of the block in flight
-    __shared__ int s_total, s_stop;
-    const int n = frame_n(d, f);
-    const int nb = (n + 63) >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long *tiles = d.tiles + (long long)f * d.ntiles * 64;
-    unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
-    int32_t *cstate = d.cstate + 4 * f;
-    int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
-    const int b0 = d.b0, b1 = min(d.b1, nb);
-    for (int w = threadIdx.x; w < b0; w += blockDim.x) s_K[w] = kstate[w];   // earlier rounds
-    if (threadIdx.x == 0) { s_rem = 0ull; s_total = d.first_round ? 0 : cstate[0]; s_stop = 0; }
-    __syncthreads();
-    int total = s_total;                                      // tracked by wave 0
-    // cur / dcur hold column b: pull wave w has the tiles of row blocks rb = (w - 1) + 15 k  (< b)
-    unsigned long long cur[KMAX], dcur = 0ull, dnxt = 0ull;
-    if (b0 < b1) {
-        const long long base = (long long)b0 * (b0 + 1) / 2;
-        if (wave == 0) dcur = tiles[(base + b0) * 64 + lane];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int rb = wave - 1 + NMS_PULL * k;
-            cur[k] = (wave > 0 && rb < b0) ? tiles[(base + rb) * 64 + lane] : 0ull;
-        }
-    }
-    for (int b = b0; b < b1; ++b) {
-        const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-        if (wave > 0) {
-            unsigned long long part = 0ull;
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int rb = wave - 1 + NMS_PULL * k;
-                if (rb < b) part |= __ballot((cur[k] & s_K[rb]) != 0ull);
-            }
-            if (lane == 0 && part) atomicOr(&s_rem, part);
-        }
-        if (b + 1 < b1) {
-            // cur is dead: refill it with column b + 1; the loads fly under the two barriers and the
-            // diagonal step below (all addresses are static)
-            const long long base = (long long)(b + 1) * (b + 2) / 2;
-            if (wave == 0) dnxt = tiles[(base + b + 1) * 64 + lane];
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const int rb = wave - 1 + NMS_PULL * k;
-                cur[k] = (wave > 0 && rb < b + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const long long t0 = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-            const int p = b * 64 + lane;
-            const bool alive = (p < n) && !((s_rem >> lane) & 1ull);
-            unsigned long long K = __ballot(alive);
-            int iters = 0;
-            // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in
-            // the block, so index k is final after k+1 steps; the fixed point is the greedy set.
-            for (;;) {
-                const unsigned long long K2 = __ballot(alive && !(dcur & K));
-                ++iters;
-                if (K2 == K) break;
-                K = K2;
-            }
-            const bool kept = (K >> lane) & 1ull;
-            const int pos = total + __popcll(K & ((1ull << lane) - 1ull));
-            if (kept && (d.max_keep <= 0 || pos < d.max_keep)) keep[pos] = p;
-            total += __popcll(K);
-            if (lane == 0) {
-                s_K[b] = K;
-                kstate[b] = K;
-                s_rem = 0ull;
-                s_total = total;
-                if (d.max_keep > 0 && total >= d.max_keep) s_stop = 1;
-                if (d.trace && f == 0) {
-                    long long *tr = d.trace + 4 * b;
-                    tr[0] = t_begin; tr[1] = t0; tr[2] = (long long)__builtin_readcyclecounter();
-                    tr[3] = ((long long)iters << 32) | (unsigned)__popcll(K);
-                }
-            }
-            dcur = dnxt;
-        }
-        __syncthreads();
-        if (s_stop) break;
-    }
-    const bool finished = s_stop || (b1 >= nb);
-    int nk = s_total;
-    if (d.max_keep > 0 && nk > d.max_keep) nk = d.max_keep;
-    if (threadIdx.x == 0) { cstate[0] = s_total; cstate[1] = finished ? 1 : 0; }
-    if (!finished) return;
-    if (threadIdx.x == 0) d.num_keep[f] = nk;
-    if (d.emit.enabled) {
-        // proposal_layer_tf.py:188-191: the three ROI blobs, batch column = frame index
-        const EmitDev &e = d.emit;
-        if (threadIdx.x == 0) e.num_out[f] = nk;
-        for (int r = threadIdx.x; r < e.cap; r += blockDim.x) {
-            float *obv = e.blob_bv + ((long long)f * e.cap + r) * 5;
-            float *oim = e.blob_img + ((long long)f * e.cap + r) * 5;
-            float *o3 = e.blob_3d + ((long long)f * e.cap + r) * 7;
-            if (r < nk) {
-                const int c = e.order[(long long)f * e.order_cap + keep[r]];
-                const long long o = (long long)f * e.N + c;
-                const float4 bx = e.bv[o];
-                const int4 im = e.img[o];
-                const float bi = (float)f;
-                obv[0] = bi; obv[1] = bx.x; obv[2] = bx.y; obv[3] = bx.z; obv[4] = bx.w;
-                oim[0] = bi; oim[1] = (float)im.x; oim[2] = (float)im.y; oim[3] = (float)im.z; oim[4] = (float)im.w;
-                o3[0] = bi;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) o3[1 + j] = e.p3[o * 6 + j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) { obv[j] = 0.0f; oim[j] = 0.0f; }
-#pragma unroll
-                for (int j = 0; j < 7; ++j) o3[j] = 0.0f;
-            }
-        }
-    }
-}
-
-template <int KMAX>
-__global__ __launch_bounds__(1024) void nms_chain_kernel(NmsDev d)
-{
-    const int f = blockIdx.x;
-    if (!d.first_round && d.cstate[4 * f + 1]) return;       // finished in an earlier round
-    chain_round<KMAX>(d, f);
-}
-
-// Single-wave form of the same round (grid: (batch); block 64), used while a column block has at
-// most KMAX row-block tiles: no barriers and no LDS atomics at all -- the wave pulls all b tiles of
-// column b itself (registers, refilled one column ahead) and then resolves the diagonal tile.  The
-// per-block critical path is ~25 cycles per tile plus the fixed point.
+// The chain of a LATER round (columns [b0, b1), b1 - b0 <= KMAX), run by one workgroup: the greedy
+// dependency in "pull" form.  removed(j) of block b = remv[b] (everything the blocks of earlier rounds
+// remove, reduced by the tile phase) | OR over the round's own row blocks rb in [b0, b) of
+// (tile(rb,b)[j] & K_rb) != 0 -- the wave pulls those tiles itself (registers, refilled one column ahead,
+// static addresses) -- then it resolves the diagonal tile by fixed-point iteration on ballots (converges
+// to the unique greedy set).  State (K_b, kept count, done flag) persists in the workspace between
+// rounds; the round that finishes the frame (max_keep kept boxes = the reference's
+// keep[:post_nms_topN], or the last block) also gathers the ROI blobs of proposal_layer_3d.
 template <int KMAX, int THREADS>
 __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
 {
@@ -376,30 +257,32 @@ __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
     if (threadIdx.x < 64) {
     const unsigned long long *tiles = d.tiles + (long long)f * d.ntiles * 64;
     unsigned long long *kstate = d.kstate + (long long)f * d.nbw;
+    const unsigned long long *remv = d.rem + (long long)f * d.nbw;
     int32_t *keep = d.keep + (long long)f * d.keep_frame_stride;
     const int b0 = d.b0, b1 = min(d.b1, nb);
-    for (int w = lane; w < NMS_MAX_WORDS; w += 64) s_K[w] = (w < b0) ? kstate[w] : 0ull;   // earlier rounds
-    int total = d.first_round ? 0 : cstate[0];
+    for (int w = lane; w < NMS_MAX_WORDS; w += 64) s_K[w] = 0ull;          // K of the round's blocks, by absolute index
+    int total = cstate[0];
     bool stop = false;
-    unsigned long long cur[KMAX], dcur = 0ull;
-    if (b0 < b1) {
-        const long long base = (long long)b0 * (b0 + 1) / 2;
-        dcur = tiles[(base + b0) * 64 + lane];
+    // cur[q] = tile(b0 + q, b): the rows of THIS round only (earlier rounds arrive reduced in remv)
+    unsigned long long cur[KMAX], dcur = 0ull, rcur = 0ull;
 #pragma unroll
-        for (int rb = 0; rb < KMAX; ++rb) cur[rb] = (rb < b0) ? tiles[(base + rb) * 64 + lane] : 0ull;
+    for (int q = 0; q < KMAX; ++q) cur[q] = 0ull;
+    if (b0 < b1) {
+        dcur = tiles[((long long)b0 * (b0 + 1) / 2 + b0) * 64 + lane];
+        rcur = __hip_atomic_load(&remv[b0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // s_K visible to every lane's reads
     for (int b = b0; b < b1; ++b) {
         const long long t_begin = d.trace ? (long long)__builtin_readcyclecounter() : 0;
-        unsigned long long rem = 0ull;
+        unsigned long long rem = rcur;
         const int bu = __builtin_amdgcn_readfirstlane(b);     // scalar: whole chunks of 8 tiles are branched over
 #pragma unroll
         for (int c = 0; c < KMAX / 8; ++c) {
-            if (8 * c < bu) {
+            if (8 * c < bu - b0) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int rb = 8 * c + u;                 // cur[rb] == 0 for rb >= b (never refilled)
-                    rem |= __ballot((cur[rb] & s_K[rb]) != 0ull);
+                    const int q = 8 * c + u;                  // cur[q] == 0 for b0 + q >= b (never refilled)
+                    rem |= __ballot((cur[q] & s_K[b0 + q]) != 0ull);
                 }
             }
         }
@@ -407,13 +290,14 @@ __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
         if (bu + 1 < b1) {                                    // refill with column b + 1 (static addresses)
             const long long base = (long long)(bu + 1) * (bu + 2) / 2;
             dcur = tiles[(base + bu + 1) * 64 + lane];
+            rcur = __hip_atomic_load(&remv[bu + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int c = 0; c < KMAX / 8; ++c) {
-                if (8 * c < bu + 1) {
+                if (8 * c < bu + 1 - b0) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int rb = 8 * c + u;
-                        cur[rb] = (rb < bu + 1) ? tiles[(base + rb) * 64 + lane] : 0ull;
+                        const int q = 8 * c + u;
+                        cur[q] = (q < bu + 1 - b0) ? tiles[(base + b0 + q) * 64 + lane] : 0ull;
                     }
                 }
             }
@@ -489,6 +373,7 @@ __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
 // finishes last (ticket in cstate[2]) runs the round's chain.  The tile words are written through at
 // agent scope and complete (vmcnt 0) before the ticket is taken; the chain side starts with an
 // agent-scope acquire, so it reads what the other XCDs wrote.
+template <int KMAX>
 __global__ __launch_bounds__(256) void nms_round_kernel(NmsDev d)
 {
     __shared__ float4 s_box[4][64];
@@ -511,7 +396,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(NmsDev d)
     if (!s_last) return;
     if (threadIdx.x == 0) cstate[2] = 0;                      // ready for the next launch on this workspace
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    chain1_round<128, 256>(d, f);
+    chain1_round<KMAX, 256>(d, f);
 }
 
 // Round-1 form of the chain (column blocks [0, b1 <= 32)).  A single wave executes ~1 instruction per
@@ -798,6 +683,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     const bool finished = (d.max_keep > 0 && ktotal >= d.max_keep) || (b1 >= nb);
     const int nk = (d.max_keep > 0 && ktotal > d.max_keep) ? d.max_keep : ktotal;
     if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;
+    if (threadIdx.x < d.nbw) d.rem[(long long)f * d.nbw + threadIdx.x] = 0ull;   // accumulated by the later rounds' tile phases
     if (threadIdx.x == 0) {
         cstate[0] = ktotal; cstate[1] = finished ? 1 : 0; cstate[2] = 0;
         if (finished) d.num_keep[f] = nk;
@@ -855,7 +741,7 @@ size_t mv3d_nms_ws_bytes(int n_cap, int batch)
 {
     const size_t nbw = (size_t)(n_cap + 63) / 64;
     const size_t ntiles = nbw * (nbw + 1) / 2;
-    return (size_t)batch * mv3d_align_up(ntiles * 64 * 8) + mv3d_align_up((size_t)batch * nbw * 8) +
+    return (size_t)batch * mv3d_align_up(ntiles * 64 * 8) + 2 * mv3d_align_up((size_t)batch * nbw * 8) +
            mv3d_align_up((size_t)batch * 4 * 4);
 }
 
@@ -877,26 +763,34 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     d.kstate = (unsigned long long *)ws;
     ws += mv3d_align_up((size_t)L.batch * nbw * 8);
     d.cstate = (int32_t *)ws;
+    ws += mv3d_align_up((size_t)L.batch * 4 * 4);
+    d.rem = (unsigned long long *)ws;
     d.keep = L.keep; d.keep_frame_stride = L.keep_frame_stride; d.num_keep = L.num_keep; d.status = L.status;
     d.emit = L.emit;
     d.trace = L.trace;
-    // rounds over column-block ranges; every kernel of a later round returns at once for a frame that
-    // is already finished.  A frame with no boxes is finished by the first chain launch.
-    int bounds[5] = {0, 32, nbw, nbw, nbw};
-    if (nbw > 128) { bounds[2] = 96; bounds[3] = nbw; }
-    for (int r = 0; r < 4; ++r) {
-        d.b0 = bounds[r]; d.b1 = bounds[r + 1] < nbw ? bounds[r + 1] : nbw;
+    // Rounds over column-block ranges; a later round returns at once for a frame that is already finished
+    // (a frame with no boxes is finished by the first round).  The first round is 32 blocks: the greedy pass
+    // almost always reaches a small max_keep (TEST: 300) inside it and the rest is one skipped launch.  A
+    // large or absent max_keep (TRAIN: 2000 = at least 32 blocks) gets narrow later rounds, so that the
+    // chain only ever pulls the tiles of its own round and little is computed past the stopping point.
+    int bounds[6] = {0, 32, nbw, nbw, nbw, nbw};
+    if (L.max_keep <= 0 || L.max_keep > 512) { bounds[2] = 64; bounds[3] = 128; bounds[4] = nbw; }
+    else if (nbw > 128) { bounds[2] = 128; bounds[3] = nbw; }
+    for (int r = 0; r < 5; ++r) {
+        d.b0 = bounds[r] < nbw ? bounds[r] : nbw; d.b1 = bounds[r + 1] < nbw ? bounds[r + 1] : nbw;
         d.first_round = (r == 0);
-        if (r > 0 && d.b0 >= nbw) break;
+        if (r > 0 && d.b0 >= d.b1) break;
         const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
-        if (r > 0 && d.b1 <= 128) {                           // a column block has at most b1 - 1 off-diagonal tiles
-            const int wgs = (ntr + 3) / 4 < 256 ? (ntr + 3) / 4 : 256;
-            hipLaunchKernelGGL(nms_round_kernel, dim3(wgs, 1, L.batch), dim3(256), 0, stream, d);
+        if (r == 0) {
+            if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
+            hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
             continue;
         }
-        if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
-        if (r == 0) hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
-        else hipLaunchKernelGGL(nms_chain_kernel<18>, dim3(L.batch), dim3(1024), 0, stream, d);
+        const int wgs = (ntr + 3) / 4 < 256 ? (ntr + 3) / 4 : 256;
+        const int width = d.b1 - d.b0;                         // <= 128 by construction
+        if (width <= 32) hipLaunchKernelGGL(nms_round_kernel<32>, dim3(wgs, 1, L.batch), dim3(256), 0, stream, d);
+        else if (width <= 64) hipLaunchKernelGGL(nms_round_kernel<64>, dim3(wgs, 1, L.batch), dim3(256), 0, stream, d);
+        else hipLaunchKernelGGL(nms_round_kernel<128>, dim3(wgs, 1, L.batch), dim3(256), 0, stream, d);
     }
     return mv3d_launch_status();
 }
