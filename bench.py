@@ -132,7 +132,9 @@ def pmc_traffic(kernel):
     FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes); None if no profile is committed."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
-        return int(json.load(open(path))[kernel]["hbm_bytes_per_launch"])
+        table = json.load(open(path))
+        key = next(k for k in table if kernel in k)       # template instances carry a "void ...<N>" decoration
+        return int(table[key]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
