@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
 // while the overlapping bins of neighbouring ROIs re-read it.  The bin geometry (f32 divides,
 // round / floor / ceil) is computed once per bin by the first lanes and broadcast through LDS.
 #define FWD_MAX_PASSES 8
+#define LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local")
 struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
 
 template <int FWD_PASSES>
@@ -235,13 +236,59 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack
 
 #define BWD_CHUNK 1024      // ROIs whose geometry is staged in LDS at a time
 #define BWD_PIX 4           // input pixels per workgroup (1 per wave)
+#define BWD_CAND 128        // candidate (roi, bin) records a wave collects before it drains them
 
 // grid = ceil(B*H*W / BWD_PIX) workgroups of 256 threads.  The rounded ROI geometry (the part with
-// the f32 multiplies / round()) is computed once per workgroup into LDS; every WAVE then owns whole
-// input pixels: it scans the table 64 ROIs per ballot (ascending, so the reference's summation order
-// roi -> ph -> pw is kept and the f32 sums are bit-identical), and its lanes walk only the
-// containing ROIs' candidate bins with 16-byte loads over the channels.  No atomics, no barriers
-// after the table is built, nothing depends on scheduling.
+// the f32 multiplies / round()) is computed once per workgroup into LDS; every WAVE then owns one
+// input pixel: it scans the table 64 ROIs per ballot (ascending) and, for every containing ROI, appends
+// the offsets of the candidate bins (ph, pw ascending) to a per-wave list in LDS.  The list is drained
+// four candidates at a time -- across ROI boundaries, so that every round of 16-byte loads is full and the
+// kernel's critical path (the pixel under the most ROIs) is a quarter as many memory round trips as it
+// has candidates -- and the adds happen in list order = the reference's summation order roi -> ph -> pw:
+// the f32 sums are bit-identical.  No atomics, no barriers after the table is built, nothing depends on
+// scheduling.
+template <int VEC, int NACC>
+__device__ __forceinline__ void bwd_drain(const long long *cand, const int ncand, const int want0, const int lane, const int CV,
+                                          const float *__restrict__ top_diff, const int *__restrict__ argmax,
+                                          float (&acc)[NACC][VEC])
+{
+    for (int t0 = 0; t0 < ncand; t0 += 4) {
+        long long o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = cand[min(t0 + u, ncand - 1)];       // wave-uniform (LDS broadcast)
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            const int cv = lane + 64 * k;
+            if (cv < CV) {
+                const int c0 = cv * VEC;
+                const int want = want0 + c0;
+                if (VEC == 4) {
+                    int4 am[4];
+                    float4 td[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        am[u] = *reinterpret_cast<const int4 *>(argmax + o[u] + c0);
+                        td[u] = *reinterpret_cast<const float4 *>(top_diff + o[u] + c0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (t0 + u < ncand) {
+                            if (am[u].x == want + 0) acc[k][0] += td[u].x;
+                            if (am[u].y == want + 1) acc[k][1 % VEC] += td[u].y;
+                            if (am[u].z == want + 2) acc[k][2 % VEC] += td[u].z;
+                            if (am[u].w == want + 3) acc[k][3 % VEC] += td[u].w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + u < ncand && argmax[o[u] + c0] == want) acc[k][0] += top_diff[o[u] + c0];
+                }
+            }
+        }
+    }
+}
+
 template <int VEC, int NACC>
 __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restrict__ top_diff, float scale, int B, int R,
                                                            int H, int W, int C, int PH, int PW,
@@ -250,16 +297,20 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restri
 {
     __shared__ int4 s_geom[BWD_CHUNK];
     __shared__ int s_bi[BWD_CHUNK];
+    __shared__ long long s_cand[BWD_PIX][BWD_CAND];
     const int CV = C / VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long npix = (long long)B * H * W;
-    float acc[BWD_PIX / 4][NACC][VEC];
+    const long long pix = (long long)blockIdx.x * BWD_PIX + wave;
+    const bool live = pix < npix;                             // wave-uniform
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+    const int want0 = (h * W + w) * C;
+    long long *cand = s_cand[wave];
+    float acc[NACC][VEC];
 #pragma unroll
-    for (int q = 0; q < BWD_PIX / 4; ++q)
+    for (int k = 0; k < NACC; ++k)
 #pragma unroll
-        for (int k = 0; k < NACC; ++k)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[q][k][v] = 0.0f;
+        for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0f;
 
     for (int base = 0; base < R; base += BWD_CHUNK) {
         const int cnt = min(R - base, BWD_CHUNK);
@@ -271,92 +322,58 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restri
             s_bi[r] = (int)roi[0];
         }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < BWD_PIX / 4; ++q) {
-            const long long pix = (long long)blockIdx.x * BWD_PIX + q * 4 + wave;
-            if (pix >= npix) continue;                // wave-uniform
-            const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
-            for (int r0 = 0; r0 < cnt; r0 += 64) {
-                const int r = r0 + lane;
-                bool in = false;
-                if (r < cnt) {
-                    const int4 g = s_geom[r];
-                    // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
-                    in = (n == s_bi[r]) && (w >= g.x && w <= g.z && h >= g.y && h <= g.w);
-                }
-                unsigned long long bal = __ballot(in);
-                while (bal) {                         // ascending ROI order
-                    const int rr = r0 + __builtin_ctzll(bal);
-                    bal &= bal - 1;
-                    const int4 g = s_geom[rr];
-                    const int rw = max(g.z - g.x + 1, 1), rh = max(g.w - g.y + 1, 1);
-                    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-                    // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
-                    int phs = (int)floorf((float)(h - g.y) / bh), phe = (int)ceilf((float)(h - g.y + 1) / bh);
-                    int pws = (int)floorf((float)(w - g.x) / bw), pwe = (int)ceilf((float)(w - g.x + 1) / bw);
-                    phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
-                    pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
-                    const long long off = (long long)(base + rr) * PH * PW * C;
-                    // candidate bins in (ph, pw) order, four at a time: the 16-byte loads of a group are
-                    // all in flight before the first is consumed; the adds stay in reference order
-                    const int nw = pwe - pws, nbins = (phe - phs) * nw;
-                    for (int t0 = 0; t0 < nbins; t0 += 4) {
-#pragma unroll
-                        for (int k = 0; k < NACC; ++k) {
-                            const int cv = lane + 64 * k;
-                            if (cv < CV) {
-                                const int c0 = cv * VEC;
-                                const int want = (h * W + w) * C + c0;
-                                if (VEC == 4) {
-                                    int4 am[4];
-                                    float4 td[4];
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        const int t = min(t0 + u, nbins - 1);
-                                        const long long o = off + ((long long)(phs + t / nw) * PW + (pws + t % nw)) * C + c0;
-                                        am[u] = *reinterpret_cast<const int4 *>(argmax + o);
-                                        td[u] = *reinterpret_cast<const float4 *>(top_diff + o);
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        if (t0 + u < nbins) {
-                                            if (am[u].x == want + 0) acc[q][k][0] += td[u].x;
-                                            if (am[u].y == want + 1) acc[q][k][1 % VEC] += td[u].y;
-                                            if (am[u].z == want + 2) acc[q][k][2 % VEC] += td[u].z;
-                                            if (am[u].w == want + 3) acc[q][k][3 % VEC] += td[u].w;
-                                        }
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        if (t0 + u < nbins) {
-                                            const int t = t0 + u;
-                                            const long long o = off + ((long long)(phs + t / nw) * PW + (pws + t % nw)) * C + c0;
-                                            if (argmax[o] == want) acc[q][k][0] += top_diff[o];
-                                        }
-                                    }
-                                }
-                            }
-                        }
+        if (!live) continue;
+        int ncand = 0;
+        for (int r0 = 0; r0 < cnt; r0 += 64) {
+            const int r = r0 + lane;
+            bool in = false;
+            if (r < cnt) {
+                const int4 g = s_geom[r];
+                // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
+                in = (n == s_bi[r]) && (w >= g.x && w <= g.z && h >= g.y && h <= g.w);
+            }
+            unsigned long long bal = __ballot(in);
+            while (bal) {                             // ascending ROI order
+                const int rr = r0 + __builtin_ctzll(bal);
+                bal &= bal - 1;
+                const int4 g = s_geom[rr];
+                const int rw = max(g.z - g.x + 1, 1), rh = max(g.w - g.y + 1, 1);
+                const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+                // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
+                int phs = (int)floorf((float)(h - g.y) / bh), phe = (int)ceilf((float)(h - g.y + 1) / bh);
+                int pws = (int)floorf((float)(w - g.x) / bw), pwe = (int)ceilf((float)(w - g.x + 1) / bw);
+                phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+                pws = min(max(pws, 0), PW); pwe = min(max(pwe, 0), PW);
+                const long long off = (long long)(base + rr) * PH * PW * C;
+                const int nw = pwe - pws, nbins = (phe - phs) * nw;    // <= PH * PW candidates, (ph, pw) order
+                for (int b0 = 0; b0 < nbins; b0 += 64) {
+                    const int take = min(nbins - b0, 64);
+                    if (ncand + take > BWD_CAND) {            // list full: drain it, in order
+                        LDS_FENCE();
+                        bwd_drain<VEC, NACC>(cand, ncand, want0, lane, CV, top_diff, argmax, acc);
+                        LDS_FENCE();
+                        ncand = 0;
                     }
+                    const int t = b0 + lane;
+                    if (lane < take) cand[ncand + lane] = off + ((long long)(phs + t / nw) * PW + (pws + t % nw)) * C;
+                    ncand += take;
                 }
             }
         }
+        LDS_FENCE();
+        bwd_drain<VEC, NACC>(cand, ncand, want0, lane, CV, top_diff, argmax, acc);
+        LDS_FENCE();
     }
+    if (!live) return;
+    float *out = bottom_diff + pix * C;
 #pragma unroll
-    for (int q = 0; q < BWD_PIX / 4; ++q) {
-        const long long pix = (long long)blockIdx.x * BWD_PIX + q * 4 + wave;
-        if (pix >= npix) continue;
-        float *out = bottom_diff + pix * C;
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) {
-            const int cv = lane + 64 * k;
-            if (cv < CV) {
-                if (VEC == 4)
-                    *reinterpret_cast<float4 *>(out + cv * 4) = make_float4(acc[q][k][0], acc[q][k][1 % VEC], acc[q][k][2 % VEC], acc[q][k][3 % VEC]);
-                else
-                    out[cv] = acc[q][k][0];
-            }
+    for (int k = 0; k < NACC; ++k) {
+        const int cv = lane + 64 * k;
+        if (cv < CV) {
+            if (VEC == 4)
+                *reinterpret_cast<float4 *>(out + cv * 4) = make_float4(acc[k][0], acc[k][1 % VEC], acc[k][2 % VEC], acc[k][3 % VEC]);
+            else
+                out[cv] = acc[k][0];
         }
     }
 }
