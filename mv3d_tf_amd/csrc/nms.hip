@@ -352,7 +352,7 @@ __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
             for (int l = lt; l < lines; l += nt) sink ^= *reinterpret_cast<const unsigned *>(tl + colbase + (long long)l * 128);
             if (__hip_atomic_load(&s_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // wave 0 is through
         }
-        if (sink == 0x9e3779b9u) s_sink = 1;                   // keeps the loads alive
+        if (sink == 0x9e3779b9u) __hip_atomic_store(&s_sink, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // keeps the loads alive
     }
     __syncthreads();                                          // also orders wave 0's keep[] stores for the readers
     if (!s_fin) return;
