@@ -22,6 +22,7 @@ kernel, measured live with HIP events on the launch stream) and `cpu_baseline` (
 oracle, single thread, bounded sample) objects.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -58,6 +59,11 @@ def parse():
                          "the 7 launches of a step are enqueued ahead of the GPU either way, and graph nodes carry more "
                          "per-node overhead than in-order stream launches)")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="frames in flight: step i runs on stream i %% S with its own outputs and workspace, so the "
+                         "latency-bound kernels of one frame overlap the RoiPool of another (each step is still one batch). "
+                         "0 = auto: 3 up to batch 4 (batch 1: 16.3k / 24.5k / 28.8k / 22.7k frames/s for 1-4 streams; batch 4: 27.9k / "
+                         "34.4k / 35.2k for 1-3), 1 above (batch 16: 31k alone, 24k with 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests on one GPU)")
@@ -67,9 +73,10 @@ def parse():
 class Frames:
     """Per-rank device-resident inputs and the step closure."""
 
-    def __init__(self, args, rank):
+    def __init__(self, args, rank, stream=None):
         from mv3d_tf_amd import ops, synth
         self.ops, self.args = ops, args
+        self.stream = stream                          # None: whatever stream is current when step() runs
         B = args.batch
         heads = [synth.rpn_head(1000 + rank * 64 + b, 76, 76, args.variant) for b in range(B)]
         self.host_frame0 = heads[0]
@@ -89,7 +96,7 @@ class Frames:
         """one pass of the hot path over the batch: mv3d_proposal_3d (6 launches) + both RoiPool views (1 launch).
         After the first call the two C entry points are called with pre-built arguments (nothing is allocated,
         looked up or converted per step; the host side of a step is two ctypes calls)."""
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = self.stream.cuda_stream if self.stream is not None else torch.cuda.current_stream().cuda_stream
         bound = self._bound.get(sid) if hasattr(self, "_bound") else None
         if bound is None:
             bound = self._bind(sid)
@@ -107,7 +114,8 @@ class Frames:
         from mv3d_tf_amd._lib import RoiView, lib
         o = self.ops
         if self.out is None:                                                # first call: outputs (through the wrappers)
-            self.out = o.proposal_3d(self.prob, self.pred, self.info, self.calib, self.params)
+            with torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext():
+                self.out = o.proposal_3d(self.prob, self.pred, self.info, self.calib, self.params)
             R = self.out[0].shape[0] * self.out[0].shape[1]
             mk = lambda c, dt: torch.empty((R, 7, 7, c), dtype=dt, device="cuda")
             self.tops = (mk(BEV_MAP[2], torch.float32), mk(BEV_MAP[2], torch.int32),
@@ -117,7 +125,7 @@ class Frames:
         B, H, W, _ = self.prob.shape
         P = lambda t: C.c_void_p(t.data_ptr())
         nbytes = lib().mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(self.params))
-        ws = o._workspace(nbytes, self.prob.device, "proposal")
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.prob.device)     # one per (Frames, stream)
         st = C.c_void_p(sid)
         a1 = (P(self.prob), P(self.pred), B, H, W, P(self.info), P(self.calib), C.byref(self.params), P(bv), P(img), P(b3),
               P(num), P(status), P(ws), C.c_size_t(ws.numel()), st)
@@ -243,10 +251,14 @@ def main():
     from mv3d_tf_amd import build
     build.build()
 
-    fr = Frames(args, rank)
-    run = fr.step
+    nstreams = args.streams if args.streams > 0 else (3 if args.batch <= 4 and not args.graph else 1)
+    if nstreams == 1:
+        frs = [Frames(args, rank)]
+    else:
+        frs = [Frames(args, rank, torch.cuda.Stream()) for _ in range(nstreams)]
+    fr = frs[0]
     graph = None
-    if args.graph and not args.no_graph:
+    if args.graph and not args.no_graph and nstreams == 1:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -257,6 +269,14 @@ def main():
         with torch.cuda.graph(graph):
             fr.step()
         run = graph.replay
+    elif nstreams == 1:
+        run = fr.step
+    else:
+        turn = [0]
+
+        def run():
+            frs[turn[0] % nstreams].step()
+            turn[0] += 1
 
     def barrier():
         if dist is not None:
@@ -272,6 +292,16 @@ def main():
     t_enq = time.perf_counter() - t0                    # host time to enqueue the steps (eager: must stay < dt)
     barrier()
     dt = time.perf_counter() - t0
+    lat = None
+    if nstreams > 1:                                   # the same step alone on one stream: its latency
+        for _ in range(10):
+            fr.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            fr.step()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 100
     from mv3d_tf_amd import sharding
     dt = sharding.max_over_ranks(dt, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
 
@@ -288,7 +318,8 @@ def main():
                                                                    CFGS[args.cfg]["RPN_POST_NMS_TOP_N"],
                                                                    fr.out[0].shape[1], args.variant),
                        "batch_per_gpu": args.batch, "hipgraph": graph is not None,
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "streams": nstreams,
+                       "one_stream_ms_per_step": None if lat is None else round(lat * 1e3, 4), "parallelism": "frames/%d" % world},
             "kept_rois_frame0": int(fr.out[3][0].item()),
         }
         res["roofline"] = roofline(fr)
