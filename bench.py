@@ -66,6 +66,7 @@ def parse():
                          "34.4k / 35.2k for 1-3), 1 above (batch 16: 31k alone, 24k with 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--only", default="", choices=["", "proposal", "roi"], help="diagnostics: run only one half of the step")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests on one GPU)")
     return ap.parse_args()
 
@@ -100,8 +101,9 @@ class Frames:
         bound = self._bound.get(sid) if hasattr(self, "_bound") else None
         if bound is None:
             bound = self._bind(sid)
-        rc = bound[0](*bound[1])
-        if rc == 0:
+        only = self.args.only
+        rc = bound[0](*bound[1]) if only != "roi" else 0
+        if rc == 0 and only != "proposal":
             rc = bound[2](*bound[3])
         if rc != 0:
             from mv3d_tf_amd._lib import check

@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void nms_round_kernel(NmsDev d)
 #define CHL_HELPERS 4                                   // waves 1..4
 #define CHL_LOADER0 5                                   // waves 5..7
 #define CHL_LOADERS 3
-#define CHL_ARENA 276                                   // tiles (columns 0..22)
+#define CHL_ARENA 231                                   // tiles (columns 0..20): 138 KB of LDS in all, so that the workgroup
+                                                        // fits on a CU next to the small-LDS workgroups of another stream
 #define CHL_PER (CHL_LOADERS * 64)                      // 16-B units per load instruction of the loader group
 #define CHL_LU 8                                        // loads per loader thread and batch
 #define CHL_BATCH (CHL_LU * CHL_PER)                    // units per batch (48 tiles, 24 KB)
