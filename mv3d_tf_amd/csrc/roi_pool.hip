@@ -137,10 +137,14 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(const unsigned block, con
         g.hs = g.he = g.ws = g.we = 0; g.base = -1; g.pad0 = g.pad1 = g.pad2 = 0;
         const long long bin = bin0 + threadIdx.x;
         if (bin < nbins) {
-            const int pw = (int)(bin % PW);
-            const int ph = (int)((bin / PW) % PH);
-            const int n = (int)(bin / ((long long)PW * PH));
-            const float *roi = rois + 5 * n;
+            // 32-bit divisions (the launcher guarantees R*PH*PW < 2^31): a 64-bit divide is ~100 instructions,
+            // three of them in front of the barrier were the long pole of every workgroup
+            const unsigned ub = (unsigned)bin, upw = (unsigned)PW, uph = (unsigned)PH;
+            const unsigned t = ub / upw;
+            const int pw = (int)(ub - t * upw);
+            const unsigned n = t / uph;
+            const int ph = (int)(t - n * uph);
+            const float *roi = rois + 5 * (long long)n;
             const int bi = (int)roi[0];
             const RoiGeom q = roi_geom(roi, scale);
             const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);   // roi_pooling_op.cc:146-147
@@ -393,6 +397,7 @@ extern "C" int mv3d_roi_pool_forward(const float *bottom_data, float spatial_sca
         pooled_width <= 0 || !bottom_data || !top_data || (num_rois > 0 && !bottom_rois))
         return MV3D_ERR_INVALID_ARG;
     if ((long long)height * width * channels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;   // argmax is i32
+    if ((long long)num_rois * pooled_height * pooled_width > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
     if (num_rois == 0) return MV3D_OK;
     const bool v4 = (channels % 4 == 0) && aligned16(bottom_data) && aligned16(top_data) &&
                     (!argmax_data || aligned16(argmax_data));
@@ -469,7 +474,8 @@ extern "C" int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *v
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_view &w = views[k];
         if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_data ||
-            !w.top_data || (w.num_rois > 0 && !w.bottom_rois))
+            !w.top_data || (w.num_rois > 0 && !w.bottom_rois) ||
+            (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
             return MV3D_ERR_INVALID_ARG;
         const int cv4 = w.channels / 4;
         fast = fast && (w.channels % 4 == 0) && (cv4 == 64 || cv4 == 128 || cv4 == 256) && aligned16(w.bottom_data) &&
