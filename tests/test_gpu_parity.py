@@ -56,6 +56,26 @@ def test_nms_device_presorted_matches_reference(ops, torch_cuda, name):
         assert keep[:m].cpu().numpy().tolist() == g["keep_presorted"][:cap].tolist()
 
 
+def test_nms_round_structure_sweep_vs_oracle(ops, torch_cuda, oracle):
+    """sizes around the round boundaries (32 / 64 / 128 blocks of 64 boxes), small / large / no caps (the caps
+    select the round layout), dense and sparse suppression: keep lists equal to the oracle's."""
+    rng = np.random.RandomState(2024)
+    sizes = [1, 63, 64, 65, 2047, 2048, 2049, 4096, 4100, 8191, 8200, 13000]
+    cases = [(n, v, t, c) for n in sizes for (v, t, c) in (("clustered", 0.7, 0), ("rand", 0.5, 300))]
+    cases += [(int(rng.randint(1, 13000)), ("clustered", "rand")[int(rng.randint(2))], float(rng.choice([0.3, 0.5, 0.7, 0.9])),
+               int(rng.choice([0, 1, 50, 300, 513, 700, 2000, 5000]))) for _ in range(24)]
+    for k, (n, variant, thr, cap) in enumerate(cases):
+        dets = synth.nms_dets(500 + k, n, variant, integer=(k % 3 != 0))
+        dets = np.ascontiguousarray(dets[np.argsort(-dets[:, 4], kind="stable")])
+        want = oracle.cpu_nms(dets, thr, presorted=True)
+        if cap > 0:
+            want = want[:cap]
+        keep, num, status = ops.nms_device(dev(dets, torch_cuda), thr, max_keep=cap)
+        m = int(num.item())
+        assert m == len(want), (n, variant, thr, cap, m, len(want))
+        assert keep[:m].cpu().numpy().tolist() == want, (n, variant, thr, cap)
+
+
 def test_nms_exact_iou_double_compare(ops):
     g = golden("nms_exact_iou")
     for i in range(4):
