@@ -50,6 +50,18 @@ def proposal_params(cfg_section, feat_stride=8, img_height=375, img_width=1242, 
                           float(cfg_section["RPN_MIN_SIZE"]))
 
 
+def proposal_3d_outputs(B, cap, dev):
+    """The five outputs of proposal_3d as views of ONE buffer (bv | img | 3d | num | status, 4-byte slots), so that
+    a host consumer fetches them with a single device-to-host copy.  Returns (pack, (bv, img, b3, num, status))."""
+    n5, n7 = B * cap * 5, B * cap * 7
+    pack = torch.empty((2 * n5 + n7 + 2 * B,), dtype=torch.float32, device=dev)
+    bv = pack[:n5].view(B, cap, 5)
+    img = pack[n5:2 * n5].view(B, cap, 5)
+    b3 = pack[2 * n5:2 * n5 + n7].view(B, cap, 7)
+    tail = pack[2 * n5 + n7:].view(torch.int32)
+    return pack, (bv, img, b3, tail[:B], tail[B:])
+
+
 def proposal_3d(prob, pred, im_info, calib, params, out=None):
     """prob (B,H,W,8), pred (B,H,W,24), im_info (B,3), calib (B,4,12) device f32 tensors.
     Returns (blob_bv (B,cap,5), blob_img (B,cap,5), blob_3d (B,cap,7), num_out (B) i32,
@@ -62,11 +74,7 @@ def proposal_3d(prob, pred, im_info, calib, params, out=None):
     nbytes = lib().mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(params))
     ws = _workspace(nbytes, dev, "proposal")
     if out is None:
-        out = (torch.empty((B, cap, 5), dtype=torch.float32, device=dev),
-               torch.empty((B, cap, 5), dtype=torch.float32, device=dev),
-               torch.empty((B, cap, 7), dtype=torch.float32, device=dev),
-               torch.empty((B,), dtype=torch.int32, device=dev),
-               torch.empty((B,), dtype=torch.int32, device=dev))
+        out = proposal_3d_outputs(B, cap, dev)[1]
     bv, img, b3, num, status = out
     rc = lib().mv3d_proposal_3d(_ptr(prob), _ptr(pred), B, H, W, _ptr(im_info), _ptr(calib), C.byref(params),
                                 _ptr(bv), _ptr(img), _ptr(b3), _ptr(num), _ptr(status), _ptr(ws), ws.numel(),

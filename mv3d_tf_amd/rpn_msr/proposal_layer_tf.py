@@ -4,10 +4,13 @@ tf.py_func, same name / arguments / return tuple as lib/rpn_msr/proposal_layer_t
 Inputs may be numpy arrays (the py_func contract: host arrays in, fresh host arrays out,
 one frame) or torch device tensors (no host round trip, any batch).  All arithmetic runs
 in libmv3d_hip.so (csrc/proposal.hip)."""
+import ctypes as C
+
 import numpy as np
 import torch
 
 from .. import ops
+from .._lib import ERR_INVALID_ARG, check, lib
 from ..fast_rcnn.config import cfg
 
 
@@ -31,15 +34,26 @@ def proposal_layer_3d(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, calib, cfg_k
         cal = cal.expand(B, 4, 12).contiguous()
     stride = int(np.asarray(_feat_stride).reshape(-1)[0])
     params = ops.proposal_params(cfg[cfg_key], feat_stride=stride)
-    bv, img, b3, num, status = ops.proposal_3d(prob, pred, info, cal, params)
+    H, W = int(prob.shape[1]), int(prob.shape[2])
+    cap = lib().mv3d_proposal_3d_capacity(H, W, C.byref(params))
+    if cap < 0:
+        check(ERR_INVALID_ARG, "mv3d_proposal_3d_capacity")
+    pack, out = ops.proposal_3d_outputs(B, cap, prob.device)
+    bv, img, b3, num, status = ops.proposal_3d(prob, pred, info, cal, params, out=out)
+    if as_numpy:
+        # numpy contract (one frame): ONE device-to-host copy of the packed outputs, sliced on the host
+        host = pack.cpu().numpy()
+        n5, n7 = cap * 5, cap * 7
+        tail = host[2 * n5 + n7:].view(np.int32)
+        if int(tail[1]) & 1:
+            raise ZeroDivisionError("float division")
+        r = int(tail[0])
+        return (host[:n5].reshape(cap, 5)[:r], host[n5:2 * n5].reshape(cap, 5)[:r],
+                host[2 * n5:2 * n5 + n7].reshape(cap, 7)[:r])
     counts = num.cpu().numpy()                     # the only host sync: ROI counts
     if int(status.max().item()) & 1:
         raise ZeroDivisionError("float division")
     if B == 1:
         r = int(counts[0])
-        outs = (bv[0, :r], img[0, :r], b3[0, :r])
-    else:
-        outs = tuple(torch.cat([t[b, :int(counts[b])] for b in range(B)], 0) for t in (bv, img, b3))
-    if as_numpy:
-        return tuple(o.cpu().numpy() for o in outs)
-    return outs
+        return (bv[0, :r], img[0, :r], b3[0, :r])
+    return tuple(torch.cat([t[b, :int(counts[b])] for b in range(B)], 0) for t in (bv, img, b3))
