@@ -31,6 +31,55 @@ def _dev(t, dtype=torch.float32, device=None):
 _ws_cache = {}
 
 
+def upload_packed(arrays, device):
+    """Several small host arrays (f32 / i32, any shape) -> ONE host-to-device copy; returns device views with the
+    arrays' shapes (4-byte slots; an int32 array comes back as an int32 view)."""
+    flat = [np.ascontiguousarray(a, np.int32 if np.issubdtype(np.asarray(a).dtype, np.integer) else np.float32) for a in arrays]
+    sizes = [a.size for a in flat]
+    host = np.empty((max(sum(sizes), 1),), np.float32)
+    o = 0
+    for a, n in zip(flat, sizes):
+        host[o:o + n] = a.reshape(-1).view(np.float32)
+        o += n
+    devbuf = torch.from_numpy(host).to(device)
+    views, o = [], 0
+    for a, n in zip(flat, sizes):
+        v = devbuf[o:o + n]
+        if a.dtype == np.int32:
+            v = v.view(torch.int32)
+        views.append(v.view(a.shape))
+        o += n
+    return views
+
+
+def packed_views(spec, device):
+    """spec: [(shape, torch dtype of 4 bytes)] -> (pack f32 buffer, views): outputs that a host consumer fetches with
+    ONE device-to-host copy (`unpack_host`)."""
+    sizes = [int(np.prod(sh)) for sh, _ in spec]
+    pack = torch.empty((max(sum(sizes), 1),), dtype=torch.float32, device=device)
+    views, o = [], 0
+    for (sh, dt), n in zip(spec, sizes):
+        v = pack[o:o + n]
+        if dt != torch.float32:
+            v = v.view(dt)
+        views.append(v.view(sh))
+        o += n
+    return pack, views
+
+
+def unpack_host(pack, spec):
+    host = pack.cpu().numpy()
+    outs, o = [], 0
+    for sh, dt in spec:
+        n = int(np.prod(sh))
+        a = host[o:o + n]
+        if dt != torch.float32:
+            a = a.view(np.int32)
+        outs.append(a.reshape(sh))
+        o += n
+    return outs
+
+
 def _workspace(nbytes, device, tag):
     """Reused per (device, stream, tag) so hot calls never allocate (buffers are 256-B aligned)."""
     key = (str(device), torch.cuda.current_stream().cuda_stream, tag)
@@ -143,32 +192,38 @@ def roi_pool_backward(top_diff, rois, argmax, data_shape, pooled_height, pooled_
 
 
 # ------------------------------------------------------------------ anchor_target_layer
-def anchor_target_stage1(H, W, im_info, gt_bv, gt_3d, params):
+def anchor_target_stage1(H, W, im_info, gt_bv, gt_3d, params, labels=None, targets=None):
     dev = gt_bv.device
     N = H * W * 4
     G = gt_bv.shape[0]
-    labels = torch.empty((N,), dtype=torch.float32, device=dev)
-    targets = torch.empty((N, 6), dtype=torch.float32, device=dev)
-    counts = torch.empty((8,), dtype=torch.int32, device=dev)
-    fg_hi = torch.empty((N,), dtype=torch.uint8, device=dev)
+    if labels is None:
+        labels = torch.empty((N,), dtype=torch.float32, device=dev)
+        targets = torch.empty((N, 6), dtype=torch.float32, device=dev)
+    # counts (8 x i32) and the per-foreground flags in ONE buffer: the host reads both with one copy
+    cf = torch.empty((32 + N,), dtype=torch.uint8, device=dev)
+    counts = cf[:32].view(torch.int32)
+    fg_hi = cf[32:]
     ws = _workspace(lib().mv3d_anchor_target_workspace_bytes(H, W, G), dev, "anchor_target")
     rc = lib().mv3d_anchor_target_stage1(H, W, _ptr(im_info), _ptr(gt_bv), _ptr(gt_3d), G, C.byref(params),
                                          _ptr(labels), _ptr(targets), _ptr(counts), _ptr(fg_hi), _ptr(ws),
                                          ws.numel(), _stream())
     check(rc, "mv3d_anchor_target_stage1")
-    return labels, targets, counts, fg_hi, ws
+    return labels, targets, counts, fg_hi, ws, cf
 
 
-def anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, anchors_cap):
+def anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, anchors_cap, out=None):
     dev = labels.device
-
-    def up(a):
-        return None if a is None or len(a) == 0 else torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(dev)
-
-    t_fg, t_b1, t_b2 = up(dis_fg), up(dis_bg1), up(dis_bg2)
-    anchors = torch.empty((anchors_cap, 5), dtype=torch.float32, device=dev)
-    anchors_3d = torch.empty((anchors_cap, 7), dtype=torch.float32, device=dev)
-    n_anchors = torch.empty((1,), dtype=torch.int32, device=dev)
+    lists = [np.zeros(0, np.int32) if a is None else np.ascontiguousarray(a, np.int32) for a in (dis_fg, dis_bg1, dis_bg2)]
+    t_fg = t_b1 = t_b2 = None
+    if sum(len(a) for a in lists):
+        v = upload_packed(lists, dev)                          # the three index lists in one upload
+        t_fg, t_b1, t_b2 = (x if x.numel() else None for x in v)
+    if out is None:
+        anchors = torch.empty((anchors_cap, 5), dtype=torch.float32, device=dev)
+        anchors_3d = torch.empty((anchors_cap, 7), dtype=torch.float32, device=dev)
+        n_anchors = torch.empty((1,), dtype=torch.int32, device=dev)
+    else:
+        anchors, anchors_3d, n_anchors = out
     rc = lib().mv3d_anchor_target_stage2(H, W, C.byref(params), _ptr(t_fg), 0 if t_fg is None else t_fg.numel(),
                                          _ptr(t_b1), 0 if t_b1 is None else t_b1.numel(),
                                          _ptr(t_b2), 0 if t_b2 is None else t_b2.numel(),
@@ -190,19 +245,22 @@ def proposal_target_stage1(rois_bv, rois_3d, gt_bv, gt_3d, params):
     return counts, ws
 
 
-def proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, calib, params, fg_pick, bg_pick, ws):
+def proposal_target_spec(S, nc):
+    return [((S, 5), torch.float32), ((S, 5), torch.float32), ((S, 1), torch.int32), ((S, 24 * nc), torch.float32),
+            ((S, 7), torch.float32)]
+
+
+def proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, calib, params, fg_pick, bg_pick, ws, out=None):
     dev = gt_bv.device
     R, G = rois_bv.shape[0], gt_bv.shape[0]
-
-    def up(a):
-        return None if len(a) == 0 else torch.as_tensor(np.ascontiguousarray(a, np.int32)).to(dev)
-
-    t_fg, t_bg = up(fg_pick), up(bg_pick)
+    t_fg = t_bg = None
+    if len(fg_pick) + len(bg_pick):
+        v = upload_packed([np.ascontiguousarray(fg_pick, np.int32), np.ascontiguousarray(bg_pick, np.int32)], dev)
+        t_fg, t_bg = (x if x.numel() else None for x in v)
     S = len(fg_pick) + len(bg_pick)
     nc = params.num_classes
-    out = (torch.empty((S, 5), dtype=torch.float32, device=dev), torch.empty((S, 5), dtype=torch.float32, device=dev),
-           torch.empty((S, 1), dtype=torch.int32, device=dev), torch.empty((S, 24 * nc), dtype=torch.float32, device=dev),
-           torch.empty((S, 7), dtype=torch.float32, device=dev))
+    if out is None:
+        out = tuple(torch.empty(sh, dtype=dt, device=dev) for sh, dt in proposal_target_spec(S, nc))
     rc = lib().mv3d_proposal_target_stage2(_ptr(rois_bv), _ptr(rois_3d), R, _ptr(gt_bv), _ptr(gt_3d), _ptr(gt_cnr), G,
                                            _ptr(calib), C.byref(params), _ptr(t_fg), len(fg_pick), _ptr(t_bg), len(bg_pick),
                                            _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]),

@@ -22,15 +22,28 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_str
     as_numpy = not isinstance(rpn_cls_score, torch.Tensor)
     H, W = int(rpn_cls_score.shape[1]), int(rpn_cls_score.shape[2])
     dev = rpn_cls_score.device if not as_numpy else torch.device("cuda", cfg.GPU_ID)
-    gt_bv = ops._dev(gt_boxes, device=dev)
-    gt_3d = ops._dev(gt_boxes_3d, device=dev)
-    info = ops._dev(im_info, device=dev).reshape(-1)[:3].contiguous()
+    if as_numpy:
+        # numpy contract: the three small inputs travel in one upload
+        gt_bv, gt_3d, info = ops.upload_packed([np.asarray(gt_boxes, np.float32), np.asarray(gt_boxes_3d, np.float32),
+                                                np.asarray(im_info, np.float32).reshape(-1)[:3]], dev)
+    else:
+        gt_bv = ops._dev(gt_boxes, device=dev)
+        gt_3d = ops._dev(gt_boxes_3d, device=dev)
+        info = ops._dev(im_info, device=dev).reshape(-1)[:3].contiguous()
     T = cfg.TRAIN
     stride = int(np.asarray(_feat_stride).reshape(-1)[0])
     params = AnchorTargetParams(stride, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP),
                                 float(T.RPN_POSITIVE_OVERLAP))
-    labels, targets, counts, fg_hi, ws = ops.anchor_target_stage1(H, W, info, gt_bv, gt_3d, params)
-    n_inside, n_fg, n_bg, n_low = (int(v) for v in counts[:4].cpu().numpy())     # host sync #1
+    N = H * W * 4
+    cap = max(int(T.RPN_BATCHSIZE), 1) * 2
+    spec = [((N,), torch.float32), ((N, 6), torch.float32), ((cap, 5), torch.float32), ((cap, 7), torch.float32),
+            ((1,), torch.int32)]
+    pack, (labels, targets, anchors, anchors_3d, n_anc) = ops.packed_views(spec, dev)   # all outputs: one buffer
+    labels, targets, counts, fg_hi, ws, cf = ops.anchor_target_stage1(H, W, info, gt_bv, gt_3d, params, labels, targets)
+    # host sync #1: the counts and (usually all of) the foreground flags in one copy
+    first = min(32 + N, 4096)
+    head = cf[:first].cpu().numpy()
+    n_inside, n_fg, n_bg, n_low = (int(v) for v in head[:16].view(np.int32))
     # anchor_target_layer_tf.py:146-151
     num_fg = int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE)
     dis_fg = None
@@ -43,7 +56,10 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_str
         dis_bg1 = npr.permutation(n_bg)[:n_bg - num_bg]
     # :176-183 positives that survive `labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0`
     if n_fg:
-        alive = fg_hi[:n_fg].cpu().numpy().astype(bool)                            # host sync #2 (n_fg bytes)
+        if 32 + n_fg <= first:
+            alive = head[32:32 + n_fg].astype(bool)
+        else:
+            alive = fg_hi[:n_fg].cpu().numpy().astype(bool)                        # host sync #2 (rare: > 4064 positives)
         if dis_fg is not None:
             alive[dis_fg] = False
         n_pos = int(alive.sum())
@@ -53,12 +69,14 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_str
     dis_bg2 = None
     if n_low > num_bg2:
         dis_bg2 = npr.permutation(n_low)[:n_low - num_bg2]
-    cap = max(int(T.RPN_BATCHSIZE), 1) * 2
-    anchors, anchors_3d, n_anc = ops.anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, cap)
-    m = int(n_anc.item())
-    if m > cap:                                      # more than 2*RPN_BATCHSIZE debug rows: redo with room
-        raise RuntimeError("anchor_target_layer: %d labelled anchors exceed capacity %d" % (m, cap))
-    outs = (labels, targets, anchors[:m], anchors_3d[:m])
+    ops.anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, cap, out=(anchors, anchors_3d, n_anc))
     if as_numpy:
-        return tuple(o.cpu().numpy() for o in outs)
-    return outs
+        h_labels, h_targets, h_anchors, h_anchors_3d, h_n = ops.unpack_host(pack, spec)   # ONE device-to-host copy
+        m = int(h_n[0])
+        if m > cap:
+            raise RuntimeError("anchor_target_layer: %d labelled anchors exceed capacity %d" % (m, cap))
+        return (h_labels, h_targets, h_anchors[:m], h_anchors_3d[:m])
+    m = int(n_anc.item())
+    if m > cap:                                      # more than 2*RPN_BATCHSIZE debug rows
+        raise RuntimeError("anchor_target_layer: %d labelled anchors exceed capacity %d" % (m, cap))
+    return (labels, targets, anchors[:m], anchors_3d[:m])

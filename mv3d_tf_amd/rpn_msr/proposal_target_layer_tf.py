@@ -19,12 +19,19 @@ def proposal_target_layer_3d(rpn_rois_bv, rpn_rois_3d, gt_boxes_bv, gt_boxes_3d,
     rois_3d (S,7) f32), S <= cfg.TRAIN.BATCH_SIZE, foreground rows first."""
     as_numpy = not isinstance(rpn_rois_bv, torch.Tensor)
     dev = rpn_rois_bv.device if not as_numpy else torch.device("cuda", cfg.GPU_ID)
-    rois_bv = ops._dev(rpn_rois_bv, device=dev).reshape(-1, 5)
-    rois_3d = ops._dev(rpn_rois_3d, device=dev).reshape(-1, 7)
-    gt_bv = ops._dev(gt_boxes_bv, device=dev).reshape(-1, 5)
-    gt_3d = ops._dev(gt_boxes_3d, device=dev).reshape(-1, 7)
-    gt_cnr = ops._dev(gt_boxes_corners, device=dev).reshape(-1, 25)
-    cal = ops._dev(calib, device=dev).reshape(4, 12)
+    if as_numpy:
+        # numpy contract: the six inputs travel in one upload
+        f = lambda a, c: np.asarray(a, np.float32).reshape(-1, c)
+        rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, cal = ops.upload_packed(
+            [f(rpn_rois_bv, 5), f(rpn_rois_3d, 7), f(gt_boxes_bv, 5), f(gt_boxes_3d, 7), f(gt_boxes_corners, 25),
+             np.asarray(calib, np.float32).reshape(4, 12)], dev)
+    else:
+        rois_bv = ops._dev(rpn_rois_bv, device=dev).reshape(-1, 5)
+        rois_3d = ops._dev(rpn_rois_3d, device=dev).reshape(-1, 7)
+        gt_bv = ops._dev(gt_boxes_bv, device=dev).reshape(-1, 5)
+        gt_3d = ops._dev(gt_boxes_3d, device=dev).reshape(-1, 7)
+        gt_cnr = ops._dev(gt_boxes_corners, device=dev).reshape(-1, 25)
+        cal = ops._dev(calib, device=dev).reshape(4, 12)
     T = cfg.TRAIN
     if as_numpy:
         # Sanity check of the reference (:52-53): single batch only
@@ -39,7 +46,9 @@ def proposal_target_layer_3d(rpn_rois_bv, rpn_rois_3d, gt_boxes_bv, gt_boxes_3d,
     fg_pick = npr.permutation(n_fg)[:fg_n] if n_fg > 0 else np.zeros(0, np.int64)   # :253-255
     bg_n = int(min(rois_per_image - fg_n, n_bg))                                  # :264-266
     bg_pick = npr.permutation(n_bg)[:bg_n] if n_bg > 0 else np.zeros(0, np.int64)   # :268-269
-    out = ops.proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, cal, params, fg_pick, bg_pick, ws)
     if as_numpy:
-        return tuple(o.cpu().numpy() for o in out)
-    return out
+        spec = ops.proposal_target_spec(len(fg_pick) + len(bg_pick), nc)
+        pack, views = ops.packed_views(spec, dev)
+        ops.proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, cal, params, fg_pick, bg_pick, ws, out=tuple(views))
+        return tuple(ops.unpack_host(pack, spec))              # ONE device-to-host copy
+    return ops.proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, cal, params, fg_pick, bg_pick, ws)

@@ -44,7 +44,7 @@ t0 = time.perf_counter()
 for _ in range(20):
     anchor_target_layer(score, gtbv, gt3d, info, [8, ])
 torch.cuda.synchronize()
-print(f"anchor_target_layer (numpy in/out, 2 host syncs): {(time.perf_counter()-t0)/20*1e6:.0f} us/call")
+print(f"anchor_target_layer (numpy in/out, 1-2 host syncs): {(time.perf_counter()-t0)/20*1e6:.0f} us/call")
 t0 = time.perf_counter()
 for _ in range(20):
     proposal_target_layer_3d(bv, b3, gtbv, gt3d, gtc, calib, 2)
