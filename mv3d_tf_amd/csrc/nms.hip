@@ -29,7 +29,6 @@
 #define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
 #define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
-#define NMS_PULL 15         // pull waves of the chain workgroup (waves 1..15; wave 0 = diagonal)
 
 // lib/nms/cpu_nms.pyx:55-65 for one (kept box i, later box j) pair.  f32, separate IEEE
 // ops.  Cython emits ((xx2 - xx1) + 1.0) with a double literal and narrows to f32; for
@@ -309,7 +308,9 @@ __device__ __forceinline__ void chain1_round(const NmsDev &d, const int f)
         const bool alive = (p < n) && !((rem >> lane) & 1ull);
         unsigned long long K = __ballot(alive);
         int iters = 0;
-        for (;;) {                                            // fixed point = greedy set (see chain_round)
+        // K_{t+1} = { alive j : no i in K_t suppresses j }.  Box b*64 has no predecessor in the block, so index k
+        // is final after k+1 steps; the fixed point is the greedy set.
+        for (;;) {
             const unsigned long long K2 = __ballot(alive && !(dg & K));
             ++iters;
             if (K2 == K) break;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
                 const unsigned long long dgc = dg;
                 unsigned long long K = A;
                 int iters = 0;
-                for (;;) {                                        // fixed point = greedy set (see chain_round)
+                for (;;) {                                        // fixed point = greedy set (see chain1_round)
                     const unsigned long long K2 = A & __ballot((dgc & K) == 0ull);
                     ++iters;
                     if (K2 == K) break;

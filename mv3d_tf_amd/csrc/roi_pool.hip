@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
 // group b / 8 -- each XCD then only ever touches its own 1/8 of the map (<= 1.8 MB, L2 resident)
 // while the overlapping bins of neighbouring ROIs re-read it.  The bin geometry (f32 divides,
 // round / floor / ceil) is computed once per bin by the first lanes and broadcast through LDS.
-#define FWD_MAX_PASSES 8
 #define LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local")
 struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
 
