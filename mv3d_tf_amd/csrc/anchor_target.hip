@@ -157,16 +157,16 @@ __global__ __launch_bounds__(256) void at_label_kernel(AtDev d)
     for (int j = 0; j < 6; ++j) d.targets[6 * (long long)n + j] = T[j];
 }
 
-// ---- ordered compaction in one workgroup (mv3d_block_compact, common.h) ----------------------
+// ---- ordered compaction over a grid of workgroups (mv3d_grid_compact, common.h) ---------------
 struct AtLists {
     int32_t *fg, *bg, *low;          // (N) each: anchor indices, ascending
 };
 
-__global__ __launch_bounds__(1024) void at_compact_kernel(const float *labels, const double *max_ov, int N, double neg_ov,
-                                                          AtLists L, int32_t *counts, uint8_t *fg_hi)
+__global__ __launch_bounds__(256) void at_compact_kernel(const float *labels, const double *max_ov, int N, double neg_ov,
+                                                         AtLists L, int32_t *counts, uint8_t *fg_hi, int32_t *agg)
 {
     int tot[4];
-    mv3d_block_compact<4>(
+    mv3d_grid_compact<4>(
         N,
         [&](int n, bool f[4]) {
             const double mx = max_ov[n];
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(1024) void at_compact_kernel(const float *labels, c
             else if (k == 2) L.bg[pos] = n;
             else if (k == 3) L.low[pos] = n;
         },
-        tot);
-    if (threadIdx.x == 0) {
+        agg, tot);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         counts[0] = tot[0]; counts[1] = tot[1]; counts[2] = tot[2]; counts[3] = tot[3];
         counts[4] = counts[5] = counts[6] = counts[7] = 0;
     }
@@ -192,11 +192,11 @@ __global__ void at_disable_kernel(float *labels, const int32_t *list, const int3
 }
 
 // anchor_target_layer_tf.py:170-174: rows of (0, anchor) and (0, anchor_3d) for labels != -1
-__global__ __launch_bounds__(1024) void at_emit_anchors_kernel(AtDev d, float *anchors, float *anchors_3d, int32_t *n_out,
-                                                               int cap)
+__global__ __launch_bounds__(256) void at_emit_anchors_kernel(AtDev d, float *anchors, float *anchors_3d, int32_t *n_out,
+                                                              int cap, int32_t *agg)
 {
     int tot[1];
-    mv3d_block_compact<1>(
+    mv3d_grid_compact<1>(
         d.N,
         [&](int n, bool f[1]) { f[0] = (d.max_ov[n] >= 0.0) && (d.labels[n] != -1.0f); },
         [&](int, int r, int n) {
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(1024) void at_emit_anchors_kernel(AtDev d, float *a
             B[3] = (float)(-(1.73 - 1.56 / 2.0));
             B[4] = (float)ex_len; B[5] = (float)ex_wid; B[6] = (float)1.56;
         },
-        tot);
-    if (threadIdx.x == 0) n_out[0] = tot[0];
+        agg, tot);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_out[0] = tot[0];
 }
 
 // anchor_target_layer_tf.py:176: labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0 (inside anchors)
@@ -228,7 +228,7 @@ __global__ void at_relabel_low_kernel(float *labels, const double *max_ov, int N
 }
 
 // ------------------------------------------------------------------------ workspace / C-ABI
-struct AtLayout { size_t o_maxov, o_argmax, o_gtmax, o_fg, o_bg, o_low, total; int N; };
+struct AtLayout { size_t o_maxov, o_argmax, o_gtmax, o_agg1, o_agg2, zero_bytes, o_fg, o_bg, o_low, total; int N, ncwg; };
 
 static bool at_layout(int H, int W, int G, AtLayout &L)
 {
@@ -240,6 +240,11 @@ static bool at_layout(int H, int W, int G, AtLayout &L)
     L.o_maxov = o; o += mv3d_align_up((size_t)N * 8);
     L.o_argmax = o; o += mv3d_align_up((size_t)N * 4);
     L.o_gtmax = o; o += mv3d_align_up((size_t)AT_MAX_GT * 8);
+    // look-back words of the two grid compactions, zeroed together with gtmax by the stage-1 memset
+    L.ncwg = (int)((N + MV3D_GC_ITEMS - 1) / MV3D_GC_ITEMS);
+    L.o_agg1 = o; o += mv3d_align_up((size_t)(L.ncwg * 4 + 1) * 4);
+    L.o_agg2 = o; o += mv3d_align_up((size_t)(L.ncwg * 1 + 1) * 4);
+    L.zero_bytes = o - L.o_gtmax;
     L.o_fg = o; o += mv3d_align_up((size_t)N * 4);
     L.o_bg = o; o += mv3d_align_up((size_t)N * 4);
     L.o_low = o; o += mv3d_align_up((size_t)N * 4);
@@ -276,13 +281,13 @@ extern "C" int mv3d_anchor_target_stage1(int H, int W, const float *im_info_dev,
     AtDev d;
     at_fill(d, L, H, W, G, p, ws);
     d.im_info = im_info_dev; d.gt_bv = gt_bv_dev; d.gt_3d = gt_3d_dev; d.labels = labels_dev; d.targets = targets_dev;
-    MV3D_HIP_TRY(hipMemsetAsync(d.gtmax, 0, (size_t)AT_MAX_GT * 8, s));
+    MV3D_HIP_TRY(hipMemsetAsync(d.gtmax, 0, L.zero_bytes, s));   // gtmax + the compactions' look-back words
     const int blocks = (L.N + 255) / 256;
     hipLaunchKernelGGL(at_overlap_kernel, dim3(blocks), dim3(256), 0, s, d);
     hipLaunchKernelGGL(at_label_kernel, dim3(blocks), dim3(256), 0, s, d);
     AtLists lists = {(int32_t *)(ws + L.o_fg), (int32_t *)(ws + L.o_bg), (int32_t *)(ws + L.o_low)};
-    hipLaunchKernelGGL(at_compact_kernel, dim3(1), dim3(1024), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov, lists,
-                       counts_dev, fg_hi_dev);
+    hipLaunchKernelGGL(at_compact_kernel, dim3(L.ncwg), dim3(256), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov, lists,
+                       counts_dev, fg_hi_dev, (int32_t *)(ws + L.o_agg1));
     return mv3d_launch_status();
 }
 
@@ -307,7 +312,8 @@ extern "C" int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_
     if (n_dis_fg) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_fg + 255) / 256), dim3(256), 0, s, labels_dev, fg, disable_fg_dev, n_dis_fg);
     if (n_dis_bg1) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg1 + 255) / 256), dim3(256), 0, s, labels_dev, bg, disable_bg1_dev, n_dis_bg1);
     if (anchors_dev && anchors_3d_dev && n_anchors_dev)
-        hipLaunchKernelGGL(at_emit_anchors_kernel, dim3(1), dim3(1024), 0, s, d, anchors_dev, anchors_3d_dev, n_anchors_dev, anchors_cap);
+        hipLaunchKernelGGL(at_emit_anchors_kernel, dim3(L.ncwg), dim3(256), 0, s, d, anchors_dev, anchors_3d_dev, n_anchors_dev,
+                           anchors_cap, (int32_t *)(ws + L.o_agg2));
     hipLaunchKernelGGL(at_relabel_low_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov);
     if (n_dis_bg2) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg2 + 255) / 256), dim3(256), 0, s, labels_dev, low, disable_bg2_dev, n_dis_bg2);
     return mv3d_launch_status();
