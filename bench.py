@@ -208,7 +208,10 @@ def roofline(fr):
 
 
 def cpu_baseline(fr, seconds):
-    """The C oracle (single thread) on the same frame-0 workload, bounded sample."""
+    """The C oracle on the same frame-0 workload, bounded sample: first one thread (the scalar port, ~1/3 of the
+    time), then `cores` threads that each process whole frames (ctypes releases the GIL inside the C calls) --
+    the frame-parallel way a CPU deployment of the reference would use the host."""
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from mv3d_tf_amd import synth
@@ -216,18 +219,41 @@ def cpu_baseline(fr, seconds):
     bev = synth.feature_map(7, *BEV_MAP[:2], BEV_MAP[2], 1)
     rgb = synth.feature_map(8, *RGB_MAP[:2], RGB_MAP[2], 1)
     cfg = {fr.args.cfg: CFGS[fr.args.cfg]}
-    n, t0 = 0, time.perf_counter()
-    while True:
+
+    def frame():
         bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, fr.args.cfg, [8, ], cfg=cfg)
         oracle.roi_pool(bev, bv, 7, 7, 0.125)
         oracle.roi_pool(rgb, img, 7, 7, 0.125)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 400:
+
+    n1, t0 = 0, time.perf_counter()
+    while True:
+        frame()
+        n1 += 1
+        dt1 = time.perf_counter() - t0
+        if dt1 >= seconds / 3 or n1 >= 400:
             break
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload (frame 0, %s cfg, %s scores) in %.1f s; C restatement "
-                      "oracle/mv3d_oracle.c, gcc -O2, 1 thread; host has %d cores" % (n, fr.args.cfg, fr.args.variant, dt, os.cpu_count())}
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    done = [0] * cores
+    stop_at = time.perf_counter() + 2 * seconds / 3
+
+    def worker(k):
+        while time.perf_counter() < stop_at:
+            frame()
+            done[k] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dtm = time.perf_counter() - t0
+    nm = sum(done)
+    return {"value": round(nm / dtm, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "one_thread_frames_per_s": round(n1 / dt1, 3),
+            "sample": "%d frames on %d threads in %.1f s (frame-parallel) after %d frames on 1 thread in %.1f s; same workload "
+                      "(frame 0, %s cfg, %s scores); C restatement oracle/mv3d_oracle.c, gcc -O2; host has %d cores"
+                      % (nm, cores, dtm, n1, dt1, fr.args.cfg, fr.args.variant, os.cpu_count())}
 
 
 def main():
