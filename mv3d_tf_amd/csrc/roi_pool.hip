@@ -393,8 +393,8 @@ extern "C" int mv3d_roi_pool_forward(const float *bottom_data, float spatial_sca
                                      const float *bottom_rois, float *top_data, int32_t *argmax_data, void *stream)
 {
     if (batch_size <= 0 || num_rois < 0 || height <= 0 || width <= 0 || channels <= 0 || pooled_height <= 0 ||
-        pooled_width <= 0 || !bottom_data || !top_data || (num_rois > 0 && !bottom_rois))
-        return MV3D_ERR_INVALID_ARG;
+        pooled_width <= 0 || !bottom_data || (num_rois > 0 && (!bottom_rois || !top_data)))
+        return MV3D_ERR_INVALID_ARG;                         // no ROIs: empty outputs, their pointers may be NULL
     if ((long long)height * width * channels > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;   // argmax is i32
     if ((long long)num_rois * pooled_height * pooled_width > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
     if (num_rois == 0) return MV3D_OK;
@@ -473,7 +473,7 @@ extern "C" int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *v
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_view &w = views[k];
         if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_data ||
-            !w.top_data || (w.num_rois > 0 && !w.bottom_rois) ||
+            (w.num_rois > 0 && (!w.bottom_rois || !w.top_data)) ||
             (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
             return MV3D_ERR_INVALID_ARG;
         const int cv4 = w.channels / 4;

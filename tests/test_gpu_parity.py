@@ -249,6 +249,37 @@ def test_roi_pool_other_pool_sizes_and_scales(ops, torch_cuda, oracle):
         assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am)
 
 
+def test_roi_pool_random_shape_sweep_vs_oracle(ops, torch_cuda, oracle):
+    """random maps / channel counts (fast XCD path: 256, 512, 1024; vector path: multiples of 4; scalar path: the
+    rest), pooled sizes, scales, batches, many ROIs over one pixel (the backward's candidate list overflows and
+    drains more than once), R = 0: forward and backward equal to the oracle."""
+    torch = torch_cuda
+    rng = np.random.RandomState(77)
+    for k in range(28):
+        C_ = int(rng.choice([1, 3, 6, 16, 20, 64, 256, 512, 1024]))
+        B = int(rng.randint(1, 4)); H = int(rng.randint(1, 24)); W = int(rng.randint(1, 24))
+        if C_ >= 512:
+            H, W = min(H, 10), min(W, 10)
+        R = int(rng.choice([0, 1, 7, 40, 150])) if k else 260
+        ph, pw = int(rng.randint(1, 8)), int(rng.randint(1, 8))
+        sc = float(rng.choice([0.125, 0.0625, 1.0 / 3, 0.5]))
+        data = synth.feature_map(200 + k, H, W, C_, B)
+        if R:
+            rois = roi_cases(200 + k, max(R, 5), H, W, B)[:R] if R >= 5 else roi_cases(200 + k, 5, H, W, B)[:R]
+            if k == 0:                                    # 260 ROIs that all contain pixel (1, 1) of frame 0
+                rois[:, 0] = 0; rois[:, 1:3] = 0; rois[:, 3:] = np.float32(min(W, H) * 8 - 1)
+        else:
+            rois = np.zeros((0, 5), np.float32)
+        top, am = ops.roi_pool_forward(dev(data, torch), dev(rois, torch), ph, pw, sc)
+        o_top, o_am = oracle.roi_pool(data, rois, ph, pw, np.float32(sc))
+        assert np.array_equal(top.cpu().numpy(), o_top), (k, B, H, W, C_, R, ph, pw, sc)
+        assert np.array_equal(am.cpu().numpy(), o_am), (k, B, H, W, C_, R, ph, pw, sc)
+        grad = np.random.RandomState(300 + k).uniform(-1, 1, o_top.shape).astype(np.float32)
+        bd = ops.roi_pool_backward(dev(grad, torch), dev(rois, torch), am, data.shape, ph, pw, sc)
+        assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(data, rois, o_am, grad, ph, pw, np.float32(sc))), \
+            (k, B, H, W, C_, R, ph, pw, sc)
+
+
 def test_roi_pool_autograd_function(ops, torch_cuda, oracle):
     torch = torch_cuda
     from mv3d_tf_amd.roi_pooling_layer.roi_pooling_op import roi_pool, roi_pool_grad
