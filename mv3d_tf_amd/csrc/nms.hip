@@ -26,7 +26,7 @@
 #include <math.h>
 #include "kernels.h"
 
-#define NMS_MAX_WORDS 256   // up to 16384 boxes per frame
+#define NMS_MAX_WORDS 512   // up to 32768 boxes per frame (a full 76x76x4 grid is 23104)
 #define LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     const bool finished = (d.max_keep > 0 && ktotal >= d.max_keep) || (b1 >= nb);
     const int nk = (d.max_keep > 0 && ktotal > d.max_keep) ? d.max_keep : ktotal;
     if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;
-    if (threadIdx.x < d.nbw) d.rem[(long long)f * d.nbw + threadIdx.x] = 0ull;   // accumulated by the later rounds' tile phases
+    for (int w = threadIdx.x; w < d.nbw; w += CHL_POST) d.rem[(long long)f * d.nbw + w] = 0ull;   // accumulated by the later rounds' tile phases
     if (threadIdx.x == 0) {
         cstate[0] = ktotal; cstate[1] = finished ? 1 : 0; cstate[2] = 0;
         if (finished) d.num_keep[f] = nk;
@@ -813,10 +813,11 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
     // almost always reaches a small max_keep (TEST: 300) inside it and the rest is one skipped launch.  A
     // large or absent max_keep (TRAIN: 2000 = at least 32 blocks) gets narrow later rounds, so that the
     // chain only ever pulls the tiles of its own round and little is computed past the stopping point.
-    int bounds[6] = {0, 32, nbw, nbw, nbw, nbw};
-    if (L.max_keep <= 0 || L.max_keep > 512) { bounds[2] = 64; bounds[3] = 128; bounds[4] = nbw; }
-    else if (nbw > 128) { bounds[2] = 128; bounds[3] = nbw; }
-    for (int r = 0; r < 5; ++r) {
+    // (a later round is at most 128 blocks wide: chain1_round<128>)
+    int bounds[8] = {0, 32, nbw, nbw, nbw, nbw, nbw, nbw};
+    if (L.max_keep <= 0 || L.max_keep > 512) { bounds[2] = 64; bounds[3] = 128; bounds[4] = 256; bounds[5] = 384; bounds[6] = nbw; }
+    else if (nbw > 128) { bounds[2] = 128; bounds[3] = 256; bounds[4] = 384; bounds[5] = nbw; }
+    for (int r = 0; r < 7; ++r) {
         d.b0 = bounds[r] < nbw ? bounds[r] : nbw; d.b1 = bounds[r + 1] < nbw ? bounds[r + 1] : nbw;
         d.first_round = (r == 0);
         if (r > 0 && d.b0 >= d.b1) break;

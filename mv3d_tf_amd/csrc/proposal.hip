@@ -112,7 +112,7 @@ static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params 
     if (N > 16384 * 4) return false;
     L.N = (int)N;
     L.order_cap = (p->pre_nms_topN > 0 && p->pre_nms_topN < L.N) ? p->pre_nms_topN : L.N;
-    if ((L.order_cap + 63) / 64 > 256) return false;        // NMS bitmap limit (16384 boxes)
+    if ((L.order_cap + 63) / 64 > 512) return false;        // NMS limit (32768 boxes per frame)
     L.cap = (p->post_nms_topN > 0 && p->post_nms_topN < L.order_cap) ? p->post_nms_topN : L.order_cap;
     size_t o = 0;
     const size_t b = (size_t)batch;

@@ -163,6 +163,33 @@ def test_proposal_3d_batch_is_per_frame(ops, torch_cuda, oracle):
     assert int(status.max().item()) == 0
 
 
+def test_proposal_3d_config_sweep_vs_oracle(ops, torch_cuda, oracle):
+    """pre / post-NMS sizes (they select the sort path, the NMS round layout and the stopping point), thresholds and
+    minimum sizes over full 76x76 frames of both score shapes: ROI blobs equal to the oracle's."""
+    torch = torch_cuda
+    rng = np.random.RandomState(99)
+    cases = [(6000, 300, 0.7, 5), (12000, 2000, 0.7, 5), (100, 50, 0.5, 5), (2000, 2000, 0.9, 16), (16384, 700, 0.7, 5), (0, 300, 0.7, 5), (23104, 0, 0.6, 5),
+             (6000, 6000, 0.3, 5), (12000, 513, 0.8, 8), (4097, 1, 0.7, 5)]
+    for k, (pre, post, thr, mins) in enumerate(cases):
+        frame = synth.rpn_head(400 + k, 76, 76, "peaky" if k % 2 == 0 else "rand")
+        sec = dict(RPN_PRE_NMS_TOP_N=pre, RPN_POST_NMS_TOP_N=post, RPN_NMS_THRESH=thr, RPN_MIN_SIZE=mins)
+        bv, img, b3, num, status = ops.proposal_3d(dev(frame[0], torch), dev(frame[1], torch), dev(frame[2], torch),
+                                                   dev(frame[3][None], torch), ops.proposal_params(sec))
+        o_bv, o_img, o_3d = oracle.proposal_layer_3d(*frame, "TEST", [8, ], cfg={"TEST": sec})
+        r = int(num[0].item())
+        assert r == o_bv.shape[0], (pre, post, thr, mins, r, o_bv.shape[0])
+        assert np.array_equal(bv[0, :r].cpu().numpy(), o_bv), (pre, post, thr, mins)
+        assert np.array_equal(img[0, :r].cpu().numpy(), o_img), (pre, post, thr, mins)
+        assert np.array_equal(b3[0, :r].cpu().numpy(), o_3d), (pre, post, thr, mins)
+        assert int(status[0].item()) == 0
+    # documented limit: more than 32768 pre-NMS boxes per frame is refused, loudly
+    from mv3d_tf_amd._lib import Mv3dError
+    frame = synth.rpn_head(400, 96, 96, "rand")
+    with pytest.raises(Mv3dError):
+        ops.proposal_3d(dev(frame[0], torch), dev(frame[1], torch), dev(frame[2], torch), dev(frame[3][None], torch),
+                        ops.proposal_params(dict(RPN_PRE_NMS_TOP_N=0, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)))
+
+
 @pytest.mark.parametrize("H,W,seed", [(1, 1, 1), (3, 5, 2), (16, 16, 3), (17, 33, 4)])
 def test_proposal_3d_small_and_ragged_grids_vs_oracle(ops, oracle, H, W, seed):
     from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
