@@ -369,6 +369,41 @@ def test_anchor_target_rng_stream_position(ops, oracle):
         assert np.array_equal(x, y)
 
 
+def test_training_layers_random_sweep_vs_oracle(ops, oracle):
+    """anchor_target_layer and proposal_target_layer_3d over random ground truth (1..30 cars, grids 20..76), each
+    seeded identically for the device path and the oracle: outputs and the RNG position afterwards are equal."""
+    from mv3d_tf_amd.rpn_msr.anchor_target_layer_tf import anchor_target_layer
+    from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
+    from mv3d_tf_amd.rpn_msr.proposal_target_layer_tf import proposal_target_layer_3d
+    rng = np.random.RandomState(4242)
+    for k in range(10):
+        G = int(rng.choice([1, 2, 5, 12, 30]))
+        H = int(rng.choice([20, 37, 76]))
+        gtbv, gt3d, gtc = synth.gt_cars(np.random.RandomState(600 + k), G)
+        if H < 76:                                                 # keep some cars inside the smaller BEV
+            gtbv[:, :4] = np.clip(gtbv[:, :4] * (H / 76.0), 0, H * 8 - 1).astype(np.float32)
+        info = np.array([[H * 8, H * 8, 1]], np.float32)
+        score = np.zeros((1, H, H, 8), np.float32)
+        np.random.seed(100 + k)
+        a = anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+        pos_a = np.random.randint(1 << 30)
+        np.random.seed(100 + k)
+        b = oracle.anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+        assert pos_a == np.random.randint(1 << 30), (k, G, H)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (k, G, H)
+        prob, pred, info76, calib = synth.rpn_head(700 + k, 76, 76, "peaky" if k % 2 else "rand")
+        bv, img, b3 = proposal_layer_3d(prob, pred, info76, calib, "TRAIN", [8, ])
+        np.random.seed(200 + k)
+        c = proposal_target_layer_3d(bv, b3, gtbv, gt3d, gtc, calib, 2)
+        pos_c = np.random.randint(1 << 30)
+        np.random.seed(200 + k)
+        dd = oracle.proposal_target_layer_3d(bv, b3, gtbv, gt3d, gtc, calib, 2)
+        assert pos_c == np.random.randint(1 << 30), (k, G)
+        for x, y in zip(c, dd):
+            assert np.array_equal(x, y), (k, G)
+
+
 # ------------------------------------------------------------------ proposal_target_layer_3d
 @pytest.mark.parametrize("name", ["proposal_target_few", "proposal_target_many"])
 def test_proposal_target_layer_3d_matches_reference(ops, name):
