@@ -7,6 +7,8 @@ faster_rcnn_end2end.yml` values are available as `apply_end2end_yml()`.
 """
 import ast
 
+import os
+
 import numpy as np
 
 
@@ -39,6 +41,7 @@ cfg.PIXEL_MEANS = np.array([[[95.8814, 98.7743, 93.8549]]])
 cfg.RNG_SEED = 3
 cfg.EPS = 1e-14
 cfg.EXP_DIR = 'default'
+cfg.ROOT_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 # The reference keys this on `nvcc` being on PATH (config.py:235-242).  Here the device path
 # is the only implementation, so it is always on; GPU_ID selects the HIP device.
 cfg.USE_GPU_NMS = True
@@ -96,3 +99,15 @@ def apply_end2end_yml():
                       "BG_THRESH_LO": 0.0, "BG_THRESH_HI": 0.5, "FG_THRESH": 0.7,
                       "RPN_PRE_NMS_TOP_N": 12000, "RPN_POST_NMS_TOP_N": 2000},
             "TEST": {"RPN_PRE_NMS_TOP_N": 6000, "RPN_POST_NMS_TOP_N": 300, "HAS_RPN": True, "NMS": 0.1}}, cfg)
+
+
+def get_output_dir(imdb, weights_filename):
+    """Directory for the detections of `imdb` (lib/fast_rcnn/config.py:245-257): ROOT_DIR/output/EXP_DIR/<imdb.name>
+    [/<weights_filename>]; created if missing."""
+    outdir = os.path.abspath(os.path.join(cfg.ROOT_DIR, 'output', cfg.EXP_DIR, imdb.name))
+    if weights_filename is not None:
+        outdir = os.path.join(outdir, weights_filename)
+    if not os.path.exists(outdir):
+        os.makedirs(outdir)
+    return outdir
+

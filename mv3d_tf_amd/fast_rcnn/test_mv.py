@@ -1,13 +1,21 @@
-"""`box_detect(sess, net, im, bv, calib, boxes=None)`: interface of
+"""Test-time entry points of lib/fast_rcnn/test_mv.py: `box_detect` (:149-264), the per-frame post-processing of
+`test_net` (:420-499: per-class score cut, NMS, cap over all classes) and the `test_net` loop itself (:321-518, without
+the drawing).
+
+`box_detect(sess, net, im, bv, calib, boxes=None)`: interface of
 lib/fast_rcnn/test_mv.py:149-264.  `sess` is an opaque context (ignored: there is no TF
 session).  Returns (scores (R,K), pred_boxes_bv (R,4K) f64, pred_boxes_cnr (R,24K) f32,
 pred_boxes_cnr_r (R,24K) f32) like the reference, K = 2; the geometric tail runs in
 libmv3d_hip.so (mv3d_box_detect_tail)."""
+import os
+import pickle
+
 import numpy as np
 import torch
 
 from .. import ops
-from .config import cfg
+from .config import cfg, get_output_dir
+from .nms_wrapper import nms
 from ..networks.mv3d import n_classes
 
 
@@ -25,3 +33,72 @@ def box_detect(sess, net, im, bv, calib, boxes=None):
         cnr, pred_r, pred_bv, _ = ops.box_detect_tail(rois[2].contiguous(), L["bbox_pred"].contiguous(), n_classes)
         pred_cnr = torch.cat([cnr] * n_classes, dim=1)
     return (scores.cpu().numpy(), pred_bv.cpu().numpy().astype(np.float64), pred_cnr.cpu().numpy(), pred_r.cpu().numpy())
+
+
+def class_detections(scores, boxes_bv, boxes_cnr, boxes_cnr_r, num_classes, thresh=0.05):
+    """One frame of test_net's inner loop (lib/fast_rcnn/test_mv.py:423-444): for every foreground class j the rows
+    with score > thresh, as (N,5) BEV dets / (N,25) corner dets / (N,25) regressed-corner dets [.., score], after
+    `nms(cls_dets, cfg.TEST.NMS)` on the BEV boxes.  Index 0 (background) is an empty list, like all_boxes[0][i]."""
+    dets, dets_cnr, dets_cnr_r = [[]], [[]], [[]]
+    for j in range(1, num_classes):                                    # :423 skip j = 0, the background class
+        inds = np.where(scores[:, j] > thresh)[0]
+        cls_scores = scores[inds, j]
+        cls_dets = np.hstack((boxes_bv[inds, j * 4:(j + 1) * 4], cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        cls_dets_cnr = np.hstack((boxes_cnr[inds, j * 24:(j + 1) * 24], cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        cls_dets_cnr_r = np.hstack((boxes_cnr_r[inds, j * 24:(j + 1) * 24], cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        keep = nms(cls_dets, cfg.TEST.NMS)                             # :440 (greedy NMS on the device)
+        dets.append(cls_dets[keep, :]); dets_cnr.append(cls_dets_cnr[keep, :]); dets_cnr_r.append(cls_dets_cnr_r[keep, :])
+    return dets, dets_cnr, dets_cnr_r
+
+
+def limit_detections(dets, dets_cnr, max_per_image):
+    """lib/fast_rcnn/test_mv.py:488-499: keep at most max_per_image detections over all classes (score >= the
+    max_per_image-th largest score; ties may keep more, as in the reference)."""
+    if max_per_image > 0:
+        image_scores = np.hstack([dets[j][:, -1] for j in range(1, len(dets))]) if len(dets) > 1 else np.zeros(0)
+        if len(image_scores) > max_per_image:
+            image_thresh = np.sort(image_scores)[-max_per_image]
+            for j in range(1, len(dets)):
+                keep = np.where(dets[j][:, -1] >= image_thresh)[0]
+                dets[j] = dets[j][keep, :]
+                dets_cnr[j] = dets_cnr[j][keep, :]
+    return dets, dets_cnr
+
+
+def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, vis=False):
+    """lib/fast_rcnn/test_mv.py:321-518 without the drawing: runs `box_detect` on every frame of `imdb`, collects
+    all_boxes[cls][image] (N,5) and all_boxes_cnr[cls][image] (N,25), pickles them under get_output_dir() and calls
+    imdb.evaluate_detections.  `imdb` is duck-typed: image_index, num_classes, name, calib_at(i), evaluate_detections,
+    and either image_at(i) / bv_at(i) (arrays) or image_path_at(i) / lidar_path_at(i) (files: .npy for the BEV, an
+    image readable by numpy / PIL).  As in the reference the `thresh` argument is shadowed by 0.05 (:421)."""
+    num_images = len(imdb.image_index)
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]
+    all_boxes_cnr = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]
+    output_dir = get_output_dir(imdb, weights_filename)
+    for i in range(num_images):
+        if hasattr(imdb, "image_at"):
+            im, bv = imdb.image_at(i), imdb.bv_at(i)
+        else:
+            bv = np.load(imdb.lidar_path_at(i))
+            path = imdb.image_path_at(i)
+            if path.endswith(".npy"):
+                im = np.load(path)
+            else:
+                from PIL import Image                               # (the reference uses cv2.imread: BGR)
+                im = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
+        calib = imdb.calib_at(i)
+        scores, boxes_bv, boxes_cnr, boxes_cnr_r = box_detect(sess, net, im, bv, calib, None)
+        dets, dets_cnr, _ = class_detections(scores, boxes_bv, boxes_cnr, boxes_cnr_r, imdb.num_classes, 0.05)
+        dets, dets_cnr = limit_detections(dets, dets_cnr, max_per_image)
+        for j in range(1, imdb.num_classes):
+            all_boxes[j][i] = dets[j]
+            all_boxes_cnr[j][i] = dets_cnr[j]
+        print('im_detect: {:d}/{:d}'.format(i + 1, num_images))
+    with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
+        pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+    with open(os.path.join(output_dir, 'detections_cnr.pkl'), 'wb') as f:
+        pickle.dump(all_boxes_cnr, f, pickle.HIGHEST_PROTOCOL)
+    print('Evaluating detections')
+    imdb.evaluate_detections(all_boxes, all_boxes_cnr, output_dir)
+    return all_boxes, all_boxes_cnr
+

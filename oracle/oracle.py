@@ -340,3 +340,27 @@ def point_cloud_2_top(points):
     top = np.zeros((601, 601, 9), np.float32)
     lib().mv3d_ref_point_cloud_2_top(_p(p), C.c_int(p.shape[0]), _p(top))
     return top
+
+
+def test_net_frame(scores, boxes_bv, boxes_cnr, boxes_cnr_r, num_classes, nms_thresh, max_per_image=300):
+    """lib/fast_rcnn/test_mv.py:420-444, 483-499 for one frame: per-class score cut (thresh is re-set to 0.05 at :421),
+    cpu_nms on the (N,5) BEV dets, cap over all classes.  Returns (dets[cls], dets_cnr[cls]) with index 0 empty."""
+    thresh = 0.05
+    dets, dets_cnr = [[]], [[]]
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > thresh)[0]
+        cls_scores = scores[inds, j]
+        cls_dets = np.hstack((boxes_bv[inds, j * 4:(j + 1) * 4], cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        cls_dets_cnr = np.hstack((boxes_cnr[inds, j * 24:(j + 1) * 24], cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        keep = cpu_nms(cls_dets, nms_thresh)
+        dets.append(cls_dets[keep, :]); dets_cnr.append(cls_dets_cnr[keep, :])
+    if max_per_image > 0:
+        image_scores = np.hstack([dets[j][:, -1] for j in range(1, num_classes)])
+        if len(image_scores) > max_per_image:
+            image_thresh = np.sort(image_scores)[-max_per_image]
+            for j in range(1, num_classes):
+                keep = np.where(dets[j][:, -1] >= image_thresh)[0]
+                dets[j] = dets[j][keep, :]
+                dets_cnr[j] = dets_cnr[j][keep, :]
+    return dets, dets_cnr
+

@@ -2,6 +2,8 @@
 (a) the golden vectors captured from the reference and (b) the CPU oracle on the same
 seeded inputs.  Integer / index / byte results must be bit-exact; the f32 regressions are
 asked to be within 1e-4 by BASELINE.json and are in fact required to be equal here."""
+import os
+
 import numpy as np
 import pytest
 
@@ -520,6 +522,70 @@ def test_get_network_and_box_detect_end_to_end(ops, torch_cuda, oracle):
     assert np.array_equal(pred_cnr, pc) and np.array_equal(pred_cnr_r, pr) and np.array_equal(pred_bv, bvv)
     with pytest.raises(KeyError):
         get_network("VGGnet_test")
+
+
+def test_test_net_postprocessing_and_loop(ops, torch_cuda, oracle, tmp_path):
+    """per-frame tail of test_net (per-class score cut, NMS, cap over all classes) == the oracle's restatement; the
+    test_net loop over a tiny in-memory imdb writes the two pickles and calls evaluate_detections."""
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.fast_rcnn import test_mv
+    from mv3d_tf_amd.networks import get_network
+    rng = np.random.RandomState(5)
+    for K, R, cap in ((2, 300, 300), (2, 300, 40), (4, 200, 25), (3, 60, 0)):
+        scores = rng.random_sample((R, K)).astype(np.float32) ** 3
+        scores[:, 0] = 1 - scores[:, 1:].max(1)
+        ctr = rng.uniform(20, 580, (R, 1, 2)); wh = rng.uniform(8, 40, (R, K, 2))
+        bx = np.concatenate([ctr - wh / 2, ctr + wh / 2], 2).reshape(R, 4 * K)          # f64 like pred_boxes_bv
+        cnr = rng.uniform(-30, 60, (R, 24 * K)).astype(np.float32)
+        cnr_r = (cnr + rng.uniform(-1, 1, cnr.shape)).astype(np.float32)
+        dets, dets_cnr, dets_cnr_r = test_mv.class_detections(scores, bx, cnr, cnr_r, K, 0.05)
+        dets, dets_cnr = test_mv.limit_detections(dets, dets_cnr, cap)
+        o_dets, o_cnr = oracle.test_net_frame(scores, bx, cnr, cnr_r, K, cfg.TEST.NMS, cap)
+        assert dets[0] == [] and len(dets) == K
+        for j in range(1, K):
+            assert np.array_equal(dets[j], o_dets[j]) and np.array_equal(dets_cnr[j], o_cnr[j]), (K, R, cap, j)
+            assert dets[j].dtype == np.float32 and dets[j].shape[1] == 5 and dets_cnr[j].shape[1] == 25
+        if cap > 0:                                          # (tie-free scores: the cap is exact)
+            assert sum(len(dets[j]) for j in range(1, K)) <= cap
+
+    class Imdb:                                              # duck-typed stand-in for datasets.kitti_mv3d
+        name = "synthetic_2frames"
+        num_classes = 2
+        image_index = ["000000", "000001"]
+        evaluated = None
+
+        def __init__(self):
+            r = np.random.RandomState(1)
+            self.bvs = [(r.random_sample((64, 72, 9)) * (r.random_sample((64, 72, 9)) < 0.05)).astype(np.float32) for _ in range(2)]
+            self.ims = [r.randint(0, 255, (48, 160, 3)).astype(np.float32) for _ in range(2)]
+
+        def image_at(self, i): return self.ims[i]
+        def bv_at(self, i): return self.bvs[i]
+        def calib_at(self, i): return synth.KITTI_CALIB
+
+        def evaluate_detections(self, all_boxes, all_boxes_cnr, output_dir):
+            self.evaluated = (all_boxes, all_boxes_cnr, output_dir)
+
+    net = get_network("MV3D_test")
+    with torch_cuda.no_grad():
+        net.params["rpn_cls_score"][0].mul_(40.0)
+        net.params["rpn_bbox_pred"][0].mul_(5.0)
+    imdb = Imdb()
+    saved, root = dict(cfg.TEST), cfg.ROOT_DIR
+    cfg.TEST.update(RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=50)
+    cfg.ROOT_DIR = str(tmp_path)
+    try:
+        all_boxes, all_cnr = test_mv.test_net(None, net, imdb, "w", max_per_image=10)
+        out = imdb.evaluated[2]
+        assert os.path.isfile(os.path.join(out, "detections.pkl")) and os.path.isfile(os.path.join(out, "detections_cnr.pkl"))
+        assert out.endswith(os.path.join("output", cfg.EXP_DIR, imdb.name, "w"))
+        for i in range(2):                                   # the loop == box_detect + the per-frame tail
+            sc, bvb, cn, cr = test_mv.box_detect(None, net, imdb.ims[i], imdb.bvs[i], synth.KITTI_CALIB)
+            o_dets, o_cnr = oracle.test_net_frame(sc, bvb, cn, cr, 2, cfg.TEST.NMS, 10)
+            assert np.array_equal(all_boxes[1][i], o_dets[1]) and np.array_equal(all_cnr[1][i], o_cnr[1])
+    finally:
+        cfg.TEST.update(saved)
+        cfg.ROOT_DIR = root
 
 
 def test_train_graph_backward_through_roi_pool(ops, torch_cuda):
