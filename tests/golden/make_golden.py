@@ -114,6 +114,95 @@ def build_scratch(d):
         sys.path.insert(0, os.path.join(d, p))
 
 
+KITTI_CALIB_TXT = """P0: 7.215377000000e+02 0.000000000000e+00 6.095593000000e+02 0.000000000000e+00 0.000000000000e+00 7.215377000000e+02 1.728540000000e+02 0.000000000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 0.000000000000e+00
+P1: 7.215377000000e+02 0.000000000000e+00 6.095593000000e+02 -3.875744000000e+02 0.000000000000e+00 7.215377000000e+02 1.728540000000e+02 0.000000000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 0.000000000000e+00
+P2: 7.215377000000e+02 0.000000000000e+00 6.095593000000e+02 4.485728000000e+01 0.000000000000e+00 7.215377000000e+02 1.728540000000e+02 2.163791000000e-01 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 2.745884000000e-03
+P3: 7.215377000000e+02 0.000000000000e+00 6.095593000000e+02 -3.395242000000e+02 0.000000000000e+00 7.215377000000e+02 1.728540000000e+02 2.199936000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 2.729905000000e-03
+R0_rect: 9.999239000000e-01 9.837760000000e-03 -7.445048000000e-03 -9.869795000000e-03 9.999421000000e-01 -4.278459000000e-03 7.402527000000e-03 4.351614000000e-03 9.999631000000e-01
+Tr_velo_to_cam: 7.533745000000e-03 -9.999714000000e-01 -6.166020000000e-04 -4.069766000000e-03 1.480249000000e-02 7.280733000000e-04 -9.998902000000e-01 -7.631618000000e-02 9.998621000000e-01 7.523790000000e-03 1.480755000000e-02 -2.717806000000e-01
+Tr_imu_to_velo: 9.999976000000e-01 7.553071000000e-04 -2.035826000000e-03 -8.086759000000e-01 -7.854027000000e-04 9.998898000000e-01 -1.482298000000e-02 3.195559000000e-01 2.024406000000e-03 1.482454000000e-02 9.998881000000e-01 -7.997231000000e-01
+"""
+
+
+def gen_kitti(d):
+    """KITTI calib / label files -> GT encodings, through the reference's own loader
+    (lib/datasets/kitti_mv3d.py, imported with a stub `datasets` package: the real one drags in every dataset) and
+    the gt part of lib/roi_data_layer/minibatch_mv3d.py:get_minibatch (cv2.imread stubbed to np.load)."""
+    L = os.path.join(d, "lib")
+    os.makedirs(f"{L}/datasets", exist_ok=True)
+    os.makedirs(f"{L}/roi_data_layer", exist_ok=True)
+    shutil.copy(f"{REF}/datasets/kitti_mv3d.py", f"{L}/datasets/kitti_mv3d.py")
+    shutil.copy(f"{REF}/roi_data_layer/minibatch_mv3d.py", f"{L}/roi_data_layer/minibatch_mv3d.py")
+    shutil.copy(f"{REF}/utils/boxes_grid.py", f"{L}/utils/boxes_grid.py")
+    shutil.copy(f"{REF}/utils/blob.py", f"{L}/utils/blob.py")
+    open(f"{L}/roi_data_layer/__init__.py", "w").close()
+    open(f"{L}/datasets/__init__.py", "w").write("import os.path as osp\nROOT_DIR = osp.dirname(__file__)\nfrom .imdb import imdb\n")
+    open(f"{L}/datasets/imdb.py", "w").write("class imdb(object):\n    def __init__(self, name):\n        self._name = name\n"
+                                               "    name = property(lambda s: s._name)\n    classes = property(lambda s: s._classes)\n"
+                                               "    num_classes = property(lambda s: len(s._classes))\n"
+                                               "    image_index = property(lambda s: s._image_index)\n")
+    open(f"{d}/shim/cv2.py", "w").write("import numpy as np\ndef imread(p):\n    return np.load(p + '.npy')\n")
+    for f in (f"{L}/datasets/kitti_mv3d.py", f"{L}/roi_data_layer/minibatch_mv3d.py", f"{L}/utils/boxes_grid.py", f"{L}/utils/blob.py"):
+        subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", f], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    from datasets.kitti_mv3d import kitti_mv3d
+    from roi_data_layer.minibatch_mv3d import get_minibatch
+    rng = np.random.RandomState(71)
+    root = os.path.join(d, "KITTI")
+    for sub_ in ("ImageSets", "object/training/calib", "object/training/label_2", "object/training/image_2", "object/training/lidar_bv"):
+        os.makedirs(os.path.join(root, sub_))
+    types = ["Car", "Van", "Car", "Pedestrian", "DontCare", "Car", "Cyclist", "Car", "Truck", "Car", "Car", "Misc", "Car"]
+    frames, calib_txt = [], []
+    for fi in range(3):
+        lines = []
+        for t in (types if fi < 2 else ["DontCare", "Van"]):
+            tx, tz = rng.uniform(-20, 20), rng.uniform(4, 58)
+            ty = rng.uniform(1.2, 2.0)
+            h, w, l = rng.uniform(1.3, 1.9), rng.uniform(1.4, 1.9), rng.uniform(3.0, 4.8)
+            ry = rng.uniform(-3.14, 3.14)
+            x1, y1 = rng.uniform(0, 1100), rng.uniform(100, 300)
+            vals = [rng.choice([0.0, 0.25, 0.6]), int(rng.randint(0, 3)), rng.uniform(-3.14, 3.14), x1, y1, x1 + rng.uniform(20, 140),
+                    y1 + rng.uniform(15, 70), h, w, l, tx, ty, tz, ry]
+            if t == "DontCare":
+                vals[7:14] = [-1, -1, -1, -1000, -1000, -1000, -10]
+            lines.append(t + " " + " ".join(("%d" % v) if isinstance(v, int) else ("%.2f" % v) for v in vals))
+        txt = "\n".join(lines) + "\n"
+        # per-frame calibration: frame 0 = KITTI 000000 values, the others perturbed in the printed digits
+        ctxt = KITTI_CALIB_TXT
+        if fi:
+            rows = []
+            for row in KITTI_CALIB_TXT.strip().split("\n"):
+                k, v = row.split(": ")
+                v = [float(x) * (1 + 1e-3 * rng.uniform(-1, 1)) for x in v.split(" ")]
+                rows.append(k + ": " + " ".join("%.12e" % x for x in v))
+            ctxt = "\n".join(rows) + "\n"
+        idx = "%06d" % fi
+        open(os.path.join(root, "object/training/label_2", idx + ".txt"), "w").write(txt)
+        open(os.path.join(root, "object/training/calib", idx + ".txt"), "w").write(ctxt)
+        np.save(os.path.join(root, "object/training/image_2", idx + ".png.npy"), rng.randint(0, 255, (12, 40, 3)).astype(np.uint8))
+        open(os.path.join(root, "object/training/image_2", idx + ".png"), "w").close()
+        np.save(os.path.join(root, "object/training/lidar_bv", idx + ".npy"), rng.random_sample((601, 601, 9)).astype(np.float32)[:8, :9])
+        frames.append(txt); calib_txt.append(ctxt)
+    open(os.path.join(root, "ImageSets", "train.txt"), "w").write("000000\n000001\n000002\n")
+    db = kitti_mv3d("train", root)
+    kw = dict(n_frames=3)
+    from fast_rcnn.config import cfg
+    for fi in range(3):
+        idx = "%06d" % fi
+        ann = db._load_kitti_annotation(idx)
+        cal = db.calib_at(fi)
+        kw["labels_txt_%d" % fi] = np.array(frames[fi]); kw["calib_txt_%d" % fi] = np.array(calib_txt[fi])
+        kw["calib_%d" % fi] = cal
+        for k_, v in ann.items():
+            if k_ == "gt_overlaps":
+                v = v.toarray()
+            kw["ann%d_%s" % (fi, k_)] = np.asarray(v)
+        entry = dict(ann, image_path=db.image_path_at(fi), lidar_bv_path=db.lidar_path_at(fi), calib=cal)
+        blobs = get_minibatch([entry], db.num_classes)
+        for k_ in ("gt_boxes", "gt_boxes_bv", "gt_boxes_3d", "gt_boxes_corners", "im_info", "calib"):
+            kw["blob%d_%s" % (fi, k_)] = np.asarray(blobs[k_])
+    save("kitti_label", **kw)
+
+
 def save(name, **kw):
     kw["numpy_version"] = np.__version__
     kw["scratch_patches"] = PATCH_NOTE
@@ -125,9 +214,15 @@ def save(name, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep-scratch", action="store_true")
+    ap.add_argument("--only", default="", help="'kitti': regenerate only the KITTI label / calib fixture")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="mv3d_ref_")
     build_scratch(d)
+    if args.only == "kitti":
+        gen_kitti(d)
+        if not args.keep_scratch:
+            shutil.rmtree(d, ignore_errors=True)
+        return
     from fast_rcnn.config import cfg
     cfg.USE_GPU_NMS = False
     from rpn_msr.proposal_layer_tf import proposal_layer_3d
@@ -301,6 +396,8 @@ def main():
         nz = np.flatnonzero(top)
         save(f"point_cloud_top_{name}", seed=seed, P=P, sha_points=synth.sha256(pts), shape=np.array(top.shape),
              nz_index=nz.astype(np.int32), nz_value=top.ravel()[nz], sha_top=synth.sha256(top))
+
+    gen_kitti(d)
 
     if args.keep_scratch:
         print("scratch kept at", d)
