@@ -231,6 +231,21 @@ int mv3d_box_detect_tail(const float *rois_3d_dev, const float *bbox_pred_dev, i
                          float *corners_dev, float *pred_cnr_r_dev, float *pred_bv_dev, float *pred_bv_r_dev,
                          void *stream);
 
+/* Training losses and their gradients (lib/fast_rcnn/train_mv.py:74-136), fused: losses_dev[0] = mean softmax
+ * cross-entropy, losses_dev[1] = mean over rows of sum smooth-L1 (sigma = 3 in the reference) of pred - target;
+ * d_*_dev (may be NULL) receive d loss / d logits and d loss / d pred.  A mean over no rows is NaN, as in TF.
+ * RPN (:92-113): rpn_cls_score (N,2) = rpn_cls_score_reshape, labels f32 in {-1,0,1} = rpn_data[0]; cross-entropy
+ * over label != -1, box loss over label == 1, rpn_bbox_pred / targets (N,6).
+ * RCNN (:115-127): cls_score (S,K), labels i32 = roi_data_3d[2], bbox_pred / targets (S, box_dim = 24 K); all rows. */
+size_t mv3d_loss_workspace_bytes(int rows);
+int mv3d_rpn_loss(const float *rpn_cls_score_dev, const float *rpn_labels_dev, const float *rpn_bbox_pred_dev,
+                  const float *rpn_bbox_targets_dev, int num_anchors, float sigma, float *losses_dev,
+                  float *d_cls_score_dev, float *d_bbox_pred_dev, void *workspace, size_t workspace_bytes, void *stream);
+int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_dev, const float *bbox_pred_dev,
+                   const float *bbox_targets_dev, int num_rois, int num_classes, int box_dim, float sigma,
+                   float *losses_dev, float *d_cls_score_dev, float *d_bbox_pred_dev, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,9 @@ _SIGS = {
                                               _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_point_cloud_2_top": (C.c_int, [_P, C.c_int, _P, _P]),
     "mv3d_box_detect_tail": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "mv3d_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mv3d_rpn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mv3d_rcnn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)

@@ -136,8 +136,9 @@ class MV3D:
         L["rpn_cls_prob_reshape"] = L["rpn_cls_prob"].reshape(n, h, w, c)
         stride = _feat_stride[0]
         if self.phase == "TRAIN":
-            L["rpn-data"] = anchor_target_layer(score.detach(), L["gt_boxes_bv"], L["gt_boxes_3d"], L["im_info"], [stride, ],
-                                                anchor_scales)
+            L["rpn_data"] = anchor_target_layer(score.detach(), L["gt_boxes_bv"], L["gt_boxes_3d"], L["im_info"], [stride, ],
+                                                anchor_scales)                       # MV3D_train.py:88
+            L["rpn-data"] = L["rpn_data"]                                             # (the Faster-RCNN spelling)
         bv, img, b3 = proposal_layer_3d(L["rpn_cls_prob_reshape"].detach(), L["rpn_bbox_pred"].detach(), L["im_info"],
                                         L["calib"], self.phase, [stride, ], anchor_scales)
         rois = (bv, img, b3, b3)                                                      # network.py:234

@@ -308,3 +308,29 @@ def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None):
     check(lib().mv3d_roi_pool_forward_views(len(views), arr, pooled_height, pooled_width, _stream()),
           "mv3d_roi_pool_forward_views")
     return res
+
+
+# ------------------------------------------------------------------ training losses
+def _loss_call(fn, name, cls, labels, pred, tgt, extra, sigma, want_grad):
+    dev = cls.device
+    R = cls.shape[0]
+    losses = torch.empty((2,), dtype=torch.float32, device=dev)
+    d_cls = torch.empty_like(cls) if want_grad else None
+    d_pred = torch.empty_like(pred) if want_grad else None
+    ws = _workspace(lib().mv3d_loss_workspace_bytes(R), dev, "loss")
+    check(fn(_ptr(cls), _ptr(labels), _ptr(pred), _ptr(tgt), R, *extra, C.c_float(sigma), _ptr(losses), _ptr(d_cls), _ptr(d_pred),
+             _ptr(ws), ws.numel(), _stream()), name)
+    return losses, d_cls, d_pred
+
+
+def rpn_loss(rpn_cls_score, rpn_labels, rpn_bbox_pred, rpn_bbox_targets, sigma=3.0, want_grad=True):
+    """(N,2) logits, (N) f32 labels in {-1,0,1}, (N,6) pred / targets -> (losses[2] = [cross-entropy, box], d_cls, d_pred)."""
+    return _loss_call(lib().mv3d_rpn_loss, "mv3d_rpn_loss", rpn_cls_score, rpn_labels, rpn_bbox_pred, rpn_bbox_targets, (),
+                      sigma, want_grad)
+
+
+def rcnn_loss(cls_score, labels, bbox_pred, bbox_targets, sigma=3.0, want_grad=True):
+    """(S,K) logits, (S) i32 labels, (S,D) pred / targets -> (losses[2], d_cls, d_pred)."""
+    return _loss_call(lib().mv3d_rcnn_loss, "mv3d_rcnn_loss", cls_score, labels, bbox_pred, bbox_targets,
+                      (cls_score.shape[1], bbox_pred.shape[1]), sigma, want_grad)
+

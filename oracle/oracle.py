@@ -364,3 +364,29 @@ def test_net_frame(scores, boxes_bv, boxes_cnr, boxes_cnr_r, num_classes, nms_th
                 dets_cnr[j] = dets_cnr[j][keep, :]
     return dets, dets_cnr
 
+
+def detection_losses(cls_score, labels, bbox_pred, bbox_targets, rpn, sigma=3.0):
+    """lib/fast_rcnn/train_mv.py:74-127 in numpy f32 (parity unpinned: the reference's losses are TensorFlow ops and
+    TensorFlow is not available here; formula restated).  rpn: rows label != -1 for the cross-entropy, label == 1 for
+    the box loss; otherwise every row.  Returns (cross_entropy, loss_box, d_cls, d_pred)."""
+    z = _f32(cls_score); p = _f32(bbox_pred); t = _f32(bbox_targets)
+    lab = np.asarray(labels).reshape(-1)
+    keep = (lab != -1) if rpn else np.ones(lab.shape, bool)
+    pos = (lab == 1) if rpn else np.ones(lab.shape, bool)
+    sigma2 = np.float32(sigma * sigma)
+    m = z.max(1, keepdims=True)
+    e = np.exp(z - m)
+    se = e.sum(1, keepdims=True)
+    li = lab.astype(np.int64).clip(0, z.shape[1] - 1)
+    ce_rows = np.log(se[:, 0]) - (z[np.arange(len(li)), li] - m[:, 0])
+    with np.errstate(all="ignore"):
+        ce = np.float32(ce_rows[keep].astype(np.float64).sum() / keep.sum())
+        d = p - t
+        quad = np.abs(d) < np.float32(1.0) / sigma2
+        l1 = np.where(quad, (d * d) * (np.float32(0.5) * sigma2), np.abs(d) - np.float32(0.5) / sigma2)
+        box = np.float32(l1.sum(1)[pos].astype(np.float64).sum() / pos.sum())
+        onehot = np.zeros_like(z); onehot[np.arange(len(li)), li] = 1
+        d_cls = np.where(keep[:, None], (e / se - onehot) * np.float32(1.0 / keep.sum()), 0).astype(np.float32)
+        d_pred = np.where(pos[:, None], np.where(quad, sigma2 * d, np.sign(d)) * np.float32(1.0 / pos.sum()), 0).astype(np.float32)
+    return ce, box, d_cls, d_pred
+

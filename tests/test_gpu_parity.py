@@ -588,6 +588,52 @@ def test_test_net_postprocessing_and_loop(ops, torch_cuda, oracle, tmp_path):
         cfg.ROOT_DIR = root
 
 
+def test_training_losses_vs_oracle_and_torch(ops, torch_cuda, oracle):
+    """train_mv.py:74-130: fused loss kernels == the numpy restatement and a plain torch fp32 reference (values and
+    gradients, 1e-5 relative); row selection of the RPN losses, the |x| == 1/sigma^2 boundary, empty selections -> NaN."""
+    torch = torch_cuda
+    import torch.nn.functional as F
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    rng = np.random.RandomState(8)
+    N = 23104
+    z = rng.normal(0, 2, (N, 2)).astype(np.float32)
+    lab = np.full(N, -1, np.float32); idx = rng.permutation(N)[:256]; lab[idx[:60]] = 1; lab[idx[60:]] = 0
+    pred = rng.normal(0, 0.3, (N, 6)).astype(np.float32); tgt = rng.normal(0, 0.3, (N, 6)).astype(np.float32)
+    pred[idx[0], 0] = tgt[idx[0], 0] + np.float32(1.0 / 9.0); pred[idx[1], 1] = tgt[idx[1], 1]       # boundary, zero
+    zt, pt = dev(z, torch).requires_grad_(True), dev(pred, torch).requires_grad_(True)
+    ce, box = train_mv.rpn_losses(zt, (lab, tgt), pt)
+    (ce + 2 * box).backward()
+    o_ce, o_box, o_dz, o_dp = oracle.detection_losses(z, lab, pred, tgt, rpn=True)
+    assert np.isclose(ce.item(), o_ce, rtol=1e-5) and np.isclose(box.item(), o_box, rtol=1e-5)
+    assert np.allclose(zt.grad.cpu().numpy(), o_dz, rtol=1e-5, atol=1e-9) and np.allclose(pt.grad.cpu().numpy(), 2 * o_dp, rtol=1e-5, atol=1e-9)
+    keep, pos = lab != -1, lab == 1                                                                  # torch reference
+    z2, p2 = dev(z, torch).requires_grad_(True), dev(pred, torch).requires_grad_(True)
+    t_ce = F.cross_entropy(z2[dev(keep, torch)], dev(lab[keep].astype(np.int64), torch))
+    t_box = train_mv.modified_smooth_l1(3.0, p2[dev(pos, torch)], dev(tgt[pos], torch)).sum(1).mean()
+    (t_ce + 2 * t_box).backward()
+    assert np.isclose(ce.item(), t_ce.item(), rtol=1e-5) and np.isclose(box.item(), t_box.item(), rtol=1e-5)
+    assert np.allclose(zt.grad.cpu().numpy(), z2.grad.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    assert np.allclose(pt.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    # RCNN: every row, K classes, 24 K targets
+    for S, K in ((128, 2), (37, 4), (1, 2)):
+        cs = rng.normal(0, 3, (S, K)).astype(np.float32); lb = rng.randint(0, K, (S, 1)).astype(np.int32)
+        bp = rng.normal(0, 0.5, (S, 24 * K)).astype(np.float32); bt = (rng.normal(0, 0.5, (S, 24 * K)) * (rng.random_sample((S, 24 * K)) < 0.5)).astype(np.float32)
+        c1, b1 = dev(cs, torch).requires_grad_(True), dev(bp, torch).requires_grad_(True)
+        ce, box = train_mv.rcnn_losses(c1, (None, None, lb, bt, None), b1)
+        (ce + box).backward()
+        o_ce, o_box, o_dz, o_dp = oracle.detection_losses(cs, lb, bp, bt, rpn=False)
+        assert np.isclose(ce.item(), o_ce, rtol=1e-5) and np.isclose(box.item(), o_box, rtol=1e-5), (S, K)
+        assert np.allclose(c1.grad.cpu().numpy(), o_dz, rtol=1e-5, atol=1e-9) and np.allclose(b1.grad.cpu().numpy(), o_dp, rtol=1e-5, atol=1e-9)
+        assert np.isclose(ce.item(), F.cross_entropy(dev(cs, torch), dev(lb.reshape(-1).astype(np.int64), torch)).item(), rtol=1e-5)
+    # no positive anchor: the box loss is the mean of nothing = NaN (tf.reduce_mean), the cross-entropy is not
+    lab0 = np.where(lab == 1, 0, lab).astype(np.float32)
+    ce, box = train_mv.rpn_losses(dev(z, torch), (lab0, tgt), dev(pred, torch))
+    assert np.isfinite(ce.item()) and np.isnan(box.item())
+    # snapshot name and the .npy weight dict round trip
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    assert train_mv.snapshot_filename("/x", 4999).endswith("/x/%s_iter_5000.ckpt" % cfg.TRAIN.SNAPSHOT_PREFIX)
+
+
 def test_train_graph_backward_through_roi_pool(ops, torch_cuda):
     """MV3D_train graph: anchor / proposal targets + RoiPoolGrad compose (roi_pooling_op_test.py's intent)."""
     from mv3d_tf_amd.networks import get_network
@@ -610,7 +656,13 @@ def test_train_graph_backward_through_roi_pool(ops, torch_cuda):
     rois_bv, rois_img, labels, targets, rois_3d = L["roi_data_3d"]
     S = rois_bv.shape[0]
     assert 0 < S <= 128 and labels.shape == (S, 1) and targets.shape == (S, 48) and L["cls_score"].shape == (S, 2)
-    loss = L["cls_score"].square().mean() + L["bbox_pred"].square().mean()
+    assert L["rpn_data"] is L["rpn-data"]
+    # the reference's four losses (train_mv.py:92-130) on the graph's own layers, then backward through everything
+    from mv3d_tf_amd.fast_rcnn.train_mv import total_loss
+    loss, (ce, box, rpn_ce, rpn_box) = total_loss(L)
+    assert all(np.isfinite(v.item()) for v in (ce, box, rpn_ce, rpn_box)) and loss.item() > 0
     loss.backward()
     g = net.params["conv5_3"][0].grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0      # gradient came through RoiPoolGrad
+    g2 = net.params["rpn_bbox_pred"][0].grad
+    assert g2 is not None and torch.isfinite(g2).all() and float(g2.abs().sum()) > 0   # ... and through the RPN box loss
