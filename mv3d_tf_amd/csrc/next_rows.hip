@@ -19,12 +19,17 @@
 #define BEV_W 601
 #define BEV_C 9
 
-// zero keys: one 16-byte store per thread (hipMemsetAsync splits the 13 MB clear into two 6 us fills)
+// zero keys: four 16-byte stores per thread, a workgroup clears 16 KB contiguous (hipMemsetAsync splits the 13 MB
+// clear into two 6 us fills)
 __global__ __launch_bounds__(256) void bev_clear_kernel(float *top, long long n)
 {
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x, e = q * 4;
-    if (e + 4 <= n) reinterpret_cast<float4 *>(top)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    else for (long long t = e; t < n; ++t) top[t] = 0.0f;
+    const long long base = (long long)blockIdx.x * 1024 + threadIdx.x;       // float4 index
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long q = base + u * 256, e = q * 4;
+        if (e + 4 <= n) reinterpret_cast<float4 *>(top)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (long long t = e; t < n; ++t) top[t] = 0.0f;
+    }
 }
 
 __global__ __launch_bounds__(256) void bev_scatter_kernel(const float *__restrict__ pts, int P, unsigned *keys)
@@ -70,7 +75,7 @@ extern "C" int mv3d_point_cloud_2_top(const float *points_dev, int num_points, f
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)BEV_H * BEV_W * BEV_C;
     if (((uintptr_t)top_dev & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bev_clear_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, top_dev, n);
+    hipLaunchKernelGGL(bev_clear_kernel, dim3((unsigned)((n / 4 + 1024) / 1024)), dim3(256), 0, s, top_dev, n);
     if (num_points > 0) {
         hipLaunchKernelGGL(bev_scatter_kernel, dim3((num_points + 255) / 256), dim3(256), 0, s, points_dev, num_points,
                            reinterpret_cast<unsigned *>(top_dev));
