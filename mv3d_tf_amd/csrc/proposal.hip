@@ -33,11 +33,13 @@ struct ProposalDev {
     int32_t *status;    // (batch) flag word, zeroed here (may be NULL)
 };
 
-// grid (ceil(N/256), batch)
-__global__ __launch_bounds__(256) void proposal_decode_kernel(ProposalDev d)
+// grid (key_stride / DEC_THREADS, batch): 128 threads per workgroup = 184 workgroups for a KITTI grid, so the f64-heavy
+// decode spreads over most of the 256 CUs
+#define DEC_THREADS 128
+__global__ __launch_bounds__(DEC_THREADS) void proposal_decode_kernel(ProposalDev d)
 {
     const int f = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.x * DEC_THREADS + threadIdx.x;
     bool ok = false;
     if (n < d.N) {
         const int a = n & 3, cell = n >> 2, w = cell % d.W, h = cell / d.W;
@@ -88,12 +90,15 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(ProposalDev d)
     } else if (n < d.key_stride) {
         d.key[(long long)f * d.key_stride + n] = 0u;          // padding the rank kernel relies on
     }
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[DEC_THREADS / 64];
     const unsigned long long bal = __ballot(ok);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {
-        d.blockcnt[(long long)f * gridDim.x + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < DEC_THREADS / 64; ++w) c += s_cnt[w];
+        d.blockcnt[(long long)f * gridDim.x + blockIdx.x] = c;
         if (blockIdx.x == 0 && d.status) d.status[f] = 0;
     }
 }
@@ -124,7 +129,7 @@ static bool proposal_layout(int batch, int H, int W, const mv3d_proposal_params 
     L.o_order = o; o += mv3d_align_up(b * L.order_cap * 4);
     L.o_sbox = o; o += mv3d_align_up(b * L.order_cap * 16);       // BEV boxes in score order (NMS input)
     L.o_keep = o; o += mv3d_align_up(b * L.order_cap * 4);
-    L.n_blocks = L.key_stride / 256;
+    L.n_blocks = L.key_stride / DEC_THREADS;
     L.o_cnt = o; o += mv3d_align_up(b * (2 + L.n_blocks) * 4);   // nvalid[batch], num_keep[batch], blockcnt[batch][n_blocks]
     L.o_rank = o; o += mv3d_rank_ws_bytes(L.N, batch);
     L.o_nms = o; o += mv3d_nms_ws_bytes(L.order_cap, batch);
@@ -166,7 +171,7 @@ extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, in
     d.min_size = (float)p->min_size;
     d.bv = (float4 *)(ws + L.o_bv); d.img = (int4 *)(ws + L.o_img); d.p3 = (float *)(ws + L.o_p3);
     d.key = (uint32_t *)(ws + L.o_key); d.blockcnt = cnt + 2 * batch; d.status = status_dev;
-    hipLaunchKernelGGL(proposal_decode_kernel, dim3(L.n_blocks, batch), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3(L.n_blocks, batch), dim3(DEC_THREADS), 0, s, d);
 
     int32_t *order = (int32_t *)(ws + L.o_order), *keep = (int32_t *)(ws + L.o_keep);
     float4 *sbox = (float4 *)(ws + L.o_sbox);
