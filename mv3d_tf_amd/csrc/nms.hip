@@ -128,7 +128,8 @@ __device__ __forceinline__ bool tame(float4 b)
 template <bool DIAG_SWAPPED>
 __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const float larea, const float4 *s_box,
                                                         const float *s_area, const float tf, const float neg_h,
-                                                        const int lane, float &min_den, bool &undecided)
+                                                        const int lane, float &min_den, bool &undecided,
+                                                        const int c_begin = 0, const int c_end = 64)
 {
     unsigned long long word = 0;
     bool amb = false;
@@ -136,7 +137,7 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
     // 4 chunks of 16 columns: the chunk body is straight-line (constant shifts, loads hoisted), the
     // chunk loop is kept rolled so that the live set stays well inside 128 VGPRs
 #pragma unroll 1
-    for (int c = 0; c < 64; c += 16) {
+    for (int c = c_begin; c < c_end; c += 16) {
         unsigned bits = 0;
 #pragma unroll
         for (int u = 0; u < 16; u += 2) {
@@ -166,10 +167,13 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
 
 // One tile by one wave.  `s_box/s_area` are the wave's own 64-entry LDS staging arrays.  AGENT_STORE: the
 // word is written through at agent scope (read later in the SAME kernel by another workgroup).
-template <bool AGENT_STORE>
+// HALVES = 2: the wave computes only rows [32 half, 32 half + 32) of the tile and stores that 32-bit half of
+// every word (two waves per tile: the round-1 tile kernel is bound by the ~1600 VALU instructions of a tile).
+template <bool AGENT_STORE, int HALVES = 1>
 __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const int t, const int lane, float4 *s_box,
-                                             float *s_area)
+                                             float *s_area, const int half = 0)
 {
+    const int r_begin = (HALVES == 2) ? 32 * half : 0, r_end = (HALVES == 2) ? r_begin + 32 : 64;
     const int n = frame_n(d, f);
     // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
     int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -195,15 +199,15 @@ __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const
     if (d.fast_ok && lds_tame && __all(tame(lb))) {
         float min_den = 1.0f;
         bool und;
-        if (diag) word = tile_fast<true>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und);
-        else word = tile_fast<false>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und);
+        if (diag) word = tile_fast<true>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und, r_begin, r_end);
+        else word = tile_fast<false>(lb, larea, s_box, s_area, d.tf, d.neg_h, lane, min_den, und, r_begin, r_end);
         // a denominator that is not safely positive, or an undecided compare: redo the tile exactly
         done = !__any(und || !(min_den >= 0x1p-20f));
     }
     if (!done) {
         // exact path: ragged blocks, NaN / huge coordinates, zero / negative unions, undecided compares
         word = 0;
-        for (int j = 0; j < 64; ++j) {
+        for (int j = r_begin; j < r_end; ++j) {
             const float4 q = s_box[j];
             bool zd;
             // (kept box i = row j of the LDS side, later box = my column), the argument order of cpu_nms.pyx
@@ -222,18 +226,21 @@ __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const
         const unsigned long long m = __ballot((word & K) != 0ull);
         if (m && lane == 0) __hip_atomic_fetch_or(&d.rem[(long long)f * d.nbw + cb], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (AGENT_STORE) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (HALVES == 2) reinterpret_cast<unsigned *>(dst)[half] = (unsigned)(word >> r_begin);
     else *dst = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
 }
 
-// grid: (tiles of the round, 1, batch); block 64 = one wave per tile.
-__global__ __launch_bounds__(64) void nms_tiles_kernel(NmsDev d)
+// grid: (tiles of the round, 1, batch); block 128 = two waves per tile, each with its own staging arrays and its
+// own half of the rows (no barrier between them).
+__global__ __launch_bounds__(128) void nms_tiles_kernel(NmsDev d)
 {
-    __shared__ float4 s_box[64];
-    __shared__ float s_area[64];
+    __shared__ float4 s_box[2][64];
+    __shared__ float s_area[2][64];
     const int f = blockIdx.z;
     if (!d.first_round && d.cstate[4 * f + 1]) return;       // frame already finished in an earlier round
-    nms_one_tile<false>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x, s_box, s_area);
+    const int h = threadIdx.x >> 6;
+    nms_one_tile<false, 2>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x & 63, s_box[h], s_area[h], h);
 }
 
 // The chain of a LATER round (columns [b0, b1), b1 - b0 <= KMAX), run by one workgroup: the greedy
@@ -823,7 +830,7 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
         if (r > 0 && d.b0 >= d.b1) break;
         const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
         if (r == 0) {
-            if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(64), 0, stream, d);
+            if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(128), 0, stream, d);
             hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
             continue;
         }
