@@ -9,7 +9,7 @@
 // frame is already finished returns at once, so the tiles nobody will read are never computed
 // (a TEST-config frame needs ~15 of its 94 column blocks: 528 tiles instead of 4465).
 //
-//  nms_tiles_kernel     round 1, all CUs, one single-wave workgroup per tile.  lane = column box
+//  nms_tiles_kernel     round 1, all CUs, one workgroup per tile (four waves, a quarter of the rows each).  lane = column box
 //        (registers), the 64 row boxes staged in LDS and read back as broadcasts; packed-f32 math and
 //        a division-free exact compare (tile_fast()); the lane's word is a plain accumulation of bits.
 //  nms_chain_lds_kernel round 1, one workgroup per frame: the greedy dependency.  Loader waves stream the
@@ -167,13 +167,14 @@ __device__ __forceinline__ unsigned long long tile_fast(const float4 lb, const f
 
 // One tile by one wave.  `s_box/s_area` are the wave's own 64-entry LDS staging arrays.  AGENT_STORE: the
 // word is written through at agent scope (read later in the SAME kernel by another workgroup).
-// HALVES = 2: the wave computes only rows [32 half, 32 half + 32) of the tile and stores that 32-bit half of
-// every word (two waves per tile: the round-1 tile kernel is bound by the ~1600 VALU instructions of a tile).
-template <bool AGENT_STORE, int HALVES = 1>
+// PARTS = 2 / 4: the wave computes only rows [64/PARTS * part, +64/PARTS) of the tile and stores that 32- / 16-bit
+// piece of every word (several waves per tile: the round-1 tile kernel is bound by the ~1600 VALU instructions of
+// a tile; 6.4 us with one wave per tile, ~3.5 us with four).
+template <bool AGENT_STORE, int PARTS = 1>
 __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const int t, const int lane, float4 *s_box,
-                                             float *s_area, const int half = 0)
+                                             float *s_area, const int part = 0)
 {
-    const int r_begin = (HALVES == 2) ? 32 * half : 0, r_end = (HALVES == 2) ? r_begin + 32 : 64;
+    const int r_begin = (64 / PARTS) * part, r_end = r_begin + 64 / PARTS;
     const int n = frame_n(d, f);
     // tile t -> (cb, rb <= cb): t = cb(cb+1)/2 + rb
     int cb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -226,21 +227,22 @@ __device__ __forceinline__ void nms_one_tile(const NmsDev &d, const int f, const
         const unsigned long long m = __ballot((word & K) != 0ull);
         if (m && lane == 0) __hip_atomic_fetch_or(&d.rem[(long long)f * d.nbw + cb], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (AGENT_STORE) __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (HALVES == 2) reinterpret_cast<unsigned *>(dst)[half] = (unsigned)(word >> r_begin);
+    else if (PARTS == 2) reinterpret_cast<unsigned *>(dst)[part] = (unsigned)(word >> r_begin);
+    else if (PARTS == 4) reinterpret_cast<unsigned short *>(dst)[part] = (unsigned short)(word >> r_begin);
     else *dst = word;
     if (d.status && __any(any_zero) && lane == 0) atomicOr(&d.status[f], MV3D_FLAG_ZERO_DIVISION);
 }
 
-// grid: (tiles of the round, 1, batch); block 128 = two waves per tile, each with its own staging arrays and its
-// own half of the rows (no barrier between them).
-__global__ __launch_bounds__(128) void nms_tiles_kernel(NmsDev d)
+// grid: (tiles of the round, 1, batch); block 256 = four waves per tile, each with its own staging arrays and its
+// own quarter of the rows (no barrier between them).
+__global__ __launch_bounds__(256) void nms_tiles_kernel(NmsDev d)
 {
-    __shared__ float4 s_box[2][64];
-    __shared__ float s_area[2][64];
+    __shared__ float4 s_box[4][64];
+    __shared__ float s_area[4][64];
     const int f = blockIdx.z;
     if (!d.first_round && d.cstate[4 * f + 1]) return;       // frame already finished in an earlier round
     const int h = threadIdx.x >> 6;
-    nms_one_tile<false, 2>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x & 63, s_box[h], s_area[h], h);
+    nms_one_tile<false, 4>(d, f, d.b0 * (d.b0 + 1) / 2 + blockIdx.x, threadIdx.x & 63, s_box[h], s_area[h], h);
 }
 
 // The chain of a LATER round (columns [b0, b1), b1 - b0 <= KMAX), run by one workgroup: the greedy
@@ -830,7 +832,7 @@ int mv3d_launch_nms(const NmsLaunch &L, hipStream_t stream)
         if (r > 0 && d.b0 >= d.b1) break;
         const int ntr = d.b1 * (d.b1 + 1) / 2 - d.b0 * (d.b0 + 1) / 2;
         if (r == 0) {
-            if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(128), 0, stream, d);
+            if (ntr > 0) hipLaunchKernelGGL(nms_tiles_kernel, dim3(ntr, 1, L.batch), dim3(256), 0, stream, d);
             hipLaunchKernelGGL(nms_chain_lds_kernel, dim3(L.batch), dim3(CHL_THREADS), 0, stream, d);
             continue;
         }
