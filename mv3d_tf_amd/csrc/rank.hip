@@ -92,37 +92,39 @@ __global__ __launch_bounds__(256) void rank_partial_kernel(const uint32_t *__res
 // written at all; cnt128[f][run] = candidates of the run (counted by the run's first workgroup) lets the
 // consumer treat the tail of every run as zeros.  (128 keys per workgroup: 184 workgroups for a KITTI frame, so the counting --
 // the kernel is VALU-bound -- spreads over most of the 256 CUs.)
-#define RANK_LK 128
-__global__ __launch_bounds__(4 * RANK_LK) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
-                                                                 uint32_t *__restrict__ sorted, uint16_t *__restrict__ sidx,
-                                                                 int32_t *__restrict__ cnt128)
+#define RANK_LK 128                                 // keys per workgroup
+#define RANK_SUBW 128                               // keys per sub-tile
+#define RANK_NSUB (RANK_RUN / RANK_SUBW)            // sub-tiles = thread groups of the workgroup (8)
+__global__ __launch_bounds__(RANK_NSUB * RANK_LK) void rank_local_kernel(const uint32_t *__restrict__ keys, int key_stride,
+                                                                         uint32_t *__restrict__ sorted,
+                                                                         uint16_t *__restrict__ sidx, int32_t *__restrict__ cnt128)
 {
-    // 512 threads = 128 keys x 4 sub-tiles of the run: thread (t, sub) counts its key against the 256
-    // keys of sub-tile `sub`.
-    __shared__ unsigned s_part[4][RANK_LK];
-    __shared__ int s_wc[4 * RANK_LK / 64];
+    // 1024 threads = 128 keys x 8 sub-tiles of the run: thread (t, sub) counts its key against the 128 keys of
+    // sub-tile `sub` (the kernel is VALU-bound: 16 waves of 260 instructions finish sooner than 8 of 520).
+    __shared__ unsigned s_part[RANK_NSUB][RANK_LK];
+    __shared__ int s_wc[RANK_NSUB * RANK_LK / 64];
     const int f = blockIdx.y, bi = blockIdx.x;
     const int t = threadIdx.x & (RANK_LK - 1), sub = __builtin_amdgcn_readfirstlane(threadIdx.x / RANK_LK);
     const int run = bi >> 3, kb = bi & 7;
     const int i = kb * RANK_LK + t;                 // key index inside the run
-    const int my_sub = kb >> 1;                     // its 256-key sub-tile
+    const int my_sub = i / RANK_SUBW;               // its sub-tile (workgroup-uniform)
     const uint32_t *__restrict__ k = keys + (long long)f * key_stride + run * RANK_RUN;
     const uint32_t ki = k[i];
     const uint32_t kim1 = ki - 1u;                  // kj >= ki  <=>  kj > ki - 1   (ki >= 1 for candidates)
     unsigned cnt = 0, cnt2 = 0;
-    const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * 256);
+    const u32x16 *__restrict__ q = reinterpret_cast<const u32x16 *>(k + sub * RANK_SUBW);
     if (sub < my_sub) {                             // all j < i : only a strictly larger key precedes
 #pragma unroll 4
-        for (int u = 0; u < 16; ++u) count16<false>(cnt, cnt2, ki, q[u]);
+        for (int u = 0; u < RANK_SUBW / 16; ++u) count16<false>(cnt, cnt2, ki, q[u]);
     } else if (sub > my_sub) {                      // all j > i : an equal key precedes too
 #pragma unroll 4
-        for (int u = 0; u < 16; ++u) count16<true>(cnt, cnt2, ki, q[u]);
+        for (int u = 0; u < RANK_SUBW / 16; ++u) count16<true>(cnt, cnt2, ki, q[u]);
     } else {
-        // own sub-tile: per 64-key quarter the rule is again uniform for a whole wave, except
-        // for the wave's own quarter, where the later index wins a tie lane by lane
-        const int wq = __builtin_amdgcn_readfirstlane((i & 255) >> 6);
-        const int il = i & 255;                     // index inside the sub-tile
-        for (int qq = 0; qq < 4; ++qq) {
+        // own sub-tile: per 64-key part the rule is again uniform for a whole wave, except for the wave's own
+        // part, where the later index wins a tie lane by lane
+        const int il = i & (RANK_SUBW - 1);         // index inside the sub-tile
+        const int wq = __builtin_amdgcn_readfirstlane(il >> 6);
+        for (int qq = 0; qq < RANK_SUBW / 64; ++qq) {
             if (qq < wq) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) count16<false>(cnt, cnt2, ki, q[qq * 4 + u]);
@@ -132,16 +134,16 @@ __global__ __launch_bounds__(4 * RANK_LK) void rank_local_kernel(const uint32_t 
             } else {
 #pragma unroll 16
                 for (int j = qq * 64; j < qq * 64 + 64; ++j) {
-                    const uint32_t kj = k[sub * 256 + j];       // wave-uniform: scalar load
-                    const uint32_t thr = (j > il) ? kim1 : ki;  // kj >= ki  <=>  kj > ki - 1
+                    const uint32_t kj = k[sub * RANK_SUBW + j];  // wave-uniform: scalar load
+                    const uint32_t thr = (j > il) ? kim1 : ki;   // kj >= ki  <=>  kj > ki - 1
                     cnt += (kj > thr) ? 1u : 0u;
                 }
             }
         }
     }
     s_part[sub][t] = cnt + cnt2;
-    if (kb == 0) {                                  // candidates of the whole run: two keys per thread
-        const int c = __popcll(__ballot(k[threadIdx.x] != 0u)) + __popcll(__ballot(k[threadIdx.x + 4 * RANK_LK] != 0u));
+    if (kb == 0) {                                  // candidates of the whole run: one key per thread
+        const int c = __popcll(__ballot(k[threadIdx.x] != 0u));
         if ((threadIdx.x & 63) == 0) s_wc[threadIdx.x >> 6] = c;
     }
     __syncthreads();
@@ -149,11 +151,13 @@ __global__ __launch_bounds__(4 * RANK_LK) void rank_local_kernel(const uint32_t 
         if (kb == 0 && t == 0) {
             int c = 0;
 #pragma unroll
-            for (int w = 0; w < 4 * RANK_LK / 64; ++w) c += s_wc[w];
+            for (int w = 0; w < RANK_NSUB * RANK_LK / 64; ++w) c += s_wc[w];
             cnt128[(long long)f * (gridDim.x >> 3) + run] = c;
         }
         if (ki != 0u) {
-            const unsigned r = s_part[0][t] + s_part[1][t] + s_part[2][t] + s_part[3][t];
+            unsigned r = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < RANK_NSUB; ++s2) r += s_part[s2][t];
             const long long o = (long long)f * key_stride + run * RANK_RUN + r;
             sorted[o] = ki;
             sidx[o] = (uint16_t)i;
@@ -310,7 +314,7 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
         uint32_t *sorted = (uint32_t *)workspace;
         uint16_t *sidx = (uint16_t *)((char *)workspace + mv3d_align_up((size_t)batch * key_stride * 4));
         int32_t *cnt128 = (int32_t *)((char *)sidx + mv3d_align_up((size_t)batch * key_stride * 2));
-        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 128, batch), dim3(4 * RANK_LK), 0, stream, keys, key_stride, sorted, sidx,
+        hipLaunchKernelGGL(rank_local_kernel, dim3(key_stride / 128, batch), dim3(RANK_NSUB * RANK_LK), 0, stream, keys, key_stride, sorted, sidx,
                            cnt128);
         hipLaunchKernelGGL(rank_merge_kernel, dim3(key_stride / 128, batch), dim3(256), 0, stream, sorted, sidx, cnt128, N,
                            key_stride, order, cap, part_counts, n_parts, n_valid, gather_src, gather_dst);
