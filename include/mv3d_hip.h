@@ -48,7 +48,9 @@ const char *mv3d_status_string(int status);
 /* Device entry: dets_dev (n,5) f32 [x1,y1,x2,y2,score], ALREADY in processing order
  * (descending score).  keep_dev receives positions 0..n-1 of the kept boxes in order,
  * at most max_keep of them (max_keep <= 0: no cap; the result equals the reference's
- * keep[:max_keep]); num_keep_dev[0] the count; status_dev[0] flag bits (may be NULL). */
+ * keep[:max_keep]); num_keep_dev[0] the count; status_dev (may be NULL): flag bits are OR-ed into
+ * status_dev[0], which the caller zeroes once when it allocates it (the call is kernel launches only:
+ * no memset node, so it can be captured in a hipGraph and replayed). */
 size_t mv3d_nms_workspace_bytes(int max_boxes);
 int mv3d_nms_device(const float *dets_dev, int n, double thresh, int max_keep,
                     int32_t *keep_dev, int32_t *num_keep_dev, int32_t *status_dev,
@@ -113,8 +115,11 @@ int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, int batch, in
 /* ------------------------------------------------------------------ RoiPool / RoiPoolGrad
  * Replace lib/roi_pooling_layer/roi_pooling_op_gpu.h:18-27 (ROIPoolForwardLaucher /
  * ROIPoolBackwardLaucher, bodies roi_pooling_op_gpu.cu.cc:20-110,113-215) and the CPU
- * kernels roi_pooling_op.cc:74-190,319-452: same argument order, a stream handle where
- * the reference takes `const Eigen::GpuDevice&`, a status instead of exit(-1).
+ * kernels roi_pooling_op.cc:74-190,319-452: the launchers' argument lists with a stream
+ * handle where the reference takes `const Eigen::GpuDevice&` and a status instead of
+ * exit(-1).  ONE DELIBERATE DEVIATION from roi_pooling_op_gpu.h:18-22: the forward takes
+ * `batch_size` after `spatial_scale` (the reference's forward launcher has no such argument;
+ * its backward launcher has it in the same place), see below.
  * NHWC f32 data, rois (R,5) [batch_idx,x1,y1,x2,y2], argmax = flat index inside the
  * frame (h*W+w)*C+c or -1; argmax_data may be NULL on forward.  `batch_size` lets the
  * kernel refuse out-of-range batch indices (outputs 0 / -1) instead of reading out of
@@ -142,6 +147,29 @@ typedef struct {
 } mv3d_roi_view;
 int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
                                 void *stream);
+
+/* RoiPoolGrad of several views behind one call (the three RoiPool layers of a training step): same results as
+ * one mv3d_roi_pool_backward per view.  In a backward view `top_data` is READ (top_diff, (num_rois,PH,PW,C)),
+ * `argmax_data` is read and `bottom_data` is WRITTEN (bottom_diff, (batch_size,H,W,C)); the struct is shared with the
+ * forward so that a caller fills it once per layer. */
+typedef struct {
+    float *bottom_diff;          /* out: (batch_size, height, width, channels) */
+    const float *bottom_rois;    /* (num_rois, 5) */
+    const float *top_diff;       /* (num_rois, pooled_height, pooled_width, channels) */
+    const int32_t *argmax_data;  /* same shape */
+    float spatial_scale;
+    int32_t batch_size, num_rois, height, width, channels;
+} mv3d_roi_grad_view;
+int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                 void *stream);
+
+/* ------------------------------------------------------------------ third (front-view) ROI
+ * rois_3d_dev (R,7) [b,x,y,z,l,w,h] -> rois_fv_dev (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical front-view map
+ * of the MV3D paper (azimuth [-45,+45] deg -> 512 columns, elevation [-24.9,+2] deg -> 64 rows; min/max over the 8
+ * corners, clipped to the map).  Fills the hook the reference leaves empty: `proposal_transform` returns None for
+ * anything but 'bv' / 'img' (lib/networks/network.py:293-315).  PARITY UNPINNED (no reference code); the definition
+ * is restated in oracle/mv3d_oracle.c and both agree bit for bit. */
+int mv3d_rois_3d_to_fv(const float *rois_3d_dev, int num_rois, float *rois_fv_dev, void *stream);
 
 /* ------------------------------------------------------------------ anchor_target_layer
  * Replaces the deterministic part of lib/rpn_msr/anchor_target_layer_tf.py:21-250 plus

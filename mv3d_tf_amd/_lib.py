@@ -37,6 +37,13 @@ class RoiView(C.Structure):
                 ("num_rois", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
 
 
+class RoiGradView(C.Structure):
+    """mv3d_roi_grad_view"""
+    _fields_ = [("bottom_diff", C.c_void_p), ("bottom_rois", C.c_void_p), ("top_diff", C.c_void_p),
+                ("argmax_data", C.c_void_p), ("spatial_scale", C.c_float), ("batch_size", C.c_int32),
+                ("num_rois", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
+
+
 class ProposalTargetParams(C.Structure):
     """mv3d_proposal_target_params"""
     _fields_ = [("num_classes", C.c_int32), ("reserved", C.c_int32), ("fg_thresh", C.c_double),
@@ -76,6 +83,8 @@ _SIGS = {
     "mv3d_rpn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_rcnn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
+    "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P]),
+    "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

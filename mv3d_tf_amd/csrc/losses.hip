@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void loss_final_kernel(LossDev d)
     }
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= d.R) return;
-    const float ice = (float)(1.0 / n_ce), ibox = (float)(1.0 / n_box);
+    // an empty selection gives a NaN loss VALUE but ZERO gradients (TF: reduce_mean over an empty gather back-propagates
+    // nothing), so the scale of the zero-filled gradient rows must not become 1/0
+    const float ice = n_ce > 0.0 ? (float)(1.0 / n_ce) : 0.0f, ibox = n_box > 0.0 ? (float)(1.0 / n_box) : 0.0f;
     if (d.d_cls) { float *dz = d.d_cls + (long long)r * d.K; for (int k = 0; k < d.K; ++k) dz[k] *= ice; }
     if (d.d_pred) { float *dp = d.d_pred + (long long)r * d.D; for (int j = 0; j < d.D; ++j) dp[j] *= ibox; }
 }

@@ -584,14 +584,17 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
                     const int u = k * CHL_BATCH + lt, v = u + CHL_BATCH;
                     CHL_REP(CHL_LDB)
                     CHL_REP(CHL_STA)
+                    // the sorted order of the round's boxes is staged BEFORE the first progress word is published: the
+                    // release below then covers it, and every reader of s_order (the emit gather of waves 0..4) is
+                    // ordered after it through wave 0's acquire of s_prog and the s_halt hand-off
+                    if (k == 0 && c0 == 0 && want_order) {
+                        s_order[lt] = o0; s_order[lt + CHL_PER] = o1; s_order[lt + 2 * CHL_PER] = o2; s_order[lt + 3 * CHL_PER] = o3;
+                        s_order[lt + 4 * CHL_PER] = o4; s_order[lt + 5 * CHL_PER] = o5; s_order[lt + 6 * CHL_PER] = o6;
+                        s_order[lt + 7 * CHL_PER] = o7; s_order[lt + 8 * CHL_PER] = o8; s_order[lt + 9 * CHL_PER] = o9;
+                        if (lt + 10 * CHL_PER < CHL_BOXES) s_order[lt + 10 * CHL_PER] = o10;
+                    }
                     LDS_RELEASE();
                     if (lane == 0) lds_st(&s_prog[wave], (k + 1) * CHL_BATCH);
-                }
-                if (k == 0 && c0 == 0 && want_order) {
-                    s_order[lt] = o0; s_order[lt + CHL_PER] = o1; s_order[lt + 2 * CHL_PER] = o2; s_order[lt + 3 * CHL_PER] = o3;
-                    s_order[lt + 4 * CHL_PER] = o4; s_order[lt + 5 * CHL_PER] = o5; s_order[lt + 6 * CHL_PER] = o6;
-                    s_order[lt + 7 * CHL_PER] = o7; s_order[lt + 8 * CHL_PER] = o8; s_order[lt + 9 * CHL_PER] = o9;
-                    if (lt + 10 * CHL_PER < CHL_BOXES) s_order[lt + 10 * CHL_PER] = o10;
                 }
                 if (k + 1 >= nbatch || lds_ld(&s_halt)) break;
                 {   // batch k+1 from B while batch k+2 flies into A
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
                 if (last_one) { stop = true; break; }
             }
             frame_done = stop || ce >= b1;
+            LDS_RELEASE();                                 // everything wave 0 acquired (tiles, s_order) before the halt word
             if (lane == 0) {
                 if (frame_done) lds_st(&s_stop, 1);        // stop first, then halt (LDS keeps the order)
                 lds_st(&s_halt, 1);
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
         }
         if (wave != 0) {
             while (!lds_ld(&s_halt)) __builtin_amdgcn_s_sleep(1);
+            LDS_ACQUIRE();                                 // s_order / s_K reads below are ordered after the halt word
             frame_done = __builtin_amdgcn_readfirstlane(lds_ld(&s_stop)) != 0;
         }
         // a finished frame needs no more tiles: its loaders leave at once (their last batch may still be in
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(CHL_THREADS) void nms_chain_lds_kernel(NmsDev d)
     const int ktotal = __shfl(inc, 31);
     const bool finished = (d.max_keep > 0 && ktotal >= d.max_keep) || (b1 >= nb);
     const int nk = (d.max_keep > 0 && ktotal > d.max_keep) ? d.max_keep : ktotal;
-    if (threadIdx.x < 32) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;
+    if (threadIdx.x < min(32, d.nbw)) d.kstate[(long long)f * d.nbw + threadIdx.x] = Kl;   // a frame's slice has nbw words
     for (int w = threadIdx.x; w < d.nbw; w += CHL_POST) d.rem[(long long)f * d.nbw + w] = 0ull;   // accumulated by the later rounds' tile phases
     if (threadIdx.x == 0) {
         cstate[0] = ktotal; cstate[1] = finished ? 1 : 0; cstate[2] = 0;
@@ -875,7 +880,6 @@ static int nms_device_impl(const float *dets_dev, int n, double thresh, int max_
     if (workspace_bytes < mv3d_nms_ws_bytes(n, 1) || (n > 0 && !workspace) || ((uintptr_t)workspace % MV3D_ALIGN))
         return MV3D_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (status_dev) MV3D_HIP_TRY(hipMemsetAsync(status_dev, 0, sizeof(int32_t), s));
     NmsLaunch L = {};
     L.boxes = dets_dev; L.box_stride = 5; L.n_cap = n; L.batch = 1;
     L.thresh_f32 = mv3d_ceil_f32(thresh); L.strict_gt = 0; L.max_keep = max_keep;

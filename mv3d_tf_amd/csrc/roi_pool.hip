@@ -514,3 +514,16 @@ extern "C" int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *v
     else hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return mv3d_launch_status();
 }
+
+extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                            void *stream)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[k];
+        const int rc = mv3d_roi_pool_backward(w.top_diff, w.spatial_scale, w.batch_size, w.num_rois, w.height, w.width, w.channels,
+                                              pooled_height, pooled_width, w.bottom_rois, w.bottom_diff, w.argmax_data, stream);
+        if (rc != MV3D_OK) return rc;
+    }
+    return MV3D_OK;
+}

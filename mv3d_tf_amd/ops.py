@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AnchorTargetParams, ProposalParams, ProposalTargetParams, RoiView, check, lib
+from ._lib import AnchorTargetParams, ProposalParams, ProposalTargetParams, RoiGradView, RoiView, check, lib
 
 
 def _stream():
@@ -308,6 +308,32 @@ def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None):
     check(lib().mv3d_roi_pool_forward_views(len(views), arr, pooled_height, pooled_width, _stream()),
           "mv3d_roi_pool_forward_views")
     return res
+
+
+def roi_pool_backward_views(views, pooled_height, pooled_width, outs=None):
+    """views: list of (top_diff (R,PH,PW,C), rois (R,5), argmax (R,PH,PW,C) i32, data_shape (B,H,W,C), spatial_scale);
+    RoiPoolGrad of all of them behind one call.  Returns [bottom_diff, ...]; pass `outs` to reuse output tensors."""
+    arr = (RoiGradView * len(views))()
+    res = []
+    for k, (top_diff, rois, argmax, shape, scale) in enumerate(views):
+        B, H, W, Cc = shape
+        out = outs[k] if outs is not None else torch.empty((B, H, W, Cc), dtype=torch.float32, device=top_diff.device)
+        arr[k] = RoiGradView(out.data_ptr(), rois.data_ptr(), top_diff.data_ptr(), argmax.data_ptr(), float(scale), B,
+                             rois.shape[0], H, W, Cc)
+        res.append(out)
+    check(lib().mv3d_roi_pool_backward_views(len(views), arr, pooled_height, pooled_width, _stream()),
+          "mv3d_roi_pool_backward_views")
+    return res
+
+
+def rois_3d_to_fv(rois_3d, out=None):
+    """rois_3d (R,7) device f32 [b,x,y,z,l,w,h] -> rois_fv (R,5) [b,x1,y1,x2,y2] on the 64 x 512 front-view map."""
+    r3 = rois_3d.contiguous()
+    R = r3.shape[0]
+    if out is None:
+        out = torch.empty((R, 5), dtype=torch.float32, device=r3.device)
+    check(lib().mv3d_rois_3d_to_fv(_ptr(r3), R, _ptr(out), _stream()), "mv3d_rois_3d_to_fv")
+    return out
 
 
 # ------------------------------------------------------------------ training losses (SURVEY §8(f) rank 4)

@@ -127,6 +127,11 @@ void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc,
  * reflectance channel) wins a cell, as numpy fancy assignment does. */
 void mv3d_ref_point_cloud_2_top(const float *points, int P, float *top);
 
+/* Front-view ROI of a 3D proposal (PARITY UNPINNED: no reference code, lib/networks/network.py:293-315 is a TODO):
+ * rois_3d (R,7) [b,x,y,z,l,w,h] -> rois_fv (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical map. */
+double mv3d_ref_fv_atan2(double y, double x);
+void mv3d_ref_rois_3d_to_fv(const float *rois_3d, int R, float *rois_fv);
+
 #ifdef __cplusplus
 }
 #endif

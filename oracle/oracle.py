@@ -390,3 +390,20 @@ def detection_losses(cls_score, labels, bbox_pred, bbox_targets, rpn, sigma=3.0)
         d_pred = np.where(pos[:, None], np.where(quad, sigma2 * d, np.sign(d)) * np.float32(1.0 / pos.sum()), 0).astype(np.float32)
     return ce, box, d_cls, d_pred
 
+
+
+# ------------------------------------------------------------------ X1: front-view ROI (parity unpinned: no reference code)
+def rois_3d_to_fv(rois_3d):
+    """rois_3d (R,7) [b,x,y,z,l,w,h] -> rois_fv (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical front-view map
+    (definition: mv3d_tf_amd/csrc/front_view.hip; the reference leaves this view a TODO, network.py:293-315)."""
+    r3 = _f32(rois_3d).reshape(-1, 7)
+    out = np.zeros((r3.shape[0], 5), np.float32)
+    lib().mv3d_ref_rois_3d_to_fv(_p(r3), C.c_int(r3.shape[0]), _p(out))
+    return out
+
+
+def fv_atan2(y, x):
+    f = lib().mv3d_ref_fv_atan2
+    f.restype = C.c_double
+    f.argtypes = [C.c_double, C.c_double]
+    return np.array([f(float(a), float(b)) for a, b in zip(np.ravel(y), np.ravel(x))])

@@ -1,0 +1,177 @@
+"""-m gpu tests for the BASELINE.json configurations the per-function tests do not reach at full size:
+
+  configs[2]  full 3-view path: BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512 feature maps, batch 2,
+              RoiPool forward + backward of every view, against the oracle;
+  configs[4]  per-GPU inference workload: batch 16, TEST cfg (6000 -> 300), the step captured in a hipGraph and
+              replayed: replay == eager == oracle, frame by frame;
+  a11 edges   the `project_edge` boxes (NaN, 1e30, behind the camera, 200 m) through the DEVICE projection
+              (mv3d_proposal_target_stage2's rois_img) against the reference-generated golden.
+All calls go through the C-ABI (ctypes, mv3d_tf_amd.ops)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from mv3d_tf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TEST_CFG = dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)
+TRAIN_CFG = dict(RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)
+VIEWS = {"bev": (76, 76), "rgb": (46, 155), "fv": (8, 64)}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from mv3d_tf_amd import build, ops
+    build.build()
+    return torch, ops
+
+
+def dev(torch, a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).cuda()
+
+
+def three_view_rois(oracle, B, per_frame, seed0):
+    """per-frame sampled ROIs of a batch: BEV / image boxes of real proposals, FV boxes from the cylindrical projection
+    of the same 3D proposals; column 0 = frame index"""
+    from mv3d_tf_amd.utils import front_view
+    bev, rgb, fv = [], [], []
+    for b in range(B):
+        prob, pred, info, calib = synth.rpn_head(seed0 + b, 76, 76, "peaky")
+        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ], cfg={"TRAIN": TRAIN_CFG})
+        for dst, src in ((bev, bv), (rgb, img)):
+            r = src[:per_frame].copy(); r[:, 0] = b; dst.append(r)
+        r3 = b3[:per_frame].copy(); r3[:, 0] = b
+        f = front_view.rois_3d_to_fv(r3)                              # device kernel ...
+        assert np.array_equal(f, oracle.rois_3d_to_fv(r3))            # ... equal to the oracle's restatement
+        fv.append(f)
+    return {"bev": np.concatenate(bev), "rgb": np.concatenate(rgb), "fv": np.concatenate(fv)}
+
+
+def test_config2_three_views_batch2_forward_backward(gpu, oracle):
+    """BASELINE configs[2] RoiPool workload at full size: 3 maps x batch 2, 128 sampled ROIs per frame (R = 256 per view),
+    one forward launch for all views, one backward launch for all views; equal to the oracle bit for bit."""
+    torch, ops = gpu
+    B, per = 2, 128
+    rois = three_view_rois(oracle, B, per, 700)
+    maps = {k: synth.feature_map(70 + i, H, W, 512, B) for i, (k, (H, W)) in enumerate(VIEWS.items())}
+    d_maps = {k: dev(torch, v) for k, v in maps.items()}
+    d_rois = {k: dev(torch, v) for k, v in rois.items()}
+    outs = ops.roi_pool_forward_views([(d_maps[k], d_rois[k], 0.125) for k in VIEWS], 7, 7)
+    grads, want_am = {}, {}
+    for (k, (top, am)) in zip(VIEWS, outs):
+        o_top, o_am = oracle.roi_pool(maps[k], rois[k], 7, 7, 0.125)
+        assert np.array_equal(top.cpu().numpy(), o_top), k
+        assert np.array_equal(am.cpu().numpy(), o_am), k
+        want_am[k] = o_am
+        grads[k] = np.random.RandomState({"bev": 11, "rgb": 12, "fv": 13}[k]).uniform(-1, 1, o_top.shape).astype(np.float32)
+    bds = ops.roi_pool_backward_views([(dev(torch, grads[k]), d_rois[k], am, maps[k].shape, 0.125)
+                                       for k, (_, am) in zip(VIEWS, outs)], 7, 7)
+    for k, bd in zip(VIEWS, bds):
+        want = oracle.roi_pool_grad(maps[k], rois[k], want_am[k], grads[k], 7, 7, 0.125)
+        assert np.array_equal(bd.cpu().numpy(), want), k
+        # the single-view entry gives the same bytes
+        one = ops.roi_pool_backward(dev(torch, grads[k]), d_rois[k], dev(torch, want_am[k]), maps[k].shape, 7, 7, 0.125)
+        assert np.array_equal(one.cpu().numpy(), want), k
+
+
+def test_config4_batch16_hipgraph_replay_equals_eager_equals_oracle(gpu, oracle):
+    """BASELINE configs[4] per-GPU step: 16 frames, TEST cfg, proposal_3d + both RoiPool views.  The captured hipGraph,
+    replayed twice (the second time on fresh inputs written into the same buffers), gives the eager results and the
+    oracle's, frame by frame."""
+    torch, ops = gpu
+    B = 16
+    params = ops.proposal_params(TEST_CFG)
+
+    def frames(seed0):
+        hs = [synth.rpn_head(seed0 + b, 76, 76, "peaky" if b % 2 == 0 else "rand") for b in range(B)]
+        return (np.concatenate([h[0] for h in hs]), np.concatenate([h[1] for h in hs]), np.concatenate([h[2] for h in hs]),
+                np.stack([h[3] for h in hs]))
+
+    host = frames(2000)
+    prob, pred, info, calib = (dev(torch, a) for a in host)
+    bev_h, rgb_h = synth.feature_map(81, 76, 76, 512, B), synth.feature_map(82, 46, 155, 512, B)
+    bev, rgb = dev(torch, bev_h), dev(torch, rgb_h)
+    eager = ops.proposal_3d(prob, pred, info, calib, params)
+    cap = eager[0].shape[1]
+    e_views = ops.roi_pool_forward_views([(bev, eager[0].view(-1, 5), 0.125), (rgb, eager[1].view(-1, 5), 0.125)], 7, 7)
+    torch.cuda.synchronize()
+    e_host = [t.cpu().numpy().copy() for t in eager] + [t.cpu().numpy().copy() for pair in e_views for t in pair]
+
+    out = tuple(torch.empty_like(t) for t in eager)
+    v_out = [(torch.empty_like(t), torch.empty_like(a)) for (t, a) in e_views]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                              # warm-up on the capture stream (workspace allocation)
+        ops.proposal_3d(prob, pred, info, calib, params, out=out)
+        ops.roi_pool_forward_views([(bev, out[0].view(-1, 5), 0.125), (rgb, out[1].view(-1, 5), 0.125)], 7, 7, outs=v_out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.proposal_3d(prob, pred, info, calib, params, out=out)
+        ops.roi_pool_forward_views([(bev, out[0].view(-1, 5), 0.125), (rgb, out[1].view(-1, 5), 0.125)], 7, 7, outs=v_out)
+    for t in out:
+        t.zero_()
+    for rep in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in out] + [t.cpu().numpy() for pair in v_out for t in pair]
+        for a, b in zip(got, e_host):
+            assert np.array_equal(a, b), "replay %d differs from the eager step" % rep
+    # oracle, frame by frame (every frame must reach 300 rows or fewer; rows past num_out are zero)
+    num = out[3].cpu().numpy()
+    for b in range(B):
+        bv, img, b3 = oracle.proposal_layer_3d(host[0][b:b + 1], host[1][b:b + 1], host[2][b:b + 1], host[3][b], "TEST", [8, ],
+                                               cfg={"TEST": TEST_CFG})
+        n = bv.shape[0]
+        assert num[b] == n and n <= cap
+        bv[:, 0] = b; img[:, 0] = b; b3[:, 0] = b
+        assert np.array_equal(got[0][b, :n], bv) and np.array_equal(got[1][b, :n], img) and np.array_equal(got[2][b, :n], b3)
+        assert not got[0][b, n:].any()
+    for b in (0, B - 1):                                        # RoiPool rows of the first and last frame vs the oracle
+        rows = slice(b * cap, b * cap + int(num[b]))
+        for k, (fmap, blob) in enumerate(((bev_h, got[0]), (rgb_h, got[1]))):
+            o_top, o_am = oracle.roi_pool(fmap, blob.reshape(-1, 5)[rows], 7, 7, 0.125)
+            assert np.array_equal(got[5 + 2 * k][rows], o_top) and np.array_equal(got[6 + 2 * k][rows], o_am)
+    # new inputs written into the captured buffers: the replay follows them
+    host2 = frames(3000)
+    for t, a in zip((prob, pred, info, calib), host2):
+        t.copy_(torch.as_tensor(a))
+    graph.replay()
+    torch.cuda.synchronize()
+    bv, img, b3 = oracle.proposal_layer_3d(host2[0][3:4], host2[1][3:4], host2[2][3:4], host2[3][3], "TEST", [8, ], cfg={"TEST": TEST_CFG})
+    n = bv.shape[0]
+    assert int(out[3][3].item()) == n and np.array_equal(out[0][3, :n, 1:].cpu().numpy(), bv[:, 1:])
+
+
+def test_project_edge_boxes_through_device_projection(gpu):
+    """a11 edge set on the device: the golden `img` of tests/golden/project_edge.npz (generated by the reference's
+    lidar_cnr_to_img: NaN / 1e30 / depth <= 0 / 200 m boxes -> INT32_MIN and overflowed values) must come out of
+    image_box() as used by mv3d_proposal_target_stage2 (rois_img = projected sampled 3D ROIs)."""
+    torch, ops = gpu
+    from mv3d_tf_amd._lib import ProposalTargetParams
+    g = golden("project_edge")
+    n = g["boxes3d"].shape[0]
+    rois_3d = np.zeros((n, 7), np.float32); rois_3d[:, 1:] = g["boxes3d"]
+    rois_bv = np.zeros((n, 5), np.float32); rois_bv[:, 1:] = [400, 400, 420, 440]          # IoU 0 with the GT below
+    gt_bv = np.array([[100, 100, 116, 139, 1]], np.float32)
+    gt_3d = np.array([[30.0, 10.0, -0.95, 3.9, 1.6, 1.56, 1]], np.float32)
+    gt_cnr = np.concatenate([np.arange(24, dtype=np.float32), [1]])[None]
+    params = ProposalTargetParams(2, 0, 0.5, 0.5, 0.0)                                       # bg = [0, 0.5): every edge roi
+    d = lambda a: dev(torch, a)
+    counts, ws = ops.proposal_target_stage1(d(rois_bv), d(rois_3d), d(gt_bv), d(gt_3d), params)
+    ncand, n_fg, n_bg, _ = (int(v) for v in counts.cpu().numpy())
+    assert (ncand, n_fg, n_bg) == (n + 1, 1, n)
+    out = ops.proposal_target_stage2(d(rois_bv), d(rois_3d), d(gt_bv), d(gt_3d), d(gt_cnr), d(g["calib"]), params,
+                                     np.arange(1), np.arange(n), ws)
+    rois_img = out[1].cpu().numpy()
+    assert rois_img.shape == (n + 1, 5)
+    assert np.array_equal(rois_img[1:, 1:], g["img"].astype(np.float32))                     # int32 -> f32 like :88-92
+    assert np.array_equal(out[4].cpu().numpy()[1:, 1:], g["boxes3d"], equal_nan=True)

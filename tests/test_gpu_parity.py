@@ -627,8 +627,19 @@ def test_training_losses_vs_oracle_and_torch(ops, torch_cuda, oracle):
         assert np.isclose(ce.item(), F.cross_entropy(dev(cs, torch), dev(lb.reshape(-1).astype(np.int64), torch)).item(), rtol=1e-5)
     # no positive anchor: the box loss is the mean of nothing = NaN (tf.reduce_mean), the cross-entropy is not
     lab0 = np.where(lab == 1, 0, lab).astype(np.float32)
-    ce, box = train_mv.rpn_losses(dev(z, torch), (lab0, tgt), dev(pred, torch))
+    z0, p0 = dev(z, torch).requires_grad_(True), dev(pred, torch).requires_grad_(True)
+    ce, box = train_mv.rpn_losses(z0, (lab0, tgt), p0)
     assert np.isfinite(ce.item()) and np.isnan(box.item())
+    # ... but its GRADIENT is zero (TF back-propagates nothing through the mean of an empty gather): training survives
+    (ce + box).backward()
+    assert torch.isfinite(z0.grad).all() and float(z0.grad.abs().sum()) > 0
+    assert float(p0.grad.abs().sum()) == 0.0 and torch.isfinite(p0.grad).all()
+    # nothing selected at all: both losses NaN, both gradients zero
+    zn, pn = dev(z, torch).requires_grad_(True), dev(pred, torch).requires_grad_(True)
+    ce, box = train_mv.rpn_losses(zn, (np.full(N, -1, np.float32), tgt), pn)
+    assert np.isnan(ce.item()) and np.isnan(box.item())
+    _, d_cls, d_pred = ops.rpn_loss(zn.detach(), dev(np.full(N, -1, np.float32), torch), pn.detach(), dev(tgt, torch))
+    assert float(d_cls.abs().sum()) == 0.0 and float(d_pred.abs().sum()) == 0.0
     # snapshot name and the .npy weight dict round trip
     from mv3d_tf_amd.fast_rcnn.config import cfg
     assert train_mv.snapshot_filename("/x", 4999).endswith("/x/%s_iter_5000.ckpt" % cfg.TRAIN.SNAPSHOT_PREFIX)
