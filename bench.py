@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- KITTI-shape frames/s through the MV3D hot path on MI355X.
+"""bench.py -- KITTI-shape frames/s through the MV3D hot path on MI355X (BASELINE.json's metric).
 
-A "step" = one pass of the hot path over one batch of synthetic KITTI-shaped frames whose
-inputs are already resident in HBM:
+Default workload = BASELINE configs[2], path only (the largest single-GPU configuration):
 
-    proposal_layer_3d (decode + project + clip/filter + score sort + NMS + top-N)
-      -> RoiPool 7x7 on the BEV feature map (76x76x512) with rois_bv
-      -> RoiPool 7x7 on the RGB feature map (46x155x512) with rois_img
-    [--train adds anchor_target stage-1, and RoiPoolGrad on both views]
+    batch of 2 frames, three views, training step of the path
+      mv3d_proposal_3d           TRAIN cfg: 23 104 BEV anchors -> 12 000 pre-NMS -> NMS 0.7 -> 2 000 proposals / frame
+      mv3d_anchor_target_*       RPN labels / 6-d targets of every frame
+      mv3d_proposal_target_*     <= 128 sampled ROIs / frame (fg first), corner targets, image boxes
+      mv3d_rois_3d_to_fv         third (front-view) ROIs
+      mv3d_roi_pool_forward_views   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7
+      mv3d_roi_pool_backward_views  the same three layers, RoiPoolGrad
 
-i.e. BASELINE.json configs[1] (1 GPU, BEV RPN with 76x76x4 = 23 104 anchors + HIP NMS,
-batch 1) widened by the two RoiPool views the reference has; the VGG16 trunks are not part
-of the path.  One process per GPU; frames shard across ranks with no
-data-path collective ("weak" scaling: per-GPU work fixed).
+A "step" = one pass over `--batches-per-step` such batches (default 64 batches = 128 frames), cycling through a ring of
+`--ring` (default 16) DISTINCT batches per GPU -- distinct frames and distinct feature maps (1.1 GB of maps + 3.3 GB of
+outputs per ring), so that nothing is served from the 256 MB Infinity Cache by re-reading the previous step's frame.
+Batches are enqueued round-robin on `--streams` HIP streams (a batch is a dependent chain of ~20 small launches +
+two HBM-bound RoiPool launches; independent batches overlap).  Inputs are resident in HBM before the timed region,
+including the random-subsample index lists of the two target layers, which are arguments of the C-ABI (drawn from the
+numpy RNG exactly as the reference draws them, during set-up; see mv3d_tf_amd/hot_path.py).  No host synchronisation
+happens inside the timed region.  The VGG16 trunks / FC head are not part of the path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--cfg TEST|TRAIN]
-                    [--variant peaky|rand] [--graph] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|test] [--ring R] [--batches-per-step M]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, measured live with HIP events on the launch stream) and `cpu_baseline` (the C
-oracle, single thread, bounded sample) objects.
+`--gpus N` with N > 1 and no launcher environment re-executes itself under `python -m torch.distributed.run` with one
+rank per GPU (RCCL); under the driver's own torchrun launch the ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  Frames
+shard across ranks with no data-path collective ("weak" scaling); the bracketing barrier and the max-over-ranks of the
+timed region are the only collectives of the path-only line.
+
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel of the step (largest share of GPU time), measured live
+with HIP events on the stream it is launched on; `roofline_kernels` lists the RoiPool forward and backward launches
+separately; `cpu_baseline` = the C oracle on the same workload on the host cores (bounded sample); `secondary` holds
+the TEST-cfg (configs[1]/[4]) line and, with --with-trunk, the full training step with the torch VGG16 trunks
+and the bucketed gradient all-reduce.
 """
 import argparse
-import contextlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,200 +46,154 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-
-CFGS = {
-    # experiments/cfgs/faster_rcnn_end2end.yml:15-20 (what experiments/scripts/mv3d.sh tests with)
-    "TEST": dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5),
-    # lib/fast_rcnn/config.py:126-148
-    "TRAIN": dict(RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5),
-}
-BEV_MAP = (76, 76, 512)      # conv5_3 of the 608x608 BEV, stride 8
-RGB_MAP = (46, 155, 512)     # conv5_3 of the 375x1242 image, stride 8
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "KITTI-shape frames/sec (RPN+3-view ROI-pool+NMS) at 1/2/4/8 MI355X"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
-    ap.add_argument("--cfg", default="TEST", choices=list(CFGS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="train", choices=["train", "test"],
+                    help="train: BASELINE configs[2] path-only (default); test: configs[4] per-GPU path (batch 16, TEST cfg)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per batch per GPU (default: 2 for train, 16 for test)")
+    ap.add_argument("--ring", type=int, default=0, help="distinct resident batches per GPU (default: 16 train, 4 test)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step (default: 64 train, 8 test)")
+    ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph instead of launching eagerly (measured ~5 %% slower at batch 1: "
-                         "the 7 launches of a step are enqueued ahead of the GPU either way, and graph nodes carry more "
-                         "per-node overhead than in-order stream launches)")
-    ap.add_argument("--no-graph", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="frames in flight: step i runs on stream i %% S with its own outputs and workspace, so the "
-                         "latency-bound kernels of one frame overlap the RoiPool of another (each step is still one batch). "
-                         "0 = auto: 3 up to batch 4 (batch 1: 16.3k / 24.5k / 28.8k / 22.7k frames/s for 1-4 streams; batch 4: 27.9k / "
-                         "34.4k / 35.2k for 1-3), 1 above (batch 16: 31k alone, 24k with 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--only", default="", choices=["", "proposal", "roi"], help="diagnostics: run only one half of the step")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests on one GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--with-trunk", action="store_true", help="add the full training step (torch VGG16 trunks + DP all-reduce)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests)")
     return ap.parse_args()
 
 
-class Frames:
-    """Per-rank device-resident inputs and the step closure."""
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run and relay rank 0's line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
-    def __init__(self, args, rank, stream=None):
-        from mv3d_tf_amd import ops, synth
-        self.ops, self.args = ops, args
-        self.stream = stream                          # None: whatever stream is current when step() runs
-        B = args.batch
-        heads = [synth.rpn_head(1000 + rank * 64 + b, 76, 76, args.variant) for b in range(B)]
-        self.host_frame0 = heads[0]
-        t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
-        self.prob = t(np.concatenate([h[0] for h in heads]))
-        self.pred = t(np.concatenate([h[1] for h in heads]))
-        self.info = t(np.concatenate([h[2] for h in heads]))
-        self.calib = t(np.stack([h[3] for h in heads]))
-        self.bev = t(synth.feature_map(7, *BEV_MAP[:2], BEV_MAP[2], B))
-        self.rgb = t(synth.feature_map(8, *RGB_MAP[:2], RGB_MAP[2], B))
-        self.params = ops.proposal_params(CFGS[args.cfg])
-        self.out = None
-        self.step()                                   # allocates outputs / workspace
+
+class Ring:
+    """`n` distinct device-resident batches of one rank, batch k bound to stream k % S."""
+
+    def __init__(self, args, rank, workload, batch, n, streams):
+        from mv3d_tf_amd import hot_path, synth
+        self.slots = []
+        dev = torch.device("cuda", torch.cuda.current_device())
+        np.random.seed(3 + rank)                                   # cfg.RNG_SEED (tools/train_net.py:78-80), per rank
+        for k in range(n):
+            st = streams[k % len(streams)]
+            seed0 = 100000 * (rank + 1) + k * batch
+            frames = [synth.rpn_head(seed0 + b, 76, 76, args.variant, return_gt=True) for b in range(batch)]
+            maps = hot_path.synth_maps(batch, seed0, dev)
+            if workload == "train":
+                slot = hot_path.TrainPathBatch(frames, maps, stream=st, top_diff_seed=k)
+            else:
+                slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st)
+            self.slots.append(slot.setup())
+            if k == 0:
+                self.host_frames = frames
+        self.cursor = 0
+
+    def run(self, nbatches):
+        n = len(self.slots)
+        for _ in range(nbatches):
+            self.slots[self.cursor % n].run()
+            self.cursor += 1
+
+
+def events_ms(stream, fns, rounds):
+    """average duration (ms) of one call of the launches in `fns` (cycled), HIP events recorded on `stream`"""
+    with torch.cuda.stream(stream):
+        for f in fns:
+            f()
         torch.cuda.synchronize()
-
-    def step(self):
-        """one pass of the hot path over the batch: mv3d_proposal_3d (6 launches) + both RoiPool views (1 launch).
-        After the first call the two C entry points are called with pre-built arguments (nothing is allocated,
-        looked up or converted per step; the host side of a step is two ctypes calls)."""
-        sid = self.stream.cuda_stream if self.stream is not None else torch.cuda.current_stream().cuda_stream
-        bound = self._bound.get(sid) if hasattr(self, "_bound") else None
-        if bound is None:
-            bound = self._bind(sid)
-        only = self.args.only
-        rc = bound[0](*bound[1]) if only != "roi" else 0
-        if rc == 0 and only != "proposal":
-            rc = bound[2](*bound[3])
-        if rc != 0:
-            from mv3d_tf_amd._lib import check
-            check(rc, "bench step")
-        return self.out[0].shape[1]
-
-    def _bind(self, sid):
-        import ctypes as C
-        from mv3d_tf_amd import _lib
-        from mv3d_tf_amd._lib import RoiView, lib
-        o = self.ops
-        if self.out is None:                                                # first call: outputs (through the wrappers)
-            with torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext():
-                self.out = o.proposal_3d(self.prob, self.pred, self.info, self.calib, self.params)
-            R = self.out[0].shape[0] * self.out[0].shape[1]
-            mk = lambda c, dt: torch.empty((R, 7, 7, c), dtype=dt, device="cuda")
-            self.tops = (mk(BEV_MAP[2], torch.float32), mk(BEV_MAP[2], torch.int32),
-                         mk(RGB_MAP[2], torch.float32), mk(RGB_MAP[2], torch.int32))
-        bv, img, b3, num, status = self.out
-        rois_bv, rois_img = bv.view(-1, 5), img.view(-1, 5)                 # (B*cap, 5), column 0 = frame index
-        B, H, W, _ = self.prob.shape
-        P = lambda t: C.c_void_p(t.data_ptr())
-        nbytes = lib().mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(self.params))
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.prob.device)     # one per (Frames, stream)
-        st = C.c_void_p(sid)
-        a1 = (P(self.prob), P(self.pred), B, H, W, P(self.info), P(self.calib), C.byref(self.params), P(bv), P(img), P(b3),
-              P(num), P(status), P(ws), C.c_size_t(ws.numel()), st)
-        arr = (RoiView * 2)()
-        for k, (data, rois, top, am) in enumerate(((self.bev, rois_bv, self.tops[0], self.tops[1]),
-                                                   (self.rgb, rois_img, self.tops[2], self.tops[3]))):
-            Bd, Hd, Wd, Cd = data.shape
-            arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bd, rois.shape[0], Hd, Wd, Cd)
-        a2 = (2, arr, 7, 7, st)
-        if not hasattr(self, "_bound"):
-            self._bound = {}
-        self._keep = getattr(self, "_keep", []) + [ws, arr]
-        self._bound[sid] = (lib().mv3d_proposal_3d, a1, lib().mv3d_roi_pool_forward_views, a2)
-        return self._bound[sid]
-
-    def _roi_views(self, rois_bv, rois_img):
-        """both RoiPool layers of the step (MV3D_test.py:95-107) in one launch"""
-        from mv3d_tf_amd import ops as o
-        o.roi_pool_forward_views([(self.bev, rois_bv, 0.125), (self.rgb, rois_img, 0.125)], 7, 7,
-                                 outs=[(self.tops[0], self.tops[1]), (self.tops[2], self.tops[3])])
-
-    def _roi(self, data, rois, top, argmax):
-        import ctypes as C
-        from mv3d_tf_amd._lib import check, lib
-        B, H, W, Cc = data.shape
-        rc = lib().mv3d_roi_pool_forward(C.c_void_p(data.data_ptr()), C.c_float(0.125), B, rois.shape[0], H, W, Cc,
-                                         7, 7, C.c_void_p(rois.data_ptr()), C.c_void_p(top.data_ptr()),
-                                         C.c_void_p(argmax.data_ptr()),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        check(rc, "mv3d_roi_pool_forward")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(rounds):
+            for f in fns:
+                f()
+        e1.record(stream)
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (rounds * len(fns))
 
 
-def time_kernel_events(fn, iters=50):
-    """average duration (ms) of fn()'s launches with HIP events on the current stream"""
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC passes (tools/gpu_pmc.sh + tools/pmc_summary.py:
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes); None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(kernel, signature):
+    """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r02_pmc_traffic.json holds
+    the signature it was collected with); None otherwise -- never a stale number."""
     try:
-        table = json.load(open(path))
-        key = next(k for k in table if kernel in k)       # template instances carry a "void ...<N>" decoration
-        return int(table[key]["hbm_bytes_per_launch"])
+        table = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if table.get("signature") != signature:
+            return None
+        key = next(k for k in table["kernels"] if kernel in k)
+        return int(table["kernels"][key]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
 
-def roofline(fr):
-    """Dominant kernel = the RoiPool forward launch (BEV + RGB views; largest share of the step and of
-    its traffic).  Algorithmic bytes per launch: each feature map once + rois + (top f32 +
-    argmax i32) outputs of both views."""
-    B = fr.args.batch
-    R = fr.out[0].shape[0] * fr.out[0].shape[1]
-    alg = 0
-    for (H, W, C) in (BEV_MAP, RGB_MAP):
-        alg += B * H * W * C * 4 + R * 20 + R * 49 * C * 8
-    rois_bv, rois_img = fr.out[0].view(-1, 5), fr.out[1].view(-1, 5)
-    ms = time_kernel_events(lambda: fr._roi_views(rois_bv, rois_img))
-    gbs = alg / (ms * 1e-3) / 1e9
-    name = "roi_pool_fwd_xcd_multi_kernel"
-    return {"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 views, R=%d rows each)" % (name, R), "bound": "hbm",
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(name),
-            "alg_bytes_per_launch": alg, "avg_launch_us": round(ms * 1e3, 2),
-            "note": "HIP events over 50 back-to-back launches on the launch stream; traffic = PMC FETCH_SIZE*2+WRITE_SIZE "
-                    "per launch (profiles/r01_pmc_traffic.txt); write-only fill ceiling on this box 5.8-6.0 TB/s (profiles/r01_hbm_probe.txt)"}
+def roofline_entries(ring, workload, signature):
+    """RoiPool forward / backward launches (all three views each), cycled over the stream-0 batches of the ring so that
+    consecutive launches touch different maps and outputs."""
+    s0 = ring.slots[0].stream
+    mine = [s for s in ring.slots if s.stream is s0]
+    out = []
+    legs = [("roi_pool_fwd_xcd_multi_kernel", "roi_forward", "roi_forward_bytes")]
+    if workload == "train":
+        legs.append(("roi_pool_bwd", "roi_backward", "roi_backward_bytes"))
+    for kname, meth, bytes_meth in legs:
+        ms = events_ms(s0, [getattr(s, meth) for s in mine], 6)
+        alg = getattr(mine[0], bytes_meth)()
+        gbs = alg / (ms * 1e-3) / 1e9
+        out.append({"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512 views, R=%d rows each, batch %d)"
+                              % (kname, mine[0].num_rois, mine[0].B),
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, signature),
+                    "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2)})
+    return out
 
 
-def cpu_baseline(fr, seconds):
-    """The C oracle on the same frame-0 workload, bounded sample: first one thread (the scalar port, ~1/3 of the
-    time), then `cores` threads that each process whole frames (ctypes releases the GIL inside the C calls) --
-    the frame-parallel way a CPU deployment of the reference would use the host."""
+def cpu_baseline(ring, workload, seconds):
+    """The C oracle on the same per-frame workload (frame 0 of batch 0), bounded sample: one thread first, then `cores`
+    threads that each process whole frames (ctypes releases the GIL inside the C calls)."""
     import threading
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    from mv3d_tf_amd import synth
-    prob, pred, info, calib = fr.host_frame0
-    bev = synth.feature_map(7, *BEV_MAP[:2], BEV_MAP[2], 1)
-    rgb = synth.feature_map(8, *RGB_MAP[:2], RGB_MAP[2], 1)
-    cfg = {fr.args.cfg: CFGS[fr.args.cfg]}
+    from mv3d_tf_amd import hot_path
+    prob, pred, info, calib, (gt_bv, gt_3d, gt_cnr) = ring.host_frames[0]
+    slot = ring.slots[0]
+    maps = {v: m[0:1].cpu().numpy() for v, m in slot.maps.items()}
+    key = "TRAIN" if workload == "train" else "TEST"
+    cfg = {key: hot_path.TRAIN_CFG if workload == "train" else hot_path.TEST_CFG}
+    score = np.zeros((1, 76, 76, 8), np.float32)
+    lock = threading.Lock()
 
-    def frame():
-        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, fr.args.cfg, [8, ], cfg=cfg)
-        oracle.roi_pool(bev, bv, 7, 7, 0.125)
-        oracle.roi_pool(rgb, img, 7, 7, 0.125)
+    def frame(rng_guard):
+        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, key, [8, ], cfg=cfg)
+        if workload == "train":
+            with rng_guard:                                    # the numpy global RNG is not thread-safe
+                oracle.anchor_target_layer(score, gt_bv, gt_3d, info, [8, ])
+                r_bv, r_img, _, _, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2)
+            rois = {"bev": r_bv, "rgb": r_img, "fv": oracle.rois_3d_to_fv(r_3d)}
+        else:
+            rois = {"bev": bv, "rgb": img, "fv": oracle.rois_3d_to_fv(b3)}
+        for v in hot_path.VIEWS:
+            top, am = oracle.roi_pool(maps[v], rois[v], 7, 7, 0.125)
+            if workload == "train":
+                oracle.roi_pool_grad(maps[v], rois[v], am, top, 7, 7, 0.125)
 
     n1, t0 = 0, time.perf_counter()
     while True:
-        frame()
+        frame(lock)
         n1 += 1
         dt1 = time.perf_counter() - t0
         if dt1 >= seconds / 3 or n1 >= 400:
@@ -238,7 +204,7 @@ def cpu_baseline(fr, seconds):
 
     def worker(k):
         while time.perf_counter() < stop_at:
-            frame()
+            frame(lock)
             done[k] += 1
 
     t0 = time.perf_counter()
@@ -251,13 +217,28 @@ def cpu_baseline(fr, seconds):
     nm = sum(done)
     return {"value": round(nm / dtm, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "one_thread_frames_per_s": round(n1 / dt1, 3),
-            "sample": "%d frames on %d threads in %.1f s (frame-parallel) after %d frames on 1 thread in %.1f s; same workload "
-                      "(frame 0, %s cfg, %s scores); C restatement oracle/mv3d_oracle.c, gcc -O2; host has %d cores"
-                      % (nm, cores, dtm, n1, dt1, fr.args.cfg, fr.args.variant, os.cpu_count())}
+            "sample": "%d frames on %d threads in %.1f s (frame-parallel) after %d frames on 1 thread in %.1f s; the same "
+                      "per-frame workload (%s cfg path incl. target layers, 3-view RoiPool fwd%s, frame 0 of the ring); C "
+                      "restatement oracle/mv3d_oracle.c, gcc -O2; host has %d cores"
+                      % (nm, cores, dtm, n1, dt1, key, "+bwd" if workload == "train" else "", os.cpu_count())}
+
+
+def timed(ring, nbatches, steps, warmup, barrier):
+    for _ in range(warmup):
+        ring.run(nbatches)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ring.run(nbatches)
+    t_enq = time.perf_counter() - t0
+    barrier()
+    return time.perf_counter() - t0, t_enq
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -266,7 +247,7 @@ def main():
     ndev = torch.cuda.device_count()
     if local >= ndev and args.dist_backend == "nccl":
         raise SystemExit("rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local, ndev))
-    local = local % ndev                               # gloo logic tests may share one GPU
+    local = local % ndev
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -276,83 +257,83 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    from mv3d_tf_amd import build
-    build.build()
-
-    nstreams = args.streams if args.streams > 0 else (3 if args.batch <= 4 and not args.graph else 1)
-    if nstreams == 1:
-        frs = [Frames(args, rank)]
-    else:
-        frs = [Frames(args, rank, torch.cuda.Stream()) for _ in range(nstreams)]
-    fr = frs[0]
-    graph = None
-    if args.graph and not args.no_graph and nstreams == 1:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fr.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fr.step()
-        run = graph.replay
-    elif nstreams == 1:
-        run = fr.step
-    else:
-        turn = [0]
-
-        def run():
-            frs[turn[0] % nstreams].step()
-            turn[0] += 1
+    from mv3d_tf_amd import build, sharding
+    if rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    t_enq = time.perf_counter() - t0                    # host time to enqueue the steps (eager: must stay < dt)
-    barrier()
-    dt = time.perf_counter() - t0
-    lat = None
-    if nstreams > 1:                                   # the same step alone on one stream: its latency
-        for _ in range(10):
-            fr.step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(100):
-            fr.step()
-        torch.cuda.synchronize()
-        lat = (time.perf_counter() - t1) / 100
-    from mv3d_tf_amd import sharding
+    wl = args.workload
+    batch = args.batch or (2 if wl == "train" else 16)
+    nb = args.batches_per_step or (64 if wl == "train" else 8)
+    ring_n = args.ring or (16 if wl == "train" else 4)
+    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    ring = Ring(args, rank, wl, batch, ring_n, streams)
+    dt, t_enq = timed(ring, nb, args.steps, args.warmup, barrier)
     dt = sharding.max_over_ranks(dt, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
 
     if rank == 0:
-        frames = args.steps * args.batch * world
+        frames = args.steps * nb * batch * world
+        s0 = ring.slots[0]
+        if wl == "train":
+            desc = ("BASELINE configs[2] path-only: batch %d, 3 views; proposal_layer_3d TRAIN cfg (23104 BEV anchors, "
+                    "pre/post-NMS 12000/2000, NMS 0.7) + anchor_target + proposal_target (%d sampled ROIs in batch 0) + FV ROIs "
+                    "+ RoiPool 7x7 fwd+bwd on BEV 76x76x512 / RGB 46x155x512 / FV 8x64x512; %s scores"
+                    % (batch, s0.num_rois, args.variant))
+        else:
+            desc = ("BASELINE configs[4] per-GPU path: batch %d, TEST cfg (pre/post-NMS 6000/300, NMS 0.7) proposal_layer_3d + FV "
+                    "ROIs + RoiPool 7x7 fwd on 3 views, R=%d rows; %s scores" % (batch, s0.num_rois, args.variant))
+        signature = "%s/b%d/r%d/%s" % (wl, batch, s0.num_rois, args.variant)
         res = {
-            "metric": "KITTI-shape frames/sec (RPN+ROI-pool+NMS hot path)",
-            "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] + RoiPool views: proposal_layer_3d (76x76x4=23104 BEV anchors, "
-                                   "%s cfg pre/post-NMS %d/%d, NMS 0.7) -> RoiPool 7x7 BEV 76x76x512 + RGB 46x155x512, "
-                                   "R=%d rows/frame; %s scores" % (args.cfg, CFGS[args.cfg]["RPN_PRE_NMS_TOP_N"],
-                                                                   CFGS[args.cfg]["RPN_POST_NMS_TOP_N"],
-                                                                   fr.out[0].shape[1], args.variant),
-                       "batch_per_gpu": args.batch, "hipgraph": graph is not None,
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "streams": nstreams,
-                       "one_stream_ms_per_step": None if lat is None else round(lat * 1e3, 4), "parallelism": "frames/%d" % world},
-            "kept_rois_frame0": int(fr.out[3][0].item()),
+            "config": {"workload": desc, "batch_per_gpu": batch, "batches_per_step": nb, "frames_per_step_per_gpu": nb * batch,
+                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": False,
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
         }
-        res["roofline"] = roofline(fr)
+        # one batch alone on one stream: the latency of the path
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            s0.run()
+        torch.cuda.synchronize()
+        res["config"]["one_batch_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
+        entries = roofline_entries(ring, wl, signature)
+        dom = max(entries, key=lambda e: e["avg_launch_us"])
+        res["roofline"] = dict(dom, note="dominant kernel of the step; HIP events on the launch stream over launches that "
+                                         "cycle through the stream's ring batches; traffic = PMC pass of this exact "
+                                         "configuration or null")
+        res["roofline_kernels"] = entries
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(fr, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(ring, wl, args.cpu_seconds)
+    if not args.no_secondary and wl == "train":
+        sec = {}
+        del ring
+        torch.cuda.empty_cache()
+        args2 = argparse.Namespace(**vars(args))
+        r2 = Ring(args2, rank, "test", 16, 3, streams[:1])
+        dt2, _ = timed(r2, 3, max(2, args.steps // 2), 2, barrier)
+        dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        if rank == 0:
+            sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
+                                           "views, one stream, eager launches, ring of 3 batches",
+                               "frames_per_s": round(max(2, args.steps // 2) * 3 * 16 * world / dt2, 2),
+                               "roofline_kernels": roofline_entries(r2, "test", "test/b16")}
+        del r2
+        torch.cuda.empty_cache()
+        if args.with_trunk:
+            from mv3d_tf_amd.fast_rcnn import train_mv
+            sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
+        if rank == 0:
+            res["secondary"] = sec
+    if rank == 0:
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

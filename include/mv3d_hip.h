@@ -223,7 +223,8 @@ int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
  * labels (S) i32, bbox_targets (S, 24*num_classes), rois_3d (S,7), S = n_fg + n_bg rows, fg first. */
 typedef struct {
     int32_t num_classes;         /* n_classes = 2: lib/networks/MV3D_train.py:4 */
-    int32_t reserved;
+    int32_t frame_index;         /* batch column written for the appended ground-truth rows: 0 = the reference
+                                    (single-frame batches, :38-44); a batched caller passes the frame's index */
     double fg_thresh;            /* cfg.TRAIN.FG_THRESH    */
     double bg_thresh_hi;         /* cfg.TRAIN.BG_THRESH_HI */
     double bg_thresh_lo;         /* cfg.TRAIN.BG_THRESH_LO */

@@ -46,7 +46,7 @@ class RoiGradView(C.Structure):
 
 class ProposalTargetParams(C.Structure):
     """mv3d_proposal_target_params"""
-    _fields_ = [("num_classes", C.c_int32), ("reserved", C.c_int32), ("fg_thresh", C.c_double),
+    _fields_ = [("num_classes", C.c_int32), ("frame_index", C.c_int32), ("fg_thresh", C.c_double),
                 ("bg_thresh_hi", C.c_double), ("bg_thresh_lo", C.c_double)]
 
 

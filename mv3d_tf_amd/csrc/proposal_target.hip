@@ -20,22 +20,24 @@ struct PtDev {
     const float *rois_bv, *rois_3d;      // (R,5), (R,7)
     const float *gt_bv, *gt_3d;          // (G,5), (G,7)
     int R, G;
+    float gt_frame;                      // batch column of the appended ground-truth rows (0 in the reference)
     double fg_thresh, bg_hi, bg_lo;
     double *max_ov;                      // (R+G)
     int32_t *assign;                     // (R+G)
     int32_t *fg_list, *bg_list;          // (R+G) each
 };
 
-// row r of the candidate set: proposals then ground truth with a 0 batch column (:38-44)
+// row r of the candidate set: proposals then ground truth with a 0 batch column (:38-44); a batched caller sets
+// params.frame_index so that the ground-truth rows of frame b carry b like the frame's proposals do
 __device__ __forceinline__ void cand_bv(const PtDev &d, int r, float o[5])
 {
     if (r < d.R) { for (int j = 0; j < 5; ++j) o[j] = d.rois_bv[5 * r + j]; }
-    else { o[0] = 0.0f; for (int j = 0; j < 4; ++j) o[1 + j] = d.gt_bv[5 * (r - d.R) + j]; }
+    else { o[0] = d.gt_frame; for (int j = 0; j < 4; ++j) o[1 + j] = d.gt_bv[5 * (r - d.R) + j]; }
 }
 __device__ __forceinline__ void cand_3d(const PtDev &d, int r, float o[7])
 {
     if (r < d.R) { for (int j = 0; j < 7; ++j) o[j] = d.rois_3d[7 * r + j]; }
-    else { o[0] = 0.0f; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - d.R) + j]; }
+    else { o[0] = d.gt_frame; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - d.R) + j]; }
 }
 
 __global__ __launch_bounds__(256) void pt_overlap_kernel(PtDev d)
@@ -161,7 +163,7 @@ static void pt_fill(PtDev &d, const PtLayout &L, char *ws, const float *rois_bv,
                     const float *gt_bv, const float *gt_3d, int G, const mv3d_proposal_target_params *p)
 {
     d.rois_bv = rois_bv; d.rois_3d = rois_3d; d.gt_bv = gt_bv; d.gt_3d = gt_3d; d.R = R; d.G = G;
-    d.fg_thresh = p->fg_thresh; d.bg_hi = p->bg_thresh_hi; d.bg_lo = p->bg_thresh_lo;
+    d.fg_thresh = p->fg_thresh; d.bg_hi = p->bg_thresh_hi; d.bg_lo = p->bg_thresh_lo; d.gt_frame = (float)p->frame_index;
     d.max_ov = (double *)(ws + L.o_maxov); d.assign = (int32_t *)(ws + L.o_assign);
     d.fg_list = (int32_t *)(ws + L.o_fg); d.bg_list = (int32_t *)(ws + L.o_bg);
 }

@@ -1,0 +1,325 @@
+"""Device-resident batches of the MV3D hot path (the path BASELINE.json's north_star names), bound once to the C-ABI
+and replayed as plain kernel launches -- what bench.py times and what a training / serving loop drives.
+
+    TrainPathBatch   BASELINE configs[2] path-only, B frames per batch:
+        mv3d_proposal_3d (TRAIN cfg 12000 -> 2000)                          lib/rpn_msr/proposal_layer_tf.py:25-202
+        per frame: mv3d_anchor_target_stage1 / stage2                       lib/rpn_msr/anchor_target_layer_tf.py:21-250
+        per frame: mv3d_proposal_target_stage1 / stage2 (<= 128 sampled)    lib/rpn_msr/proposal_target_layer_tf.py:19-94
+        mv3d_rois_3d_to_fv                                                  (third view; network.py:293-315 is a TODO)
+        mv3d_roi_pool_forward_views  BEV + RGB + FV                         roi_pooling_op.cc:74-190 x 3 layers
+        mv3d_roi_pool_backward_views BEV + RGB + FV                         roi_pooling_op.cc:319-452 x 3 layers
+    TestPathBatch    BASELINE configs[1] / configs[4] path: mv3d_proposal_3d (TEST cfg 6000 -> 300), FV ROIs,
+        RoiPool forward on the three views.
+
+The random subsamplings of the two target layers are ARGUMENTS of the C-ABI (index lists drawn by the caller from the
+numpy global RNG): `setup()` runs the batch once with the host in the loop -- counts to the host,
+`npr.permutation` draws exactly like the numpy-contract callables, index lists back to the device -- and keeps the lists
+resident.  `run()` then replays the batch with NO host synchronisation: every launch reads device-resident inputs only.
+(The dense layers between these calls -- VGG16 trunks, FC head, whose backward produces the RoiPool top_diff -- are not part
+of the path; `top_diff` is a resident synthetic tensor.)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import AnchorTargetParams, ProposalTargetParams, RoiGradView, RoiView, check, lib
+from .rpn_msr.anchor_target_layer_tf import draw_subsamples
+from .rpn_msr.proposal_target_layer_tf import draw_samples
+
+TRAIN_CFG = dict(RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)   # config.py:126-148
+TEST_CFG = dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=5)      # faster_rcnn_end2end.yml:15-20
+# conv5_3 maps at stride 8 (no pool4): 608x608 BEV, 375x1242 RGB, 64x512 FV (BASELINE.json: "512x64 FV")
+VIEW_MAPS = {"bev": (76, 76, 512), "rgb": (46, 155, 512), "fv": (8, 64, 512)}
+VIEWS = ("bev", "rgb", "fv")
+
+
+def _P(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def synth_maps(batch, seed, device, views=VIEWS):
+    """post-ReLU-like NHWC feature maps drawn on the device (~half zeros, rest U(0,2)), one per view"""
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    out = {}
+    for v in views:
+        H, W, Cc = VIEW_MAPS[v]
+        out[v] = torch.clamp(torch.rand((batch, H, W, Cc), generator=g, device=device) * 4.0 - 2.0, min=0.0)
+    return out
+
+
+class _Bound:
+    """a list of (C function, prebuilt argument tuple): run() = the launches of one batch, nothing else"""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []            # ctypes structs / tensors the argument tuples point into
+
+    def add(self, fn, *args):
+        self.calls.append((fn, args))
+
+    def run(self):
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc:
+                check(rc, fn.__name__)
+
+
+class TrainPathBatch:
+    def __init__(self, frames, maps, stream=None, views=VIEWS, num_classes=2, top_diff_seed=0):
+        """frames: list (len B) of synth.rpn_head(..., return_gt=True) tuples (host numpy); maps: {view: (B,H,W,C) device
+        tensor}.  Everything is uploaded / allocated here; setup() must run once before run()."""
+        self.B = len(frames)
+        self.views = tuple(views)
+        self.stream = stream
+        self.maps = maps
+        dev = next(iter(maps.values())).device
+        self.dev = dev
+        t = lambda a, dt=np.float32: torch.as_tensor(np.ascontiguousarray(a, dt)).to(dev)
+        self.prob = t(np.concatenate([f[0] for f in frames]))
+        self.pred = t(np.concatenate([f[1] for f in frames]))
+        self.info = t(np.concatenate([f[2] for f in frames]))
+        self.calib = t(np.stack([f[3] for f in frames]))
+        self.gt = [tuple(t(a) for a in f[4]) for f in frames]            # (gt_bv (G,5), gt_3d (G,7), gt_corners (G,25))
+        self.H, self.W = int(self.prob.shape[1]), int(self.prob.shape[2])
+        self.nc = int(num_classes)
+        self.pparams = ops.proposal_params(TRAIN_CFG)
+        from .fast_rcnn.config import cfg
+        T = cfg.TRAIN
+        self.aparams = AnchorTargetParams(8, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP),
+                                          float(T.RPN_POSITIVE_OVERLAP))
+        self.tparams = [ProposalTargetParams(self.nc, b, float(T.FG_THRESH), float(T.BG_THRESH_HI), float(T.BG_THRESH_LO))
+                        for b in range(self.B)]
+        self.anchor_cap = max(int(T.RPN_BATCHSIZE), 1) * 2
+        self.top_diff_seed = top_diff_seed
+        self.bound = None
+
+    def _sid(self):
+        return self.stream.cuda_stream if self.stream is not None else torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ one pass with the host in the loop
+    def setup(self):
+        """Run the batch once, drawing the subsample index lists from the numpy global RNG (frame order, anchor targets
+        before proposal targets within a frame), and bind the sync-free replay.  Returns self."""
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        with ctx:
+            self._setup()
+        torch.cuda.synchronize()
+        return self
+
+    def _setup(self):
+        dev, B, H, W, nc = self.dev, self.B, self.H, self.W, self.nc
+        L = lib()
+        N = H * W * 4
+        bnd = _Bound()
+        st = C.c_void_p(self._sid())
+        # ---- proposal_layer_3d on the whole batch
+        cap = L.mv3d_proposal_3d_capacity(H, W, C.byref(self.pparams))
+        self.cap = cap
+        _, self.prop = ops.proposal_3d_outputs(B, cap, dev)
+        pws = torch.empty(max(L.mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(self.pparams)), 256), dtype=torch.uint8, device=dev)
+        bv, img, b3, num, status = self.prop
+        a = (_P(self.prob), _P(self.pred), B, H, W, _P(self.info), _P(self.calib), C.byref(self.pparams), _P(bv), _P(img),
+             _P(b3), _P(num), _P(status), _P(pws), C.c_size_t(pws.numel()), st)
+        check(L.mv3d_proposal_3d(*a), "mv3d_proposal_3d")
+        bnd.add(L.mv3d_proposal_3d, *a)
+        bnd.keep += [pws]
+        nums = [int(v) for v in num.cpu().numpy()]
+        if int(status.max().item()) & 1:
+            raise ZeroDivisionError("float division")
+        self.num_proposals = nums
+        # ---- per frame: anchor targets, then proposal targets (the order of the reference's train graph is not
+        # defined across the two py_funcs; this is the one the numpy-contract graph here uses)
+        self.rpn_labels = torch.empty((B, N), dtype=torch.float32, device=dev)
+        self.rpn_targets = torch.empty((B, N, 6), dtype=torch.float32, device=dev)
+        self.anchors = torch.empty((B, self.anchor_cap, 5), dtype=torch.float32, device=dev)
+        self.anchors_3d = torch.empty((B, self.anchor_cap, 7), dtype=torch.float32, device=dev)
+        self.n_anchors = torch.empty((B,), dtype=torch.int32, device=dev)
+        picks, self.S = [], []
+        at_calls, pt_calls = [], []
+        for b in range(B):
+            gt_bv, gt_3d, gt_cnr = self.gt[b]
+            G = gt_bv.shape[0]
+            info_b = self.info[b]
+            aws = torch.empty(max(L.mv3d_anchor_target_workspace_bytes(H, W, G), 256), dtype=torch.uint8, device=dev)
+            cf = torch.empty((32 + N,), dtype=torch.uint8, device=dev)
+            a1 = (H, W, _P(info_b), _P(gt_bv), _P(gt_3d), G, C.byref(self.aparams), _P(self.rpn_labels[b]),
+                  _P(self.rpn_targets[b]), _P(cf[:32]), _P(cf[32:]), _P(aws), C.c_size_t(aws.numel()), st)
+            check(L.mv3d_anchor_target_stage1(*a1), "mv3d_anchor_target_stage1")
+            dis = draw_subsamples(cf, cf[32:], N)
+            lists = [np.zeros(0, np.int32) if d is None else np.ascontiguousarray(d, np.int32) for d in dis]
+            dl = ops.upload_packed(lists, dev) if sum(len(x) for x in lists) else [None, None, None]
+            dl = [x if (x is not None and x.numel()) else None for x in dl]
+            a2 = (H, W, C.byref(self.aparams), _P(dl[0]), len(lists[0]), _P(dl[1]), len(lists[1]), _P(dl[2]), len(lists[2]),
+                  _P(self.rpn_labels[b]), _P(self.anchors[b]), _P(self.anchors_3d[b]), _P(self.n_anchors[b:b + 1]),
+                  self.anchor_cap, _P(aws), C.c_size_t(aws.numel()), st)
+            check(L.mv3d_anchor_target_stage2(*a2), "mv3d_anchor_target_stage2")
+            at_calls += [(L.mv3d_anchor_target_stage1, a1), (L.mv3d_anchor_target_stage2, a2)]
+            bnd.keep += [aws, cf, dl, info_b]
+            # proposal targets of frame b on its num_proposals[b] rows
+            R = nums[b]
+            tws = torch.empty(max(L.mv3d_proposal_target_workspace_bytes(R, G), 256), dtype=torch.uint8, device=dev)
+            counts = torch.empty((4,), dtype=torch.int32, device=dev)
+            p1 = (_P(bv[b]), _P(b3[b]), R, _P(gt_bv), _P(gt_3d), G, C.byref(self.tparams[b]), _P(counts), _P(tws),
+                  C.c_size_t(tws.numel()), st)
+            check(L.mv3d_proposal_target_stage1(*p1), "mv3d_proposal_target_stage1")
+            fg_pick, bg_pick = draw_samples(counts)
+            pl = ops.upload_packed([np.ascontiguousarray(fg_pick, np.int32), np.ascontiguousarray(bg_pick, np.int32)], dev) \
+                if len(fg_pick) + len(bg_pick) else [None, None]
+            pl = [x if (x is not None and x.numel()) else None for x in pl]
+            picks.append((p1, pl, len(fg_pick), len(bg_pick), tws, counts, gt_cnr))
+            self.S.append(len(fg_pick) + len(bg_pick))
+        # ---- sampled-ROI arrays of the whole batch (frame b's rows at [off_b, off_b + S_b), foreground first)
+        St = sum(self.S)
+        self.rois = {"bev": torch.empty((St, 5), dtype=torch.float32, device=dev),
+                     "rgb": torch.empty((St, 5), dtype=torch.float32, device=dev),
+                     "fv": torch.empty((St, 5), dtype=torch.float32, device=dev)}
+        self.rois_3d = torch.empty((St, 7), dtype=torch.float32, device=dev)
+        self.labels = torch.empty((St, 1), dtype=torch.int32, device=dev)
+        self.bbox_targets = torch.empty((St, 24 * nc), dtype=torch.float32, device=dev)
+        off = 0
+        for b, (p1, pl, n_fg, n_bg, tws, counts, gt_cnr) in enumerate(picks):
+            gt_bv, gt_3d, _ = self.gt[b]
+            G = gt_bv.shape[0]
+            S = n_fg + n_bg
+            p2 = (_P(bv[b]), _P(b3[b]), nums[b], _P(gt_bv), _P(gt_3d), _P(gt_cnr), G, _P(self.calib[b]), C.byref(self.tparams[b]),
+                  _P(pl[0]), n_fg, _P(pl[1]), n_bg, _P(self.rois["bev"][off:off + S]), _P(self.rois["rgb"][off:off + S]),
+                  _P(self.labels[off:off + S]), _P(self.bbox_targets[off:off + S]), _P(self.rois_3d[off:off + S]), _P(tws),
+                  C.c_size_t(tws.numel()), st)
+            check(L.mv3d_proposal_target_stage2(*p2), "mv3d_proposal_target_stage2")
+            pt_calls += [(L.mv3d_proposal_target_stage1, p1), (L.mv3d_proposal_target_stage2, p2)]
+            bnd.keep += [pl, tws, counts]
+            off += S
+        for fn, args in at_calls + pt_calls:
+            bnd.add(fn, *args)
+        # ---- third view's ROIs, RoiPool forward + backward on every view
+        self.tops, self.top_diff, self.bottom_diff = {}, {}, {}
+        g = torch.Generator(device=dev).manual_seed(1000 + int(self.top_diff_seed))
+        fwd = (RoiView * len(self.views))()
+        bwd = (RoiGradView * len(self.views))()
+        if "fv" in self.views:
+            a = (_P(self.rois_3d), St, _P(self.rois["fv"]), st)
+            check(L.mv3d_rois_3d_to_fv(*a), "mv3d_rois_3d_to_fv")
+            bnd.add(L.mv3d_rois_3d_to_fv, *a)
+        for k, v in enumerate(self.views):
+            m = self.maps[v]
+            Bm, Hm, Wm, Cm = m.shape
+            top = torch.empty((St, 7, 7, Cm), dtype=torch.float32, device=dev)
+            am = torch.empty((St, 7, 7, Cm), dtype=torch.int32, device=dev)
+            td = torch.rand((St, 7, 7, Cm), generator=g, device=dev) * 2.0 - 1.0
+            bd = torch.empty_like(m)
+            self.tops[v], self.top_diff[v], self.bottom_diff[v] = (top, am), td, bd
+            fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
+            bwd[k] = RoiGradView(bd.data_ptr(), self.rois[v].data_ptr(), td.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
+        af = (len(self.views), fwd, 7, 7, st)
+        ab = (len(self.views), bwd, 7, 7, st)
+        check(L.mv3d_roi_pool_forward_views(*af), "mv3d_roi_pool_forward_views")
+        check(L.mv3d_roi_pool_backward_views(*ab), "mv3d_roi_pool_backward_views")
+        bnd.add(L.mv3d_roi_pool_forward_views, *af)
+        bnd.add(L.mv3d_roi_pool_backward_views, *ab)
+        bnd.keep += [fwd, bwd]
+        self.fwd_args, self.bwd_args = af, ab
+        self.num_rois = St
+        self.bound = bnd
+
+    # ------------------------------------------------------------------ replay, no host sync
+    def run(self):
+        self.bound.run()
+
+    def roi_forward(self):
+        check(lib().mv3d_roi_pool_forward_views(*self.fwd_args), "mv3d_roi_pool_forward_views")
+
+    def roi_backward(self):
+        check(lib().mv3d_roi_pool_backward_views(*self.bwd_args), "mv3d_roi_pool_backward_views")
+
+    # algorithmic HBM bytes: maps once + rois + (top f32 + argmax i32) / (grad + argmax) + map write
+    def roi_forward_bytes(self):
+        return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 8 for v in self.views)
+
+    def roi_backward_bytes(self):
+        return sum(self.num_rois * 49 * self.maps[v].shape[3] * 8 + self.num_rois * 20 + self.maps[v].numel() * 4 for v in self.views)
+
+    def snapshot(self):
+        """host copies of every output of the batch (for replay == setup checks)"""
+        ts = [*self.prop, self.rpn_labels, self.rpn_targets, self.n_anchors, self.rois_3d, self.labels, self.bbox_targets]
+        ts += [self.rois[v] for v in ("bev", "rgb", "fv")]
+        for v in self.views:
+            ts += [self.tops[v][0], self.tops[v][1], self.bottom_diff[v]]
+        return [x.cpu().numpy().copy() for x in ts]
+
+
+class TestPathBatch:
+    """proposal_layer_3d (TEST cfg) -> FV ROIs -> RoiPool forward on the views, B frames; R = B * 300 ROI rows
+    (rows past a frame's count are zero boxes, as the fixed-shape serving graph pools them)."""
+
+    def __init__(self, frames, maps, stream=None, views=VIEWS):
+        self.B = len(frames)
+        self.views = tuple(views)
+        self.stream = stream
+        self.maps = maps
+        dev = next(iter(maps.values())).device
+        self.dev = dev
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+        self.prob = t(np.concatenate([f[0] for f in frames]))
+        self.pred = t(np.concatenate([f[1] for f in frames]))
+        self.info = t(np.concatenate([f[2] for f in frames]))
+        self.calib = t(np.stack([f[3] for f in frames]))
+        self.pparams = ops.proposal_params(TEST_CFG)
+        self.bound = None
+
+    def setup(self):
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        with ctx:
+            dev, B = self.dev, self.B
+            H, W = int(self.prob.shape[1]), int(self.prob.shape[2])
+            L = lib()
+            sid = self.stream.cuda_stream if self.stream is not None else torch.cuda.current_stream().cuda_stream
+            st = C.c_void_p(sid)
+            bnd = _Bound()
+            cap = L.mv3d_proposal_3d_capacity(H, W, C.byref(self.pparams))
+            _, self.prop = ops.proposal_3d_outputs(B, cap, dev)
+            pws = torch.empty(max(L.mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(self.pparams)), 256), dtype=torch.uint8, device=dev)
+            bv, img, b3, num, status = self.prop
+            a = (_P(self.prob), _P(self.pred), B, H, W, _P(self.info), _P(self.calib), C.byref(self.pparams), _P(bv), _P(img),
+                 _P(b3), _P(num), _P(status), _P(pws), C.c_size_t(pws.numel()), st)
+            bnd.add(L.mv3d_proposal_3d, *a)
+            R = B * cap
+            self.rois = {"bev": bv.view(-1, 5), "rgb": img.view(-1, 5)}
+            if "fv" in self.views:
+                self.rois["fv"] = torch.empty((R, 5), dtype=torch.float32, device=dev)
+                bnd.add(L.mv3d_rois_3d_to_fv, _P(b3.view(-1, 7)), R, _P(self.rois["fv"]), st)
+            fwd = (RoiView * len(self.views))()
+            self.tops = {}
+            for k, v in enumerate(self.views):
+                m = self.maps[v]
+                Bm, Hm, Wm, Cm = m.shape
+                top = torch.empty((R, 7, 7, Cm), dtype=torch.float32, device=dev)
+                am = torch.empty((R, 7, 7, Cm), dtype=torch.int32, device=dev)
+                self.tops[v] = (top, am)
+                fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, R, Hm, Wm, Cm)
+            self.fwd_args = (len(self.views), fwd, 7, 7, st)
+            bnd.add(L.mv3d_roi_pool_forward_views, *self.fwd_args)
+            bnd.keep += [pws, fwd]
+            self.num_rois = R
+            self.bound = bnd
+            bnd.run()
+        torch.cuda.synchronize()
+        return self
+
+    def run(self):
+        self.bound.run()
+
+    def roi_forward(self):
+        check(lib().mv3d_roi_pool_forward_views(*self.fwd_args), "mv3d_roi_pool_forward_views")
+
+    def roi_forward_bytes(self):
+        return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 8 for v in self.views)
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

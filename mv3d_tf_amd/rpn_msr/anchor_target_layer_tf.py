@@ -16,30 +16,11 @@ from .._lib import AnchorTargetParams
 from ..fast_rcnn.config import cfg
 
 
-def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_stride=[8, ], anchor_scales=[1.0, 1.0]):
-    """Returns (rpn_labels (N,), rpn_bbox_targets (N,6), anchors (M,5), anchors_3d (M,7)), f32."""
-    assert rpn_cls_score.shape[0] == 1, 'Only single item batches are supported'
-    as_numpy = not isinstance(rpn_cls_score, torch.Tensor)
-    H, W = int(rpn_cls_score.shape[1]), int(rpn_cls_score.shape[2])
-    dev = rpn_cls_score.device if not as_numpy else torch.device("cuda", cfg.GPU_ID)
-    if as_numpy:
-        # numpy contract: the three small inputs travel in one upload
-        gt_bv, gt_3d, info = ops.upload_packed([np.asarray(gt_boxes, np.float32), np.asarray(gt_boxes_3d, np.float32),
-                                                np.asarray(im_info, np.float32).reshape(-1)[:3]], dev)
-    else:
-        gt_bv = ops._dev(gt_boxes, device=dev)
-        gt_3d = ops._dev(gt_boxes_3d, device=dev)
-        info = ops._dev(im_info, device=dev).reshape(-1)[:3].contiguous()
+def draw_subsamples(cf, fg_hi, N):
+    """The three random subsamplings of anchor_target_layer_tf.py:146-183, drawn from the numpy GLOBAL RNG in the
+    reference's order given stage 1's device results (`cf` = counts + per-foreground flags in one buffer).  Returns the
+    positions to disable in the fg list, the first bg list and the second bg list (None = no subsampling)."""
     T = cfg.TRAIN
-    stride = int(np.asarray(_feat_stride).reshape(-1)[0])
-    params = AnchorTargetParams(stride, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP),
-                                float(T.RPN_POSITIVE_OVERLAP))
-    N = H * W * 4
-    cap = max(int(T.RPN_BATCHSIZE), 1) * 2
-    spec = [((N,), torch.float32), ((N, 6), torch.float32), ((cap, 5), torch.float32), ((cap, 7), torch.float32),
-            ((1,), torch.int32)]
-    pack, (labels, targets, anchors, anchors_3d, n_anc) = ops.packed_views(spec, dev)   # all outputs: one buffer
-    labels, targets, counts, fg_hi, ws, cf = ops.anchor_target_stage1(H, W, info, gt_bv, gt_3d, params, labels, targets)
     # host sync #1: the counts and (usually all of) the foreground flags in one copy
     first = min(32 + N, 4096)
     head = cf[:first].cpu().numpy()
@@ -69,6 +50,34 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_str
     dis_bg2 = None
     if n_low > num_bg2:
         dis_bg2 = npr.permutation(n_low)[:n_low - num_bg2]
+    return dis_fg, dis_bg1, dis_bg2
+
+
+def anchor_target_layer(rpn_cls_score, gt_boxes, gt_boxes_3d, im_info, _feat_stride=[8, ], anchor_scales=[1.0, 1.0]):
+    """Returns (rpn_labels (N,), rpn_bbox_targets (N,6), anchors (M,5), anchors_3d (M,7)), f32."""
+    assert rpn_cls_score.shape[0] == 1, 'Only single item batches are supported'
+    as_numpy = not isinstance(rpn_cls_score, torch.Tensor)
+    H, W = int(rpn_cls_score.shape[1]), int(rpn_cls_score.shape[2])
+    dev = rpn_cls_score.device if not as_numpy else torch.device("cuda", cfg.GPU_ID)
+    if as_numpy:
+        # numpy contract: the three small inputs travel in one upload
+        gt_bv, gt_3d, info = ops.upload_packed([np.asarray(gt_boxes, np.float32), np.asarray(gt_boxes_3d, np.float32),
+                                                np.asarray(im_info, np.float32).reshape(-1)[:3]], dev)
+    else:
+        gt_bv = ops._dev(gt_boxes, device=dev)
+        gt_3d = ops._dev(gt_boxes_3d, device=dev)
+        info = ops._dev(im_info, device=dev).reshape(-1)[:3].contiguous()
+    T = cfg.TRAIN
+    stride = int(np.asarray(_feat_stride).reshape(-1)[0])
+    params = AnchorTargetParams(stride, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP),
+                                float(T.RPN_POSITIVE_OVERLAP))
+    N = H * W * 4
+    cap = max(int(T.RPN_BATCHSIZE), 1) * 2
+    spec = [((N,), torch.float32), ((N, 6), torch.float32), ((cap, 5), torch.float32), ((cap, 7), torch.float32),
+            ((1,), torch.int32)]
+    pack, (labels, targets, anchors, anchors_3d, n_anc) = ops.packed_views(spec, dev)   # all outputs: one buffer
+    labels, targets, counts, fg_hi, ws, cf = ops.anchor_target_stage1(H, W, info, gt_bv, gt_3d, params, labels, targets)
+    dis_fg, dis_bg1, dis_bg2 = draw_subsamples(cf, fg_hi, N)
     ops.anchor_target_stage2(H, W, params, dis_fg, dis_bg1, dis_bg2, labels, ws, cap, out=(anchors, anchors_3d, n_anc))
     if as_numpy:
         h_labels, h_targets, h_anchors, h_anchors_3d, h_n = ops.unpack_host(pack, spec)   # ONE device-to-host copy

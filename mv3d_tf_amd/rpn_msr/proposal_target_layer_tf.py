@@ -14,6 +14,20 @@ from .._lib import ProposalTargetParams
 from ..fast_rcnn.config import cfg
 
 
+def draw_samples(counts):
+    """The two `npr.choice(..., replace=False)` draws of _sample_rois_3d (:246-269) from the numpy GLOBAL RNG given stage 1's
+    device counts: positions in the fg / bg candidate lists."""
+    T = cfg.TRAIN
+    _, n_fg, n_bg, _ = (int(v) for v in counts.cpu().numpy())                    # the one host sync
+    rois_per_image = T.BATCH_SIZE // 1                                            # :55-57
+    fg_rois_per_image = np.round(T.FG_FRACTION * rois_per_image)
+    fg_n = int(min(fg_rois_per_image, n_fg))                                      # :251
+    fg_pick = npr.permutation(n_fg)[:fg_n] if n_fg > 0 else np.zeros(0, np.int64)   # :253-255
+    bg_n = int(min(rois_per_image - fg_n, n_bg))                                  # :264-266
+    bg_pick = npr.permutation(n_bg)[:bg_n] if n_bg > 0 else np.zeros(0, np.int64)   # :268-269
+    return fg_pick, bg_pick
+
+
 def proposal_target_layer_3d(rpn_rois_bv, rpn_rois_3d, gt_boxes_bv, gt_boxes_3d, gt_boxes_corners, calib, _num_classes):
     """Returns (rois_bv (S,5) f32, rois_img (S,5) f32, labels (S,1) i32, bbox_targets (S,24*nc) f32,
     rois_3d (S,7) f32), S <= cfg.TRAIN.BATCH_SIZE, foreground rows first."""
@@ -39,13 +53,7 @@ def proposal_target_layer_3d(rpn_rois_bv, rpn_rois_3d, gt_boxes_bv, gt_boxes_3d,
     nc = int(_num_classes)
     params = ProposalTargetParams(nc, 0, float(T.FG_THRESH), float(T.BG_THRESH_HI), float(T.BG_THRESH_LO))
     counts, ws = ops.proposal_target_stage1(rois_bv, rois_3d, gt_bv, gt_3d, params)
-    _, n_fg, n_bg, _ = (int(v) for v in counts.cpu().numpy())                    # the one host sync
-    rois_per_image = T.BATCH_SIZE // 1                                            # :55-57
-    fg_rois_per_image = np.round(T.FG_FRACTION * rois_per_image)
-    fg_n = int(min(fg_rois_per_image, n_fg))                                      # :251
-    fg_pick = npr.permutation(n_fg)[:fg_n] if n_fg > 0 else np.zeros(0, np.int64)   # :253-255
-    bg_n = int(min(rois_per_image - fg_n, n_bg))                                  # :264-266
-    bg_pick = npr.permutation(n_bg)[:bg_n] if n_bg > 0 else np.zeros(0, np.int64)   # :268-269
+    fg_pick, bg_pick = draw_samples(counts)
     if as_numpy:
         spec = ops.proposal_target_spec(len(fg_pick) + len(bg_pick), nc)
         pack, views = ops.packed_views(spec, dev)

@@ -175,3 +175,72 @@ def test_project_edge_boxes_through_device_projection(gpu):
     assert rois_img.shape == (n + 1, 5)
     assert np.array_equal(rois_img[1:, 1:], g["img"].astype(np.float32))                     # int32 -> f32 like :88-92
     assert np.array_equal(out[4].cpu().numpy()[1:, 1:], g["boxes3d"], equal_nan=True)
+
+
+def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle):
+    """BASELINE configs[2] path-only step as bench.py runs it (mv3d_tf_amd.hot_path.TrainPathBatch): batch 2, TRAIN cfg
+    12000 -> 2000, anchor targets, <= 128 sampled ROIs per frame, FV ROIs, RoiPool forward + backward on three views.
+    setup() (host RNG in the loop) and the sync-free replay give identical bytes, equal to the oracle run frame by
+    frame with the same numpy seed (draw for draw), the ROI batch column being the frame index."""
+    torch, ops = gpu
+    from mv3d_tf_amd import hot_path
+    B = 2
+    frames = [synth.rpn_head(900 + b, 76, 76, "peaky", return_gt=True) for b in range(B)]
+    maps = hot_path.synth_maps(B, 5, torch.device("cuda"))
+    batch = hot_path.TrainPathBatch(frames, maps, top_diff_seed=3)
+    np.random.seed(11)
+    batch.setup()
+    first = batch.snapshot()
+    for t in (batch.rpn_labels, batch.rois_3d, batch.bbox_targets, batch.tops["bev"][0], batch.bottom_diff["rgb"]):
+        t.fill_(7.0)                                            # the replay must rewrite everything
+    batch.run()
+    batch.run()
+    torch.cuda.synchronize()
+    again = batch.snapshot()
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b, equal_nan=True)
+    # ---- oracle, frame by frame, same seed and draw order
+    np.random.seed(11)
+    off = 0
+    maps_h = {v: m.cpu().numpy() for v, m in maps.items()}
+    exp = {v: [] for v in hot_path.VIEWS}
+    for b in range(B):
+        prob, pred, info, calib, (gt_bv, gt_3d, gt_cnr) = frames[b]
+        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ], cfg={"TRAIN": TRAIN_CFG})
+        n = bv.shape[0]
+        assert batch.num_proposals[b] == n
+        lab, tg, anc, anc3 = oracle.anchor_target_layer(np.zeros((1, 76, 76, 8), np.float32), gt_bv, gt_3d, info, [8, ])
+        assert np.array_equal(batch.rpn_labels[b].cpu().numpy(), lab) and np.array_equal(batch.rpn_targets[b].cpu().numpy(), tg)
+        m = int(batch.n_anchors[b].item())
+        assert m == anc.shape[0] and np.array_equal(batch.anchors[b, :m].cpu().numpy(), anc)
+        assert np.array_equal(batch.anchors_3d[b, :m].cpu().numpy(), anc3)
+        r_bv, r_img, r_lab, r_tg, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2)
+        S = r_bv.shape[0]
+        assert batch.S[b] == S and 0 < S <= 128
+        r_bv[:, 0] = b; r_img[:, 0] = b; r_3d[:, 0] = b           # batched extension: the frame index
+        sl = slice(off, off + S)
+        assert np.array_equal(batch.rois["bev"][sl].cpu().numpy(), r_bv) and np.array_equal(batch.rois["rgb"][sl].cpu().numpy(), r_img)
+        assert np.array_equal(batch.labels[sl].cpu().numpy(), r_lab) and np.array_equal(batch.bbox_targets[sl].cpu().numpy(), r_tg)
+        assert np.array_equal(batch.rois_3d[sl].cpu().numpy(), r_3d)
+        exp["bev"].append(r_bv); exp["rgb"].append(r_img); exp["fv"].append(oracle.rois_3d_to_fv(r_3d))
+        off += S
+    assert off == batch.num_rois
+    for v in hot_path.VIEWS:
+        rois = np.concatenate(exp[v])
+        assert np.array_equal(batch.rois[v].cpu().numpy(), rois), v
+        o_top, o_am = oracle.roi_pool(maps_h[v], rois, 7, 7, 0.125)
+        assert np.array_equal(batch.tops[v][0].cpu().numpy(), o_top) and np.array_equal(batch.tops[v][1].cpu().numpy(), o_am), v
+        want = oracle.roi_pool_grad(maps_h[v], rois, o_am, batch.top_diff[v].cpu().numpy(), 7, 7, 0.125)
+        assert np.array_equal(batch.bottom_diff[v].cpu().numpy(), want), v
+    # the TEST-cfg batch (configs[1] / configs[4] path) binds and replays too
+    tb = hot_path.TestPathBatch([f[:4] for f in frames], maps).setup()
+    tb.run()
+    torch.cuda.synchronize()
+    for b in range(B):
+        bv, img, b3 = oracle.proposal_layer_3d(*frames[b][:4], "TEST", [8, ], cfg={"TEST": TEST_CFG})
+        n = bv.shape[0]
+        assert int(tb.prop[3][b].item()) == n and np.array_equal(tb.prop[0][b, :n, 1:].cpu().numpy(), bv[:, 1:])
+    fv_want = oracle.rois_3d_to_fv(tb.prop[2].view(-1, 7).cpu().numpy())
+    assert np.array_equal(tb.rois["fv"].cpu().numpy(), fv_want)
+    o_top, o_am = oracle.roi_pool(maps_h["fv"], fv_want, 7, 7, 0.125)
+    assert np.array_equal(tb.tops["fv"][0].cpu().numpy(), o_top) and np.array_equal(tb.tops["fv"][1].cpu().numpy(), o_am)
