@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--ring", type=int, default=0, help="distinct resident batches per GPU (default: 16 train, 4 test)")
     ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step (default: 64 train, 8 test)")
     ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="graph: every ring batch is captured once into a hipGraph on its stream and replayed (one host call "
+                         "per batch; eager enqueueing of a batch's ~28 launches costs the host more than the GPU needs to run "
+                         "them once three batches are in flight); eager: plain in-order launches")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -104,11 +108,27 @@ class Ring:
             if k == 0:
                 self.host_frames = frames
         self.cursor = 0
+        self.play = [s.run for s in self.slots]
+        if args.launch == "graph":
+            self.graphs = []
+            for s in self.slots:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s.stream):           # the bound launches target s.stream = the capture stream
+                    s.run()
+                self.graphs.append(g)
+            torch.cuda.synchronize()
+
+            def player(g, st):
+                def play():
+                    with torch.cuda.stream(st):                       # CUDAGraph.replay() launches on the current stream
+                        g.replay()
+                return play
+            self.play = [player(g, s.stream) for g, s in zip(self.graphs, self.slots)]
 
     def run(self, nbatches):
         n = len(self.slots)
         for _ in range(nbatches):
-            self.slots[self.cursor % n].run()
+            self.play[self.cursor % n]()
             self.cursor += 1
 
 
@@ -176,13 +196,14 @@ def cpu_baseline(ring, workload, seconds):
     cfg = {key: hot_path.TRAIN_CFG if workload == "train" else hot_path.TEST_CFG}
     score = np.zeros((1, 76, 76, 8), np.float32)
     lock = threading.Lock()
+    YML_TRAIN = dict(oracle.TRAIN, BG_THRESH_LO=0.0, BG_THRESH_HI=0.5, FG_THRESH=0.7)      # faster_rcnn_end2end.yml:10-12
 
     def frame(rng_guard):
         bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, key, [8, ], cfg=cfg)
         if workload == "train":
             with rng_guard:                                    # the numpy global RNG is not thread-safe
                 oracle.anchor_target_layer(score, gt_bv, gt_3d, info, [8, ])
-                r_bv, r_img, _, _, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2)
+                r_bv, r_img, _, _, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2, train=YML_TRAIN)
             rois = {"bev": r_bv, "rgb": r_img, "fv": oracle.rois_3d_to_fv(r_3d)}
         else:
             rois = {"bev": bv, "rgb": img, "fv": oracle.rois_3d_to_fv(b3)}
@@ -258,6 +279,10 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     from mv3d_tf_amd import build, sharding
+    from mv3d_tf_amd.fast_rcnn.config import apply_end2end_yml
+    # the configuration the reference trains / tests MV3D with (experiments/scripts/mv3d.sh --cfg
+    # experiments/cfgs/faster_rcnn_end2end.yml): 128 sampled ROIs per frame, bg = IoU in [0, 0.5), fg >= 0.7
+    apply_end2end_yml()
     if rank == 0:
         build.build()
     if dist is not None:
@@ -295,7 +320,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": batch, "batches_per_step": nb, "frames_per_step_per_gpu": nb * batch,
-                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": False,
+                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": args.launch == "graph",
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
         }
         # one batch alone on one stream: the latency of the path

@@ -160,8 +160,14 @@ typedef struct {
     float spatial_scale;
     int32_t batch_size, num_rois, height, width, channels;
 } mv3d_roi_grad_view;
+size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height,
+                                              int pooled_width);
+/* workspace (optional, 256-B aligned): with at least mv3d_roi_pool_backward_workspace_bytes() bytes the call runs as two
+ * launches -- per-pixel candidate index, then a gather that reads every (roi, bin) record slice on one XCD -- which is the
+ * fast path (C % 64 == 0, pooled sizes <= 15).  Its first 256 bytes must be ZERO on the first call (the kernels leave them
+ * zero again: no memset node per call).  With workspace == NULL the call needs no scratch memory and is slower. */
 int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
-                                 void *stream);
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ third (front-view) ROI
  * rois_3d_dev (R,7) [b,x,y,z,l,w,h] -> rois_fv_dev (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical front-view map

@@ -83,7 +83,8 @@ _SIGS = {
     "mv3d_rpn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_rcnn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
-    "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P]),
+    "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
+    "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)

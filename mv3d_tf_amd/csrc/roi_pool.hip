@@ -14,6 +14,7 @@
 //            then only the containing ROIs' candidate bins, 16-byte loads over the channels.
 //            No atomics, no dependence on scheduling.
 #include <float.h>
+#include <stdlib.h>
 #include <math.h>
 #include "common.h"
 
@@ -381,6 +382,425 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const float *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast RoiPoolGrad for C % 64 == 0 (C = 512: the MV3D maps), all views of a step in ONE launch.
+//
+// Same gather and the same f32 summation order as above (ROIs ascending, ph, pw ascending), re-shaped around what
+// bounded the kernel above on the training workload (3 views x 2 frames x 128 sampled ROIs: 228 us, 0.11 of the HBM
+// roofline):
+//   * XCD / L2: a wave there owned all C channels of a pixel and neighbouring pixels ran on different XCDs, so every
+//     (roi, bin) record was pulled over the fabric by up to 8 private L2s.  Here the CHANNELS are sliced like in the
+//     forward: workgroup b works on channels [64 (b % nsl), +64) -- with nsl = 8 slice s only ever lives on XCD s, its
+//     L2 sees 1/8 of every record, and the re-reads of a record (each is a candidate of 1.4 - 3.4 pixels on the
+//     training workload) hit that L2.
+//   * geometry: ~80 % of the pixels lie in no ROI at all and the rest in a handful.  A workgroup = one row segment of
+//     16 (or 4) pixels x one slice first filters the ROIs by frame, row and column span (256 ROIs per pass, the f32
+//     divides only for survivors) into an ordered LDS list, typically 0 - 30 entries; the pixels then only walk that.
+//   * critical path: a wave handles ONE pixel at a time with one channel per lane -- per candidate two dword loads,
+//     a compare, a select and an add, four candidates in flight -- so the pixel under the most bins (328 on the 8 x 64
+//     front-view map) costs ~2.5 k instructions instead of ~8 k.
+// Adding +0.0f for a non-matching channel is bit-neutral: the running sum starts at +0.0f and a sum that started at
+// +0.0f is never -0.0f.
+#define BW_THREADS 256
+#define BW_CHUNK 256                 // ROIs filtered per pass
+#define BW_CAND 512                  // candidate records a wave lists before it drains them
+#define BW_MAXPXG 64                 // pixels of a row segment per workgroup, at most
+struct RoiGradViewDev {
+    const float *top_diff, *rois;
+    const int *argmax;
+    float *bottom_diff;
+    float scale;
+    int B, R, H, W, C;
+    int pxg;                         // pixels per workgroup (a row segment), <= BW_MAXPXG
+    int gpr;                         // segments per row = ceil(W / pxg)
+    int nsl;                         // channel slices = C / 64
+    unsigned first_block;
+};
+struct RoiGradPack { RoiGradViewDev v[MV3D_MAX_ROI_VIEWS]; int n, PH, PW; };
+
+template <int U>
+__device__ __forceinline__ float bwd_drain_records(const int *cand, const int t0, const int ncand, const int *__restrict__ am,
+                                                   const float *__restrict__ td, const int C, const int want, float a)
+{
+    int am_v[U];
+    float td_v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long o = (long long)__builtin_amdgcn_readfirstlane(cand[min(t0 + u, ncand - 1)]) * C;
+        am_v[u] = am[o];
+        td_v[u] = td[o];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (t0 + u < ncand) a += (am_v[u] == want) ? td_v[u] : 0.0f;
+    return a;
+}
+
+__global__ __launch_bounds__(BW_THREADS) void roi_pool_bwd_sliced_kernel(RoiGradPack p)
+{
+    __shared__ int s_roi[BW_CHUNK], s_rsw[BW_CHUNK], s_rew[BW_CHUNK], s_prow[BW_CHUNK];
+    __shared__ float s_bw[BW_CHUNK];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_cand[4][BW_CAND];
+    extern __shared__ float s_carry[];                   // [pxg][64] partial sums between ROI passes (only when R > BW_CHUNK)
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
+    const RoiGradViewDev &v = p.v[k];
+    const int PH = p.PH, PW = p.PW, H = v.H, W = v.W, C = v.C, R = v.R;
+    const unsigned b = blockIdx.x - v.first_block;
+    const int slice = (int)(b % (unsigned)v.nsl);
+    const unsigned g = b / (unsigned)v.nsl;
+    const int w0 = (int)(g % (unsigned)v.gpr) * v.pxg;
+    const int npx = min(v.pxg, W - w0);                  // pixels of this segment
+    const unsigned gh = g / (unsigned)v.gpr;
+    const int h = (int)(gh % (unsigned)H), n = (int)(gh / (unsigned)H);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = slice * 64 + lane;
+    const int *am = v.argmax + c;
+    const float *td = v.top_diff + c;
+    float *out = v.bottom_diff + (((long long)n * H + h) * W + w0) * C + c;
+    int *cand = s_cand[wave];
+    const int esub = max(1, min(64, BW_CAND / (PH * PW)));      // entries whose bins always fit the candidate list
+    const int npass = max(1, (R + BW_CHUNK - 1) / BW_CHUNK);
+
+    for (int pass = 0; pass < npass; ++pass) {
+        // ---- pass part 1: ROIs of this frame that contain row h and touch the columns of the segment, in ROI order
+        if (pass) __syncthreads();                         // the previous list is fully consumed
+        const int r = pass * BW_CHUNK + (int)threadIdx.x;
+        bool ok = false;
+        int rsw = 0, rew = 0, prow = 0;
+        float bw = 1.0f;
+        if (r < R) {
+            const float *roi = v.rois + 5 * (long long)r;
+            const RoiGeom q = roi_geom(roi, v.scale);
+            // roi_pooling_op.cc:392-403: batch match, containment on the unclamped rounded ROI
+            ok = ((int)roi[0] == n) && h >= q.rsh && h <= q.reh && q.rew >= w0 && q.rsw < w0 + npx;
+            if (ok) {
+                const int rh = max(q.reh - q.rsh + 1, 1), rw = max(q.rew - q.rsw + 1, 1);
+                const float bh = (float)rh / (float)PH;
+                // :423-426 (identical to the CUDA form roi_pooling_op_gpu.cu.cc:169-172)
+                int phs = (int)floorf((float)(h - q.rsh) / bh), phe = (int)ceilf((float)(h - q.rsh + 1) / bh);
+                phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+                ok = phe > phs;
+                rsw = q.rsw; rew = q.rew; prow = phs | (phe << 8);
+                bw = (float)rw / (float)PW;
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        int nlist = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int t = s_wcnt[q]; if (q < wave) pos += t; nlist += t; }
+        if (ok) { s_roi[pos] = r; s_rsw[pos] = rsw; s_rew[pos] = rew; s_prow[pos] = prow; s_bw[pos] = bw; }
+        __syncthreads();
+        const bool last = (pass == npass - 1);
+        // ---- part 2: pixel j of the segment belongs to wave j % 4 (neighbouring, similarly loaded pixels spread over the
+        // waves); one pixel at a time, one channel per lane
+        for (int j = wave; j < npx; j += 4) {
+            const int w = w0 + j;
+            const int want = (h * W + w) * C + c;
+            float a = pass ? s_carry[j * 64 + lane] : 0.0f;
+            for (int e0 = 0; e0 < nlist; e0 += 64) {
+                // lane i: entry e0 + i -> its candidate bins for pixel (h, w)
+                const int e = e0 + lane;
+                int nb = 0, phs = 0, pws = 0, nw = 1, rec0 = 0;
+                if (e < nlist) {
+                    const int xs = s_rsw[e], xe = s_rew[e];
+                    if (w >= xs && w <= xe) {
+                        const float fbw = s_bw[e];
+                        int x0 = (int)floorf((float)(w - xs) / fbw), x1 = (int)ceilf((float)(w - xs + 1) / fbw);
+                        x0 = min(max(x0, 0), PW); x1 = min(max(x1, 0), PW);
+                        if (x1 > x0) {
+                            const int pr = s_prow[e];
+                            phs = pr & 255; pws = x0; nw = x1 - x0;
+                            nb = ((pr >> 8) - phs) * nw;
+                            rec0 = s_roi[e] * PH * PW;
+                        }
+                    }
+                }
+                if (!__any(nb > 0)) continue;
+                int tot = nb;                                     // inclusive prefix over the lanes
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { const int t = __shfl_up(tot, m); if (lane >= m) tot += t; }
+                const int all = __builtin_amdgcn_readfirstlane(__shfl(tot, 63));
+                // entries are taken in pieces whose candidates fit the list: all 64 at once when they do (the normal
+                // case), `esub` at a time otherwise
+                const int step = (all <= BW_CAND) ? 64 : esub;
+                for (int s0 = 0; s0 < 64; s0 += step) {
+                    const int before = (s0 == 0) ? 0 : __shfl(tot, s0 - 1);
+                    const int upto = __shfl(tot, min(s0 + step, 64) - 1);
+                    const int ncand = __builtin_amdgcn_readfirstlane(upto - before);
+                    if (ncand == 0) continue;
+                    if (lane >= s0 && lane < s0 + step && nb > 0) {
+                        int o = tot - nb - before;                // exclusive prefix inside the piece
+                        for (int ph = phs; ph < phs + nb / nw; ++ph)
+                            for (int pw = pws; pw < pws + nw; ++pw) cand[o++] = rec0 + ph * PW + pw;
+                    }
+                    LDS_FENCE();
+                    // drain in list order = reference order roi -> ph -> pw; 16 (then 4) records in flight: the walk of a
+                    // pixel is a chain of dependent memory round trips, and the hottest pixel sets the kernel's time
+                    int t0 = 0;
+                    for (; t0 + 16 <= ncand; t0 += 16) a = bwd_drain_records<16>(cand, t0, ncand, am, td, C, want, a);
+                    for (; t0 < ncand; t0 += 4) a = bwd_drain_records<4>(cand, t0, ncand, am, td, C, want, a);
+                    LDS_FENCE();                                  // the list is reused by the next piece
+                }
+            }
+            if (last) __builtin_nontemporal_store(a, out + (long long)j * C);
+            else s_carry[j * 64 + lane] = a;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Indexed RoiPoolGrad (used when the caller passes a workspace): the same gather, split into
+//   roi_bwd_index_kernel   ONCE per launch and per pixel (not per channel slice): which (roi, bin) records are candidates
+//                          of pixel (n, h, w), in reference order roi -> ph -> pw.  A workgroup = 16 pixels of a row: it
+//                          zero-fills its pixels of bottom_diff (streaming stores, issued first), filters the ROIs (frame,
+//                          row, column span), evaluates the (pixel, roi) pairs in parallel (the f32 divides of
+//                          roi_pooling_op.cc:423-426), sizes the pixels' lists, takes one slab of the candidate pool and one
+//                          of the item list with two atomicAdds, writes the lists and one item (pixel, offset, count) per
+//                          pixel that has candidates -- ~80 % of the pixels have none and are finished here.
+//   roi_bwd_gather_kernel  a fixed grid; wave = (item, 64-channel slice): walks the item's list with wave-uniform record
+//                          indices, 16 records (2 x 16 dword loads per lane) in flight, adds in list order and overwrites
+//                          the pixel's slice.  Slice s of every record is only ever read by XCD s.  No LDS, no barrier.
+// Why two kernels: a launch is paced by the workgroup dispatcher (~2.5 workgroups / ns on this chip: a kernel with one
+// 4-wave workgroup per 4 pixels and slice, 54 k workgroups, takes 20 us to do NOTHING), and a wave that walks pixels one
+// after the other pays every pixel's memory round trips in sequence (the sliced kernel above: 102 us on the training
+// batch).  Here the per-pixel work that is not the sum itself happens once, in 2.4 k workgroups, and the sums run as ~34 k
+// independent waves.
+// Workspace: [0, 256) header {pool cursor, item count, ticket}: zero on entry, left zero by the gather kernel's last
+// workgroup; then the item list (int4 per pixel of all views), then the candidate pool.  Pool bound per ROI: the sum over
+// the rows of (phe - phs) is <= PH + 2 rows + 3 (floor / ceil slack), likewise over the columns.
+#define BWI_PIX 16
+#define BWG_GROUPS 192                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
+struct RoiGradIdxPack { int4 *items; int *pool; int *header; int *seg_tot, *seg_ne; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; };
+
+// FILL = false: zero-fill + sizes (seg_tot / seg_ne per segment); FILL = true: slab offsets from the sizes of the preceding
+// segments (a plain sum: the sizing launch is complete), items and candidate lists.  No atomics on global memory, no state
+// that has to be zero on entry.
+template <bool FILL>
+__global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGradIdxPack ix)
+{
+    __shared__ int s_red[8];
+    __shared__ int s_roi[BW_CHUNK], s_rsw[BW_CHUNK], s_rew[BW_CHUNK], s_prow[BW_CHUNK];
+    __shared__ float s_bw[BW_CHUNK];
+    __shared__ unsigned char s_nb[BW_CHUNK][BWI_PIX], s_xr[BW_CHUNK][BWI_PIX];
+    __shared__ int s_off[BW_CHUNK][BWI_PIX];
+    __shared__ int s_wcnt[4], s_cnt[BWI_PIX], s_base[BWI_PIX], s_run[BWI_PIX];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blockIdx.x >= ix.first_block[j]) k = j;
+    const RoiGradViewDev &v = p.v[k];
+    const int PH = p.PH, PW = p.PW, H = v.H, W = v.W, R = v.R, C = v.C;
+    const unsigned g = blockIdx.x - ix.first_block[k];
+    const int gpr = ix.gpr[k];
+    const int w0 = (int)(g % (unsigned)gpr) * BWI_PIX;
+    const int npx = min(BWI_PIX, W - w0);
+    const unsigned gh = g / (unsigned)gpr;
+    const int h = (int)(gh % (unsigned)H), n = (int)(gh / (unsigned)H);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = threadIdx.x & (BWI_PIX - 1), q = threadIdx.x / BWI_PIX;      // pixel of the segment, entry stripe
+    const int npass = (R + BW_CHUNK - 1) / BW_CHUNK;
+    const long long pix0 = ((long long)n * H + h) * W + w0;
+    if (!FILL) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have candidates): the
+        // segment's npx * C floats are contiguous
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * C);
+        const int n4 = npx * (C / 4);
+        for (int t = threadIdx.x; t < n4; t += 256) __builtin_nontemporal_store(z, dst + t);
+    }
+    if (threadIdx.x < BWI_PIX) { s_cnt[threadIdx.x] = 0; s_run[threadIdx.x] = 0; }
+    int nlist = 0;
+
+    // filter one pass of ROIs into the ordered LDS list, then evaluate every (entry, pixel) pair: number of candidate
+    // bins and the column range
+    auto build = [&](const int pass) -> int {
+        __syncthreads();
+        const int r = pass * BW_CHUNK + (int)threadIdx.x;
+        bool ok = false;
+        int rsw = 0, rew = 0, prow = 0;
+        float bw = 1.0f;
+        if (r < R) {
+            const float *roi = v.rois + 5 * (long long)r;
+            const RoiGeom t = roi_geom(roi, v.scale);
+            ok = ((int)roi[0] == n) && h >= t.rsh && h <= t.reh && t.rew >= w0 && t.rsw < w0 + npx;   // roi_pooling_op.cc:392-403
+            if (ok) {
+                const int rh = max(t.reh - t.rsh + 1, 1), rw = max(t.rew - t.rsw + 1, 1);
+                const float bh = (float)rh / (float)PH;
+                int phs = (int)floorf((float)(h - t.rsh) / bh), phe = (int)ceilf((float)(h - t.rsh + 1) / bh);   // :423-426
+                phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+                ok = phe > phs;
+                rsw = t.rsw; rew = t.rew; prow = phs | (phe << 8);
+                bw = (float)rw / (float)PW;
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        int nl = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int cw = s_wcnt[t]; if (t < wave) pos += cw; nl += cw; }
+        if (ok) { s_roi[pos] = r; s_rsw[pos] = rsw; s_rew[pos] = rew; s_prow[pos] = prow; s_bw[pos] = bw; }
+        __syncthreads();
+        int local = 0;
+        const int w = w0 + j;
+        for (int e = q; e < nl; e += 256 / BWI_PIX) {
+            int nb = 0, xr = 0;
+            const int xs = s_rsw[e], xe = s_rew[e];
+            if (j < npx && w >= xs && w <= xe) {
+                const float fbw = s_bw[e];
+                int x0 = (int)floorf((float)(w - xs) / fbw), x1 = (int)ceilf((float)(w - xs + 1) / fbw);
+                x0 = min(max(x0, 0), PW); x1 = min(max(x1, 0), PW);
+                if (x1 > x0) {
+                    const int pr = s_prow[e];
+                    nb = ((pr >> 8) - (pr & 255)) * (x1 - x0);
+                    xr = x0 | (x1 << 4);
+                }
+            }
+            s_nb[e][j] = (unsigned char)nb;
+            s_xr[e][j] = (unsigned char)xr;
+            local += nb;
+        }
+        if (local) atomicAdd(&s_cnt[j], local);
+        return nl;
+    };
+
+    for (int pass = 0; pass < npass; ++pass) nlist = build(pass);
+    __syncthreads();
+    if (!FILL) {
+        if (threadIdx.x < 64) {
+            const int c = (lane < BWI_PIX) ? s_cnt[lane] : 0;
+            int tot = c;
+#pragma unroll
+            for (int m = 1; m < BWI_PIX; m <<= 1) tot += __shfl_xor(tot, m);
+            const unsigned long long ne = __ballot(c > 0);
+            if (lane == 0) { ix.seg_tot[blockIdx.x] = tot; ix.seg_ne[blockIdx.x] = __popcll(ne); }
+        }
+        return;
+    }
+    {   // slab offsets = sums over the preceding segments' sizes
+        int a = 0, b = 0;
+        for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) { a += ix.seg_tot[t]; b += ix.seg_ne[t]; }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (lane == 0) { s_red[wave] = a; s_red[4 + wave] = b; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {                      // sizes -> offsets inside the segment's slabs; items
+        const int base0 = s_red[0] + s_red[1] + s_red[2] + s_red[3], ibase = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+        const int c = (lane < BWI_PIX) ? s_cnt[lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int m = 1; m < BWI_PIX; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
+        const unsigned long long ne = __ballot(c > 0);
+        if (lane < BWI_PIX) s_base[lane] = base0 + inc - c;
+        if (c > 0) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, c, k);
+        if (lane == 0 && blockIdx.x == gridDim.x - 1) ix.header[1] = ibase + __popcll(ne);    // number of items of the launch
+    }
+    __syncthreads();
+    for (int pass = 0; pass < npass; ++pass) {
+        if (npass > 1) { nlist = build(pass); }
+        __syncthreads();
+        if (threadIdx.x < BWI_PIX) {                              // per pixel: where each entry's bins go, in entry order
+            int run = s_run[threadIdx.x];
+            for (int e = 0; e < nlist; ++e) { s_off[e][threadIdx.x] = run; run += s_nb[e][threadIdx.x]; }
+            s_run[threadIdx.x] = run;
+        }
+        __syncthreads();
+        for (int e = q; e < nlist; e += 256 / BWI_PIX) {
+            const int nb = s_nb[e][j];
+            if (nb == 0) continue;
+            const int xr = s_xr[e][j], x0 = xr & 15, x1 = xr >> 4, pr = s_prow[e];
+            int *dst = ix.pool + s_base[j] + s_off[e][j];
+            const int rec0 = s_roi[e] * PH * PW;
+            for (int ph = pr & 255; ph < (pr >> 8); ++ph)
+                for (int pw = x0; pw < x1; ++pw) *dst++ = (rec0 + ph * PW + pw) * C * 4;     // the record's byte offset
+        }
+    }
+}
+
+// records u0 .. u0 + W - 1 of the 64 whose byte offsets sit in the lanes of `cur`: per record one v_readlane (-> SGPR) and two
+// buffer loads whose scalar offset is that SGPR, then compare / select / add -- six instructions; W x 2 loads per lane in flight
+template <int W, bool MASKED>
+__device__ __forceinline__ float bwd_drain_lanes(const int cur, const int u0, const int m, const __amdgpu_buffer_rsrc_t ra,
+                                                 const __amdgpu_buffer_rsrc_t rt, const int voff, const int want, float a)
+{
+    int am_v[W];
+    float td_v[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const int so = __builtin_amdgcn_readlane(cur, MASKED ? min(u0 + u, 63) : u0 + u);
+        am_v[u] = __builtin_amdgcn_raw_buffer_load_b32(ra, voff, so, 0);
+        td_v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, so, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u)
+        if (!MASKED || u0 + u < m) a += (am_v[u] == want) ? td_v[u] : 0.0f;
+    return a;
+}
+
+// A persistent grid sized to what the chip holds at once; wave = (item, 64-channel slice); slice s of every record is only
+// ever read by XCD s (workgroup b -> slice b % nsl).  A wave walks its items i, i + stride, ...; an item costs three
+// dependent memory round trips (item -> record offsets -> records), so the walk is software-pipelined: while item n's
+// records are in flight, the offsets of item n + 1 and the header of item n + 2 are already requested.
+__global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl)
+{
+    const int slice = (int)(blockIdx.x % (unsigned)nsl);
+    const int lane = threadIdx.x & 63;
+    const int stride = (int)(gridDim.x / (unsigned)nsl) * 4;
+    const int n_items = __builtin_amdgcn_readfirstlane(ix.header[1]);
+    const int c = slice * 64 + lane;
+    int i = (int)(blockIdx.x / (unsigned)nsl) * 4 + (int)(threadIdx.x >> 6);
+    if (i >= n_items) return;
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int4 it = ix.items[i];
+    int4 it1 = (i + stride < n_items) ? ix.items[i + stride] : zero4;
+    int idx = ix.pool[it.y + min(lane, it.z - 1)];
+    const int voff = lane * 4;
+    for (; i < n_items; i += stride) {
+        const int pix = __builtin_amdgcn_readfirstlane(it.x), off = __builtin_amdgcn_readfirstlane(it.y);
+        const int cnt = __builtin_amdgcn_readfirstlane(it.z), k = __builtin_amdgcn_readfirstlane(it.w);
+        const bool more = i + stride < n_items;                        // wave-uniform
+        const int4 nxt = it1;
+        if (i + 2 * stride < n_items) it1 = ix.items[i + 2 * stride];
+        int idx1 = 0;
+        if (more) idx1 = ix.pool[__builtin_amdgcn_readfirstlane(nxt.y) + min(lane, __builtin_amdgcn_readfirstlane(nxt.z) - 1)];
+        const RoiGradViewDev &v = p.v[k];
+        const int C = v.C;
+        const int want = (pix % (v.H * v.W)) * C + c;
+        const int *cand = ix.pool + off;
+        // the slice lives in the (wave-uniform) base address, the lane in the vector offset, the record's byte offset is
+        // the scalar offset of the load
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(v.argmax + slice * 64), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64), 0, 0x7fffffff, 0x00020000);
+        float a = 0.0f;
+        // 64 record offsets per vector load (lane l holds candidate t0 + l); the next 64 are requested before the current
+        // ones are consumed
+        for (int t0 = 0; t0 < cnt; t0 += 64) {
+            const int cur = idx;
+            if (t0 + 64 < cnt) idx = cand[min(t0 + 64 + lane, cnt - 1)];
+            const int m = min(64, cnt - t0);
+            int u0 = 0;
+            for (; u0 + 32 <= m; u0 += 32) a = bwd_drain_lanes<32, false>(cur, u0, m, ra, rt, voff, want, a);
+            if (u0 + 16 <= m) { a = bwd_drain_lanes<16, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 16; }
+            if (u0 + 8 <= m) { a = bwd_drain_lanes<8, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 8; }
+            if (u0 + 4 <= m) { a = bwd_drain_lanes<4, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 4; }
+            if (u0 < m) a = bwd_drain_lanes<4, true>(cur, u0, m, ra, rt, voff, want, a);
+        }
+        __builtin_nontemporal_store(a, v.bottom_diff + (long long)pix * C + c);
+        it = nxt; idx = idx1;
+    }
+}
+
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // Bins per workgroup (passes x bins per pass).  A small job (one frame: 2 x 14 700 bins) wants many
@@ -432,10 +852,10 @@ extern "C" int mv3d_roi_pool_forward(const float *bottom_data, float spatial_sca
     return mv3d_launch_status();
 }
 
-extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale, int batch_size, int num_rois,
-                                      int height, int width, int channels, int pooled_height, int pooled_width,
-                                      const float *bottom_rois, float *bottom_diff, const int32_t *argmax_data,
-                                      void *stream)
+static int roi_pool_backward_generic(const float *top_diff, float spatial_scale, int batch_size, int num_rois,
+                                     int height, int width, int channels, int pooled_height, int pooled_width,
+                                     const float *bottom_rois, float *bottom_diff, const int32_t *argmax_data,
+                                     void *stream)
 {
     if (batch_size <= 0 || num_rois < 0 || height <= 0 || width <= 0 || channels <= 0 || pooled_height <= 0 ||
         pooled_width <= 0 || !bottom_diff || (num_rois > 0 && (!bottom_rois || !top_diff || !argmax_data)))
@@ -515,15 +935,134 @@ extern "C" int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *v
     return mv3d_launch_status();
 }
 
-extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
-                                            void *stream)
+static bool bwd_fast_ok(int channels, int pooled_height, int pooled_width, int height, int width, int batch_size)
 {
-    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
+    return channels % 64 == 0 && channels / 64 <= 64 && (long long)pooled_height * pooled_width <= BW_CAND &&
+           pooled_height < 256 && pooled_width < 256 && (long long)batch_size * height * width < (1ll << 26);
+}
+
+static size_t bwd_pool_entries(const mv3d_roi_grad_view &w, int PH, int PW)
+{
+    return (size_t)w.num_rois * (size_t)(PH + 2 * w.height + 3) * (size_t)(PW + 2 * w.width + 3);
+}
+
+extern "C" size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height,
+                                                         int pooled_width)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0) return 0;
+    size_t total = MV3D_ALIGN;
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_grad_view &w = views[k];
-        const int rc = mv3d_roi_pool_backward(w.top_diff, w.spatial_scale, w.batch_size, w.num_rois, w.height, w.width, w.channels,
-                                              pooled_height, pooled_width, w.bottom_rois, w.bottom_diff, w.argmax_data, stream);
-        if (rc != MV3D_OK) return rc;
+        if (w.batch_size <= 0 || w.height <= 0 || w.width <= 0 || w.num_rois < 0) return 0;
+        total += mv3d_align_up((size_t)w.batch_size * w.height * w.width * sizeof(int4));
+        total += 2 * mv3d_align_up((size_t)w.batch_size * w.height * ((w.width + BWI_PIX - 1) / BWI_PIX) * sizeof(int) * MV3D_MAX_ROI_VIEWS);
+        total += mv3d_align_up(bwd_pool_entries(w, pooled_height, pooled_width) * sizeof(int));
     }
-    return MV3D_OK;
+    return total + MV3D_ALIGN;
+}
+
+extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0)
+        return MV3D_ERR_INVALID_ARG;
+    bool fast = true;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[k];
+        if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_diff ||
+            (w.num_rois > 0 && (!w.bottom_rois || !w.top_diff || !w.argmax_data)) ||
+            (long long)w.height * w.width * w.channels > 0x7fffffffLL ||
+            (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
+            return MV3D_ERR_INVALID_ARG;
+        fast = fast && bwd_fast_ok(w.channels, pooled_height, pooled_width, w.height, w.width, w.batch_size);
+    }
+    if (workspace && ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    if (!fast) {                                          // generic shapes: one launch of the generic kernel per view
+        for (int k = 0; k < num_views; ++k) {
+            const mv3d_roi_grad_view &w = views[k];
+            const int rc = roi_pool_backward_generic(w.top_diff, w.spatial_scale, w.batch_size, w.num_rois, w.height, w.width,
+                                                     w.channels, pooled_height, pooled_width, w.bottom_rois, w.bottom_diff,
+                                                     w.argmax_data, stream);
+            if (rc != MV3D_OK) return rc;
+        }
+        return MV3D_OK;
+    }
+    RoiGradPack p;
+    p.n = num_views; p.PH = pooled_height; p.PW = pooled_width;
+    bool same_c = true;
+    long long all_pix = 0;
+    for (int k = 0; k < num_views; ++k) {
+        same_c = same_c && views[k].channels == views[0].channels && views[k].channels % 256 == 0 && aligned16(views[k].bottom_diff) &&
+                 aligned16(views[k].top_diff) && aligned16(views[k].argmax_data);
+        all_pix += (long long)views[k].batch_size * views[k].height * views[k].width;
+    }
+    bool small = true;                                   // record byte offsets are 31-bit scalars in the gather kernel
+    for (int k = 0; k < num_views; ++k)
+        small = small && (long long)views[k].num_rois * pooled_height * pooled_width * views[k].channels * 4 < 0x7fffffffLL;
+    const bool indexed = workspace && same_c && small && all_pix < 0x7fffffffLL && pooled_height <= 15 && pooled_width <= 15 &&
+                         pooled_height * pooled_width <= 255 &&
+                         workspace_bytes >= mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width);
+    unsigned blocks = 0;
+    size_t carry = 0;
+    RoiGradIdxPack ix = {};
+    unsigned iblocks = 0;
+    char *ws = (char *)workspace;
+    size_t pool_entries = 0, n_items = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[k];
+        RoiGradViewDev &v = p.v[k];
+        v.top_diff = w.top_diff; v.rois = w.bottom_rois; v.argmax = w.argmax_data; v.bottom_diff = w.bottom_diff;
+        v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
+        v.nsl = w.channels / 64;
+        v.first_block = blocks;
+        if (indexed) {
+            v.pxg = 4; v.gpr = 0;
+            n_items += (size_t)w.batch_size * w.height * w.width;
+            ix.first_block[k] = iblocks;
+            ix.gpr[k] = (w.width + BWI_PIX - 1) / BWI_PIX;
+            iblocks += (unsigned)((long long)w.batch_size * w.height * ix.gpr[k]);
+            pool_entries += bwd_pool_entries(w, pooled_height, pooled_width);
+            continue;
+        }
+        // sliced kernel: a workgroup = one row segment x one slice.  Long segments amortise the ROI filter and the launch
+        // of a workgroup over many (mostly empty) pixels; small maps get short segments so that the launch still fills the chip
+        const long long rows = (long long)w.batch_size * w.height * v.nsl;
+        long long gpr = (w.width + BW_MAXPXG - 1) / BW_MAXPXG;
+        if (rows * gpr < 1024) gpr = (1024 + rows - 1) / rows;
+        if (gpr > w.width) gpr = w.width;
+        v.pxg = (int)((w.width + gpr - 1) / gpr);
+        v.gpr = (w.width + v.pxg - 1) / v.pxg;
+        blocks += (unsigned)(rows * v.gpr);
+        if (w.num_rois > BW_CHUNK && (size_t)v.pxg * 64 * sizeof(float) > carry) carry = (size_t)v.pxg * 64 * sizeof(float);
+    }
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) { p.v[k] = p.v[0]; ix.first_block[k] = 0; ix.gpr[k] = 1; }
+    if (indexed) {
+        size_t o = MV3D_ALIGN;
+        ix.header = (int *)ws;
+        ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
+        ix.seg_ne = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
+        ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
+        ix.pool = (int *)(ws + o);
+        if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
+        const int nsl = views[0].channels / 64;
+        hipLaunchKernelGGL(roi_bwd_index_kernel<false>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
+        hipLaunchKernelGGL(roi_bwd_index_kernel<true>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
+        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;   // tuning hook
+        hipLaunchKernelGGL(roi_bwd_gather_kernel, dim3((unsigned)(groups * nsl)), dim3(256), 0, (hipStream_t)stream, p, ix, nsl);
+        return mv3d_launch_status();
+    }
+    hipLaunchKernelGGL(roi_pool_bwd_sliced_kernel, dim3(blocks), dim3(BW_THREADS), carry, (hipStream_t)stream, p);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale, int batch_size, int num_rois,
+                                      int height, int width, int channels, int pooled_height, int pooled_width,
+                                      const float *bottom_rois, float *bottom_diff, const int32_t *argmax_data,
+                                      void *stream)
+{
+    mv3d_roi_grad_view w;
+    w.bottom_diff = bottom_diff; w.bottom_rois = bottom_rois; w.top_diff = top_diff; w.argmax_data = argmax_data;
+    w.spatial_scale = spatial_scale; w.batch_size = batch_size; w.num_rois = num_rois; w.height = height; w.width = width;
+    w.channels = channels;
+    return mv3d_roi_pool_backward_views(1, &w, pooled_height, pooled_width, nullptr, 0, stream);
 }

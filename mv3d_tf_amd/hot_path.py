@@ -213,7 +213,9 @@ class TrainPathBatch:
             fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
             bwd[k] = RoiGradView(bd.data_ptr(), self.rois[v].data_ptr(), td.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
         af = (len(self.views), fwd, 7, 7, st)
-        ab = (len(self.views), bwd, 7, 7, st)
+        bws = torch.zeros(max(L.mv3d_roi_pool_backward_workspace_bytes(len(self.views), bwd, 7, 7), 256), dtype=torch.uint8, device=dev)
+        ab = (len(self.views), bwd, 7, 7, _P(bws), C.c_size_t(bws.numel()), st)
+        bnd.keep += [bws]
         check(L.mv3d_roi_pool_forward_views(*af), "mv3d_roi_pool_forward_views")
         check(L.mv3d_roi_pool_backward_views(*ab), "mv3d_roi_pool_backward_views")
         bnd.add(L.mv3d_roi_pool_forward_views, *af)

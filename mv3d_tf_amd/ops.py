@@ -80,12 +80,13 @@ def unpack_host(pack, spec):
     return outs
 
 
-def _workspace(nbytes, device, tag):
-    """Reused per (device, stream, tag) so hot calls never allocate (buffers are 256-B aligned)."""
+def _workspace(nbytes, device, tag, zero=False):
+    """Reused per (device, stream, tag) so hot calls never allocate (buffers are 256-B aligned).  zero=True: zero-filled
+    when it is (re)allocated (workspaces whose header the kernels expect zero on first use and leave zero)."""
     key = (str(device), torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        buf = (torch.zeros if zero else torch.empty)(max(nbytes, 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
@@ -321,7 +322,9 @@ def roi_pool_backward_views(views, pooled_height, pooled_width, outs=None):
         arr[k] = RoiGradView(out.data_ptr(), rois.data_ptr(), top_diff.data_ptr(), argmax.data_ptr(), float(scale), B,
                              rois.shape[0], H, W, Cc)
         res.append(out)
-    check(lib().mv3d_roi_pool_backward_views(len(views), arr, pooled_height, pooled_width, _stream()),
+    nbytes = lib().mv3d_roi_pool_backward_workspace_bytes(len(views), arr, pooled_height, pooled_width)
+    ws = _workspace(nbytes, views[0][0].device, "roi_bwd", zero=True)
+    check(lib().mv3d_roi_pool_backward_views(len(views), arr, pooled_height, pooled_width, _ptr(ws), ws.numel(), _stream()),
           "mv3d_roi_pool_backward_views")
     return res
 

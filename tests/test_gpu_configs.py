@@ -177,19 +177,30 @@ def test_project_edge_boxes_through_device_projection(gpu):
     assert np.array_equal(out[4].cpu().numpy()[1:, 1:], g["boxes3d"], equal_nan=True)
 
 
-def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle):
+@pytest.mark.parametrize("yml", [False, True])
+def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle, yml):
     """BASELINE configs[2] path-only step as bench.py runs it (mv3d_tf_amd.hot_path.TrainPathBatch): batch 2, TRAIN cfg
     12000 -> 2000, anchor targets, <= 128 sampled ROIs per frame, FV ROIs, RoiPool forward + backward on three views.
     setup() (host RNG in the loop) and the sync-free replay give identical bytes, equal to the oracle run frame by
     frame with the same numpy seed (draw for draw), the ROI batch column being the frame index."""
     torch, ops = gpu
     from mv3d_tf_amd import hot_path
+    from mv3d_tf_amd.fast_rcnn.config import cfg
     B = 2
     frames = [synth.rpn_head(900 + b, 76, 76, "peaky", return_gt=True) for b in range(B)]
     maps = hot_path.synth_maps(B, 5, torch.device("cuda"))
-    batch = hot_path.TrainPathBatch(frames, maps, top_diff_seed=3)
-    np.random.seed(11)
-    batch.setup()
+    saved = {k: cfg.TRAIN[k] for k in ("BG_THRESH_LO", "BG_THRESH_HI", "FG_THRESH")}
+    o_train = dict(oracle.TRAIN)
+    if yml:                                                     # experiments/cfgs/faster_rcnn_end2end.yml:10-12 (bench.py's setting)
+        o_train.update(BG_THRESH_LO=0.0, BG_THRESH_HI=0.5, FG_THRESH=0.7)
+        cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.BG_THRESH_HI, cfg.TRAIN.FG_THRESH = 0.0, 0.5, 0.7
+    try:
+        batch = hot_path.TrainPathBatch(frames, maps, top_diff_seed=3)
+        np.random.seed(11)
+        batch.setup()
+    finally:
+        for k, v in saved.items():
+            cfg.TRAIN[k] = v
     first = batch.snapshot()
     for t in (batch.rpn_labels, batch.rois_3d, batch.bbox_targets, batch.tops["bev"][0], batch.bottom_diff["rgb"]):
         t.fill_(7.0)                                            # the replay must rewrite everything
@@ -214,9 +225,9 @@ def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle):
         m = int(batch.n_anchors[b].item())
         assert m == anc.shape[0] and np.array_equal(batch.anchors[b, :m].cpu().numpy(), anc)
         assert np.array_equal(batch.anchors_3d[b, :m].cpu().numpy(), anc3)
-        r_bv, r_img, r_lab, r_tg, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2)
+        r_bv, r_img, r_lab, r_tg, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2, train=o_train)
         S = r_bv.shape[0]
-        assert batch.S[b] == S and 0 < S <= 128
+        assert batch.S[b] == S and 0 < S <= 128 and (S == 128 or not yml)
         r_bv[:, 0] = b; r_img[:, 0] = b; r_3d[:, 0] = b           # batched extension: the frame index
         sl = slice(off, off + S)
         assert np.array_equal(batch.rois["bev"][sl].cpu().numpy(), r_bv) and np.array_equal(batch.rois["rgb"][sl].cpu().numpy(), r_img)

@@ -1,31 +1,78 @@
 #!/usr/bin/env python3
-"""Kernel-only timing of RoiPool forward/backward through the C-ABI with preallocated buffers."""
-import ctypes as C, os, sys
+"""Kernel-only timing of the RoiPool launches on the bench's training batches (BASELINE configs[2] path: batch 2,
+128 sampled ROIs / frame), per view and for all views, cycling over several resident batches so that consecutive
+launches touch different maps / records.  `R=0` rows = the kernels' floor (zero fill + ROI filtering only)."""
+import ctypes as C
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from mv3d_tf_amd import synth
-from mv3d_tf_amd._lib import lib, check
-P = lambda t: C.c_void_p(t.data_ptr())
-def ev(fn, it=50):
-    for _ in range(5): fn()
+import numpy as np
+import torch
+
+from mv3d_tf_amd import build, hot_path, synth
+from mv3d_tf_amd._lib import RoiGradView, RoiView, check, lib
+from mv3d_tf_amd.fast_rcnn.config import apply_end2end_yml
+
+build.build()
+apply_end2end_yml()
+NB = int(os.environ.get("NB", "6"))
+np.random.seed(3)
+dev = torch.device("cuda")
+batches = []
+for k in range(NB):
+    frames = [synth.rpn_head(100000 + 2 * k + b, 76, 76, "peaky", return_gt=True) for b in range(2)]
+    batches.append(hot_path.TrainPathBatch(frames, hot_path.synth_maps(2, k, dev), top_diff_seed=k).setup())
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ev(fns, rounds=8):
+    for f in fns:
+        f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(it): fn()
-    b.record(); torch.cuda.synchronize()
-    return a.elapsed_time(b) / it * 1e3
-for (H, W, name) in ((76, 76, "BEV"), (46, 155, "RGB")):
-    data = torch.as_tensor(synth.feature_map(7, H, W, 512, 1)).cuda()
-    for R in (0, 30, 128, 300, 2000):
-        rng = np.random.RandomState(R)
-        x1 = rng.uniform(0, W * 8 - 40, max(R, 1)); y1 = rng.uniform(0, H * 8 - 20, max(R, 1))
-        rois = np.stack([np.zeros(max(R, 1)), x1, y1, x1 + rng.uniform(10, 120, max(R, 1)), y1 + rng.uniform(10, 60, max(R, 1))], 1).astype(np.float32)
-        rt = torch.as_tensor(rois).cuda()
-        top = torch.empty((max(R, 1), 7, 7, 512), device="cuda"); am = torch.empty((max(R, 1), 7, 7, 512), dtype=torch.int32, device="cuda")
-        out = torch.empty_like(data)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        f = lambda: check(lib().mv3d_roi_pool_forward(P(data), C.c_float(0.125), 1, R, H, W, 512, 7, 7, P(rt), P(top), P(am), st), "f")
-        b = lambda: check(lib().mv3d_roi_pool_backward(P(top), C.c_float(0.125), 1, R, H, W, 512, 7, 7, P(rt), P(out), P(am), st), "b")
-        f(); tf = ev(f) if R else 0.0; tb = ev(b)
-        alg = R * 49 * 512 * 8 + H * W * 512 * 4
-        print(f"{name} R={R:5d}: fwd {tf:7.1f} us  bwd {tb:7.1f} us  bwd alg {alg/1e6:7.1f} MB -> {alg/tb/1e3:7.0f} GB/s")
+    for _ in range(rounds):
+        for f in fns:
+            f()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (rounds * len(fns)) * 1e3
+
+
+def bwd_call(bt, views, R=None):
+    arr = (RoiGradView * len(views))()
+    for k, v in enumerate(views):
+        m = bt.maps[v]
+        B, H, W, Cc = m.shape
+        arr[k] = RoiGradView(bt.bottom_diff[v].data_ptr(), bt.rois[v].data_ptr(), bt.top_diff[v].data_ptr(),
+                             bt.tops[v][1].data_ptr(), 0.125, B, bt.num_rois if R is None else R, H, W, Cc)
+    if os.environ.get("NOWS"):
+        return lambda: check(lib().mv3d_roi_pool_backward_views(len(views), arr, 7, 7, None, 0, st), "bwd")
+    ws = torch.zeros(lib().mv3d_roi_pool_backward_workspace_bytes(len(views), arr, 7, 7), dtype=torch.uint8, device=dev)
+    return lambda: check(lib().mv3d_roi_pool_backward_views(len(views), arr, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "bwd")
+
+
+def fwd_call(bt, views):
+    arr = (RoiView * len(views))()
+    for k, v in enumerate(views):
+        m = bt.maps[v]
+        B, H, W, Cc = m.shape
+        arr[k] = RoiView(m.data_ptr(), bt.rois[v].data_ptr(), bt.tops[v][0].data_ptr(), bt.tops[v][1].data_ptr(), 0.125, B,
+                         bt.num_rois, H, W, Cc)
+    return lambda: check(lib().mv3d_roi_pool_forward_views(len(views), arr, 7, 7, st), "fwd")
+
+
+R = batches[0].num_rois
+CASES = (("bev",), ("rgb",), ("fv",), ("bev", "rgb", "fv"))
+if os.environ.get("ONLY"):
+    CASES = (tuple(os.environ["ONLY"].split("+")),)
+for views in CASES:
+    maps_b = sum(batches[0].maps[v].numel() * 4 for v in views)
+    rec_b = sum(R * 49 * batches[0].maps[v].shape[3] * 8 for v in views)
+    tf = ev([fwd_call(b, views) for b in batches])
+    tb = ev([bwd_call(b, views) for b in batches])
+    t0 = ev([bwd_call(b, views, 0) for b in batches])
+    alg = maps_b + rec_b
+    print("%-12s R=%d: fwd %6.1f us (%5.0f GB/s)  bwd %6.1f us (%5.0f GB/s)  bwd with R=0 %6.1f us (zero fill %5.0f GB/s)"
+          % ("+".join(views), R, tf, alg / tf / 1e3, tb, alg / tb / 1e3, t0, maps_b / t0 / 1e3))
