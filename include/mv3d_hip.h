@@ -258,6 +258,17 @@ int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_d
  * 8 = reflectance of the last point of the highest slice (numpy fancy-assignment order). */
 int mv3d_point_cloud_2_top(const float *points_dev, int num_points, float *top_dev, void *stream);
 
+/* KITTI label rows -> ground-truth encodings (lib/datasets/kitti_mv3d.py:240-272 with computeCorners3D, camera_to_lidar_cnr,
+ * lidar_cnr_to_3d, lidar_3d_to_bv of lib/utils/transform.py:441-465,502-524,172-187,113-142), one thread per labelled object:
+ *   box_cam_dev (G,6) f32 [tx,ty,tz,l,w,h] (label columns 11-13, 10, 9, 8), cos_sin_dev (G,2) f64 = cos / sin of rotation_y,
+ *   inv_rot_dev (9) f32 = inverse of the 3x3 rotation part of Tr_velo_to_cam, tr_velo_to_cam_dev (12) f32
+ *   -> corners_cam_dev (G,24), corners_lidar_dev (G,24) [x0..7,y0..7,z0..7], boxes_3d_dev (G,6) LIDAR box, boxes_bv_dev (G,4)
+ *   BEV pixel box, all f32 as the roidb stores them.  (cos / sin and the 3x3 inverse are numpy / LAPACK calls on a handful of
+ *   host scalars in the reference and stay on the host next to the text parsing.) */
+int mv3d_gt_encode(const float *box_cam_dev, const double *cos_sin_dev, int num_objects, const float *inv_rot_dev,
+                   const float *tr_velo_to_cam_dev, float *corners_cam_dev, float *corners_lidar_dev,
+                   float *boxes_3d_dev, float *boxes_bv_dev, void *stream);
+
 /* Test-time tail of box_detect (lib/fast_rcnn/test_mv.py:240-261): rois_3d_dev (R,7) = rois[2],
  * bbox_pred_dev (R,24*nc) -> corners (R,24) [lidar_3d_to_corners], pred_cnr_r (R,24*nc)
  * [bbox_transform_inv_cnr, lib/fast_rcnn/bbox_transform.py:157-176], pred_bv / pred_bv_r (R,4*nc)

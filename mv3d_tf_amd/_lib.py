@@ -86,6 +86,7 @@ _SIGS = {
     "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
     "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),
+    "mv3d_gt_encode": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

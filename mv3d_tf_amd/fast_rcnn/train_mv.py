@@ -1,8 +1,19 @@
-"""The loss side of lib/fast_rcnn/train_mv.py: `modified_smooth_l1` (:74-90), the four
-losses of `train_model` (:92-130) as autograd functions over the fused device kernels (csrc/losses.hip), the
-snapshot file name (:48-65) and the `.npy` weight-dict format that `network.load` reads (network.py:45-64).
-The optimiser / data-layer loop of `train_model` is out of scope."""
+"""Training entry points with the reference's names and arguments (lib/fast_rcnn/train_mv.py): `train_net` (:373),
+`SolverWrapper` with `snapshot` (:49-65) and `train_model` (:87-219), `get_training_roidb` (:315), `get_data_layer` (:333),
+`filter_roidb` (:345); plus the loss side: `modified_smooth_l1` (:74-90) and the four losses of `train_model` (:92-130) as
+autograd functions over the fused device kernels (csrc/losses.hip), the snapshot file name and the `.npy` weight-dict format
+that `network.load` reads (network.py:45-64).
+
+The loop is the reference's: Adam(lr = 1e-5) on cross_entropy + loss_box + rpn_cross_entropy + rpn_loss_box, one frame per
+iteration from `RoIDataLayer`, the `iter: ... / speed: ...` lines every cfg.TRAIN.DISPLAY iterations, a snapshot every
+cfg.TRAIN.SNAPSHOT_ITERS and at the end.  `sess` / `saver` are opaque here (no TensorFlow): pass None.
+
+Data parallel (BASELINE configs[3]): when torch.distributed is initialised (one process per GPU, backend
+"nccl" = RCCL), every rank trains on its shard of the roidb (frame r, r + W, ...) and the gradients are averaged by
+`sharding.GradBucketer` (25 MB buckets, last layer first, overlapping backward) before the optimiser step; rank 0 writes
+the snapshots and prints.  `frames_per_step` > 1 accumulates that many frames per rank and step (per-GPU batch)."""
 import os
+import time
 
 import numpy as np
 import torch
@@ -84,3 +95,199 @@ def save_weights_npy(net, path):
     d = {name: {'weights': w.detach().cpu().numpy(), 'biases': b.detach().cpu().numpy()} for name, (w, b) in net.params.items()}
     np.save(path, d, allow_pickle=True)
     return path
+
+
+# ---------------------------------------------------------------------------------------------------- training loop
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+class SolverWrapper(object):
+    """lib/fast_rcnn/train_mv.py:26-219.  `sess` and `saver` are accepted for signature compatibility and ignored."""
+
+    LEARNING_RATE = 0.00001                                   # train_mv.py:143
+
+    def __init__(self, sess, saver, network, imdb, roidb, output_dir, pretrained_model=None):
+        self.net, self.imdb, self.roidb = network, imdb, roidb
+        self.output_dir, self.pretrained_model = output_dir, pretrained_model
+        self.saver = saver
+        self.optimizer = None
+        self.log = print
+
+    def snapshot(self, sess, iter):
+        """<output_dir>/<SNAPSHOT_PREFIX>[_<INFIX>]_iter_<iter+1>.ckpt (:49-65).  The file holds the `.npy` weight dict
+        that `network.load` reads; the optimiser state goes next to it (<name>.optim.pt) so that training can resume."""
+        if not os.path.exists(self.output_dir):
+            os.makedirs(self.output_dir)
+        filename = snapshot_filename(self.output_dir, iter)
+        with open(filename, 'wb') as f:
+            np.save(f, {name: {'weights': _tf_layout(w), 'biases': b.detach().cpu().numpy()}
+                        for name, (w, b) in self.net.params.items()}, allow_pickle=True)
+        if self.optimizer is not None:
+            torch.save({'iter': iter + 1, 'optimizer': self.optimizer.state_dict()}, filename + '.optim.pt')
+        self.log('Wrote snapshot to: {:s}'.format(filename))
+        return filename
+
+    def train_model(self, sess, max_iters, frames_per_step=1, start_iter=0):
+        """Network training loop (:87-219).  Returns the list of per-iteration loss tuples
+        (total, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box)."""
+        from .. import sharding
+        dist = _dist()
+        rank = dist.get_rank() if dist is not None else 0
+        world = dist.get_world_size() if dist is not None else 1
+        roidb = self.roidb if world == 1 else [self.roidb[i] for i in sharding.frame_shard(len(self.roidb), rank, world)]
+        data_layer = get_data_layer(roidb, self.imdb.num_classes)
+        if self.pretrained_model is not None:
+            self.log('Loading pretrained model weights from {:s}'.format(self.pretrained_model))
+            self.net.load(self.pretrained_model, sess, self.saver, True)
+        params = self.net.parameters()
+        if dist is not None:                                   # identical replicas: rank 0's weights everywhere
+            for p_ in params:
+                dist.broadcast(p_.data, src=0)
+        lr = self.LEARNING_RATE
+        self.optimizer = torch.optim.Adam(params, lr=lr)       # tf.train.AdamOptimizer(lr) defaults: beta 0.9 / 0.999, eps 1e-8
+        bucketer = sharding.GradBucketer(params, dist)
+        history, last_snapshot_iter, spent = [], -1, 0.0
+        it = start_iter - 1
+        for it in range(start_iter, max_iters):
+            t0 = time.perf_counter()
+            bucketer.zero_grad()
+            vals = np.zeros(4)
+            for k in range(frames_per_step):
+                blobs = data_layer.forward()                                            # get one batch (:162)
+                feed = dict(blobs, keep_prob=0.5)                                       # feed_dict (:165-173)
+                layers = self.net.forward(feed)
+                loss, parts = total_loss(layers)
+                bucketer.reset()
+                # gradients of the frames of a step add up in the flat buckets; the all-reduce starts with the LAST frame's
+                # backward pass (the hooks of the earlier frames only count)
+                bucketer.dist_enabled = (k == frames_per_step - 1)
+                (loss / frames_per_step).backward()
+                vals += np.array([float(v) for v in parts]) / frames_per_step           # (ce, box, rpn_ce, rpn_box)
+            bucketer.finish()
+            self.optimizer.step()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            spent += time.perf_counter() - t0
+            loss_cls, loss_box, rpn_loss_cls, rpn_loss_box = vals
+            history.append((rpn_loss_cls + rpn_loss_box + loss_cls + loss_box, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box))
+            if (it + 1) % cfg.TRAIN.DISPLAY == 0 and rank == 0:
+                self.log('iter: %d / %d, total loss: %.4f, rpn_loss_cls: %.4f, rpn_loss_box: %.4f, loss_cls: %.4f, loss_box: %.4f, lr: %f'
+                         % (it + 1, max_iters, history[-1][0], rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, lr))
+                self.log('speed: {:.3f}s / iter'.format(spent / (it + 1 - start_iter)))
+            if (it + 1) % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                last_snapshot_iter = it
+                if rank == 0:
+                    self.snapshot(sess, it)
+        if last_snapshot_iter != it and it >= start_iter and rank == 0:
+            self.snapshot(sess, it)
+        bucketer.close()
+        return history
+
+
+def _tf_layout(w):
+    """torch (out, in, kh, kw) / (out, in) -> the TF layouts `network.load` expects (HWIO / [in, out])"""
+    a = w.detach().cpu().numpy()
+    return a.transpose(2, 3, 1, 0) if a.ndim == 4 else a.T
+
+
+def get_training_roidb(imdb):
+    """Returns a roidb for use in training (:315-331)."""
+    if cfg.TRAIN.USE_FLIPPED:
+        print('Appending horizontally-flipped training examples...')
+        imdb.append_flipped_images()
+        print('done')
+    print('Preparing training data...')
+    from ..roi_data_layer.roidb import prepare_roidb
+    prepare_roidb(imdb)
+    print('done')
+    return imdb.roidb
+
+
+def get_data_layer(roidb, num_classes):
+    """return a data layer (:333-343; the multi-scale GtDataLayer of the 2-D Faster-RCNN graphs is out of scope)."""
+    from ..roi_data_layer.layer import RoIDataLayer
+    return RoIDataLayer(roidb, num_classes)
+
+
+def filter_roidb(roidb):
+    """Remove roidb entries that have no usable RoIs (:345-370): an entry stays if it has a foreground box (max overlap >=
+    FG_THRESH) or a background box (BG_THRESH_LO <= max overlap < BG_THRESH_HI)."""
+    T = cfg.TRAIN
+
+    def usable(entry):
+        ov = np.asarray(entry['max_overlaps'])
+        return bool(np.any(ov >= T.FG_THRESH) or np.any((ov < T.BG_THRESH_HI) & (ov >= T.BG_THRESH_LO)))
+
+    kept = [e for e in roidb if usable(e)]
+    print('Filtered {} roidb entries: {} -> {}'.format(len(roidb) - len(kept), len(roidb), len(kept)))
+    return kept
+
+
+def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters=10000):
+    """Train a Fast R-CNN network (:373-383)."""
+    roidb = filter_roidb(roidb)
+    sw = SolverWrapper(None, None, network, imdb, roidb, output_dir, pretrained_model=pretrained_model)
+    print('Solving...')
+    history = sw.train_model(None, max_iters)
+    print('done solving')
+    return history
+
+
+def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0):
+    """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
+    VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
+    frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
+    bucketed gradient all-reduce + Adam.  The VGG16 convolutions / FC layers run through torch (MIOpen / rocBLAS -- no
+    hand-written kernel is claimed for them); the hot-path layers are the HIP kernels of this repository."""
+    from .. import sharding, synth
+    from ..networks import get_network
+    np.random.seed(cfg.RNG_SEED + rank)
+    net = get_network("MV3D_train")
+    params = net.parameters()
+    opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE)
+    bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
+    rng = np.random.RandomState(100 + rank)
+    feeds = []
+    for k in range(frames_per_step):
+        _, _, info, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(7000 + 10 * rank + k, 76, 76, "peaky", return_gt=True)
+        bev = (rng.random_sample((1, 608, 608, 9)) < 0.03).astype(np.float32) * rng.uniform(0, 2.4, (1, 608, 608, 9)).astype(np.float32)
+        img = rng.randint(0, 255, (1, 375, 1242, 3)).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+        feeds.append({"lidar_bv_data": torch.as_tensor(bev).cuda(), "image_data": torch.as_tensor(img.astype(np.float32)).cuda(),
+                      "im_info": info, "calib": calib, "gt_boxes_bv": gt_bv, "gt_boxes_3d": gt_3d, "gt_boxes_corners": gt_cnr,
+                      "keep_prob": 0.5})
+
+    def step():
+        bucketer.zero_grad()
+        for k, feed in enumerate(feeds):
+            layers = net.forward(feed)
+            loss, _ = total_loss(layers)
+            bucketer.reset()
+            bucketer.dist_enabled = (k == len(feeds) - 1)
+            (loss / len(feeds)).backward()
+        bucketer.finish()
+        opt.step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cuda")
+    nparam = sum(p.numel() for p in params)
+    out = {"workload": "MV3D_train full step incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head: %d frames / GPU / step, "
+                       "608x608x9 BEV + 375x1242x3 image, fp32, Adam" % frames_per_step,
+           "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 2),
+           "parameters": nparam, "gradient_bytes_per_step": bucketer.total_bytes(), "allreduce_buckets": len(bucketer.buckets),
+           "allreduce": "RCCL, 25 MB buckets, last layer first, overlapping backward" if world > 1 else "none (1 GPU)"}
+    bucketer.close()
+    return out

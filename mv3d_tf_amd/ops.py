@@ -339,6 +339,18 @@ def rois_3d_to_fv(rois_3d, out=None):
     return out
 
 
+def gt_encode(box_cam, cos_sin, inv_rot, tr):
+    """box_cam (G,6) f32, cos_sin (G,2) f64, inv_rot (9) f32, tr (12) f32 device tensors -> (corners_cam (G,24),
+    corners_lidar (G,24), boxes_3d (G,6), boxes_bv (G,4)) f32 in ONE buffer (pack, views): a host caller fetches it with
+    one copy."""
+    G = box_cam.shape[0]
+    spec = [((G, 24), torch.float32), ((G, 24), torch.float32), ((G, 6), torch.float32), ((G, 4), torch.float32)]
+    pack, views = packed_views(spec, box_cam.device)
+    check(lib().mv3d_gt_encode(_ptr(box_cam), _ptr(cos_sin), G, _ptr(inv_rot), _ptr(tr), _ptr(views[0]), _ptr(views[1]),
+                               _ptr(views[2]), _ptr(views[3]), _stream()), "mv3d_gt_encode")
+    return pack, spec, views
+
+
 # ------------------------------------------------------------------ training losses (SURVEY §8(f) rank 4)
 def _loss_call(fn, name, cls, labels, pred, tgt, extra, sigma, want_grad):
     dev = cls.device

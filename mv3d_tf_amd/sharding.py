@@ -53,3 +53,84 @@ def gather_frame_results(local, num_frames, dist=None, device="cpu"):
         row = out[owner_of(f, world)][f // world]
         res.append(row[1:1 + int(row[0])].cpu())
     return res
+
+
+class GradBucketer:
+    """Data-parallel gradient exchange for the training step (one all-reduce of the gradients per step,
+    ~143 M fp32 for MV3D, bucketed, in reverse layer order so that it overlaps the backward pass).
+
+    * `params` in forward order; they are packed LAST LAYER FIRST into flat fp32 buffers of ~`bucket_bytes` (25 MB: over
+      xGMI a ring all-reduce is bound per link -- 7 links x ~153 GB/s per GPU -- and 25 MB buckets keep every link busy
+      without making the first bucket wait for half of the backward pass), and each parameter's `.grad` is made a VIEW
+      into its bucket: autograd accumulates straight into the buffer that goes on the wire, no copies.
+    * a post-accumulate hook per parameter counts arrivals; when a bucket is complete its all-reduce (sum) is launched
+      asynchronously (`async_op=True`: RCCL runs it on its own stream while backward continues).
+    * `finish()` waits for the handles and divides by the world size (mean gradient = what a single process would compute
+      on the concatenated batch).  With no process group the class is a no-op apart from the flat gradient views.
+
+    Pure torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests); no data-path collective of the
+    hot path itself is involved -- frames are independent."""
+
+    def __init__(self, params, dist=None, bucket_bytes=25 << 20, average=True):
+        self.dist = dist if (dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist is not None else 1
+        self.average = average
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []                   # dict(flat, params, pending, handle)
+        self._bucket_of = {}
+        cur, size = [], 0
+        for p in reversed(self.params):     # last layer first: its gradient is ready first
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self._close(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
+        self.dist_enabled = True            # False while earlier frames of an accumulated step run backward
+        self.reset()
+
+    def _close(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            self._bucket_of[id(p)] = len(self.buckets)
+        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "handle": None})
+
+    def reset(self):
+        """before every backward pass (gradients are zeroed in place: the views must stay attached)"""
+        for b in self.buckets:
+            b["pending"], b["handle"] = len(b["params"]), None
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+
+    def _arrived(self, p):
+        b = self.buckets[self._bucket_of[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0 and self.dist is not None and self.dist_enabled:
+            b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """after backward: every bucket reduced (buckets whose parameters got no gradient this step are reduced here)"""
+        if self.dist is None:
+            return
+        for b in self.buckets:
+            if b["handle"] is None:
+                b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+        for b in self.buckets:
+            b["handle"].wait()
+            if self.average:
+                b["flat"].div_(self.world)
+
+    def total_bytes(self):
+        return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()

@@ -797,3 +797,67 @@ void mv3d_ref_rois_3d_to_fv(const float *rois_3d, int R, float *rois_fv)
         o[3] = fv_clip(cmax, 511.0); o[4] = fv_clip(rmax, 63.0);
     }
 }
+
+/* ------------------------------------------------------------------ f3: KITTI label -> ground-truth encodings
+ * lib/datasets/kitti_mv3d.py:240-272 for one frame's kept objects, after the text has been parsed:
+ *   computeCorners3D (lib/utils/transform.py:441-465): camera box (f32 label row) + yaw -> 8 camera corners.  The
+ *     rotation is f64 (np.cos / np.sin of the Python float, passed in), the half extents are f32 (f32 / int), the
+ *     local corner matrix is f64 (vstack of f32, f64, f32 rows), np.dot = k-ascending fma from 0, then + centre (f32 -> f64).
+ *   camera_to_lidar_cnr (:502-524): [inv(Tr[:, :3]) (f32, numpy/LAPACK on the host: passed in) | (-Tr[1,3], -Tr[2,3], Tr[0,3])]
+ *     (f64) . [corners; 0], k-ascending fma -- the homogeneous coordinate is 0, so the translation is dropped (sic).
+ *   lidar_cnr_to_3d (:172-187): centre = f32 mean of the 8 f32 corners (numpy pairwise sum of 8), sizes = (l, w, h).
+ *   lidar_3d_to_bv (:113-142) + _lidar_to_bv_coord (:13-20): f32 corner sums, f64 floor-divide.
+ * Outputs are the f32 arrays the roidb holds: boxes3D_cam_corners (G,24), boxes_corners (G,24), boxes_3D (G,6),
+ * boxes_bv (G,4). */
+void mv3d_ref_gt_encode(const float *box_cam, const double *cos_sin, int G, const float *inv_rot, const float *Tr,
+                        float *cnr_cam, float *cnr_lidar, float *box_lidar, float *boxes_bv)
+{
+    const int Xn = grid_n(TOP_X_MIN, TOP_X_MAX), Yn = grid_n(TOP_Y_MIN, TOP_Y_MAX);           /* 600 (transform.py:8-9) */
+    for (int g = 0; g < G; ++g) {
+        const float *b = box_cam + 6 * g;
+        const double c = cos_sin[2 * g], s = cos_sin[2 * g + 1];
+        const double rot[3][3] = {{c, 0.0, s}, {0.0, 1.0, 0.0}, {-s, 0.0, c}};
+        const float hl = b[3] / 2.0f, hw = b[4] / 2.0f, hgt = b[5];
+        double loc[3][8];
+        const int sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sz[8] = {1, -1, -1, 1, 1, -1, -1, 1};
+        for (int j = 0; j < 8; ++j) {
+            loc[0][j] = (double)(sx[j] > 0 ? hl : -hl);
+            loc[1][j] = (j < 4) ? 0.0 : (double)(-hgt);
+            loc[2][j] = (double)(sz[j] > 0 ? hw : -hw);
+        }
+        double cam[3][8];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 8; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < 3; ++k) acc = fma(rot[i][k], loc[k][j], acc);
+                cam[i][j] = acc + (double)b[i];
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 8; ++j) cnr_cam[24 * g + 8 * i + j] = (float)cam[i][j];
+        const double M[3][4] = {{inv_rot[0], inv_rot[1], inv_rot[2], -(double)Tr[7]},
+                                {inv_rot[3], inv_rot[4], inv_rot[5], -(double)Tr[11]},
+                                {inv_rot[6], inv_rot[7], inv_rot[8], (double)Tr[3]}};
+        float *cl = cnr_lidar + 24 * g;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 8; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < 3; ++k) acc = fma(M[i][k], cam[k][j], acc);
+                acc = fma(M[i][3], 0.0, acc);
+                cl[8 * i + j] = (float)acc;
+            }
+        float *bl = box_lidar + 6 * g;
+        for (int i = 0; i < 3; ++i) {
+            const float *r = cl + 8 * i;
+            const float sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            bl[i] = sum / 8.0f;
+        }
+        bl[3] = b[3]; bl[4] = b[4]; bl[5] = b[5];
+        const float x1 = bl[0] + bl[3] * 0.5f, y1 = bl[1] + bl[4] * 0.5f;
+        const float x2 = bl[0] - bl[3] * 0.5f, y2 = bl[1] - bl[4] * 0.5f;
+        float *bv = boxes_bv + 4 * g;
+        bv[0] = (float)((double)Yn - mv3d_ref_floor_divide((double)y1 - (double)TOP_Y_MIN, RES));
+        bv[1] = (float)((double)Xn - mv3d_ref_floor_divide((double)x1 - (double)TOP_X_MIN, RES));
+        bv[2] = (float)((double)Yn - mv3d_ref_floor_divide((double)y2 - (double)TOP_Y_MIN, RES));
+        bv[3] = (float)((double)Xn - mv3d_ref_floor_divide((double)x2 - (double)TOP_X_MIN, RES));
+    }
+}

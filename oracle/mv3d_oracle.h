@@ -127,6 +127,12 @@ void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc,
  * reflectance channel) wins a cell, as numpy fancy assignment does. */
 void mv3d_ref_point_cloud_2_top(const float *points, int P, float *top);
 
+/* lib/datasets/kitti_mv3d.py:240-272 + lib/utils/transform.py:441-465,502-524,172-187,113-142: camera label boxes -> camera /
+ * LIDAR corners, LIDAR box, BEV pixel box (f32 outputs as stored in the roidb).  cos_sin (G,2) f64 = np.cos / np.sin of the
+ * yaw, inv_rot (9) f32 = np.linalg.inv(Tr[:, :3]) -- both taken on the host, like the text parsing. */
+void mv3d_ref_gt_encode(const float *box_cam, const double *cos_sin, int G, const float *inv_rot, const float *Tr,
+                        float *cnr_cam, float *cnr_lidar, float *box_lidar, float *boxes_bv);
+
 /* Front-view ROI of a 3D proposal (PARITY UNPINNED: no reference code, lib/networks/network.py:293-315 is a TODO):
  * rois_3d (R,7) [b,x,y,z,l,w,h] -> rois_fv (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical map. */
 double mv3d_ref_fv_atan2(double y, double x);

@@ -407,3 +407,18 @@ def fv_atan2(y, x):
     f.restype = C.c_double
     f.argtypes = [C.c_double, C.c_double]
     return np.array([f(float(a), float(b)) for a, b in zip(np.ravel(y), np.ravel(x))])
+
+
+# ------------------------------------------------------------------ f3: KITTI label rows -> ground-truth encodings
+def gt_encode(box_cam, ry, Tr):
+    """box_cam (G,6) f32 [tx,ty,tz,l,w,h], ry (G,) Python floats, Tr (3,4) f32 -> (boxes3D_cam_corners (G,24),
+    boxes_corners (G,24), boxes_3D (G,6), boxes_bv (G,4)) f32, as lib/datasets/kitti_mv3d.py:240-272 fills them."""
+    b = _f32(box_cam).reshape(-1, 6)
+    G = b.shape[0]
+    ry = np.asarray(ry, np.float64).reshape(-1)
+    cs = np.ascontiguousarray(np.stack([np.cos(ry), np.sin(ry)], 1), np.float64)
+    tr = _f32(Tr).reshape(3, 4)
+    inv = np.ascontiguousarray(np.linalg.inv(tr[:, :3]), np.float32)
+    out = [np.zeros((G, 24), np.float32), np.zeros((G, 24), np.float32), np.zeros((G, 6), np.float32), np.zeros((G, 4), np.float32)]
+    lib().mv3d_ref_gt_encode(_p(b), _p(cs), C.c_int(G), _p(inv), _p(tr), *(_p(o) for o in out))
+    return tuple(out)

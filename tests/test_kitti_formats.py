@@ -1,13 +1,15 @@
-"""SURVEY §8(f) rank 3 (host logic, no GPU): KITTI calib / label files -> ground-truth encodings and gt blobs,
-bit-for-bit against what the reference's own loader (lib/datasets/kitti_mv3d.py) and get_minibatch
-(lib/roi_data_layer/minibatch_mv3d.py) produced for the same files (tests/golden/kitti_label.npz; the file
-contents are stored in the fixture as text)."""
+"""KITTI calib / label files -> ground-truth encodings and gt blobs, bit for bit (values and dtypes)
+against what the reference's own loader (lib/datasets/kitti_mv3d.py) and get_minibatch
+(lib/roi_data_layer/minibatch_mv3d.py) produced for the same files (tests/golden/kitti_label.npz; the file contents are
+stored in the fixture as text).  CPU tests: the oracle's restatement of the geometry and the host-side parsing; `gpu` tests:
+the product (text table -> mv3d_gt_encode on the device -> roidb entry)."""
 import os
 
 import numpy as np
+import pytest
 
 from conftest import golden
-from mv3d_tf_amd.datasets import gt_blobs, kitti_mv3d, load_kitti_calib, pack_calib, parse_kitti_labels
+from mv3d_tf_amd.datasets import gt_blobs, load_kitti_calib, pack_calib
 
 ANN_KEYS = ("ry", "lwh", "boxes", "boxes_bv", "boxes_3D_cam", "boxes_3D", "boxes3D_cam_corners", "boxes_corners",
             "gt_classes", "gt_overlaps", "xyz", "alphas")
@@ -34,15 +36,54 @@ def _same(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
 
 
-def test_kitti_label_and_calib_match_reference(tmp_path):
+def _cars(g, i):
+    lines = [ln for ln in str(g["labels_txt_%d" % i]).splitlines() if ln.split(" ")[0] == "Car"]
+    return lines, [float(ln.split(" ")[14]) for ln in lines]
+
+
+def test_oracle_gt_encode_matches_reference(oracle):
+    g = golden("kitti_label")
+    for i in range(int(g["n_frames"])):
+        tr = g["calib_%d" % i][3].reshape(3, 4).astype(np.float32)
+        _, ry = _cars(g, i)
+        cam, lid, b3, bv = oracle.gt_encode(g["ann%d_boxes_3D_cam" % i], ry, tr)
+        assert _same(cam, g["ann%d_boxes3D_cam_corners" % i]) and _same(lid, g["ann%d_boxes_corners" % i])
+        assert _same(b3, g["ann%d_boxes_3D" % i]) and _same(bv, g["ann%d_boxes_bv" % i])
+
+
+def test_calib_parsing_and_gt_blobs_host_side(tmp_path):
+    g = golden("kitti_label")
+    p = tmp_path / "c.txt"
+    p.write_text(str(g["calib_txt_0"]))
+    c = load_kitti_calib(str(p))
+    assert c["P2"].dtype == np.float32 and c["Tr_velo2cam"].shape == (3, 4) and c["R0"].shape == (3, 3)
+    assert _same(pack_calib(c), g["calib_0"])                          # (4,12) f64 table of f32 values
+    for i in range(int(g["n_frames"])):
+        ann = {k: g["ann%d_%s" % (i, k)] for k in ANN_KEYS}
+        blobs = gt_blobs(ann, (8, 9, 9))
+        for k in ("gt_boxes", "gt_boxes_bv", "gt_boxes_3d", "gt_boxes_corners", "im_info"):
+            assert _same(blobs[k], g["blob%d_%s" % (i, k)]), (i, k)
+    # BEV boxes are integral pixel coordinates, x1 <= x2 (the (+,+) corner comes first)
+    bv = g["ann0_boxes_bv"]
+    assert np.array_equal(bv, np.round(bv)) and (bv[:, 0] <= bv[:, 2]).all() and (bv[:, 1] <= bv[:, 3]).all()
+
+
+@pytest.mark.gpu
+def test_kitti_label_and_calib_match_reference(tmp_path, oracle):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from mv3d_tf_amd import build
+    build.build()
+    from mv3d_tf_amd.datasets import kitti_mv3d, parse_kitti_labels
     g = golden("kitti_label")
     root, n = _tree(tmp_path, g)
     db = kitti_mv3d("train", root)
-    assert db.num_classes == 2 and db.image_index == ["%06d" % i for i in range(n)]
+    assert db.num_classes == 2 and db.image_index == ["%06d" % i for i in range(n)] and db.num_images == n
     roidb = db.gt_roidb()
     for i in range(n):
         cal = db.calib_at(i)
-        assert _same(cal, g["calib_%d" % i])                              # (4,12) f64 table of f32 values
+        assert _same(cal, g["calib_%d" % i]) and _same(cal, g["blob%d_calib" % i])
         ann = roidb[i]
         for k in ANN_KEYS:
             got = ann[k].toarray() if k == "gt_overlaps" else ann[k]
@@ -51,22 +92,20 @@ def test_kitti_label_and_calib_match_reference(tmp_path):
         blobs = gt_blobs(ann, (8, 9, 9))
         for k in ("gt_boxes", "gt_boxes_bv", "gt_boxes_3d", "gt_boxes_corners", "im_info"):
             assert _same(blobs[k], g["blob%d_%s" % (i, k)]), (i, k)
-        assert _same(cal, g["blob%d_calib" % i])
         assert db.image_path_at(i).endswith("image_2/%06d.png" % i) and db.lidar_path_at(i).endswith("lidar_bv/%06d.npy" % i)
     # frame 2 has no object of a known class: empty encodings, still well-formed
     assert roidb[2]["boxes"].shape == (0, 4) and roidb[2]["gt_overlaps"].shape == (0, 2)
     assert gt_blobs(roidb[2], (8, 9, 9))["gt_boxes_3d"].shape == (0, 7)
-
-
-def test_kitti_pieces_standalone(tmp_path):
-    g = golden("kitti_label")
-    p = tmp_path / "c.txt"
-    p.write_text(str(g["calib_txt_0"]))
-    c = load_kitti_calib(str(p))
-    assert c["P2"].dtype == np.float32 and c["Tr_velo2cam"].shape == (3, 4) and c["R0"].shape == (3, 3)
-    assert _same(pack_calib(c), g["calib_0"])
-    ann = parse_kitti_labels(str(g["labels_txt_0"]).splitlines(True), c["Tr_velo2cam"], {"__background__": 0, "Car": 1}, 2)
-    assert _same(ann["boxes_bv"], g["ann0_boxes_bv"]) and _same(ann["boxes_corners"], g["ann0_boxes_corners"])
-    # BEV boxes are integral pixel coordinates inside (or just around) the 601-pixel map, x1 < x2 (+,+ corner first)
-    bv = ann["boxes_bv"]
-    assert np.array_equal(bv, np.round(bv)) and (bv[:, 0] <= bv[:, 2]).all() and (bv[:, 1] <= bv[:, 3]).all()
+    # the device kernel against the oracle on many random objects (incl. yaw at +-pi, tiny and huge boxes)
+    rng = np.random.RandomState(4)
+    G = 3000
+    box = np.stack([rng.uniform(-40, 40, G), rng.uniform(0.5, 2.5, G), rng.uniform(0.5, 80, G), rng.uniform(0.3, 12, G),
+                    rng.uniform(0.3, 3, G), rng.uniform(0.5, 4, G)], 1).astype(np.float32)
+    ry = rng.uniform(-np.pi, np.pi, G); ry[:4] = [np.pi, -np.pi, 0.0, np.pi / 2]
+    tr = g["calib_0"][3].reshape(3, 4).astype(np.float32)
+    lines = ["Car 0 0 0 1 2 3 4 %r %r %r %r %r %r %r" % (float(b[5]), float(b[4]), float(b[3]), float(b[0]), float(b[1]), float(b[2]), float(r))
+             for b, r in zip(box, ry)]
+    ann = parse_kitti_labels(lines, tr, {"__background__": 0, "Car": 1}, 2)
+    cam, lid, b3, bv = oracle.gt_encode(box, ry, tr)
+    assert _same(ann["boxes3D_cam_corners"], cam) and _same(ann["boxes_corners"], lid)
+    assert _same(ann["boxes_3D"], b3) and _same(ann["boxes_bv"], bv)

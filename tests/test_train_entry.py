@@ -1,0 +1,193 @@
+"""Training entry points (SURVEY.md §8(b) "Entry points kept", §8(e) multi-GPU): CPU tests of the data-parallel gradient
+exchange (world_size-2 gloo) and of the host logic; `gpu` tests of train_net / SolverWrapper on a synthetic imdb."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_model(seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.3).requires_grad_(True)
+    return [mk(8, 3, 3, 3), mk(8), mk(16, 8, 3, 3), mk(16), mk(5, 16), mk(5)]
+
+
+def _tiny_loss(params, x, y):
+    import torch.nn.functional as F
+    w1, b1, w2, b2, w3, b3 = params
+    h = F.relu(F.conv2d(x, w1, b1, padding=1))
+    h = F.relu(F.conv2d(h, w2, b2, padding=1)).mean(dim=(2, 3))
+    return F.cross_entropy(F.linear(h, w3, b3), y)
+
+
+def _frame(k):
+    g = torch.Generator().manual_seed(100 + k)
+    return torch.randn(1, 3, 12, 12, generator=g), torch.randint(0, 5, (1,), generator=g)
+
+
+def _dp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mv3d_tf_amd import sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _tiny_model(1)                                   # identical replicas
+    b = sharding.GradBucketer(params, dist, bucket_bytes=1500)        # several buckets
+    assert len(b.buckets) >= 3 and b.buckets[0]["params"][0] is params[-1]       # last layer first
+    frames = sharding.frame_shard(4, rank, world)             # 4 frames over 2 ranks: 2 accumulated frames per rank and step
+    b.zero_grad()
+    for k, f in enumerate(frames):
+        b.reset()
+        b.dist_enabled = (k == len(frames) - 1)
+        (_tiny_loss(params, *_frame(f)) / len(frames)).backward()
+    b.finish()
+    torch.save([p.grad.clone() for p in params], os.path.join(out_dir, "g%d.pt" % rank))
+    owned = torch.tensor(frames)
+    gathered = [torch.zeros_like(owned) for _ in range(world)]
+    dist.all_gather(gathered, owned)
+    if rank == 0:
+        torch.save(torch.cat(gathered), os.path.join(out_dir, "frames.pt"))
+    b.close()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_single_process_mean(tmp_path):
+    """2 ranks x 2 frames, bucketed all-reduce (gloo) == one process on the 4-frame mean loss; the shards cover the
+    frames exactly once."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    params = _tiny_model(1)
+    loss = sum(_tiny_loss(params, *_frame(f)) for f in range(4)) / 4
+    want = torch.autograd.grad(loss, params)
+    for a, b, w in zip(g0, g1, want):
+        assert torch.equal(a, b)                              # every rank holds the same reduced gradient
+        assert torch.allclose(a, w, rtol=1e-5, atol=1e-7)
+    assert sorted(torch.load(tmp_path / "frames.pt").tolist()) == [0, 1, 2, 3]
+
+
+def test_bucketing_of_the_mv3d_parameter_list():
+    """the real parameter list (shapes of networks/mv3d.py, ~143 M fp32 = 573 MB): 25 MB buckets, reverse layer order,
+    gradients are views of the flat buffers"""
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd import sharding
+    shapes = []
+    for cin in (9, 3):
+        c = cin
+        for cout in (64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512):
+            shapes += [(cout, c, 3, 3), (cout,)]
+            c = cout
+    shapes += [(512, 512, 3, 3), (512,), (8, 512, 1, 1), (8,), (24, 512, 1, 1), (24,)]
+    for _ in range(2):
+        shapes += [(2048, 7 * 7 * 512), (2048,), (2048, 2048), (2048,)]
+    shapes += [(2, 4096), (2,), (48, 4096), (48,)]
+    params = [torch.empty(s, device="meta", requires_grad=True) for s in shapes]
+    nbytes = sum(int(np.prod(s)) for s in shapes) * 4
+    assert 130e6 * 4 < nbytes < 150e6 * 4                     # ~143 M fp32
+    b = sharding.GradBucketer(params, None)
+    assert b.total_bytes() == nbytes
+    assert b.buckets[0]["params"][0] is params[-1] and b.buckets[-1]["params"][-1] is params[0]
+    small = [x for x in b.buckets if x["flat"].numel() * 4 <= (25 << 20)]
+    assert len(small) >= len(b.buckets) - 2                   # only the two fc6 matrices (205 MB each) exceed a bucket
+    for x in b.buckets:
+        off = 0
+        for p in x["params"]:
+            assert p.grad.shape == p.shape
+            off += p.numel()
+        assert off == x["flat"].numel()
+    b.close()
+
+
+def test_data_layer_and_roidb_host_logic():
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.roi_data_layer import RoIDataLayer
+    from mv3d_tf_amd import synth
+    roidb = []
+    for i in range(5):
+        gt_bv, gt_3d, gt_cnr = synth.gt_cars(np.random.RandomState(i), 3)
+        roidb.append({"image": np.full((6, 8, 3), 100, np.uint8), "lidar_bv": np.zeros((16, 16, 9), np.float32),
+                      "calib": synth.KITTI_CALIB.astype(np.float64), "gt_classes": np.array([1, 1, 0], np.int32),
+                      "boxes": np.zeros((3, 4), np.float32), "boxes_bv": gt_bv[:, :4], "boxes_3D": gt_3d[:, :6],
+                      "boxes_corners": gt_cnr[:, :24], "max_overlaps": np.array([1.0, 1.0, 0.0]), "id": i})
+    saved = cfg.TRAIN.IMS_PER_BATCH
+    cfg.TRAIN.IMS_PER_BATCH = 1
+    try:
+        np.random.seed(3)
+        layer = RoIDataLayer(roidb, 2)
+        np.random.seed(3)
+        perm = np.random.permutation(np.arange(5))
+        assert np.array_equal(layer._perm, perm)              # the reference's draw (layer.py:28)
+        blobs = layer.forward()
+        assert blobs["image_data"].shape == (1, 6, 8, 3) and blobs["image_data"].dtype == np.float32
+        assert np.allclose(blobs["image_data"][0, 0, 0], 100 - cfg.PIXEL_MEANS[0, 0])
+        assert blobs["lidar_bv_data"].shape == (1, 16, 16, 9) and blobs["gt_boxes_3d"].shape == (2, 7)
+        assert np.array_equal(blobs["im_info"], np.array([[16, 16, 1]], np.float32)) and blobs["gt_boxes_corners"].shape == (2, 25)
+        seen = [int(perm[0])]
+        for _ in range(3):
+            layer.forward(); seen.append(int(layer._perm[layer._cur - 1]))
+        assert sorted(seen) == sorted(perm[:4].tolist())
+        layer.forward()                                        # cur + 1 >= 5: reshuffled before the draw
+        assert layer._cur == 1
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH = saved
+    kept = train_mv.filter_roidb(roidb + [dict(roidb[0], max_overlaps=np.array([0.05]))])
+    assert len(kept) == 5                                      # 0.05 is neither fg nor in [BG_THRESH_LO, BG_THRESH_HI)
+    assert train_mv.snapshot_filename("/x", 9).endswith("_iter_10.ckpt")
+
+
+@pytest.mark.gpu
+def test_train_net_two_iterations_and_snapshot(tmp_path, capsys):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd import build, synth
+    build.build()
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.networks import get_network
+
+    class Imdb:
+        num_classes = 2
+        name = "synthetic"
+
+    rng = np.random.RandomState(0)
+    roidb = []
+    for i in range(3):
+        _, _, _, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(40 + i, 76, 76, "peaky", return_gt=True)
+        roidb.append({"image": rng.randint(0, 255, (96, 320, 3)).astype(np.uint8),
+                      "lidar_bv": (rng.random_sample((608, 608, 9)) < 0.02).astype(np.float32), "calib": calib.astype(np.float64),
+                      "gt_classes": np.ones(len(gt_bv), np.int32), "boxes": np.zeros((len(gt_bv), 4), np.float32),
+                      "boxes_bv": gt_bv[:, :4], "boxes_3D": gt_3d[:, :6], "boxes_corners": gt_cnr[:, :24],
+                      "max_overlaps": np.ones(len(gt_bv))})
+    saved = (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS)
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = 1, 1, 2
+    try:
+        np.random.seed(cfg.RNG_SEED)
+        net = get_network("MV3D_train")
+        before = net.params["rpn_bbox_pred"][0].detach().clone()
+        hist = train_mv.train_net(net, Imdb(), roidb, str(tmp_path), max_iters=3)
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = saved
+    assert len(hist) == 3 and all(np.isfinite(h[0]) for h in hist)
+    assert not torch.equal(before, net.params["rpn_bbox_pred"][0].detach())     # Adam moved the weights
+    out = capsys.readouterr().out
+    assert "iter: 1 / 3, total loss: " in out and "rpn_loss_cls: " in out and ", lr: 0.000010" in out
+    assert "speed: " in out and "s / iter" in out and "Wrote snapshot to: " in out and "done solving" in out
+    files = sorted(os.listdir(tmp_path))
+    pref = cfg.TRAIN.SNAPSHOT_PREFIX
+    assert pref + "_iter_2.ckpt" in files and pref + "_iter_3.ckpt" in files and pref + "_iter_3.ckpt.optim.pt" in files
+    # a snapshot is the .npy weight dict network.load reads (TF layouts)
+    net2 = get_network("MV3D_train")
+    net2.load(os.path.join(tmp_path, pref + "_iter_3.ckpt"))
+    for k in ("conv5_3", "rpn_bbox_pred", "fc6_1", "bbox_pred"):
+        assert torch.equal(net2.params[k][0], net.params[k][0].detach()) and torch.equal(net2.params[k][1], net.params[k][1].detach())
