@@ -99,6 +99,9 @@ typedef struct {
     int32_t img_height;      /* 375  hard-coded at proposal_layer_tf.py:147 */
     int32_t img_width;       /* 1242 */
     int32_t img_padding;     /* 50: proposal_layer_tf.py:345 */
+    int32_t nms_strict_gt;   /* 0: cpu_nms rule, (double)IoU >= thresh (cfg.USE_GPU_NMS False, the parity target);
+                                1: gpu_nms rule, IoU > thresh in f32 (what nms_wrapper.py:19-20 picks when USE_GPU_NMS) */
+    int32_t reserved0;
     double nms_thresh;       /* cfg[key].RPN_NMS_THRESH */
     double min_size;         /* cfg[key].RPN_MIN_SIZE   */
 } mv3d_proposal_params;

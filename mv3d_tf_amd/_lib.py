@@ -21,7 +21,7 @@ class ProposalParams(C.Structure):
     """mv3d_proposal_params"""
     _fields_ = [("feat_stride", C.c_int32), ("pre_nms_topN", C.c_int32), ("post_nms_topN", C.c_int32),
                 ("img_height", C.c_int32), ("img_width", C.c_int32), ("img_padding", C.c_int32),
-                ("nms_thresh", C.c_double), ("min_size", C.c_double)]
+                ("nms_strict_gt", C.c_int32), ("reserved0", C.c_int32), ("nms_thresh", C.c_double), ("min_size", C.c_double)]
 
 
 class AnchorTargetParams(C.Structure):

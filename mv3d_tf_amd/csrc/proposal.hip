@@ -183,7 +183,9 @@ extern "C" int mv3d_proposal_3d(const float *prob_dev, const float *pred_dev, in
     nl.boxes = (const float *)sbox; nl.box_stride = 4; nl.boxes_frame_stride = (long long)L.order_cap * 4;
     nl.idx = nullptr; nl.idx_frame_stride = 0;
     nl.n_dev = cnt; nl.n_cap = L.order_cap; nl.batch = batch;
-    nl.thresh_f32 = mv3d_ceil_f32(p->nms_thresh); nl.strict_gt = 0;
+    // nms_wrapper.py:13-21: the cpu_nms rule compares (double)IoU >= thresh, the gpu_nms rule IoU > (float)thresh
+    nl.strict_gt = p->nms_strict_gt ? 1 : 0;
+    nl.thresh_f32 = nl.strict_gt ? (float)p->nms_thresh : mv3d_ceil_f32(p->nms_thresh);
     nl.max_keep = L.cap;
     nl.keep = keep; nl.keep_frame_stride = L.order_cap; nl.num_keep = cnt + batch; nl.status = status_dev;
     nl.workspace = ws + L.o_nms;

@@ -164,7 +164,7 @@ class SolverWrapper(object):
                 # backward pass (the hooks of the earlier frames only count)
                 bucketer.dist_enabled = (k == frames_per_step - 1)
                 (loss / frames_per_step).backward()
-                vals += np.array([float(v) for v in parts]) / frames_per_step           # (ce, box, rpn_ce, rpn_box)
+                vals += np.array([float(v.detach()) for v in parts]) / frames_per_step           # (ce, box, rpn_ce, rpn_box)
             bucketer.finish()
             self.optimizer.step()
             if torch.cuda.is_available():

@@ -65,6 +65,21 @@ class _Bound:
             if rc:
                 check(rc, fn.__name__)
 
+    def run_marked(self, stream, marks):
+        """run(), with a HIP event pair recorded on `stream` around every call whose C function name is a key of `marks`
+        ({name: [(start, end), ...]} is appended to): the duration of a launch IN the batch's own launch sequence"""
+        for fn, args in self.calls:
+            pair = None
+            if fn.__name__ in marks:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(stream)
+            rc = fn(*args)
+            if rc:
+                check(rc, fn.__name__)
+            if pair is not None:
+                pair[1].record(stream)
+                marks[fn.__name__].append(pair)
+
 
 class TrainPathBatch:
     def __init__(self, frames, maps, stream=None, views=VIEWS, num_classes=2, top_diff_seed=0):

@@ -92,11 +92,15 @@ def _workspace(nbytes, device, tag, zero=False):
 
 
 # ------------------------------------------------------------------ proposal_layer_3d
-def proposal_params(cfg_section, feat_stride=8, img_height=375, img_width=1242, img_padding=50):
-    """cfg[cfg_key] section (lib/rpn_msr/proposal_layer_tf.py:52-55) -> mv3d_proposal_params"""
+def proposal_params(cfg_section, feat_stride=8, img_height=375, img_width=1242, img_padding=50, use_gpu_nms=None):
+    """cfg[cfg_key] section (lib/rpn_msr/proposal_layer_tf.py:52-55) -> mv3d_proposal_params.  `use_gpu_nms` (default:
+    cfg.USE_GPU_NMS) selects the rule of the NMS inside the layer the way nms_wrapper.py:13-21 does."""
+    if use_gpu_nms is None:
+        from .fast_rcnn.config import cfg
+        use_gpu_nms = bool(cfg.USE_GPU_NMS)
     return ProposalParams(int(feat_stride), int(cfg_section["RPN_PRE_NMS_TOP_N"]),
                           int(cfg_section["RPN_POST_NMS_TOP_N"]), int(img_height), int(img_width),
-                          int(img_padding), float(cfg_section["RPN_NMS_THRESH"]),
+                          int(img_padding), 1 if use_gpu_nms else 0, 0, float(cfg_section["RPN_NMS_THRESH"]),
                           float(cfg_section["RPN_MIN_SIZE"]))
 
 

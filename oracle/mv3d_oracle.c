@@ -135,6 +135,33 @@ int mv3d_ref_cpu_nms(const float *dets, int n, double thresh, int presorted, int
     return err ? -1 : nk;
 }
 
+/* lib/nms/nms_kernel.cu:21-30 (devIoU) + :71 + the host reduce :117-133: boxes pre-sorted, all arithmetic f32, box j is
+ * removed by an earlier kept box iff IoU > thresh (f32 compare); 0/0 = NaN does not remove and nothing is raised.
+ * PARITY UNPINNED (no CUDA device to run the original): a restatement for sweeping the `_nms` entry against. */
+int mv3d_ref_gpu_nms_rule(const float *dets, int n, float thresh, int32_t *keep)
+{
+    unsigned char *supp = (unsigned char *)calloc(n > 0 ? n : 1, 1);
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (supp[i]) continue;
+        keep[nk++] = i;
+        const float *a = dets + 5 * i;
+        const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+        for (int j = i + 1; j < n; ++j) {
+            if (supp[j]) continue;
+            const float *b = dets + 5 * j;
+            const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+            const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+            const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+            const float interS = width * height;
+            const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+            if (interS / (Sa + Sb - interS) > thresh) supp[j] = 1;
+        }
+    }
+    free(supp);
+    return nk;
+}
+
 /* ------------------------------------------------------------------ defined arithmetic */
 /* f32 exp exactly as numpy computes it on AVX2/AVX512 hosts (third-party dependency of
  * the reference: numpy, version unpinned upstream, 2.2.6 in the build container;

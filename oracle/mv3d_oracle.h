@@ -37,6 +37,8 @@ void mv3d_ref_bbox_overlaps(const double *boxes, int n, const double *query, int
  * Returns number kept (indices into dets, in processing order) or -1 for the
  * reference's ZeroDivisionError (union == 0). */
 int mv3d_ref_cpu_nms(const float *dets, int n, double thresh, int presorted, int32_t *keep);
+/* lib/nms/nms_kernel.cu:21-30,71,117-133: the CUDA path's rule (IoU > thresh, all f32, pre-sorted boxes).  Parity unpinned. */
+int mv3d_ref_gpu_nms_rule(const float *dets, int n, float thresh, int32_t *keep);
 
 /* Defined arithmetic shared (by specification, not by code) with the HIP kernels. */
 float mv3d_ref_expf(float x);                 /* DESIGN.md "defined exp" */

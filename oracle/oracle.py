@@ -102,6 +102,14 @@ def cpu_nms(dets, thresh, presorted=False):
 nms = cpu_nms
 
 
+def gpu_nms_rule(sorted_dets, thresh):
+    """lib/nms/nms_kernel.cu rule on pre-sorted boxes (IoU > thresh in f32): kept positions.  Parity unpinned."""
+    d = _f32(sorted_dets)
+    keep = np.zeros(max(d.shape[0], 1), np.int32)
+    nk = lib().mv3d_ref_gpu_nms_rule(_p(d), C.c_int(d.shape[0]), C.c_float(thresh), _p(keep))
+    return keep[:nk].tolist()
+
+
 def proposal_layer_3d(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, calib, cfg_key,
                       _feat_stride=(8,), anchor_scales=(1.0, 1.0), cfg=None, debug=False):
     cfg = (cfg or CFG)[cfg_key]

@@ -123,6 +123,66 @@ def test_gpu_nms_cuda_rule(ops):
     assert ops.nms_host(d, 0.5) == [0]                                 # cpu rule: >=
 
 
+@pytest.mark.parametrize("seed,n,variant,thr", [(11, 6000, "rand", 0.7), (12, 6000, "clustered", 0.7), (13, 12000, "clustered", 0.7),
+                                                (14, 300, "clustered", 0.1), (15, 2049, "rand", 0.5), (16, 65, "clustered", 0.3)])
+def test_gpu_nms_rule_sweep_vs_oracle(ops, oracle, seed, n, variant, thr):
+    """the `_nms` symbol (CUDA rule: IoU > thresh, f32) against the oracle's restatement of nms_kernel.cu on the NMS fixture
+    generators (integer boxes: exact-threshold IoUs occur) -- parity of this entry is unpinned (no CUDA device), this pins
+    device == restatement"""
+    from mv3d_tf_amd.nms.gpu_nms import gpu_nms
+    dets = synth.nms_dets(seed, n, variant, integer=True)
+    order = dets[:, 4].argsort()[::-1]
+    sd = np.ascontiguousarray(dets[order])
+    want = [int(order[k]) for k in oracle.gpu_nms_rule(sd, np.float32(thr))]
+    assert [int(i) for i in gpu_nms(dets, thr)] == want
+    cpu = ops.nms_host(dets, thr)
+    assert len(cpu) <= len(want)                                        # `>=` removes at least what `>` removes
+
+
+def test_nms_dispatcher_honours_use_gpu_nms(ops, oracle):
+    """lib/fast_rcnn/nms_wrapper.py:13-21: cfg.USE_GPU_NMS picks the rule, force_cpu overrides; the NMS inside
+    proposal_layer_3d follows the same switch (mv3d_proposal_params.nms_strict_gt)."""
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.fast_rcnn.nms_wrapper import nms
+    from mv3d_tf_amd.rpn_msr.proposal_layer_tf import proposal_layer_3d
+    d = np.array([[0, 0, 9, 9, .9], [0, 0, 9, 4, .8]], np.float32)    # IoU exactly 0.5
+    saved = cfg.USE_GPU_NMS
+    try:
+        cfg.USE_GPU_NMS = False
+        assert nms(d, 0.5) == [0]
+        cfg.USE_GPU_NMS = True
+        assert nms(d, 0.5) == [0, 1] and nms(d, 0.5, force_cpu=True) == [0]
+        # proposal path under the gpu rule: equal to running the oracle's decode with the `>` NMS rule on its candidates
+        prob, pred, info, calib = synth.rpn_head(31, 40, 40, "peaky")
+        got_gt = proposal_layer_3d(prob, pred, info, calib, "TEST", [8, ])
+        cfg.USE_GPU_NMS = False
+        got_ge = proposal_layer_3d(prob, pred, info, calib, "TEST", [8, ])
+    finally:
+        cfg.USE_GPU_NMS = saved
+    want = oracle.proposal_layer_3d(prob, pred, info, calib, "TEST", [8, ], cfg={"TEST": dict(cfg.TEST)})
+    assert all(np.array_equal(a, b) for a, b in zip(got_ge, want))
+    # with `>` at least as many boxes survive, and the first box (highest score) is the same
+    assert got_gt[0].shape[0] >= got_ge[0].shape[0] and np.array_equal(got_gt[0][0], got_ge[0][0])
+
+
+def test_zero_union_flag_deviation_is_what_design_md_says(ops, oracle):
+    """DESIGN.md §2, documented deviation: the device raises the zero-union flag when ANY pair of the input has union 0;
+    the reference raises only if the greedy loop evaluates that pair.  A case that separates the two: the zero-union pair
+    (a negative-area and a positive-area box whose areas cancel) sits behind a box that suppresses one of them first --
+    the reference (oracle) returns a keep list, the device entry raises."""
+    big = [0, 0, 99, 99, 0.9]                       # suppresses the second box (IoU 0.81 >= 0.5) before the pair is reached
+    pos = [0, 0, 89, 89, 0.8]                       # area 8100
+    neg = [200.0, 0.0, 109.0, 89.0, 0.7]            # x2 < x1 - 1: area (109 - 200 + 1) * 90 = -8100; union with `pos` = 0
+    d = np.array([big, pos, neg], np.float32)
+    assert oracle.cpu_nms(d, 0.5) == [0, 2]         # the reference never divides by that union
+    with pytest.raises(ZeroDivisionError):
+        ops.nms_host(d, 0.5)
+    with pytest.raises(ZeroDivisionError):          # ... and both raise when the loop does reach the pair
+        oracle.cpu_nms(d[1:], 0.5)
+    with pytest.raises(ZeroDivisionError):
+        ops.nms_host(d[1:], 0.5)
+
+
 # ------------------------------------------------------------------ proposal_layer_3d
 @pytest.mark.parametrize("name", PROPOSAL_CASES)
 def test_proposal_layer_3d_matches_reference(ops, name):
