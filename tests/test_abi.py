@@ -38,10 +38,10 @@ def test_version_and_status_strings(hiplib):
 
 def test_workspace_queries_and_argument_validation(hiplib):
     L = hiplib.lib()
-    p = hiplib.ProposalParams(8, 12000, 2000, 375, 1242, 50, 0.7, 5.0)
+    p = hiplib.ProposalParams(8, 12000, 2000, 375, 1242, 50, 0, 0, 0.7, 5.0)
     assert L.mv3d_proposal_3d_capacity(76, 76, C.byref(p)) == 2000
     assert L.mv3d_proposal_3d_workspace_bytes(1, 76, 76, C.byref(p)) > 188 * 189 // 2 * 512   # column-form NMS tiles
-    p2 = hiplib.ProposalParams(8, 6000, 300, 375, 1242, 50, 0.7, 5.0)
+    p2 = hiplib.ProposalParams(8, 6000, 300, 375, 1242, 50, 0, 0, 0.7, 5.0)
     assert L.mv3d_proposal_3d_capacity(76, 76, C.byref(p2)) == 300
     assert L.mv3d_proposal_3d_capacity(4, 4, C.byref(p2)) == 64        # fewer anchors than top-N
     assert L.mv3d_nms_workspace_bytes(6000) >= 94 * 95 // 2 * 512
