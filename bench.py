@@ -155,8 +155,8 @@ def pmc_traffic(kernel, signature):
         table = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         if table.get("signature") != signature:
             return None
-        key = next(k for k in table["kernels"] if kernel in k)
-        return int(table["kernels"][key]["hbm_bytes_per_launch"])
+        keys = [k for k in table["kernels"] if kernel in k]          # RoiPoolGrad = three kernels behind one call: summed
+        return int(sum(table["kernels"][k]["hbm_bytes_per_launch"] for k in keys)) if keys else None
     except Exception:
         return None
 
@@ -187,7 +187,7 @@ def roofline_entries(ring, workload, signature):
         out.append({"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512 views, R=%d rows each, batch %d)"
                               % (kname, mine[0].num_rois, mine[0].B),
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname.split(" ")[0].split("<")[0], signature),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("roi_bwd_" if "bwd" in kname else kname, signature),
                     "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(marks[fn])})
     return out
 

@@ -578,8 +578,8 @@ __global__ __launch_bounds__(BW_THREADS) void roi_pool_bwd_sliced_kernel(RoiGrad
 // workgroup; then the item list (int4 per pixel of all views), then the candidate pool.  Pool bound per ROI: the sum over
 // the rows of (phe - phs) is <= PH + 2 rows + 3 (floor / ceil slack), likewise over the columns.
 #define BWI_PIX 16
-#define BWG_GROUPS 192                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
-struct RoiGradIdxPack { int4 *items; int *pool; int *header; int *seg_tot, *seg_ne; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; };
+#define BWG_GROUPS 256                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
+struct RoiGradIdxPack { long long *trace; int4 *items; int *pool; int *header; int *seg_tot, *seg_ne; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; };
 
 // FILL = false: zero-fill + sizes (seg_tot / seg_ne per segment); FILL = true: slab offsets from the sizes of the preceding
 // segments (a plain sum: the sizing launch is complete), items and candidate lists.  No atomics on global memory, no state
@@ -729,60 +729,87 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
 }
 
 // records u0 .. u0 + W - 1 of the 64 whose byte offsets sit in the lanes of `cur`: per record one v_readlane (-> SGPR) and two
-// buffer loads whose scalar offset is that SGPR, then compare / select / add -- six instructions; W x 2 loads per lane in flight
-template <int W, bool MASKED>
-__device__ __forceinline__ float bwd_drain_lanes(const int cur, const int u0, const int m, const __amdgpu_buffer_rsrc_t ra,
-                                                 const __amdgpu_buffer_rsrc_t rt, const int voff, const int want, float a)
+// buffer loads (CPL dwords per lane) whose scalar offset is that SGPR, then CPL x (compare / select / add); W x 2 loads per
+// lane in flight
+template <int CPL> struct BwdVec;
+template <> struct BwdVec<1> { typedef unsigned int T; static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, int v, int s) { return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0); } };
+template <> struct BwdVec<2> { typedef unsigned int T __attribute__((ext_vector_type(2))); static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, int v, int s) { return __builtin_amdgcn_raw_buffer_load_b64(r, v, s, 0); } };
+template <> struct BwdVec<4> { typedef unsigned int T __attribute__((ext_vector_type(4))); static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t r, int v, int s) { return __builtin_amdgcn_raw_buffer_load_b128(r, v, s, 0); } };
+template <int CPL> __device__ __forceinline__ unsigned bwd_elem(const typename BwdVec<CPL>::T &x, int j) { return x[j]; }
+template <> __device__ __forceinline__ unsigned bwd_elem<1>(const unsigned int &x, int) { return x; }
+
+template <int CPL, int W, bool MASKED>
+__device__ __forceinline__ void bwd_drain_lanes(const int cur, const int u0, const int m, const __amdgpu_buffer_rsrc_t ra,
+                                                const __amdgpu_buffer_rsrc_t rt, const int voff, const int want, float (&a)[CPL])
 {
-    int am_v[W];
-    float td_v[W];
+    typename BwdVec<CPL>::T am_v[W], td_v[W];
 #pragma unroll
     for (int u = 0; u < W; ++u) {
         const int so = __builtin_amdgcn_readlane(cur, MASKED ? min(u0 + u, 63) : u0 + u);
-        am_v[u] = __builtin_amdgcn_raw_buffer_load_b32(ra, voff, so, 0);
-        td_v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, so, 0));
+        am_v[u] = BwdVec<CPL>::ld(ra, voff, so);
+        td_v[u] = BwdVec<CPL>::ld(rt, voff, so);
     }
 #pragma unroll
     for (int u = 0; u < W; ++u)
-        if (!MASKED || u0 + u < m) a += (am_v[u] == want) ? td_v[u] : 0.0f;
-    return a;
+        if (!MASKED || u0 + u < m) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                a[j] += ((int)bwd_elem<CPL>(am_v[u], j) == want + j) ? __builtin_bit_cast(float, bwd_elem<CPL>(td_v[u], j)) : 0.0f;
+        }
 }
 
-// A persistent grid sized to what the chip holds at once; wave = (item, 64-channel slice); slice s of every record is only
-// ever read by XCD s (workgroup b -> slice b % nsl).  A wave walks its items i, i + stride, ...; an item costs three
-// dependent memory round trips (item -> record offsets -> records), so the walk is software-pipelined: while item n's
-// records are in flight, the offsets of item n + 1 and the header of item n + 2 are already requested.
+// A persistent grid; wave = (item, slice of 64 CPL channels).  XCD x (= blockIdx % 8) works on slice x % nsl of the items of
+// part x / nsl (the item list is in pixel order: a part is a band of rows / frames), so that every record slice is pulled
+// into ONE private L2.  CPL > 1 makes the pieces a slice reads from a record larger (64 CPL x 4 B: 256 B at CPL = 1, 1 KB at
+// CPL = 4): cold HBM reads of 256-B pieces scattered at 2 KB stride run at ~3 TB/s (DRAM row misses), the same bytes in
+// larger pieces do not.  A wave walks its items i, i + stride, ... software-pipelined: while item n's records are in flight,
+// the offsets of item n + 1 and the header of item n + 2 are already requested.
+template <int CPL>
 __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl)
 {
-    const int slice = (int)(blockIdx.x % (unsigned)nsl);
     const int lane = threadIdx.x & 63;
-    const int stride = (int)(gridDim.x / (unsigned)nsl) * 4;
-    const int n_items = __builtin_amdgcn_readfirstlane(ix.header[1]);
-    const int c = slice * 64 + lane;
-    int i = (int)(blockIdx.x / (unsigned)nsl) * 4 + (int)(threadIdx.x >> 6);
-    if (i >= n_items) return;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int slice = xcd % nsl, part = xcd / nsl, nparts = 8 / nsl;
+    const int n_all = __builtin_amdgcn_readfirstlane(ix.header[1]);
+    const int per = (n_all + nparts - 1) / nparts;
+    const int i_end = min(n_all, (part + 1) * per);                     // this part's items: [part * per, i_end)
+    const int stride = (int)(gridDim.x >> 3) * 4;
+    int i = part * per + (int)(blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);
+    // diagnostics (tools/roi_bwd_trace.py): 8 words per wave {start, items loaded, offsets loaded, first item done, end, items,
+    // candidates, -}
+    long long *tr = ix.trace ? ix.trace + 8 * ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) : nullptr;
+    long long t_first = 0;
+    int n_done = 0, n_cand = 0;
+    if (tr && lane == 0) tr[0] = (long long)__builtin_readcyclecounter();
+    if (i >= i_end) return;
     const int4 zero4 = make_int4(0, 0, 0, 0);
     int4 it = ix.items[i];
-    int4 it1 = (i + stride < n_items) ? ix.items[i + stride] : zero4;
+    int4 it1 = (i + stride < i_end) ? ix.items[i + stride] : zero4;
+    if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) tr[1] = (long long)__builtin_readcyclecounter(); }
     int idx = ix.pool[it.y + min(lane, it.z - 1)];
-    const int voff = lane * 4;
-    for (; i < n_items; i += stride) {
+    if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) tr[2] = (long long)__builtin_readcyclecounter(); }
+    const int voff = lane * 4 * CPL;
+    constexpr int W = CPL == 1 ? 32 : (CPL == 2 ? 16 : 8);
+    for (; i < i_end; i += stride) {
         const int pix = __builtin_amdgcn_readfirstlane(it.x), off = __builtin_amdgcn_readfirstlane(it.y);
         const int cnt = __builtin_amdgcn_readfirstlane(it.z), k = __builtin_amdgcn_readfirstlane(it.w);
-        const bool more = i + stride < n_items;                        // wave-uniform
+        const bool more = i + stride < i_end;                              // wave-uniform
         const int4 nxt = it1;
-        if (i + 2 * stride < n_items) it1 = ix.items[i + 2 * stride];
+        if (i + 2 * stride < i_end) it1 = ix.items[i + 2 * stride];
         int idx1 = 0;
         if (more) idx1 = ix.pool[__builtin_amdgcn_readfirstlane(nxt.y) + min(lane, __builtin_amdgcn_readfirstlane(nxt.z) - 1)];
         const RoiGradViewDev &v = p.v[k];
         const int C = v.C;
+        const int c = slice * 64 * CPL + lane * CPL;
         const int want = (pix % (v.H * v.W)) * C + c;
         const int *cand = ix.pool + off;
         // the slice lives in the (wave-uniform) base address, the lane in the vector offset, the record's byte offset is
         // the scalar offset of the load
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(v.argmax + slice * 64), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64), 0, 0x7fffffff, 0x00020000);
-        float a = 0.0f;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(v.argmax + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
+        float a[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) a[j] = 0.0f;
         // 64 record offsets per vector load (lane l holds candidate t0 + l); the next 64 are requested before the current
         // ones are consumed
         for (int t0 = 0; t0 < cnt; t0 += 64) {
@@ -790,15 +817,21 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
             if (t0 + 64 < cnt) idx = cand[min(t0 + 64 + lane, cnt - 1)];
             const int m = min(64, cnt - t0);
             int u0 = 0;
-            for (; u0 + 32 <= m; u0 += 32) a = bwd_drain_lanes<32, false>(cur, u0, m, ra, rt, voff, want, a);
-            if (u0 + 16 <= m) { a = bwd_drain_lanes<16, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 16; }
-            if (u0 + 8 <= m) { a = bwd_drain_lanes<8, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 8; }
-            if (u0 + 4 <= m) { a = bwd_drain_lanes<4, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 4; }
-            if (u0 < m) a = bwd_drain_lanes<4, true>(cur, u0, m, ra, rt, voff, want, a);
+            for (; u0 + W <= m; u0 += W) bwd_drain_lanes<CPL, W, false>(cur, u0, m, ra, rt, voff, want, a);
+            if (W > 8 && u0 + 8 <= m) { bwd_drain_lanes<CPL, 8, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 8; }
+            if (W > 16 && u0 + 8 <= m) { bwd_drain_lanes<CPL, 8, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 8; }
+            if (W > 16 && u0 + 8 <= m) { bwd_drain_lanes<CPL, 8, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 8; }
+            if (u0 + 4 <= m) { bwd_drain_lanes<CPL, 4, false>(cur, u0, m, ra, rt, voff, want, a); u0 += 4; }
+            if (u0 < m) bwd_drain_lanes<CPL, 4, true>(cur, u0, m, ra, rt, voff, want, a);
         }
-        __builtin_nontemporal_store(a, v.bottom_diff + (long long)pix * C + c);
+        float *out = v.bottom_diff + (long long)pix * C + c;
+        if (CPL == 1) __builtin_nontemporal_store(a[0], out);
+        else if (CPL == 2) { typedef float f2v __attribute__((ext_vector_type(2))); const f2v av = {a[0], a[1 % CPL]}; __builtin_nontemporal_store(av, reinterpret_cast<f2v *>(out)); }
+        else { typedef float f4v __attribute__((ext_vector_type(4))); const f4v av = {a[0], a[1 % CPL], a[2 % CPL], a[3 % CPL]}; __builtin_nontemporal_store(av, reinterpret_cast<f4v *>(out)); }
         it = nxt; idx = idx1;
+        if (tr) { if (n_done == 0) t_first = (long long)__builtin_readcyclecounter(); ++n_done; n_cand += cnt; }
     }
+    if (tr && lane == 0) { tr[3] = t_first; tr[4] = (long long)__builtin_readcyclecounter(); tr[5] = n_done; tr[6] = n_cand; tr[7] = 0; }
 }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -992,7 +1025,8 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
     bool same_c = true;
     long long all_pix = 0;
     for (int k = 0; k < num_views; ++k) {
-        same_c = same_c && views[k].channels == views[0].channels && views[k].channels % 256 == 0 && aligned16(views[k].bottom_diff) &&
+        same_c = same_c && views[k].channels == views[0].channels && (views[k].channels == 64 || views[k].channels == 128 || views[k].channels % 256 == 0) &&
+                 views[k].channels <= 2048 && 2048 % views[k].channels == 0 && aligned16(views[k].bottom_diff) &&
                  aligned16(views[k].top_diff) && aligned16(views[k].argmax_data);
         all_pix += (long long)views[k].batch_size * views[k].height * views[k].width;
     }
@@ -1008,8 +1042,19 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
     unsigned iblocks = 0;
     char *ws = (char *)workspace;
     size_t pool_entries = 0, n_items = 0;
+    // the densest view first (candidates per pixel ~ R PH PW / pixels: the 8 x 64 front-view map carries ~10 x the lists of
+    // the others): its pixels then head the item list and the gather's waves start with the long lists instead of ending
+    // with them -- the kernel's time is its slowest wave
+    int ord[MV3D_MAX_ROI_VIEWS] = {0, 1, 2, 3};
+    for (int a = 0; a < num_views; ++a)
+        for (int b = a + 1; b < num_views; ++b) {
+            const mv3d_roi_grad_view &x = views[ord[a]], &y = views[ord[b]];
+            const double dx = (double)x.num_rois / ((double)x.batch_size * x.height * x.width);
+            const double dy = (double)y.num_rois / ((double)y.batch_size * y.height * y.width);
+            if (dy > dx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+        }
     for (int k = 0; k < num_views; ++k) {
-        const mv3d_roi_grad_view &w = views[k];
+        const mv3d_roi_grad_view &w = views[ord[k]];
         RoiGradViewDev &v = p.v[k];
         v.top_diff = w.top_diff; v.rois = w.bottom_rois; v.argmax = w.argmax_data; v.bottom_diff = w.bottom_diff;
         v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
@@ -1039,16 +1084,28 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
     if (indexed) {
         size_t o = MV3D_ALIGN;
         ix.header = (int *)ws;
+        ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;   // diagnostics
         ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
         ix.seg_ne = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
         ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
         ix.pool = (int *)(ws + o);
         if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
-        const int nsl = views[0].channels / 64;
         hipLaunchKernelGGL(roi_bwd_index_kernel<false>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
         hipLaunchKernelGGL(roi_bwd_index_kernel<true>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
-        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;   // tuning hook
-        hipLaunchKernelGGL(roi_bwd_gather_kernel, dim3((unsigned)(groups * nsl)), dim3(256), 0, (hipStream_t)stream, p, ix, nsl);
+        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;   // tuning hooks
+        static const int cpl_env = getenv("MV3D_BWG_CPL") ? atoi(getenv("MV3D_BWG_CPL")) : 0;
+        // channels per lane: 1 (64-channel slices, 256-B pieces of a record per wave) measured best on the training batch:
+        // 75 us for the three launches vs 82 (2 channels, 512-B pieces) and 105 (4 channels, 1-KB pieces, 8 records in flight):
+        // the walk is bound by its dependent round trips, and a lane with more channels holds fewer records in flight
+        int cpl = 1;
+        if (cpl_env == 2 && views[0].channels % 128 == 0) cpl = 2;
+        if (cpl_env == 4 && views[0].channels % 256 == 0) cpl = 4;
+        if (8 % (views[0].channels / (64 * cpl)) != 0 || views[0].channels / (64 * cpl) > 8) cpl = 0;     // (C = 64 k, k not a divisor of 8)
+        const dim3 gg((unsigned)(groups * 8));
+        if (cpl == 4) hipLaunchKernelGGL(roi_bwd_gather_kernel<4>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 256);
+        else if (cpl == 2) hipLaunchKernelGGL(roi_bwd_gather_kernel<2>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 128);
+        else if (cpl == 1) hipLaunchKernelGGL(roi_bwd_gather_kernel<1>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 64);
+        else return MV3D_ERR_INVALID_ARG;
         return mv3d_launch_status();
     }
     hipLaunchKernelGGL(roi_pool_bwd_sliced_kernel, dim3(blocks), dim3(BW_THREADS), carry, (hipStream_t)stream, p);

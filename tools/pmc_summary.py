@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; own runs).
 
-    python tools/pmc_summary.py gpurun_out/pmc1 profiles/r01_pmc_traffic
+    python tools/pmc_summary.py gpurun_out/pmc1 profiles/r02_pmc_traffic [signature]
+
+`signature` (bench.py: "<workload>/b<batch>/r<rois>/<variant>") is stored in the JSON; bench.py only quotes a traffic number
+whose signature equals the configuration it is running.
 
 Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB;
 on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so the read side is
@@ -31,8 +34,9 @@ def main(src, dst):
         out[k.split("(")[0]] = dict(read_MB_corrected=round(rd, 3), write_MB=round(wr, 3), hbm_bytes_per_launch=int((rd + wr) * 1e6),
                                     fetch_kib_raw=f.get(k, {}), write_kib_raw=w.get(k, {}))
         lines.append("%-60s %6d %14.3f %14.3f %16.3f" % (k[:60], f.get(k, w.get(k))["calls"], rd, wr, rd + wr))
-    open(dst + ".json", "w").write(json.dumps(out, indent=1))
-    open(dst + ".txt", "w").write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate runs), bench.py --no-graph --steps 20\n"
+    sig = sys.argv[3] if len(sys.argv) > 3 else ""
+    open(dst + ".json", "w").write(json.dumps({"signature": sig, "kernels": out}, indent=1))
+    open(dst + ".txt", "w").write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate runs), bench.py --launch eager --streams 1 --steps 2 (tools/gpu_pmc.sh)\n"
                                   "# FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); KiB -> MB\n" + "\n".join(lines) + "\n")
     print("\n".join(lines))
 

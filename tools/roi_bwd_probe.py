@@ -24,9 +24,13 @@ for k in range(NB):
     frames = [synth.rpn_head(100000 + 2 * k + b, 76, 76, "peaky", return_gt=True) for b in range(2)]
     batches.append(hot_path.TrainPathBatch(frames, hot_path.synth_maps(2, k, dev), top_diff_seed=k).setup())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("SHARE_OUT"):                      # every batch writes the outputs of batch 0 (inputs stay distinct)
+    for b in batches[1:]:
+        if b.num_rois == batches[0].num_rois:
+            b.tops, b.bottom_diff = batches[0].tops, batches[0].bottom_diff
 
 
-def ev(fns, rounds=8):
+def ev(fns, rounds=int(os.environ.get("ROUNDS", "8"))):
     for f in fns:
         f()
     torch.cuda.synchronize()
