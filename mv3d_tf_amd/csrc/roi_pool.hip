@@ -836,6 +836,7 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+
 // Bins per workgroup (passes x bins per pass).  A small job (one frame: 2 x 14 700 bins) wants many
 // workgroups in flight -- 2 passes (4 passes cost 5 % at batch 4); a batch of 16 frames runs ~6 % faster
 // with 4 (interleaved A/B runs; the run-to-run spread at that size is larger than the effect).
