@@ -221,6 +221,22 @@ int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
                               int32_t *n_anchors_dev, int anchors_cap,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* Frames of a batch behind one launch of every kernel (the reference's layer is single-frame, lib/rpn_msr/
+ * anchor_target_layer_tf.py:42-45; the per-frame entry points above are these with batch = 1).  Host-side arrays of `batch`
+ * entries (device pointers / counts); labels_dev (batch,N), targets_dev (batch,N,6), im_info_dev (batch,3),
+ * anchors_dev (batch,cap,5), anchors_3d_dev (batch,cap,7), n_anchors_dev (batch) are contiguous over the frames; one
+ * workspace per frame.  batch <= 16.  stage2 = two launches: the three disable lists, then debug rows + final labels. */
+int mv3d_anchor_target_stage1_batch(int batch, int H, int W, const float *im_info_dev, const float *const *gt_bv_dev,
+                                    const float *const *gt_3d_dev, const int *G, const mv3d_anchor_target_params *p,
+                                    float *labels_dev, float *targets_dev, int32_t *const *counts_dev,
+                                    uint8_t *const *fg_hi_dev, void *const *workspace, size_t workspace_bytes, void *stream);
+int mv3d_anchor_target_stage2_batch(int batch, int H, int W, const mv3d_anchor_target_params *p,
+                                    const int32_t *const *disable_fg_dev, const int *n_dis_fg,
+                                    const int32_t *const *disable_bg1_dev, const int *n_dis_bg1,
+                                    const int32_t *const *disable_bg2_dev, const int *n_dis_bg2, float *labels_dev,
+                                    float *anchors_dev, float *anchors_3d_dev, int32_t *n_anchors_dev, int anchors_cap,
+                                    void *const *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ proposal_target_layer_3d
  * Replaces lib/rpn_msr/proposal_target_layer_tf.py:19-94 with _sample_rois_3d (:227-298),
  * _compute_targets_cnr (:211-225), _get_bbox_regression_labels_3d (:172-194) and the image
@@ -252,6 +268,21 @@ int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_d
                                 float *rois_bv_out, float *rois_img_out, int32_t *labels_out,
                                 float *bbox_targets_out, float *rois_3d_out,
                                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same for `batch` frames behind one launch of every kernel (host-side arrays of per-frame device pointers / counts /
+ * parameter structs -- params[b].frame_index = the batch column of frame b's appended ground-truth rows); batch <= 16. */
+int mv3d_proposal_target_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                      const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                      const int *G, const mv3d_proposal_target_params *params, int32_t *const *counts_dev,
+                                      void *const *workspace, const size_t *workspace_bytes, void *stream);
+int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                      const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                      const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
+                                      const mv3d_proposal_target_params *params, const int32_t *const *fg_pick_dev,
+                                      const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
+                                      float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
+                                      float *const *bbox_targets_out, float *const *rois_3d_out, void *const *workspace,
+                                      const size_t *workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ SURVEY §8(f) "next" rows
  * BEV rasteriser: replaces point_cloud_2_top (lib/utils/read_lidar.py:10-115, called with

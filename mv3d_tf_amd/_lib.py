@@ -72,6 +72,13 @@ _SIGS = {
                                             _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_anchor_target_stage2": (C.c_int, [C.c_int, C.c_int, C.POINTER(AnchorTargetParams), _P, C.c_int, _P,
                                             C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_anchor_target_stage1_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.POINTER(AnchorTargetParams), _P, _P, _P, _P,
+                                                  _P, C.c_size_t, _P]),
+    "mv3d_anchor_target_stage2_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(AnchorTargetParams), _P, _P, _P, _P, _P, _P, _P,
+                                                  _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_proposal_target_stage1_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv3d_proposal_target_stage2_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                    _P, _P]),
     "mv3d_proposal_target_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mv3d_proposal_target_stage1": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(ProposalTargetParams), _P, _P,
                                               C.c_size_t, _P]),

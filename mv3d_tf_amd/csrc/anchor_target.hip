@@ -65,6 +65,26 @@ struct AtDev {
     float *labels, *targets;
 };
 
+// Frames of a batch behind ONE launch of every kernel: blockIdx.y = frame (the reference's layer is single-frame; the
+// per-frame entry points pass a batch of one).
+#define AT_MAX_BATCH 16
+struct AtLists {
+    int32_t *fg, *bg, *low;          // (N) each: anchor indices, ascending
+};
+struct AtFrame {
+    AtDev d;
+    AtLists lists;
+    int32_t *counts;                 // (8)
+    uint8_t *fg_hi;                  // (N)
+    int32_t *agg1, *agg2;            // look-back words of the two grid compactions
+    // stage 2
+    const int32_t *dis_fg, *dis_bg1, *dis_bg2;
+    int n_dis_fg, n_dis_bg1, n_dis_bg2;
+    float *anchors, *anchors_3d;
+    int32_t *n_anchors;
+};
+struct AtBatch { AtFrame f[AT_MAX_BATCH]; int cap; };
+
 __device__ __forceinline__ void anchor_coords(const AtDev &d, int n, int &x1, int &y1, int &x2, int &y2)
 {
     const int a = n & 3, cell = n >> 2, w = cell % d.W, h = cell / d.W;
@@ -80,8 +100,9 @@ __device__ __forceinline__ bool anchor_box(const AtDev &d, int n, int &x1, int &
     return x1 >= 0 && y1 >= 0 && (double)x2 < (double)d.im_info[1] && (double)y2 < (double)d.im_info[0];
 }
 
-__global__ __launch_bounds__(256) void at_overlap_kernel(AtDev d)
+__global__ __launch_bounds__(256) void at_overlap_kernel(AtBatch bt)
 {
+    const AtDev &d = bt.f[blockIdx.y].d;
     __shared__ float s_gt[AT_MAX_GT * 4];
     __shared__ unsigned long long s_max[AT_MAX_GT];
     for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
@@ -111,8 +132,9 @@ __global__ __launch_bounds__(256) void at_overlap_kernel(AtDev d)
         if (s_max[g]) atomicMax(&d.gtmax[g], s_max[g]);
 }
 
-__global__ __launch_bounds__(256) void at_label_kernel(AtDev d)
+__global__ __launch_bounds__(256) void at_label_kernel(AtBatch bt)
 {
+    const AtDev &d = bt.f[blockIdx.y].d;
     __shared__ float s_gt[AT_MAX_GT * 4];
     __shared__ double s_max[AT_MAX_GT];
     for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
@@ -158,16 +180,17 @@ __global__ __launch_bounds__(256) void at_label_kernel(AtDev d)
 }
 
 // ---- ordered compaction over a grid of workgroups (mv3d_grid_compact, common.h) ---------------
-struct AtLists {
-    int32_t *fg, *bg, *low;          // (N) each: anchor indices, ascending
-};
-
-__global__ __launch_bounds__(256) void at_compact_kernel(const float *labels, const double *max_ov, int N, double neg_ov,
-                                                         AtLists L, int32_t *counts, uint8_t *fg_hi, int32_t *agg)
+__global__ __launch_bounds__(256) void at_compact_kernel(AtBatch bt)
 {
+    const AtFrame &F = bt.f[blockIdx.y];
+    const float *labels = F.d.labels;
+    const double *max_ov = F.d.max_ov;
+    const double neg_ov = F.d.neg_ov;
+    const AtLists L = F.lists;
+    uint8_t *fg_hi = F.fg_hi;
     int tot[4];
     mv3d_grid_compact<4>(
-        N,
+        F.d.N,
         [&](int n, bool f[4]) {
             const double mx = max_ov[n];
             const float lab = labels[n];
@@ -179,26 +202,42 @@ __global__ __launch_bounds__(256) void at_compact_kernel(const float *labels, co
             else if (k == 2) L.bg[pos] = n;
             else if (k == 3) L.low[pos] = n;
         },
-        agg, tot);
+        F.agg1, tot);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        int32_t *counts = F.counts;
         counts[0] = tot[0]; counts[1] = tot[1]; counts[2] = tot[2]; counts[3] = tot[3];
         counts[4] = counts[5] = counts[6] = counts[7] = 0;
     }
 }
 
-__global__ void at_disable_kernel(float *labels, const int32_t *list, const int32_t *pos, int n)
+// Stage 2, first launch: the three host-drawn disable lists of anchor_target_layer_tf.py:146-159,178-183 in one pass.
+// fg / bg1 positions are applied now (labels = -1); the second bg draw applies AFTER the relabel of :176, so its anchors
+// are only marked -- in `argmax`, which stage 1 rewrites on every call and nothing reads afterwards -- and the second
+// launch resolves them.
+__global__ __launch_bounds__(256) void at_disable_all_kernel(AtBatch bt)
 {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) labels[list[pos[t]]] = -1.0f;
+    const AtFrame &F = bt.f[blockIdx.y];
+    const int n1 = F.n_dis_fg, n2 = F.n_dis_bg1, n3 = F.n_dis_bg2;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n1 + n2 + n3; t += gridDim.x * blockDim.x) {
+        if (t < n1) F.d.labels[F.lists.fg[F.dis_fg[t]]] = -1.0f;
+        else if (t < n1 + n2) F.d.labels[F.lists.bg[F.dis_bg1[t - n1]]] = -1.0f;
+        else F.d.argmax[F.lists.low[F.dis_bg2[t - n1 - n2]]] = -1;
+    }
 }
 
-// anchor_target_layer_tf.py:170-174: rows of (0, anchor) and (0, anchor_3d) for labels != -1
-__global__ __launch_bounds__(256) void at_emit_anchors_kernel(AtDev d, float *anchors, float *anchors_3d, int32_t *n_out,
-                                                              int cap, int32_t *agg)
+// Stage 2, second launch: the debug rows of anchor_target_layer_tf.py:170-174 ((0, anchor) and (0, anchor_3d) for
+// labels != -1, an ordered compaction) and then, by the same thread for the same anchors, the final labels:
+// labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0 (:176) unless the second bg draw disabled the anchor (:178-183).
+__global__ __launch_bounds__(256) void at_emit_relabel_kernel(AtBatch bt)
 {
+    const AtFrame &F = bt.f[blockIdx.y];
+    const AtDev &d = F.d;
+    float *anchors = F.anchors, *anchors_3d = F.anchors_3d;
+    const int cap = bt.cap;
     int tot[1];
     mv3d_grid_compact<1>(
         d.N,
-        [&](int n, bool f[1]) { f[0] = (d.max_ov[n] >= 0.0) && (d.labels[n] != -1.0f); },
+        [&](int n, bool f[1]) { f[0] = anchors && (d.max_ov[n] >= 0.0) && (d.labels[n] != -1.0f); },
         [&](int, int r, int n) {
             if (r >= cap) return;
             int x1, y1, x2, y2;
@@ -213,17 +252,18 @@ __global__ __launch_bounds__(256) void at_emit_anchors_kernel(AtDev d, float *an
             B[3] = (float)(-(1.73 - 1.56 / 2.0));
             B[4] = (float)ex_len; B[5] = (float)ex_wid; B[6] = (float)1.56;
         },
-        agg, tot);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_out[0] = tot[0];
-}
-
-// anchor_target_layer_tf.py:176: labels[max_overlaps < RPN_NEGATIVE_OVERLAP] = 0 (inside anchors)
-__global__ void at_relabel_low_kernel(float *labels, const double *max_ov, int N, double neg_ov)
-{
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N) {
-        const double mx = max_ov[n];
-        if (mx >= 0.0 && mx < neg_ov) labels[n] = 0.0f;
+        F.agg2, tot);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && F.n_anchors) F.n_anchors[0] = tot[0];
+    // the items this thread classified above (mv3d_grid_compact: wave w of workgroup b owns [1024 b + 256 w, +256))
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int beg = blockIdx.x * MV3D_GC_ITEMS + wave * 256;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = beg + 64 * u + lane;
+        if (n < d.N) {
+            const double mx = d.max_ov[n];
+            if (mx >= 0.0 && mx < d.neg_ov) d.labels[n] = (d.argmax[n] < 0) ? -1.0f : 0.0f;
+        }
     }
 }
 
@@ -266,28 +306,88 @@ static void at_fill(AtDev &d, const AtLayout &L, int H, int W, int G, const mv3d
     d.gtmax = (unsigned long long *)(ws + L.o_gtmax);
 }
 
+static void at_frame(AtFrame &F, const AtLayout &L, int H, int W, int G, const mv3d_anchor_target_params *p, char *ws)
+{
+    at_fill(F.d, L, H, W, G, p, ws);
+    F.lists.fg = (int32_t *)(ws + L.o_fg); F.lists.bg = (int32_t *)(ws + L.o_bg); F.lists.low = (int32_t *)(ws + L.o_low);
+    F.agg1 = (int32_t *)(ws + L.o_agg1); F.agg2 = (int32_t *)(ws + L.o_agg2);
+}
+
+extern "C" int mv3d_anchor_target_stage1_batch(int batch, int H, int W, const float *im_info_dev, const float *const *gt_bv_dev,
+                                               const float *const *gt_3d_dev, const int *G, const mv3d_anchor_target_params *p,
+                                               float *labels_dev, float *targets_dev, int32_t *const *counts_dev,
+                                               uint8_t *const *fg_hi_dev, void *const *workspace, size_t workspace_bytes,
+                                               void *stream)
+{
+    if (batch <= 0 || batch > AT_MAX_BATCH || !p || p->feat_stride <= 0 || !im_info_dev || !labels_dev || !targets_dev ||
+        !gt_bv_dev || !gt_3d_dev || !G || !counts_dev || !fg_hi_dev || !workspace)
+        return MV3D_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    AtBatch bt = {};
+    AtLayout L = {};
+    for (int b = 0; b < batch; ++b) {
+        if (!at_layout(H, W, G[b], L)) return MV3D_ERR_INVALID_ARG;
+        if (!counts_dev[b] || !fg_hi_dev[b] || (G[b] > 0 && (!gt_bv_dev[b] || !gt_3d_dev[b]))) return MV3D_ERR_INVALID_ARG;
+        if (!workspace[b] || workspace_bytes < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+        AtFrame &F = bt.f[b];
+        at_frame(F, L, H, W, G[b], p, (char *)workspace[b]);
+        F.d.im_info = im_info_dev + 3 * b; F.d.gt_bv = gt_bv_dev[b]; F.d.gt_3d = gt_3d_dev[b];
+        F.d.labels = labels_dev + (size_t)b * L.N; F.d.targets = targets_dev + (size_t)b * L.N * 6;
+        F.counts = counts_dev[b]; F.fg_hi = fg_hi_dev[b];
+        MV3D_HIP_TRY(hipMemsetAsync(F.d.gtmax, 0, L.zero_bytes, s));   // gtmax + the compactions' look-back words
+    }
+    const int blocks = (L.N + 255) / 256;
+    hipLaunchKernelGGL(at_overlap_kernel, dim3(blocks, batch), dim3(256), 0, s, bt);
+    hipLaunchKernelGGL(at_label_kernel, dim3(blocks, batch), dim3(256), 0, s, bt);
+    hipLaunchKernelGGL(at_compact_kernel, dim3(L.ncwg, batch), dim3(256), 0, s, bt);
+    return mv3d_launch_status();
+}
+
 extern "C" int mv3d_anchor_target_stage1(int H, int W, const float *im_info_dev, const float *gt_bv_dev,
                                          const float *gt_3d_dev, int G, const mv3d_anchor_target_params *p,
                                          float *labels_dev, float *targets_dev, int32_t *counts_dev, uint8_t *fg_hi_dev,
                                          void *workspace, size_t workspace_bytes, void *stream)
 {
-    AtLayout L;
-    if (!p || !at_layout(H, W, G, L) || p->feat_stride <= 0) return MV3D_ERR_INVALID_ARG;
-    if (!im_info_dev || !labels_dev || !targets_dev || !counts_dev || !fg_hi_dev || (G > 0 && (!gt_bv_dev || !gt_3d_dev)))
+    return mv3d_anchor_target_stage1_batch(1, H, W, im_info_dev, &gt_bv_dev, &gt_3d_dev, &G, p, labels_dev, targets_dev,
+                                           &counts_dev, &fg_hi_dev, &workspace, workspace_bytes, stream);
+}
+
+extern "C" int mv3d_anchor_target_stage2_batch(int batch, int H, int W, const mv3d_anchor_target_params *p,
+                                               const int32_t *const *disable_fg_dev, const int *n_dis_fg,
+                                               const int32_t *const *disable_bg1_dev, const int *n_dis_bg1,
+                                               const int32_t *const *disable_bg2_dev, const int *n_dis_bg2, float *labels_dev,
+                                               float *anchors_dev, float *anchors_3d_dev, int32_t *n_anchors_dev,
+                                               int anchors_cap, void *const *workspace, size_t workspace_bytes, void *stream)
+{
+    if (batch <= 0 || batch > AT_MAX_BATCH || !p || !labels_dev || !workspace || !n_dis_fg || !n_dis_bg1 || !n_dis_bg2 ||
+        !disable_fg_dev || !disable_bg1_dev || !disable_bg2_dev)
         return MV3D_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    AtLayout L;
+    if (!at_layout(H, W, 0, L)) return MV3D_ERR_INVALID_ARG;
+    const bool emit = anchors_dev && anchors_3d_dev && n_anchors_dev;
+    AtBatch bt = {};
+    bt.cap = anchors_cap;
+    int most = 0;
+    for (int b = 0; b < batch; ++b) {
+        if (n_dis_fg[b] < 0 || n_dis_bg1[b] < 0 || n_dis_bg2[b] < 0) return MV3D_ERR_INVALID_ARG;
+        if ((n_dis_fg[b] && !disable_fg_dev[b]) || (n_dis_bg1[b] && !disable_bg1_dev[b]) || (n_dis_bg2[b] && !disable_bg2_dev[b]))
+            return MV3D_ERR_INVALID_ARG;
+        if (!workspace[b] || workspace_bytes < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+        AtFrame &F = bt.f[b];
+        at_frame(F, L, H, W, 0, p, (char *)workspace[b]);
+        F.d.im_info = nullptr; F.d.gt_bv = nullptr; F.d.gt_3d = nullptr; F.d.targets = nullptr;
+        F.d.labels = labels_dev + (size_t)b * L.N;
+        F.dis_fg = disable_fg_dev[b]; F.dis_bg1 = disable_bg1_dev[b]; F.dis_bg2 = disable_bg2_dev[b];
+        F.n_dis_fg = n_dis_fg[b]; F.n_dis_bg1 = n_dis_bg1[b]; F.n_dis_bg2 = n_dis_bg2[b];
+        F.anchors = emit ? anchors_dev + (size_t)b * anchors_cap * 5 : nullptr;
+        F.anchors_3d = emit ? anchors_3d_dev + (size_t)b * anchors_cap * 7 : nullptr;
+        F.n_anchors = emit ? n_anchors_dev + b : nullptr;
+        const int n = n_dis_fg[b] + n_dis_bg1[b] + n_dis_bg2[b];
+        if (n > most) most = n;
+    }
     hipStream_t s = (hipStream_t)stream;
-    char *ws = (char *)workspace;
-    AtDev d;
-    at_fill(d, L, H, W, G, p, ws);
-    d.im_info = im_info_dev; d.gt_bv = gt_bv_dev; d.gt_3d = gt_3d_dev; d.labels = labels_dev; d.targets = targets_dev;
-    MV3D_HIP_TRY(hipMemsetAsync(d.gtmax, 0, L.zero_bytes, s));   // gtmax + the compactions' look-back words
-    const int blocks = (L.N + 255) / 256;
-    hipLaunchKernelGGL(at_overlap_kernel, dim3(blocks), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(at_label_kernel, dim3(blocks), dim3(256), 0, s, d);
-    AtLists lists = {(int32_t *)(ws + L.o_fg), (int32_t *)(ws + L.o_bg), (int32_t *)(ws + L.o_low)};
-    hipLaunchKernelGGL(at_compact_kernel, dim3(L.ncwg), dim3(256), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov, lists,
-                       counts_dev, fg_hi_dev, (int32_t *)(ws + L.o_agg1));
+    if (most > 0) hipLaunchKernelGGL(at_disable_all_kernel, dim3((most + 255) / 256, batch), dim3(256), 0, s, bt);
+    hipLaunchKernelGGL(at_emit_relabel_kernel, dim3(L.ncwg, batch), dim3(256), 0, s, bt);
     return mv3d_launch_status();
 }
 
@@ -297,24 +397,7 @@ extern "C" int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_
                                          float *anchors_dev, float *anchors_3d_dev, int32_t *n_anchors_dev,
                                          int anchors_cap, void *workspace, size_t workspace_bytes, void *stream)
 {
-    AtLayout L;
-    if (!p || !at_layout(H, W, 0, L) || !labels_dev || n_dis_fg < 0 || n_dis_bg1 < 0 || n_dis_bg2 < 0)
-        return MV3D_ERR_INVALID_ARG;
-    if ((n_dis_fg && !disable_fg_dev) || (n_dis_bg1 && !disable_bg1_dev) || (n_dis_bg2 && !disable_bg2_dev))
-        return MV3D_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    char *ws = (char *)workspace;
-    AtDev d;
-    at_fill(d, L, H, W, 0, p, ws);
-    d.im_info = nullptr; d.gt_bv = nullptr; d.gt_3d = nullptr; d.labels = labels_dev; d.targets = nullptr;
-    int32_t *fg = (int32_t *)(ws + L.o_fg), *bg = (int32_t *)(ws + L.o_bg), *low = (int32_t *)(ws + L.o_low);
-    if (n_dis_fg) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_fg + 255) / 256), dim3(256), 0, s, labels_dev, fg, disable_fg_dev, n_dis_fg);
-    if (n_dis_bg1) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg1 + 255) / 256), dim3(256), 0, s, labels_dev, bg, disable_bg1_dev, n_dis_bg1);
-    if (anchors_dev && anchors_3d_dev && n_anchors_dev)
-        hipLaunchKernelGGL(at_emit_anchors_kernel, dim3(L.ncwg), dim3(256), 0, s, d, anchors_dev, anchors_3d_dev, n_anchors_dev,
-                           anchors_cap, (int32_t *)(ws + L.o_agg2));
-    hipLaunchKernelGGL(at_relabel_low_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, labels_dev, d.max_ov, L.N, d.neg_ov);
-    if (n_dis_bg2) hipLaunchKernelGGL(at_disable_kernel, dim3((n_dis_bg2 + 255) / 256), dim3(256), 0, s, labels_dev, low, disable_bg2_dev, n_dis_bg2);
-    return mv3d_launch_status();
+    return mv3d_anchor_target_stage2_batch(1, H, W, p, &disable_fg_dev, &n_dis_fg, &disable_bg1_dev, &n_dis_bg1, &disable_bg2_dev,
+                                           &n_dis_bg2, labels_dev, anchors_dev, anchors_3d_dev, n_anchors_dev, anchors_cap,
+                                           &workspace, workspace_bytes, stream);
 }

@@ -27,6 +27,19 @@ struct PtDev {
     int32_t *fg_list, *bg_list;          // (R+G) each
 };
 
+struct PtEmit {
+    const int32_t *fg_pick, *bg_pick;    // positions in the fg / bg lists
+    int n_fg, n_bg, num_classes;
+    const float *gt_corners, *calib;     // (G,25), (4,12)
+    float *rois_bv, *rois_img, *targets, *rois_3d;
+    int32_t *labels;
+};
+
+// frames of a batch behind one launch of every kernel: blockIdx.y = frame
+#define PT_MAX_BATCH 16
+struct PtFrame { PtDev d; PtEmit e; int32_t *counts; };
+struct PtBatch { PtFrame f[PT_MAX_BATCH]; };
+
 // row r of the candidate set: proposals then ground truth with a 0 batch column (:38-44); a batched caller sets
 // params.frame_index so that the ground-truth rows of frame b carry b like the frame's proposals do
 __device__ __forceinline__ void cand_bv(const PtDev &d, int r, float o[5])
@@ -40,8 +53,9 @@ __device__ __forceinline__ void cand_3d(const PtDev &d, int r, float o[7])
     else { o[0] = d.gt_frame; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - d.R) + j]; }
 }
 
-__global__ __launch_bounds__(256) void pt_overlap_kernel(PtDev d)
+__global__ __launch_bounds__(256) void pt_overlap_kernel(PtBatch bt)
 {
+    const PtDev &d = bt.f[blockIdx.y].d;
     __shared__ float s_gt[PT_MAX_GT * 4];
     for (int g = threadIdx.x; g < d.G; g += blockDim.x)
         for (int j = 0; j < 4; ++j) s_gt[4 * g + j] = d.gt_bv[5 * g + j];
@@ -72,8 +86,10 @@ __global__ __launch_bounds__(256) void pt_overlap_kernel(PtDev d)
     d.assign[r] = am;
 }
 
-__global__ __launch_bounds__(1024) void pt_compact_kernel(PtDev d, int32_t *counts)
+__global__ __launch_bounds__(1024) void pt_compact_kernel(PtBatch bt)
 {
+    const PtDev &d = bt.f[blockIdx.y].d;
+    int32_t *counts = bt.f[blockIdx.y].counts;
     const int n = d.R + d.G;
     int tot[2];
     mv3d_block_compact<2>(
@@ -88,16 +104,11 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(PtDev d, int32_t *coun
     if (threadIdx.x == 0) { counts[0] = n; counts[1] = tot[0]; counts[2] = tot[1]; counts[3] = 0; }
 }
 
-struct PtEmit {
-    const int32_t *fg_pick, *bg_pick;    // positions in the fg / bg lists
-    int n_fg, n_bg, num_classes;
-    const float *gt_corners, *calib;     // (G,25), (4,12)
-    float *rois_bv, *rois_img, *targets, *rois_3d;
-    int32_t *labels;
-};
 
-__global__ __launch_bounds__(128) void pt_emit_kernel(PtDev d, PtEmit e)
+__global__ __launch_bounds__(128) void pt_emit_kernel(PtBatch bt)
 {
+    const PtDev &d = bt.f[blockIdx.y].d;
+    const PtEmit &e = bt.f[blockIdx.y].e;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = e.n_fg + e.n_bg;
     if (t >= S) return;
@@ -174,21 +185,74 @@ extern "C" size_t mv3d_proposal_target_workspace_bytes(int num_rois, int G)
     return pt_layout(num_rois, G, L) ? L.total : 0;
 }
 
+extern "C" int mv3d_proposal_target_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                                 const int *G, const mv3d_proposal_target_params *p, int32_t *const *counts_dev,
+                                                 void *const *workspace, const size_t *workspace_bytes, void *stream)
+{
+    if (batch <= 0 || batch > PT_MAX_BATCH || !p || !rois_bv_dev || !rois_3d_dev || !num_rois || !gt_bv_dev || !gt_3d_dev || !G ||
+        !counts_dev || !workspace || !workspace_bytes)
+        return MV3D_ERR_INVALID_ARG;
+    PtBatch bt = {};
+    int most = 0;
+    for (int b = 0; b < batch; ++b) {
+        PtLayout L;
+        if (!pt_layout(num_rois[b], G[b], L) || !gt_bv_dev[b] || !gt_3d_dev[b] || !counts_dev[b] ||
+            (num_rois[b] > 0 && (!rois_bv_dev[b] || !rois_3d_dev[b])))
+            return MV3D_ERR_INVALID_ARG;
+        if (!workspace[b] || workspace_bytes[b] < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+        pt_fill(bt.f[b].d, L, (char *)workspace[b], rois_bv_dev[b], rois_3d_dev[b], num_rois[b], gt_bv_dev[b], gt_3d_dev[b], G[b], &p[b]);
+        bt.f[b].counts = counts_dev[b];
+        if (num_rois[b] + G[b] > most) most = num_rois[b] + G[b];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pt_overlap_kernel, dim3((most + 255) / 256, batch), dim3(256), 0, s, bt);
+    hipLaunchKernelGGL(pt_compact_kernel, dim3(1, batch), dim3(1024), 0, s, bt);
+    return mv3d_launch_status();
+}
+
 extern "C" int mv3d_proposal_target_stage1(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
                                            const float *gt_bv_dev, const float *gt_3d_dev, int G,
                                            const mv3d_proposal_target_params *p, int32_t *counts_dev, void *workspace,
                                            size_t workspace_bytes, void *stream)
 {
-    PtLayout L;
-    if (!p || !pt_layout(num_rois, G, L) || !gt_bv_dev || !gt_3d_dev || !counts_dev ||
-        (num_rois > 0 && (!rois_bv_dev || !rois_3d_dev)))
+    return mv3d_proposal_target_stage1_batch(1, &rois_bv_dev, &rois_3d_dev, &num_rois, &gt_bv_dev, &gt_3d_dev, &G, p, &counts_dev,
+                                             &workspace, &workspace_bytes, stream);
+}
+
+extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                                 const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
+                                                 const mv3d_proposal_target_params *p, const int32_t *const *fg_pick_dev,
+                                                 const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
+                                                 float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
+                                                 float *const *bbox_targets_out, float *const *rois_3d_out, void *const *workspace,
+                                                 const size_t *workspace_bytes, void *stream)
+{
+    if (batch <= 0 || batch > PT_MAX_BATCH || !p || !num_rois || !G || !n_fg || !n_bg || !workspace || !workspace_bytes)
         return MV3D_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
-    PtDev d;
-    pt_fill(d, L, (char *)workspace, rois_bv_dev, rois_3d_dev, num_rois, gt_bv_dev, gt_3d_dev, G, p);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(pt_overlap_kernel, dim3((num_rois + G + 255) / 256), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(pt_compact_kernel, dim3(1), dim3(1024), 0, s, d, counts_dev);
+    PtBatch bt = {};
+    int most = 0;
+    for (int b = 0; b < batch; ++b) {
+        PtLayout L;
+        if (!pt_layout(num_rois[b], G[b], L) || n_fg[b] < 0 || n_bg[b] < 0 || p[b].num_classes <= 0) return MV3D_ERR_INVALID_ARG;
+        PtEmit &e = bt.f[b].e;
+        e.n_fg = n_fg[b]; e.n_bg = n_bg[b]; e.num_classes = p[b].num_classes;
+        if (n_fg[b] + n_bg[b] == 0) continue;
+        if (!gt_bv_dev[b] || !gt_3d_dev[b] || !gt_corners_dev[b] || !calib_dev[b] || (n_fg[b] && !fg_pick_dev[b]) ||
+            (n_bg[b] && !bg_pick_dev[b]) || !rois_bv_out[b] || !rois_img_out[b] || !labels_out[b] || !bbox_targets_out[b] ||
+            !rois_3d_out[b])
+            return MV3D_ERR_INVALID_ARG;
+        if (!workspace[b] || workspace_bytes[b] < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+        pt_fill(bt.f[b].d, L, (char *)workspace[b], rois_bv_dev[b], rois_3d_dev[b], num_rois[b], gt_bv_dev[b], gt_3d_dev[b], G[b], &p[b]);
+        e.fg_pick = fg_pick_dev[b]; e.bg_pick = bg_pick_dev[b];
+        e.gt_corners = gt_corners_dev[b]; e.calib = calib_dev[b];
+        e.rois_bv = rois_bv_out[b]; e.rois_img = rois_img_out[b]; e.targets = bbox_targets_out[b]; e.rois_3d = rois_3d_out[b];
+        e.labels = labels_out[b];
+        if (n_fg[b] + n_bg[b] > most) most = n_fg[b] + n_bg[b];
+    }
+    if (most == 0) return MV3D_OK;
+    hipLaunchKernelGGL(pt_emit_kernel, dim3((most + 127) / 128, batch), dim3(128), 0, (hipStream_t)stream, bt);
     return mv3d_launch_status();
 }
 
@@ -200,20 +264,8 @@ extern "C" int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float
                                            int32_t *labels_out, float *bbox_targets_out, float *rois_3d_out,
                                            void *workspace, size_t workspace_bytes, void *stream)
 {
-    PtLayout L;
-    if (!p || !pt_layout(num_rois, G, L) || n_fg < 0 || n_bg < 0 || p->num_classes <= 0) return MV3D_ERR_INVALID_ARG;
-    if (n_fg + n_bg == 0) return MV3D_OK;
-    if (!gt_bv_dev || !gt_3d_dev || !gt_corners_dev || !calib_dev || (n_fg && !fg_pick_dev) || (n_bg && !bg_pick_dev) ||
-        !rois_bv_out || !rois_img_out || !labels_out || !bbox_targets_out || !rois_3d_out)
-        return MV3D_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
-    PtDev d;
-    pt_fill(d, L, (char *)workspace, rois_bv_dev, rois_3d_dev, num_rois, gt_bv_dev, gt_3d_dev, G, p);
-    PtEmit e;
-    e.fg_pick = fg_pick_dev; e.bg_pick = bg_pick_dev; e.n_fg = n_fg; e.n_bg = n_bg; e.num_classes = p->num_classes;
-    e.gt_corners = gt_corners_dev; e.calib = calib_dev;
-    e.rois_bv = rois_bv_out; e.rois_img = rois_img_out; e.targets = bbox_targets_out; e.rois_3d = rois_3d_out;
-    e.labels = labels_out;
-    hipLaunchKernelGGL(pt_emit_kernel, dim3((n_fg + n_bg + 127) / 128), dim3(128), 0, (hipStream_t)stream, d, e);
-    return mv3d_launch_status();
+    if (!p) return MV3D_ERR_INVALID_ARG;
+    return mv3d_proposal_target_stage2_batch(1, &rois_bv_dev, &rois_3d_dev, &num_rois, &gt_bv_dev, &gt_3d_dev, &gt_corners_dev, &G,
+                                             &calib_dev, p, &fg_pick_dev, &n_fg, &bg_pick_dev, &n_bg, &rois_bv_out, &rois_img_out,
+                                             &labels_out, &bbox_targets_out, &rois_3d_out, &workspace, &workspace_bytes, stream);
 }

@@ -152,7 +152,7 @@ class TrainPathBatch:
         self.anchors_3d = torch.empty((B, self.anchor_cap, 7), dtype=torch.float32, device=dev)
         self.n_anchors = torch.empty((B,), dtype=torch.int32, device=dev)
         picks, self.S = [], []
-        at_calls, pt_calls = [], []
+        at_calls, pt_calls, at_frames, pt_frames = [], [], [], []
         # replay plan with the frames' independent chains on side streams (see run()): side stream b carries frame b's anchor
         # targets (which do not depend on the proposals) and, for b >= 1, its proposal targets
         self.sides = [torch.cuda.Stream(device=dev) for _ in range(B)]
@@ -176,6 +176,7 @@ class TrainPathBatch:
                   self.anchor_cap, _P(aws), C.c_size_t(aws.numel()), st)
             check(L.mv3d_anchor_target_stage2(*a2), "mv3d_anchor_target_stage2")
             at_calls += [(L.mv3d_anchor_target_stage1, a1), (L.mv3d_anchor_target_stage2, a2)]
+            at_frames.append((gt_bv, gt_3d, G, cf, aws, dl, [len(x) for x in lists]))
             self.at_side[b] = [(L.mv3d_anchor_target_stage1, a1[:-1] + (side_st[b],)), (L.mv3d_anchor_target_stage2, a2[:-1] + (side_st[b],))]
             bnd.keep += [aws, cf, dl, info_b]
             # proposal targets of frame b on its num_proposals[b] rows
@@ -210,12 +211,43 @@ class TrainPathBatch:
                   C.c_size_t(tws.numel()), st)
             check(L.mv3d_proposal_target_stage2(*p2), "mv3d_proposal_target_stage2")
             pt_calls += [(L.mv3d_proposal_target_stage1, p1), (L.mv3d_proposal_target_stage2, p2)]
+            pt_frames.append((gt_bv, gt_3d, gt_cnr, G, counts, tws, pl, n_fg, n_bg, off, S))
             on = st if b == 0 else side_st[b]
             self.pt_side[b] = [(L.mv3d_proposal_target_stage1, p1[:-1] + (on,)), (L.mv3d_proposal_target_stage2, p2[:-1] + (on,))]
             bnd.keep += [pl, tws, counts]
             off += S
-        for fn, args in at_calls + pt_calls:
-            bnd.add(fn, *args)
+        # ---- the replay runs the target layers of ALL frames behind one launch of every kernel (mv3d_*_batch entries:
+        # 3 + 2 launches for the anchor targets, 2 + 1 for the proposal targets, whatever the batch size)
+        ptrs = lambda ts: (C.c_void_p * B)(*[0 if t is None else t.data_ptr() for t in ts])
+        ints = lambda vs: (C.c_int * B)(*[int(v) for v in vs])
+        A = at_frames
+        a_gtbv, a_gt3d, a_G = ptrs([f[0] for f in A]), ptrs([f[1] for f in A]), ints([f[2] for f in A])
+        a_cnt, a_fgh = ptrs([f[3][:32] for f in A]), ptrs([f[3][32:] for f in A])
+        a_ws = ptrs([f[4] for f in A])
+        a_wsz = min(f[4].numel() for f in A)
+        a_d = [ptrs([f[5][k] for f in A]) for k in range(3)]
+        a_n = [ints([f[6][k] for f in A]) for k in range(3)]
+        bnd.add(L.mv3d_anchor_target_stage1_batch, B, H, W, _P(self.info), a_gtbv, a_gt3d, a_G, C.byref(self.aparams),
+                _P(self.rpn_labels), _P(self.rpn_targets), a_cnt, a_fgh, a_ws, C.c_size_t(a_wsz), st)
+        bnd.add(L.mv3d_anchor_target_stage2_batch, B, H, W, C.byref(self.aparams), a_d[0], a_n[0], a_d[1], a_n[1], a_d[2], a_n[2],
+                _P(self.rpn_labels), _P(self.anchors), _P(self.anchors_3d), _P(self.n_anchors), self.anchor_cap, a_ws,
+                C.c_size_t(a_wsz), st)
+        P = pt_frames
+        tpar = (ProposalTargetParams * B)(*self.tparams)
+        p_bv, p_b3, p_nr = ptrs([bv[b] for b in range(B)]), ptrs([b3[b] for b in range(B)]), ints(nums)
+        p_gtbv, p_gt3d, p_gtc = ptrs([f[0] for f in P]), ptrs([f[1] for f in P]), ptrs([f[2] for f in P])
+        p_G, p_cnt, p_ws = ints([f[3] for f in P]), ptrs([f[4] for f in P]), ptrs([f[5] for f in P])
+        p_wsz = (C.c_size_t * B)(*[f[5].numel() for f in P])
+        p_cal = ptrs([self.calib[b] for b in range(B)])
+        p_fg, p_bg = ptrs([f[6][0] for f in P]), ptrs([f[6][1] for f in P])
+        p_nfg, p_nbg = ints([f[7] for f in P]), ints([f[8] for f in P])
+        sl = lambda t: ptrs([t[f[9]:f[9] + f[10]] if f[10] else None for f in P])
+        p_out = [sl(self.rois["bev"]), sl(self.rois["rgb"]), sl(self.labels), sl(self.bbox_targets), sl(self.rois_3d)]
+        bnd.add(L.mv3d_proposal_target_stage1_batch, B, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_G, tpar, p_cnt, p_ws, p_wsz, st)
+        bnd.add(L.mv3d_proposal_target_stage2_batch, B, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_gtc, p_G, p_cal, tpar, p_fg, p_nfg, p_bg,
+                p_nbg, p_out[0], p_out[1], p_out[2], p_out[3], p_out[4], p_ws, p_wsz, st)
+        bnd.keep += [a_gtbv, a_gt3d, a_G, a_cnt, a_fgh, a_ws, a_d, a_n, tpar, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_gtc, p_G, p_cnt,
+                     p_ws, p_wsz, p_cal, p_fg, p_bg, p_nfg, p_nbg, p_out]
         # ---- third view's ROIs, RoiPool forward + backward on every view
         self.tops, self.top_diff, self.bottom_diff = {}, {}, {}
         g = torch.Generator(device=dev).manual_seed(1000 + int(self.top_diff_seed))
@@ -251,8 +283,7 @@ class TrainPathBatch:
             bnd.calls = bnd.calls[-2:]
         self.bound = bnd
         self.head = bnd.calls[0]                               # mv3d_proposal_3d
-        self.tail = [c for c in bnd.calls[1:] if c[0].__name__ not in ("mv3d_anchor_target_stage1", "mv3d_anchor_target_stage2",
-                                                                       "mv3d_proposal_target_stage1", "mv3d_proposal_target_stage2")]
+        self.tail = [c for c in bnd.calls[1:] if "_target_stage" not in c[0].__name__]
         self.ev_fork, self.ev_prop = torch.cuda.Event(), torch.cuda.Event()
         self.ev_join = [torch.cuda.Event() for _ in range(B)]
         # measured: 6.9 k frames/s with the branches vs 10.6 k as one chain per batch (one batch alone: 297 vs 331 us) -- cross-queue
