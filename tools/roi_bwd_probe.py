@@ -25,6 +25,9 @@ for k in range(NB):
     frames = [synth.rpn_head(100000 + 2 * k + b, 76, 76, "peaky", return_gt=True) for b in range(FR)]
     batches.append(hot_path.TrainPathBatch(frames, hot_path.synth_maps(FR, k, dev), top_diff_seed=k).setup())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("SHARE_MAPS"):                     # every batch reads the maps of batch 0 (outputs stay distinct)
+    for b in batches[1:]:
+        b.maps = batches[0].maps
 if os.environ.get("SHARE_OUT"):                      # every batch writes the outputs of batch 0 (inputs stay distinct)
     for b in batches[1:]:
         if b.num_rois == batches[0].num_rois:
