@@ -31,15 +31,20 @@ _VGG = [("conv1_1", 64, False), ("conv1_2", 64, True), ("conv2_1", 128, False), 
         ("conv3_1", 256, False), ("conv3_2", 256, False), ("conv3_3", 256, True),
         ("conv4_1", 512, False), ("conv4_2", 512, False), ("conv4_3", 512, False),
         ("conv5_1", 512, False), ("conv5_2", 512, False), ("conv5_3", 512, False)]
-_INPUTS = ("lidar_bv_data", "image_data", "im_info", "calib", "gt_boxes", "gt_boxes_bv", "gt_boxes_3d",
+_INPUTS = ("lidar_bv_data", "image_data", "lidar_fv_data", "im_info", "calib", "gt_boxes", "gt_boxes_bv", "gt_boxes_3d",
            "gt_boxes_corners")
 
 
 class MV3D:
     """One class for both graphs; `phase` is 'TEST' (MV3D_test) or 'TRAIN' (MV3D_train)."""
 
-    def __init__(self, phase="TEST", trainable=True, device=None, seed=0):
+    def __init__(self, phase="TEST", trainable=True, device=None, seed=0, views=2):
+        """views = 2: the reference's graphs (BEV + RGB towers).  views = 3 adds the front view the MV3D paper has and the
+        reference leaves a TODO (`proposal_transform`, network.py:293-315): a third VGG16 trunk on `lidar_fv_data`
+        (1, 64, 512, 3), `rois_fv` = mv3d_rois_3d_to_fv(rois_3d), a third RoiPool `pool_5_3` and tower fc6_3 / fc7_3, the
+        three towers concatenated (6144 -> cls_score / bbox_pred).  Parity unpinned by construction."""
         self.phase = phase
+        self.views = int(views)
         self.trainable = trainable
         self.device = torch.device(device or ("cuda:%d" % cfg.GPU_ID))
         self.layers = {}
@@ -52,7 +57,8 @@ class MV3D:
             b = torch.zeros(shape[0], device=self.device, requires_grad=trainable)
             self.params[name] = [w, b]
 
-        for suffix, cin in (("", 9), ("_2", 3)):                   # BEV trunk (9 ch), RGB trunk (3 ch)
+        trunks = (("", 9), ("_2", 3)) + ((("_3", 3),) if self.views == 3 else ())
+        for suffix, cin in trunks:                                 # BEV trunk (9 ch), RGB trunk (3 ch) [, FV trunk (3 ch)]
             c = cin
             for stem, cout, _ in _VGG:
                 var(stem + suffix, (cout, c, 3, 3), 0.01)
@@ -60,11 +66,12 @@ class MV3D:
         var("rpn_conv/3x3", (512, 512, 3, 3), 0.01)
         var("rpn_cls_score", (len(anchor_scales) * 2 * 2, 512, 1, 1), 0.01)
         var("rpn_bbox_pred", (len(anchor_scales) * 2 * 6, 512, 1, 1), 0.01)
-        for t in ("_1", "_2"):
+        towers = ("_1", "_2") + (("_3",) if self.views == 3 else ())
+        for t in towers:
             var("fc6" + t, (2048, 7 * 7 * 512), 0.01)
             var("fc7" + t, (2048, 2048), 0.01)
-        var("cls_score", (n_classes, 4096), 0.01)
-        var("bbox_pred", (n_classes * 24, 4096), 0.001)            # network.py:382-384
+        var("cls_score", (n_classes, 2048 * len(towers)), 0.01)
+        var("bbox_pred", (n_classes * 24, 2048 * len(towers)), 0.001)   # network.py:382-384
 
     # ---- lib/networks/network.py plumbing
     def get_output(self, layer):
@@ -126,6 +133,8 @@ class MV3D:
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
         bev = self._trunk(to_nchw(L["lidar_bv_data"]), "")
         rgb = self._trunk(to_nchw(L["image_data"]), "_2")
+        if self.views == 3:
+            self._trunk(to_nchw(L["lidar_fv_data"]), "_3")
         # RPN (MV3D_train.py:82-103)
         rpn = self._conv(bev, "rpn_conv/3x3")
         L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
@@ -155,8 +164,15 @@ class MV3D:
         # RoI pooling on both views + fusion head (MV3D_test.py:95-123)
         L["pool_5"] = roi_pool(L["conv5_3"].contiguous(), L["roi_data_bv"].contiguous(), 7, 7, 1.0 / 8)[0]
         L["pool_5_2"] = roi_pool(L["conv5_3_2"].contiguous(), L["roi_data_img"].contiguous(), 7, 7, 1.0 / 8)[0]
+        pools = [("_1", "pool_5"), ("_2", "pool_5_2")]
+        if self.views == 3:
+            from ..utils.front_view import rois_3d_to_fv
+            r3 = data[4] if self.phase == "TRAIN" else rois[2]
+            L["roi_data_fv"] = rois_3d_to_fv(r3 if isinstance(r3, torch.Tensor) else torch.as_tensor(np.asarray(r3, np.float32)).to(dev))
+            L["pool_5_3"] = roi_pool(L["conv5_3_3"].contiguous(), L["roi_data_fv"].contiguous(), 7, 7, 1.0 / 8)[0]
+            pools.append(("_3", "pool_5_3"))
         tower = []
-        for t, pool in (("_1", "pool_5"), ("_2", "pool_5_2")):
+        for t, pool in pools:
             x = self._fc(L[pool], "fc6" + t)
             if self.phase == "TRAIN":
                 x = F.dropout(x, 1.0 - keep_prob, training=True)

@@ -255,3 +255,35 @@ def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle, yml):
     assert np.array_equal(tb.rois["fv"].cpu().numpy(), fv_want)
     o_top, o_am = oracle.roi_pool(maps_h["fv"], fv_want, 7, 7, 0.125)
     assert np.array_equal(tb.tops["fv"][0].cpu().numpy(), o_top) and np.array_equal(tb.tops["fv"][1].cpu().numpy(), o_am)
+
+
+def test_three_view_graph_forward_backward(gpu):
+    """row X1: the front view in the runnable graph (`MV3D_train_3view`): third trunk, rois_fv from the 3D ROIs, third
+    RoiPool + tower; losses back-propagate into all three conv5_3 maps through RoiPoolGrad."""
+    torch, ops = gpu
+    from mv3d_tf_amd.fast_rcnn.train_mv import total_loss
+    from mv3d_tf_amd.networks import get_network
+    net = get_network("MV3D_train_3view")
+    assert net.views == 3 and "conv5_3_3" in net.params and net.params["cls_score"][0].shape == (2, 6144)
+    rng = np.random.RandomState(1)
+    _, _, info, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(55, 76, 76, "peaky", return_gt=True)
+    np.random.seed(3)
+    with torch.no_grad():
+        net.params["rpn_cls_score"][0].mul_(40.0)
+    L = net.forward({"lidar_bv_data": (rng.random_sample((1, 608, 608, 9)) < 0.02).astype(np.float32),
+                     "image_data": rng.randint(0, 255, (1, 96, 320, 3)).astype(np.float32),
+                     "lidar_fv_data": rng.random_sample((1, 64, 512, 3)).astype(np.float32),
+                     "im_info": info, "calib": calib, "gt_boxes_bv": gt_bv, "gt_boxes_3d": gt_3d, "gt_boxes_corners": gt_cnr})
+    S = L["roi_data_3d"][0].shape[0]
+    assert L["conv5_3_3"].shape == (1, 8, 64, 512) and L["roi_data_fv"].shape == (S, 5) and L["pool_5_3"].shape == (S, 7, 7, 512)
+    fv = L["roi_data_fv"].cpu().numpy()
+    assert fv[:, 1:].min() >= 0 and fv[:, [1, 3]].max() <= 511 and fv[:, [2, 4]].max() <= 63
+    loss, _ = total_loss(L)
+    loss.backward()
+    for k in ("conv5_3", "conv5_3_3", "fc6_3"):        # (the 96 x 320 test image is smaller than the 375 x 1242 the image ROIs assume)
+        g = net.params[k][0].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, k
+    t = get_network("MV3D_test_3view")
+    Lt = t.forward({"lidar_bv_data": np.zeros((1, 608, 608, 9), np.float32), "image_data": np.zeros((1, 96, 320, 3), np.float32),
+                    "lidar_fv_data": np.zeros((1, 64, 512, 3), np.float32), "im_info": info, "calib": calib})
+    assert Lt["cls_prob"].shape[1] == 2 and Lt["pool_5_3"].shape[0] == Lt["cls_prob"].shape[0]
