@@ -165,10 +165,11 @@ typedef struct {
 } mv3d_roi_grad_view;
 size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height,
                                               int pooled_width);
-/* workspace (optional, 256-B aligned): with at least mv3d_roi_pool_backward_workspace_bytes() bytes the call runs as two
- * launches -- per-pixel candidate index, then a gather that reads every (roi, bin) record slice on one XCD -- which is the
- * fast path (C % 64 == 0, pooled sizes <= 15).  Its first 256 bytes must be ZERO on the first call (the kernels leave them
- * zero again: no memset node per call).  With workspace == NULL the call needs no scratch memory and is slower. */
+/* workspace (optional, 256-B aligned): with at least mv3d_roi_pool_backward_workspace_bytes() bytes the call runs as three
+ * launches -- per-pixel candidate index (sizes, then lists), then a gather that reads every (roi, bin) record slice on one
+ * XCD -- which is the fast path (same C for all views, C in {64, 128, 256 k}, pooled sizes <= 15, 16-byte aligned buffers).
+ * The workspace needs no initialisation (every word is written before it is read).  With workspace == NULL the call needs
+ * no scratch memory and is slower (one launch, XCD-sliced, geometry recomputed per slice). */
 int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
                                  void *workspace, size_t workspace_bytes, void *stream);
 

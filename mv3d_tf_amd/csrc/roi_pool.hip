@@ -559,24 +559,28 @@ __global__ __launch_bounds__(BW_THREADS) void roi_pool_bwd_sliced_kernel(RoiGrad
 
 // ---------------------------------------------------------------------------------------------------------------
 // Indexed RoiPoolGrad (used when the caller passes a workspace): the same gather, split into
-//   roi_bwd_index_kernel   ONCE per launch and per pixel (not per channel slice): which (roi, bin) records are candidates
+//   roi_bwd_index_kernel<false>, <true>
+//                          ONCE per launch and per pixel (not per channel slice): which (roi, bin) records are candidates
 //                          of pixel (n, h, w), in reference order roi -> ph -> pw.  A workgroup = 16 pixels of a row: it
-//                          zero-fills its pixels of bottom_diff (streaming stores, issued first), filters the ROIs (frame,
-//                          row, column span), evaluates the (pixel, roi) pairs in parallel (the f32 divides of
-//                          roi_pooling_op.cc:423-426), sizes the pixels' lists, takes one slab of the candidate pool and one
-//                          of the item list with two atomicAdds, writes the lists and one item (pixel, offset, count) per
-//                          pixel that has candidates -- ~80 % of the pixels have none and are finished here.
-//   roi_bwd_gather_kernel  a fixed grid; wave = (item, 64-channel slice): walks the item's list with wave-uniform record
-//                          indices, 16 records (2 x 16 dword loads per lane) in flight, adds in list order and overwrites
-//                          the pixel's slice.  Slice s of every record is only ever read by XCD s.  No LDS, no barrier.
-// Why two kernels: a launch is paced by the workgroup dispatcher (~2.5 workgroups / ns on this chip: a kernel with one
-// 4-wave workgroup per 4 pixels and slice, 54 k workgroups, takes 20 us to do NOTHING), and a wave that walks pixels one
-// after the other pays every pixel's memory round trips in sequence (the sliced kernel above: 102 us on the training
-// batch).  Here the per-pixel work that is not the sum itself happens once, in 2.4 k workgroups, and the sums run as ~34 k
-// independent waves.
-// Workspace: [0, 256) header {pool cursor, item count, ticket}: zero on entry, left zero by the gather kernel's last
-// workgroup; then the item list (int4 per pixel of all views), then the candidate pool.  Pool bound per ROI: the sum over
-// the rows of (phe - phs) is <= PH + 2 rows + 3 (floor / ceil slack), likewise over the columns.
+//                          filters the ROIs (frame, row, column span) and evaluates the (pixel, roi) pairs in parallel
+//                          (the f32 divides of roi_pooling_op.cc:423-426).  <false> zero-fills the pixels of bottom_diff
+//                          (streaming stores, issued first) and writes the segment's sizes; <true> takes its slab offsets
+//                          as plain sums over the preceding segments' sizes (the sizing launch is complete: no atomics,
+//                          no look-back protocol, nothing that has to be zero on entry), writes the candidate lists (byte
+//                          offsets of the records) and one item (pixel, offset, count, view) per pixel that has candidates
+//                          -- ~80 % of the pixels have none and are finished by the zero fill.
+//   roi_bwd_gather_kernel  a fixed grid; wave = (item, 64-channel slice): walks the item's list (record offset = scalar
+//                          offset of a buffer load, 32 records in flight, the next item's header and offsets requested
+//                          while this item's records fly), adds in list order and overwrites the pixel's slice.  Slice s
+//                          of every record is only ever read by XCD s.  No LDS, no barrier.
+// Why this shape (each point measured): the workgroup dispatcher hands out ~2.5 workgroups / ns (a kernel with
+// one 4-wave workgroup per 4 pixels and slice, 54 k workgroups, takes 20 us to do NOTHING) -> a fixed gather grid over the
+// compact item list; a same-address global atomic costs ~20 ns however many workgroups issue it (1 k slab allocations =
+// 20 us) -> sizes and offsets in two launches instead; a wave that walks pixels one after the other behind LDS round trips
+// pays every pixel's memory round trips in sequence (the sliced kernel above: 102 us on the training batch).
+// Workspace: [0, 256) header {-, item count}, per-segment sizes (2 ints per 16-pixel segment), the item list (int4 per
+// pixel of all views), the candidate pool.  Pool bound per ROI: the sum over the rows of (phe - phs) is <= PH + 2 rows + 3
+// (floor / ceil slack), likewise over the columns.  Every word is written before it is read: no memset, no zero contract.
 #define BWI_PIX 16
 #define BWG_GROUPS 256                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
 struct RoiGradIdxPack { long long *trace; int4 *items; int *pool; int *header; int *seg_tot, *seg_ne; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; };
