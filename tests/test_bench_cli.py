@@ -1,0 +1,62 @@
+"""bench.py host logic without a GPU: defaults of the driver contract, `--gpus N` re-execution under torch.distributed.run,
+the loud failure when no MI355X is visible, and the signature check of the PMC traffic lookup."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def bench(monkeypatch):
+    monkeypatch.syspath_prepend(ROOT)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    return importlib.import_module("bench")
+
+
+def test_defaults_match_the_driver_contract(bench, monkeypatch):
+    a = bench.parse()
+    assert (a.gpus, a.workload, a.launch, a.streams) == (1, "train", "graph", 3) and a.steps > 0 and a.warmup >= 0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+    assert "3-view" in bench.METRIC and bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_gpus_n_respawns_one_rank_per_gpu(bench, monkeypatch):
+    seen = {}
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    rc = bench.respawn_under_torchrun(bench.parse())
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_main_fails_loudly_without_a_gpu(bench, monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "MI355X" in str(e.value)
+
+
+def test_pmc_traffic_only_for_the_profiled_configuration(bench, tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r02_pmc_traffic.json").write_text(json.dumps({"signature": "train/b2/r256/peaky", "kernels": {
+        "void roi_bwd_gather_kernel<1>": {"hbm_bytes_per_launch": 100}, "void roi_bwd_index_kernel<false>": {"hbm_bytes_per_launch": 10},
+        "void roi_pool_fwd_xcd_multi_kernel<2>": {"hbm_bytes_per_launch": 7}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("roi_bwd_", "train/b2/r256/peaky") == 110            # RoiPoolGrad = its kernels summed
+    assert bench.pmc_traffic("roi_pool_fwd_xcd_multi_kernel", "train/b2/r256/peaky") == 7
+    assert bench.pmc_traffic("roi_bwd_", "train/b2/r128/peaky") is None            # another configuration: never a stale number
+    assert bench.pmc_traffic("no_such_kernel", "train/b2/r256/peaky") is None
