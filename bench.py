@@ -66,6 +66,7 @@ def parse():
                          "per batch; eager enqueueing of a batch's ~28 launches costs the host more than the GPU needs to run "
                          "them once three batches are in flight); eager: plain in-order launches")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
+    ap.add_argument("--play-default", action="store_true", help="replay on the default stream as one more lane (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true")
@@ -101,9 +102,9 @@ class Ring:
             frames = [synth.rpn_head(seed0 + b, 76, 76, args.variant, return_gt=True) for b in range(batch)]
             maps = hot_path.synth_maps(batch, seed0, dev)
             if workload == "train":
-                slot = hot_path.TrainPathBatch(frames, maps, stream=st, top_diff_seed=k)
+                slot = hot_path.TrainPathBatch(frames, maps, stream=st, top_diff_seed=k, cold_maps=True)   # ring maps: written long ago
             else:
-                slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st)
+                slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st, cold_maps=True)
             self.slots.append(slot.setup())
             if k == 0:
                 self.host_frames = frames
@@ -123,7 +124,9 @@ class Ring:
                     with torch.cuda.stream(st):                       # CUDAGraph.replay() launches on the current stream
                         g.replay()
                 return play
-            self.play = [player(g, s.stream) for g, s in zip(self.graphs, self.slots)]
+            # replay streams: the capture streams, or (diagnostic, --play-default) those plus the default stream as one more lane
+            lanes = ([torch.cuda.default_stream()] if getattr(args, "play_default", False) else []) + list(streams)
+            self.play = [player(g, lanes[k % len(lanes)]) for k, g in enumerate(self.graphs)]
 
     def run(self, nbatches):
         n = len(self.slots)
@@ -169,7 +172,8 @@ def roofline_entries(ring, workload, signature):
     a cache-warm loop."""
     s0 = ring.slots[0].stream
     mine = [s for s in ring.slots if s.stream is s0]
-    legs = [("roi_pool_fwd_xcd_multi_kernel", "mv3d_roi_pool_forward_views", "roi_forward_bytes")]
+    legs = [("roi_pool_fwd_xcd_multi%s_kernel" % ("_cold" if getattr(mine[0], "cold_maps", False) else ""),
+             mine[0].fwd_fn.__name__, "roi_forward_bytes")]
     if workload == "train":
         legs.append(("roi_bwd_index_kernel<false> + <true> + roi_bwd_gather_kernel", "mv3d_roi_pool_backward_views", "roi_backward_bytes"))
     marks = {fn: [] for _, fn, _ in legs}
@@ -181,6 +185,8 @@ def roofline_entries(ring, workload, signature):
     torch.cuda.synchronize()
     out = []
     for kname, fn, bytes_meth in legs:
+        if not marks[fn]:                                         # (diagnostic replays that drop the call: MV3D_SKIP)
+            continue
         ms = sum(a.elapsed_time(b) for a, b in marks[fn]) / len(marks[fn])
         alg = getattr(mine[0], bytes_meth)()
         gbs = alg / (ms * 1e-3) / 1e9
@@ -341,7 +347,7 @@ def main():
         torch.cuda.synchronize()
         res["config"]["one_batch_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         entries = roofline_entries(ring, wl, signature)
-        dom = max(entries, key=lambda e: e["avg_launch_us"])
+        dom = max(entries, key=lambda e: e["avg_launch_us"]) if entries else {}
         res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = index + gather kernels behind one C call); "
                                          "HIP event pairs on the launch stream around the call inside the batch's eager launch "
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "

@@ -150,6 +150,12 @@ typedef struct {
 } mv3d_roi_view;
 int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
                                 void *stream);
+/* The same call for maps that are NOT cache-resident (inputs written long ago, e.g. a ring of resident batches): prefetch
+ * workgroups at the front of the same launch stream the map pixels the ROIs cover into the memory-side cache ahead of the
+ * pooling workgroups (58 -> 40 us on the training batch of bench.py).  Same results; pointless -- a few us slower -- when the
+ * maps were just produced by the previous layer.  (No counterpart in the reference.) */
+int mv3d_roi_pool_forward_views_cold(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                     void *stream);
 
 /* RoiPoolGrad of several views behind one call (the three RoiPool layers of a training step): same results as
  * one mv3d_roi_pool_backward per view.  In a backward view `top_data` is READ (top_diff, (num_rois,PH,PW,C)),
@@ -203,6 +209,7 @@ typedef struct {
     double positive_overlap;     /* cfg.TRAIN.RPN_POSITIVE_OVERLAP  */
 } mv3d_anchor_target_params;
 
+/* The workspace size grows with G; nothing in it has to be initialised (stage 1 = three launches, no memset). */
 size_t mv3d_anchor_target_workspace_bytes(int H, int W, int G);
 int mv3d_anchor_target_stage1(int H, int W, const float *im_info_dev, const float *gt_bv_dev,
                               const float *gt_3d_dev, int G, const mv3d_anchor_target_params *p,
@@ -226,7 +233,8 @@ int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
  * anchor_target_layer_tf.py:42-45; the per-frame entry points above are these with batch = 1).  Host-side arrays of `batch`
  * entries (device pointers / counts); labels_dev (batch,N), targets_dev (batch,N,6), im_info_dev (batch,3),
  * anchors_dev (batch,cap,5), anchors_3d_dev (batch,cap,7), n_anchors_dev (batch) are contiguous over the frames; one
- * workspace per frame.  batch <= 16.  stage2 = two launches: the three disable lists, then debug rows + final labels. */
+ * workspace per frame, each of at least workspace_bytes = mv3d_anchor_target_workspace_bytes(H, W, max_b G[b]) bytes.
+ * batch <= 16.  stage2 = two launches: the three disable lists, then debug rows + final labels. */
 int mv3d_anchor_target_stage1_batch(int batch, int H, int W, const float *im_info_dev, const float *const *gt_bv_dev,
                                     const float *const *gt_3d_dev, const int *G, const mv3d_anchor_target_params *p,
                                     float *labels_dev, float *targets_dev, int32_t *const *counts_dev,
@@ -271,7 +279,9 @@ int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_d
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same for `batch` frames behind one launch of every kernel (host-side arrays of per-frame device pointers / counts /
- * parameter structs -- params[b].frame_index = the batch column of frame b's appended ground-truth rows); batch <= 16. */
+ * parameter structs -- params[b].frame_index = the batch column of frame b's appended ground-truth rows); batch <= 16.
+ * stage 2: rois_fv_out (may be NULL, as may its entries) = per-frame (S_b,5) buffers for the third view's ROIs of the sampled
+ * boxes, the values mv3d_rois_3d_to_fv gives for rois_3d_out (one launch less on the training path). */
 int mv3d_proposal_target_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
                                       const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
                                       const int *G, const mv3d_proposal_target_params *params, int32_t *const *counts_dev,
@@ -282,8 +292,8 @@ int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev
                                       const mv3d_proposal_target_params *params, const int32_t *const *fg_pick_dev,
                                       const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
                                       float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
-                                      float *const *bbox_targets_out, float *const *rois_3d_out, void *const *workspace,
-                                      const size_t *workspace_bytes, void *stream);
+                                      float *const *bbox_targets_out, float *const *rois_3d_out, float *const *rois_fv_out,
+                                      void *const *workspace, const size_t *workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ SURVEY §8(f) "next" rows
  * BEV rasteriser: replaces point_cloud_2_top (lib/utils/read_lidar.py:10-115, called with

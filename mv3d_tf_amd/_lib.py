@@ -78,7 +78,7 @@ _SIGS = {
                                                   _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_proposal_target_stage1_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mv3d_proposal_target_stage2_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                                    _P, _P]),
+                                                    _P, _P, _P]),
     "mv3d_proposal_target_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mv3d_proposal_target_stage1": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(ProposalTargetParams), _P, _P,
                                               C.c_size_t, _P]),
@@ -90,6 +90,7 @@ _SIGS = {
     "mv3d_rpn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_rcnn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
+    "mv3d_roi_pool_forward_views_cold": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
     "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
     "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),

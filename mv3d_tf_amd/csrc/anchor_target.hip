@@ -3,8 +3,11 @@
 // the N x G overlap matrix is never materialised.
 //
 //  at_overlap_kernel   per anchor: inside test, f64 IoU against the G ground-truth boxes staged
-//                      in LDS, first-argmax / max per anchor, per-GT column maximum (u64 atomicMax
-//                      on the bit pattern of the non-negative f64, LDS first, then global).
+//                      in LDS, first-argmax / max per anchor, per-GT column maximum of the workgroup's
+//                      256 anchors (u64 atomicMax in LDS on the bit pattern of the non-negative f64),
+//                      stored as one partial per (GT, workgroup): no global atomics, so nothing in the
+//                      workspace has to be zero on entry (the look-back words of the two compactions
+//                      are cleared by this launch as well) -- stage 1 is three launches and no memset.
 //  at_label_kernel     labels before any random subsampling (incl. the "every anchor tying a
 //                      GT's column max" flood) and the 6-d targets, written straight
 //                      into the full-grid (unmapped) outputs: -1 / 0 fill for outside anchors.
@@ -61,7 +64,8 @@ struct AtDev {
     const float *im_info, *gt_bv, *gt_3d;
     double *max_ov;                  // (N)  -1 for anchors outside the image
     int32_t *argmax;                 // (N)
-    unsigned long long *gtmax;       // (G)  bit pattern of the column max (>= 0)
+    unsigned long long *gtpart;      // (G, nblk) bit pattern of the column max (>= 0) over the anchors of one workgroup
+    int nblk;                        // workgroups of at_overlap_kernel per frame
     float *labels, *targets;
 };
 
@@ -83,7 +87,7 @@ struct AtFrame {
     float *anchors, *anchors_3d;
     int32_t *n_anchors;
 };
-struct AtBatch { AtFrame f[AT_MAX_BATCH]; int cap; };
+struct AtBatch { AtFrame f[AT_MAX_BATCH]; int cap, n_agg1, n_agg2; };
 
 __device__ __forceinline__ void anchor_coords(const AtDev &d, int n, int &x1, int &y1, int &x2, int &y2)
 {
@@ -103,6 +107,11 @@ __device__ __forceinline__ bool anchor_box(const AtDev &d, int n, int &x1, int &
 __global__ __launch_bounds__(256) void at_overlap_kernel(AtBatch bt)
 {
     const AtDev &d = bt.f[blockIdx.y].d;
+    if (blockIdx.x == 0) {           // the look-back words of at_compact_kernel / at_emit_relabel_kernel (later launches)
+        const AtFrame &F = bt.f[blockIdx.y];
+        for (int t = threadIdx.x; t < bt.n_agg1; t += blockDim.x) F.agg1[t] = 0;
+        for (int t = threadIdx.x; t < bt.n_agg2; t += blockDim.x) F.agg2[t] = 0;
+    }
     __shared__ float s_gt[AT_MAX_GT * 4];
     __shared__ unsigned long long s_max[AT_MAX_GT];
     for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
@@ -128,21 +137,28 @@ __global__ __launch_bounds__(256) void at_overlap_kernel(AtBatch bt)
         d.argmax[n] = am;
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < d.G; g += blockDim.x)
-        if (s_max[g]) atomicMax(&d.gtmax[g], s_max[g]);
+    for (int g = threadIdx.x; g < d.G; g += blockDim.x) d.gtpart[(long long)g * d.nblk + blockIdx.x] = s_max[g];
 }
 
 __global__ __launch_bounds__(256) void at_label_kernel(AtBatch bt)
 {
     const AtDev &d = bt.f[blockIdx.y].d;
     __shared__ float s_gt[AT_MAX_GT * 4];
-    __shared__ double s_max[AT_MAX_GT];
+    __shared__ unsigned long long s_maxu[AT_MAX_GT];
     for (int g = threadIdx.x; g < d.G; g += blockDim.x) {
         s_gt[4 * g + 0] = d.gt_bv[5 * g + 0]; s_gt[4 * g + 1] = d.gt_bv[5 * g + 1];
         s_gt[4 * g + 2] = d.gt_bv[5 * g + 2]; s_gt[4 * g + 3] = d.gt_bv[5 * g + 3];
-        s_max[g] = __longlong_as_double((long long)d.gtmax[g]);
+        s_maxu[g] = 0ull;
     }
     __syncthreads();
+    // column maxima = max over the overlap launch's per-workgroup partials (non-negative f64: the bit patterns order like
+    // the values); coalesced over the (GT, workgroup) table, folded with LDS atomics
+    for (int i = threadIdx.x; i < d.G * d.nblk; i += blockDim.x) {
+        const unsigned long long v = d.gtpart[i];
+        if (v) atomicMax(&s_maxu[i / d.nblk], v);
+    }
+    __syncthreads();
+    const double *s_max = reinterpret_cast<const double *>(s_maxu);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= d.N) return;
     int x1, y1, x2, y2;
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(256) void at_emit_relabel_kernel(AtBatch bt)
 }
 
 // ------------------------------------------------------------------------ workspace / C-ABI
-struct AtLayout { size_t o_maxov, o_argmax, o_gtmax, o_agg1, o_agg2, zero_bytes, o_fg, o_bg, o_low, total; int N, ncwg; };
+struct AtLayout { size_t o_maxov, o_argmax, o_gtpart, o_agg1, o_agg2, o_fg, o_bg, o_low, total; int N, ncwg, nblk; };
 
 static bool at_layout(int H, int W, int G, AtLayout &L)
 {
@@ -279,15 +295,16 @@ static bool at_layout(int H, int W, int G, AtLayout &L)
     size_t o = 0;
     L.o_maxov = o; o += mv3d_align_up((size_t)N * 8);
     L.o_argmax = o; o += mv3d_align_up((size_t)N * 4);
-    L.o_gtmax = o; o += mv3d_align_up((size_t)AT_MAX_GT * 8);
-    // look-back words of the two grid compactions, zeroed together with gtmax by the stage-1 memset
+    L.nblk = (int)((N + 255) / 256);
+    // look-back words of the two grid compactions (cleared by at_overlap_kernel)
     L.ncwg = (int)((N + MV3D_GC_ITEMS - 1) / MV3D_GC_ITEMS);
     L.o_agg1 = o; o += mv3d_align_up((size_t)(L.ncwg * 4 + 1) * 4);
     L.o_agg2 = o; o += mv3d_align_up((size_t)(L.ncwg * 1 + 1) * 4);
-    L.zero_bytes = o - L.o_gtmax;
     L.o_fg = o; o += mv3d_align_up((size_t)N * 4);
     L.o_bg = o; o += mv3d_align_up((size_t)N * 4);
     L.o_low = o; o += mv3d_align_up((size_t)N * 4);
+    // last, so that every other offset is the same whatever G is (stage 2 lays the workspace out without knowing G)
+    L.o_gtpart = o; o += mv3d_align_up((size_t)(G > 0 ? G : 1) * L.nblk * 8);
     L.total = o;
     return true;
 }
@@ -303,7 +320,7 @@ static void at_fill(AtDev &d, const AtLayout &L, int H, int W, int G, const mv3d
     d.H = H; d.W = W; d.N = L.N; d.G = G; d.stride = p->feat_stride; d.clobber = p->clobber_positives;
     d.neg_ov = p->negative_overlap; d.pos_ov = p->positive_overlap;
     d.max_ov = (double *)(ws + L.o_maxov); d.argmax = (int32_t *)(ws + L.o_argmax);
-    d.gtmax = (unsigned long long *)(ws + L.o_gtmax);
+    d.gtpart = (unsigned long long *)(ws + L.o_gtpart); d.nblk = L.nblk;
 }
 
 static void at_frame(AtFrame &F, const AtLayout &L, int H, int W, int G, const mv3d_anchor_target_params *p, char *ws)
@@ -334,9 +351,9 @@ extern "C" int mv3d_anchor_target_stage1_batch(int batch, int H, int W, const fl
         F.d.im_info = im_info_dev + 3 * b; F.d.gt_bv = gt_bv_dev[b]; F.d.gt_3d = gt_3d_dev[b];
         F.d.labels = labels_dev + (size_t)b * L.N; F.d.targets = targets_dev + (size_t)b * L.N * 6;
         F.counts = counts_dev[b]; F.fg_hi = fg_hi_dev[b];
-        MV3D_HIP_TRY(hipMemsetAsync(F.d.gtmax, 0, L.zero_bytes, s));   // gtmax + the compactions' look-back words
     }
-    const int blocks = (L.N + 255) / 256;
+    bt.n_agg1 = L.ncwg * 4 + 1; bt.n_agg2 = L.ncwg * 1 + 1;
+    const int blocks = L.nblk;
     hipLaunchKernelGGL(at_overlap_kernel, dim3(blocks, batch), dim3(256), 0, s, bt);
     hipLaunchKernelGGL(at_label_kernel, dim3(blocks, batch), dim3(256), 0, s, bt);
     hipLaunchKernelGGL(at_compact_kernel, dim3(L.ncwg, batch), dim3(256), 0, s, bt);

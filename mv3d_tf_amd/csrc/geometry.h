@@ -147,3 +147,45 @@ __device__ __forceinline__ void image_box(const float M[12], const float P[6], i
     out[2] = f64_to_i32(xmax); out[3] = f64_to_i32(ymax);
 }
 
+
+// ---- eight lanes per box (lane k of an aligned group of 8 = corner k): the per-corner work of image_box() and the
+// sequential first-extreme-wins scan over the 8 results, on every lane of the group
+__device__ __forceinline__ void box_corner(const float P[6], int k, float &x, float &y, float &z)
+{
+    const float hl = P[3] / 2.0f, hw = P[4] / 2.0f, hh = P[5] / 2.0f;   // transform.py:296-313
+    x = ((k & 2) ? -hl : hl) + P[0];
+    y = (((k + 1) & 2) ? -hw : hw) + P[1];
+    z = ((k & 4) ? hh : -hh) + P[2];
+}
+
+__device__ __forceinline__ void image_point(const float M[12], float x, float y, float z, double &px, double &py)
+{
+    const double cx = (double)x, cy = (double)y, cz = (double)z;
+    double v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0.0;
+        acc = fma((double)M[r * 4 + 0], cx, acc);
+        acc = fma((double)M[r * 4 + 1], cy, acc);
+        acc = fma((double)M[r * 4 + 2], cz, acc);
+        acc = fma((double)M[r * 4 + 3], 0.0, acc);   // homogeneous w = 0 (sic)
+        v[r] = acc;
+    }
+    px = v[0] / v[2]; py = v[1] / v[2];
+}
+
+__device__ __forceinline__ void group8_minmax(double v, int lane_base, double &mn, double &mx, bool &any_nan)
+{
+    any_nan = false;
+    mn = mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double x = __shfl(v, lane_base + k);
+        any_nan |= (x != x);
+        if (k == 0) { mn = mx = x; }
+        else {
+            if (x < mn) mn = x;
+            if (x > mx) mx = x;
+        }
+    }
+}

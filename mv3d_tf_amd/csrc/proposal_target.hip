@@ -9,10 +9,12 @@
 //                     (LO <= max_ov < HI) candidate lists + counts.
 //  (host)             draws npr.permutation(n_fg) / (n_bg) from the numpy global RNG: draw-for-draw
 //                     parity with `npr.choice(inds, size=k, replace=False)`.
-//  pt_emit_kernel     one thread per sampled ROI: gathers the ROI, its 8 corners (f32), corner
-//                     targets (gt - roi) / ||gt_p0 - gt_p6|| in f32, class-slot expansion, image box.
+//  pt_emit_kernel     eight lanes per sampled ROI (one per corner): gathers the ROI, its 8 corners (f32), corner
+//                     targets (gt - roi) / ||gt_p0 - gt_p6|| in f32, class-slot expansion, image box and, for the
+//                     batched entry, the third view's ROI (front_view.hip) of the same 3D box.
 #include <math.h>
 #include "geometry.h"
+#include "front_view.h"
 
 #define PT_MAX_GT 1024
 
@@ -32,6 +34,7 @@ struct PtEmit {
     int n_fg, n_bg, num_classes;
     const float *gt_corners, *calib;     // (G,25), (4,12)
     float *rois_bv, *rois_img, *targets, *rois_3d;
+    float *rois_fv;                      // third view's ROIs (front_view.hip), NULL = not wanted
     int32_t *labels;
 };
 
@@ -105,11 +108,18 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(PtBatch bt)
 }
 
 
-__global__ __launch_bounds__(128) void pt_emit_kernel(PtBatch bt)
+// Eight lanes per sampled ROI (lane k of the group = corner k): the f64 projections of the 8 corners (image box, and the
+// front-view box when asked for) run side by side and are folded by the same first-extreme-wins scan as the one-thread
+// loops of image_box() / rois_3d_to_fv_kernel; one wave per 8 ROIs instead of 64 puts the ~2 k dependent f64 instructions
+// of a ROI on eight times as many SIMDs (the kernel was a single-wave latency chain: 10 us for 256 ROIs).
+#define PT_EMIT_THREADS 128
+__global__ __launch_bounds__(PT_EMIT_THREADS) void pt_emit_kernel(PtBatch bt)
 {
     const PtDev &d = bt.f[blockIdx.y].d;
     const PtEmit &e = bt.f[blockIdx.y].e;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = gid >> 3, k = gid & 7;
+    const int lane_base = (threadIdx.x & 63) & ~7;
     const int S = e.n_fg + e.n_bg;
     if (t >= S) return;
     // keep_inds = append(fg_inds, bg_inds) (:272)
@@ -120,19 +130,15 @@ __global__ __launch_bounds__(128) void pt_emit_kernel(PtBatch bt)
     float b[5], q[7];
     cand_bv(d, r, b);
     cand_3d(d, r, q);
-    for (int j = 0; j < 5; ++j) e.rois_bv[5 * t + j] = b[j];
-    for (int j = 0; j < 7; ++j) e.rois_3d[7 * t + j] = q[j];
-    e.labels[t] = (int32_t)lab;
-    // lidar_3d_to_corners (transform.py:290-315), f32
-    const float *P = q + 1;
-    const float hl = P[3] / 2.0f, hw = P[4] / 2.0f, hh = P[5] / 2.0f;
-    float c[24];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        c[k] = ((k & 2) ? -hl : hl) + P[0];
-        c[8 + k] = (((k + 1) & 2) ? -hw : hw) + P[1];
-        c[16 + k] = ((k & 4) ? hh : -hh) + P[2];
+    if (k == 0) {
+        for (int j = 0; j < 5; ++j) e.rois_bv[5 * t + j] = b[j];
+        for (int j = 0; j < 7; ++j) e.rois_3d[7 * t + j] = q[j];
+        e.labels[t] = (int32_t)lab;
     }
+    // lidar_3d_to_corners (transform.py:290-315), f32: this lane's corner
+    const float *P = q + 1;
+    float cx, cy, cz;
+    box_corner(P, k, cx, cy, cz);
     // bbox_transform_cnr (bbox_transform.py:61-72): f32; diag = sqrt((d0^2 + d1^2) + d2^2)
     const float *gc = e.gt_corners + 25 * g;
     const float d0 = gc[0] - gc[6], d1 = gc[8] - gc[14], d2 = gc[16] - gc[22];
@@ -140,20 +146,47 @@ __global__ __launch_bounds__(128) void pt_emit_kernel(PtBatch bt)
     ss = __fadd_rn(ss, __fmul_rn(d1, d1));
     ss = __fadd_rn(ss, __fmul_rn(d2, d2));
     const float diag = sqrtf(ss);   // IEEE (correctly rounded) sqrt; __fsqrt_rn is the native approximation in HIP
-    // _get_bbox_regression_labels_3d (:172-194): class slot, zeros elsewhere
+    // _get_bbox_regression_labels_3d (:172-194): class slot, zeros elsewhere; lane k owns columns k, 8 + k, 16 + k of a slot
     const int nc = e.num_classes;
     float *T = e.targets + (long long)t * 24 * nc;
-    for (int j = 0; j < 24 * nc; ++j) T[j] = 0.0f;
     const int cls = (int)(unsigned short)lab;           // np.array(..., dtype=np.uint16)
-    if (cls > 0 && cls < nc)
-        for (int j = 0; j < 24; ++j) T[24 * cls + j] = __fdiv_rn(gc[j] - c[j], diag);
+    for (int c = 0; c < nc; ++c) {
+        const bool own = (c == cls) && cls > 0;
+        T[24 * c + k] = own ? __fdiv_rn(gc[k] - cx, diag) : 0.0f;
+        T[24 * c + 8 + k] = own ? __fdiv_rn(gc[8 + k] - cy, diag) : 0.0f;
+        T[24 * c + 16 + k] = own ? __fdiv_rn(gc[16 + k] - cz, diag) : 0.0f;
+    }
     // lidar_cnr_to_img (transform.py:483-500); first column = the ROI's batch index (:76)
     float M[12];
     proj_matrix(e.calib, M);
-    int32_t I[4];
-    image_box(M, P, I);
-    e.rois_img[5 * t] = b[0];
-    for (int j = 0; j < 4; ++j) e.rois_img[5 * t + 1 + j] = (float)I[j];
+    double px, py;
+    image_point(M, cx, cy, cz, px, py);
+    double xmin, xmax, ymin, ymax;
+    bool nanx, nany;
+    group8_minmax(px, lane_base, xmin, xmax, nanx);
+    group8_minmax(py, lane_base, ymin, ymax, nany);
+    if (nanx) xmin = xmax = NAN;
+    if (nany) ymin = ymax = NAN;
+    if (k == 0) {
+        e.rois_img[5 * t] = b[0];
+        e.rois_img[5 * t + 1] = (float)f64_to_i32(xmin); e.rois_img[5 * t + 2] = (float)f64_to_i32(ymin);
+        e.rois_img[5 * t + 3] = (float)f64_to_i32(xmax); e.rois_img[5 * t + 4] = (float)f64_to_i32(ymax);
+    }
+    if (e.rois_fv) {      // (workgroup-uniform) the third view's ROI: front_view.hip, same arithmetic per corner
+        double col, row;
+        fv_point((double)cx, (double)cy, (double)cz, col, row);
+        double cmin, cmax, rmin, rmax;
+        bool nc_, nr_;
+        group8_minmax(col, lane_base, cmin, cmax, nc_);
+        group8_minmax(row, lane_base, rmin, rmax, nr_);
+        if (nc_ || nr_) cmin = cmax = rmin = rmax = NAN;
+        if (k == 0) {
+            float *o = e.rois_fv + 5 * (long long)t;
+            o[0] = q[0];
+            o[1] = fv_clip(cmin, FV_W - 1.0); o[2] = fv_clip(rmin, FV_H - 1.0);
+            o[3] = fv_clip(cmax, FV_W - 1.0); o[4] = fv_clip(rmax, FV_H - 1.0);
+        }
+    }
 }
 
 struct PtLayout { size_t o_maxov, o_assign, o_fg, o_bg, total; };
@@ -226,7 +259,8 @@ extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *
                                                  const mv3d_proposal_target_params *p, const int32_t *const *fg_pick_dev,
                                                  const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
                                                  float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
-                                                 float *const *bbox_targets_out, float *const *rois_3d_out, void *const *workspace,
+                                                 float *const *bbox_targets_out, float *const *rois_3d_out,
+                                                 float *const *rois_fv_out, void *const *workspace,
                                                  const size_t *workspace_bytes, void *stream)
 {
     if (batch <= 0 || batch > PT_MAX_BATCH || !p || !num_rois || !G || !n_fg || !n_bg || !workspace || !workspace_bytes)
@@ -249,10 +283,12 @@ extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *
         e.gt_corners = gt_corners_dev[b]; e.calib = calib_dev[b];
         e.rois_bv = rois_bv_out[b]; e.rois_img = rois_img_out[b]; e.targets = bbox_targets_out[b]; e.rois_3d = rois_3d_out[b];
         e.labels = labels_out[b];
+        e.rois_fv = rois_fv_out ? rois_fv_out[b] : nullptr;
         if (n_fg[b] + n_bg[b] > most) most = n_fg[b] + n_bg[b];
     }
     if (most == 0) return MV3D_OK;
-    hipLaunchKernelGGL(pt_emit_kernel, dim3((most + 127) / 128, batch), dim3(128), 0, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(pt_emit_kernel, dim3((most * 8 + PT_EMIT_THREADS - 1) / PT_EMIT_THREADS, batch), dim3(PT_EMIT_THREADS), 0,
+                       (hipStream_t)stream, bt);
     return mv3d_launch_status();
 }
 
@@ -267,5 +303,5 @@ extern "C" int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float
     if (!p) return MV3D_ERR_INVALID_ARG;
     return mv3d_proposal_target_stage2_batch(1, &rois_bv_dev, &rois_3d_dev, &num_rois, &gt_bv_dev, &gt_3d_dev, &gt_corners_dev, &G,
                                              &calib_dev, p, &fg_pick_dev, &n_fg, &bg_pick_dev, &n_bg, &rois_bv_out, &rois_img_out,
-                                             &labels_out, &bbox_targets_out, &rois_3d_out, &workspace, &workspace_bytes, stream);
+                                             &labels_out, &bbox_targets_out, &rois_3d_out, nullptr, &workspace, &workspace_bytes, stream);
 }

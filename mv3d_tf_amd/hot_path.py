@@ -19,6 +19,7 @@ resident.  `run()` then replays the batch with NO host synchronisation: every la
 of the path; `top_diff` is a resident synthetic tensor.)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -82,9 +83,12 @@ class _Bound:
 
 
 class TrainPathBatch:
-    def __init__(self, frames, maps, stream=None, views=VIEWS, num_classes=2, top_diff_seed=0):
+    def __init__(self, frames, maps, stream=None, views=VIEWS, num_classes=2, top_diff_seed=0, cold_maps=True):
         """frames: list (len B) of synth.rpn_head(..., return_gt=True) tuples (host numpy); maps: {view: (B,H,W,C) device
-        tensor}.  Everything is uploaded / allocated here; setup() must run once before run()."""
+        tensor}.  Everything is uploaded / allocated here; setup() must run once before run().  cold_maps: the maps are
+        resident inputs that were written long before the batch runs (a ring of batches), not the output of a layer that
+        just ran: the forward goes through mv3d_roi_pool_forward_views_cold (same results)."""
+        self.cold_maps = bool(cold_maps)
         self.B = len(frames)
         self.views = tuple(views)
         self.stream = stream
@@ -162,7 +166,9 @@ class TrainPathBatch:
             gt_bv, gt_3d, gt_cnr = self.gt[b]
             G = gt_bv.shape[0]
             info_b = self.info[b]
-            aws = torch.empty(max(L.mv3d_anchor_target_workspace_bytes(H, W, G), 256), dtype=torch.uint8, device=dev)
+            # (one size for every frame of the batch: the batched entry takes a single workspace_bytes)
+            aws = torch.empty(max(L.mv3d_anchor_target_workspace_bytes(H, W, max(g[0].shape[0] for g in self.gt)), 256),
+                              dtype=torch.uint8, device=dev)
             cf = torch.empty((32 + N,), dtype=torch.uint8, device=dev)
             a1 = (H, W, _P(info_b), _P(gt_bv), _P(gt_3d), G, C.byref(self.aparams), _P(self.rpn_labels[b]),
                   _P(self.rpn_targets[b]), _P(cf[:32]), _P(cf[32:]), _P(aws), C.c_size_t(aws.numel()), st)
@@ -243,20 +249,21 @@ class TrainPathBatch:
         p_nfg, p_nbg = ints([f[7] for f in P]), ints([f[8] for f in P])
         sl = lambda t: ptrs([t[f[9]:f[9] + f[10]] if f[10] else None for f in P])
         p_out = [sl(self.rois["bev"]), sl(self.rois["rgb"]), sl(self.labels), sl(self.bbox_targets), sl(self.rois_3d)]
+        p_fv = sl(self.rois["fv"]) if "fv" in self.views else None         # third view's ROIs out of the same emit launch
         bnd.add(L.mv3d_proposal_target_stage1_batch, B, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_G, tpar, p_cnt, p_ws, p_wsz, st)
         bnd.add(L.mv3d_proposal_target_stage2_batch, B, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_gtc, p_G, p_cal, tpar, p_fg, p_nfg, p_bg,
-                p_nbg, p_out[0], p_out[1], p_out[2], p_out[3], p_out[4], p_ws, p_wsz, st)
+                p_nbg, p_out[0], p_out[1], p_out[2], p_out[3], p_out[4], p_fv, p_ws, p_wsz, st)
         bnd.keep += [a_gtbv, a_gt3d, a_G, a_cnt, a_fgh, a_ws, a_d, a_n, tpar, p_bv, p_b3, p_nr, p_gtbv, p_gt3d, p_gtc, p_G, p_cnt,
-                     p_ws, p_wsz, p_cal, p_fg, p_bg, p_nfg, p_nbg, p_out]
+                     p_ws, p_wsz, p_cal, p_fg, p_bg, p_nfg, p_nbg, p_out, p_fv]
         # ---- third view's ROIs, RoiPool forward + backward on every view
         self.tops, self.top_diff, self.bottom_diff = {}, {}, {}
         g = torch.Generator(device=dev).manual_seed(1000 + int(self.top_diff_seed))
         fwd = (RoiView * len(self.views))()
         bwd = (RoiGradView * len(self.views))()
-        if "fv" in self.views:
+        if "fv" in self.views:         # set-up pass: the stand-alone entry (the replay's emit launch writes the same rows)
             a = (_P(self.rois_3d), St, _P(self.rois["fv"]), st)
             check(L.mv3d_rois_3d_to_fv(*a), "mv3d_rois_3d_to_fv")
-            bnd.add(L.mv3d_rois_3d_to_fv, *a)
+            self.rois_fv_setup = self.rois["fv"].clone()
         for k, v in enumerate(self.views):
             m = self.maps[v]
             Bm, Hm, Wm, Cm = m.shape
@@ -271,16 +278,19 @@ class TrainPathBatch:
         bws = torch.zeros(max(L.mv3d_roi_pool_backward_workspace_bytes(len(self.views), bwd, 7, 7), 256), dtype=torch.uint8, device=dev)
         ab = (len(self.views), bwd, 7, 7, _P(bws), C.c_size_t(bws.numel()), st)
         bnd.keep += [bws]
-        check(L.mv3d_roi_pool_forward_views(*af), "mv3d_roi_pool_forward_views")
+        self.fwd_fn = L.mv3d_roi_pool_forward_views_cold if self.cold_maps else L.mv3d_roi_pool_forward_views
+        check(self.fwd_fn(*af), "mv3d_roi_pool_forward_views")
         check(L.mv3d_roi_pool_backward_views(*ab), "mv3d_roi_pool_backward_views")
-        bnd.add(L.mv3d_roi_pool_forward_views, *af)
+        bnd.add(self.fwd_fn, *af)
         bnd.add(L.mv3d_roi_pool_backward_views, *ab)
         bnd.keep += [fwd, bwd]
         self.fwd_args, self.bwd_args = af, ab
         self.num_rois = St
-        import os
         if os.environ.get("MV3D_ONLY_ROI"):                    # diagnostics: replay only the two RoiPool calls
             bnd.calls = bnd.calls[-2:]
+        if os.environ.get("MV3D_SKIP"):                        # diagnostics: drop replay calls by index (0 = proposal_3d, 1-2 anchor
+            drop = {int(x) for x in os.environ["MV3D_SKIP"].split(",")}     # targets, 3-4 proposal targets, 5 FV ROIs, 6 fwd, 7 bwd)
+            bnd.calls = [c for k, c in enumerate(bnd.calls) if k not in drop]
         self.bound = bnd
         self.head = bnd.calls[0]                               # mv3d_proposal_3d
         self.tail = [c for c in bnd.calls[1:] if "_target_stage" not in c[0].__name__]
@@ -321,7 +331,7 @@ class TrainPathBatch:
                 check(rc, fn.__name__)
 
     def roi_forward(self):
-        check(lib().mv3d_roi_pool_forward_views(*self.fwd_args), "mv3d_roi_pool_forward_views")
+        check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views")
 
     def roi_backward(self):
         check(lib().mv3d_roi_pool_backward_views(*self.bwd_args), "mv3d_roi_pool_backward_views")
@@ -346,11 +356,12 @@ class TestPathBatch:
     """proposal_layer_3d (TEST cfg) -> FV ROIs -> RoiPool forward on the views, B frames; R = B * 300 ROI rows
     (rows past a frame's count are zero boxes, as the fixed-shape serving graph pools them)."""
 
-    def __init__(self, frames, maps, stream=None, views=VIEWS):
+    def __init__(self, frames, maps, stream=None, views=VIEWS, cold_maps=False):
         self.B = len(frames)
         self.views = tuple(views)
         self.stream = stream
         self.maps = maps
+        self.cold_maps = bool(cold_maps)
         dev = next(iter(maps.values())).device
         self.dev = dev
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
@@ -392,7 +403,8 @@ class TestPathBatch:
                 self.tops[v] = (top, am)
                 fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, R, Hm, Wm, Cm)
             self.fwd_args = (len(self.views), fwd, 7, 7, st)
-            bnd.add(L.mv3d_roi_pool_forward_views, *self.fwd_args)
+            self.fwd_fn = L.mv3d_roi_pool_forward_views_cold if self.cold_maps else L.mv3d_roi_pool_forward_views
+            bnd.add(self.fwd_fn, *self.fwd_args)
             bnd.keep += [pws, fwd]
             self.num_rois = R
             self.bound = bnd
@@ -404,7 +416,7 @@ class TestPathBatch:
         self.bound.run()
 
     def roi_forward(self):
-        check(lib().mv3d_roi_pool_forward_views(*self.fwd_args), "mv3d_roi_pool_forward_views")
+        check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views")
 
     def roi_forward_bytes(self):
         return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 8 for v in self.views)

@@ -295,9 +295,10 @@ def box_detect_tail(rois_3d, bbox_pred, num_classes):
     return cnr, pr, bv, bvr
 
 
-def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None):
+def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_maps=False):
     """views: list of (data (B,H,W,C), rois (R,5), spatial_scale); one launch for all of them.
-    Returns [(top, argmax), ...]; pass `outs` (same structure) to reuse output tensors."""
+    Returns [(top, argmax), ...]; pass `outs` (same structure) to reuse output tensors.  cold_maps: the maps are not
+    cache-resident (mv3d_roi_pool_forward_views_cold: same results, prefetch workgroups in front of the launch)."""
     arr = (RoiView * len(views))()
     res = []
     for k, (data, rois, scale) in enumerate(views):
@@ -310,8 +311,8 @@ def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None):
             am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device)
         arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, R, H, W, Cc)
         res.append((top, am))
-    check(lib().mv3d_roi_pool_forward_views(len(views), arr, pooled_height, pooled_width, _stream()),
-          "mv3d_roi_pool_forward_views")
+    fn = lib().mv3d_roi_pool_forward_views_cold if cold_maps else lib().mv3d_roi_pool_forward_views
+    check(fn(len(views), arr, pooled_height, pooled_width, _stream()), "mv3d_roi_pool_forward_views")
     return res
 
 

@@ -202,7 +202,8 @@ def test_config2_train_path_batch_replay_vs_oracle(gpu, oracle, yml):
         for k, v in saved.items():
             cfg.TRAIN[k] = v
     first = batch.snapshot()
-    for t in (batch.rpn_labels, batch.rois_3d, batch.bbox_targets, batch.tops["bev"][0], batch.bottom_diff["rgb"]):
+    for t in (batch.rpn_labels, batch.rois_3d, batch.bbox_targets, batch.tops["bev"][0], batch.bottom_diff["rgb"], batch.rois["fv"],
+              batch.rois["rgb"]):
         t.fill_(7.0)                                            # the replay must rewrite everything
     batch.run()
     batch.run()
