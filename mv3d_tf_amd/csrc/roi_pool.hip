@@ -1127,8 +1127,9 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
     bool same_c = true;
     long long all_pix = 0;
     for (int k = 0; k < num_views; ++k) {
-        same_c = same_c && views[k].channels == views[0].channels && (views[k].channels == 64 || views[k].channels == 128 || views[k].channels % 256 == 0) &&
-                 views[k].channels <= 2048 && 2048 % views[k].channels == 0 && aligned16(views[k].bottom_diff) &&
+        // (64-channel slices, one per XCD or XCD group: C = 64, 128, 256 or 512; other widths take the sliced kernel)
+        same_c = same_c && views[k].channels == views[0].channels && views[k].channels % 64 == 0 && views[k].channels <= 512 &&
+                 512 % views[k].channels == 0 && aligned16(views[k].bottom_diff) &&
                  aligned16(views[k].top_diff) && aligned16(views[k].argmax_data);
         all_pix += (long long)views[k].batch_size * views[k].height * views[k].width;
     }

@@ -81,6 +81,34 @@ def test_config2_three_views_batch2_forward_backward(gpu, oracle):
         assert np.array_equal(one.cpu().numpy(), want), k
 
 
+@pytest.mark.parametrize("C", [64, 128, 256, 320, 1024])
+def test_views_entries_other_channel_widths(gpu, oracle, C):
+    """The several-views entries on widths other than 512: 64 / 128 / 256 take the indexed RoiPoolGrad (1, 2, 4 channel
+    slices), 1024 the sliced kernel behind the same call (the workspace is ignored), 320 the generic kernels; the cold-map
+    forward gives the bytes of the plain one."""
+    torch, ops = gpu
+    rs = np.random.RandomState(C)
+    B, H, W, R = 2, 12, 20, 40
+    maps = [rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32), rs.uniform(-1, 1, (B, 9, 7, C)).astype(np.float32)]
+    rois = []
+    for m in maps:
+        h, w = m.shape[1] * 8, m.shape[2] * 8
+        x1, y1 = rs.randint(-8, w - 8, R), rs.randint(-8, h - 8, R)
+        rois.append(np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.randint(0, w // 2, R), y1 + rs.randint(0, h // 2, R)], 1).astype(np.float32))
+    d_maps, d_rois = [dev(torch, m) for m in maps], [dev(torch, r) for r in rois]
+    outs = ops.roi_pool_forward_views([(m, r, 0.125) for m, r in zip(d_maps, d_rois)], 7, 7)
+    cold = ops.roi_pool_forward_views([(m, r, 0.125) for m, r in zip(d_maps, d_rois)], 7, 7, cold_maps=True)
+    grads, ams = [], []
+    for m, r, (top, am), (ctop, cam) in zip(maps, rois, outs, cold):
+        o_top, o_am = oracle.roi_pool(m, r, 7, 7, 0.125)
+        assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am)
+        assert np.array_equal(ctop.cpu().numpy(), o_top) and np.array_equal(cam.cpu().numpy(), o_am)
+        grads.append(rs.uniform(-1, 1, o_top.shape).astype(np.float32)); ams.append(o_am)
+    bds = ops.roi_pool_backward_views([(dev(torch, g), r, am, m.shape, 0.125) for g, r, (_, am), m in zip(grads, d_rois, outs, maps)], 7, 7)
+    for m, r, am, g, bd in zip(maps, rois, ams, grads, bds):
+        assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, r, am, g, 7, 7, 0.125))
+
+
 def test_config4_batch16_hipgraph_replay_equals_eager_equals_oracle(gpu, oracle):
     """BASELINE configs[4] per-GPU step: 16 frames, TEST cfg, proposal_3d + both RoiPool views.  The captured hipGraph,
     replayed twice (the second time on fresh inputs written into the same buffers), gives the eager results and the
