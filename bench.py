@@ -66,7 +66,6 @@ def parse():
                          "per batch; eager enqueueing of a batch's ~28 launches costs the host more than the GPU needs to run "
                          "them once three batches are in flight); eager: plain in-order launches")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
-    ap.add_argument("--play-default", action="store_true", help="replay on the default stream as one more lane (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true")
@@ -124,9 +123,7 @@ class Ring:
                     with torch.cuda.stream(st):                       # CUDAGraph.replay() launches on the current stream
                         g.replay()
                 return play
-            # replay streams: the capture streams, or (diagnostic, --play-default) those plus the default stream as one more lane
-            lanes = ([torch.cuda.default_stream()] if getattr(args, "play_default", False) else []) + list(streams)
-            self.play = [player(g, lanes[k % len(lanes)]) for k, g in enumerate(self.graphs)]
+            self.play = [player(g, s.stream) for g, s in zip(self.graphs, self.slots)]
 
     def run(self, nbatches):
         n = len(self.slots)

@@ -157,11 +157,6 @@ class TrainPathBatch:
         self.n_anchors = torch.empty((B,), dtype=torch.int32, device=dev)
         picks, self.S = [], []
         at_calls, pt_calls, at_frames, pt_frames = [], [], [], []
-        # replay plan with the frames' independent chains on side streams (see run()): side stream b carries frame b's anchor
-        # targets (which do not depend on the proposals) and, for b >= 1, its proposal targets
-        self.sides = [torch.cuda.Stream(device=dev) for _ in range(B)]
-        side_st = [C.c_void_p(sd.cuda_stream) for sd in self.sides]
-        self.at_side, self.pt_side = [[] for _ in range(B)], [[] for _ in range(B)]
         for b in range(B):
             gt_bv, gt_3d, gt_cnr = self.gt[b]
             G = gt_bv.shape[0]
@@ -183,7 +178,6 @@ class TrainPathBatch:
             check(L.mv3d_anchor_target_stage2(*a2), "mv3d_anchor_target_stage2")
             at_calls += [(L.mv3d_anchor_target_stage1, a1), (L.mv3d_anchor_target_stage2, a2)]
             at_frames.append((gt_bv, gt_3d, G, cf, aws, dl, [len(x) for x in lists]))
-            self.at_side[b] = [(L.mv3d_anchor_target_stage1, a1[:-1] + (side_st[b],)), (L.mv3d_anchor_target_stage2, a2[:-1] + (side_st[b],))]
             bnd.keep += [aws, cf, dl, info_b]
             # proposal targets of frame b on its num_proposals[b] rows
             R = nums[b]
@@ -218,8 +212,6 @@ class TrainPathBatch:
             check(L.mv3d_proposal_target_stage2(*p2), "mv3d_proposal_target_stage2")
             pt_calls += [(L.mv3d_proposal_target_stage1, p1), (L.mv3d_proposal_target_stage2, p2)]
             pt_frames.append((gt_bv, gt_3d, gt_cnr, G, counts, tws, pl, n_fg, n_bg, off, S))
-            on = st if b == 0 else side_st[b]
-            self.pt_side[b] = [(L.mv3d_proposal_target_stage1, p1[:-1] + (on,)), (L.mv3d_proposal_target_stage2, p2[:-1] + (on,))]
             bnd.keep += [pl, tws, counts]
             off += S
         # ---- the replay runs the target layers of ALL frames behind one launch of every kernel (mv3d_*_batch entries:
@@ -292,43 +284,14 @@ class TrainPathBatch:
             drop = {int(x) for x in os.environ["MV3D_SKIP"].split(",")}     # targets, 3-4 proposal targets, 5 FV ROIs, 6 fwd, 7 bwd)
             bnd.calls = [c for k, c in enumerate(bnd.calls) if k not in drop]
         self.bound = bnd
-        self.head = bnd.calls[0]                               # mv3d_proposal_3d
-        self.tail = [c for c in bnd.calls[1:] if "_target_stage" not in c[0].__name__]
-        self.ev_fork, self.ev_prop = torch.cuda.Event(), torch.cuda.Event()
-        self.ev_join = [torch.cuda.Event() for _ in range(B)]
-        # measured: 6.9 k frames/s with the branches vs 10.6 k as one chain per batch (one batch alone: 297 vs 331 us) -- cross-queue
-        # event hand-offs cost tens of us each on this platform, three batches in flight already fill the machine: OFF by default
-        self.parallel = bool(os.environ.get("MV3D_PARALLEL")) and not os.environ.get("MV3D_ONLY_ROI")
 
     # ------------------------------------------------------------------ replay, no host sync
     def run(self):
-        """Replay the batch: by default as one in-order chain of launches on the batch's stream.  MV3D_PARALLEL=1 (a
-        measured, slower alternative kept for experiments) puts frame b's anchor targets, which need nothing from the
-        proposals, and the proposal targets of frames >= 1 onto per-frame side streams with event fork / join."""
-        if not self.parallel:
-            self.bound.run()
-            return
-        main = self.stream if self.stream is not None else torch.cuda.current_stream()
-        self.ev_fork.record(main)
-        for b, side in enumerate(self.sides):
-            side.wait_event(self.ev_fork)
-            for fn, args in self.at_side[b]:
-                fn(*args)
-        self.head[0](*self.head[1])
-        self.ev_prop.record(main)
-        for b in range(1, self.B):
-            self.sides[b].wait_event(self.ev_prop)
-            for fn, args in self.pt_side[b]:
-                fn(*args)
-        for fn, args in self.pt_side[0]:
-            fn(*args)
-        for b, side in enumerate(self.sides):
-            self.ev_join[b].record(side)
-            main.wait_event(self.ev_join[b])
-        for fn, args in self.tail:
-            rc = fn(*args)
-            if rc:
-                check(rc, fn.__name__)
+        """Replay the batch as one in-order chain of launches on the batch's stream.  (Measured alternatives, all slower on
+        this platform: per-frame side streams with event fork / join, 6.9 k vs 10.6 k frames/s -- a cross-queue hand-off costs
+        tens of us; the anchor-target branch, which nothing on the path depends on, on a fourth stream without any event,
+        176.7 vs 153.5 us per batch -- a fourth busy queue slows the other three down.)"""
+        self.bound.run()
 
     def roi_forward(self):
         check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views")
