@@ -466,6 +466,25 @@ def test_training_layers_random_sweep_vs_oracle(ops, oracle):
             assert np.array_equal(x, y), (k, G)
 
 
+@pytest.mark.parametrize("G", [257, 700])
+def test_anchor_targets_many_ground_truth_boxes(ops, oracle, G):
+    """more ground-truth boxes than a workgroup has threads (the per-GT column maxima are per-workgroup partials folded by
+    the label launch; nothing in the workspace is zeroed by the host): equal to the oracle, RNG position included."""
+    from mv3d_tf_amd.rpn_msr.anchor_target_layer_tf import anchor_target_layer
+    gtbv, gt3d, _ = synth.gt_cars(np.random.RandomState(9000 + G), G)
+    info = np.array([[608, 608, 1]], np.float32)
+    score = np.zeros((1, 76, 76, 8), np.float32)
+    for rep in range(2):                                            # the second call reuses the (now dirty) cached workspace
+        np.random.seed(31 + rep)
+        a = anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+        pos = np.random.randint(1 << 30)
+        np.random.seed(31 + rep)
+        b = oracle.anchor_target_layer(score, gtbv, gt3d, info, [8, ])
+        assert pos == np.random.randint(1 << 30)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 # ------------------------------------------------------------------ proposal_target_layer_3d
 @pytest.mark.parametrize("name", ["proposal_target_few", "proposal_target_many"])
 def test_proposal_target_layer_3d_matches_reference(ops, name):
