@@ -60,3 +60,26 @@ def test_pmc_traffic_only_for_the_profiled_configuration(bench, tmp_path, monkey
     assert bench.pmc_traffic("roi_pool_fwd_xcd_multi_kernel", "train/b2/r256/peaky") == 7
     assert bench.pmc_traffic("roi_bwd_", "train/b2/r128/peaky") is None            # another configuration: never a stale number
     assert bench.pmc_traffic("no_such_kernel", "train/b2/r256/peaky") is None
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_on_the_gpu():
+    """a short run of the default workload prints ONE JSON line with the driver's keys, the roofline and the CPU baseline"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--ring", "6",
+                          "--batches-per-step", "6", "--cpu-seconds", "2", "--no-secondary"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "frames/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 2 * 6 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01      # frames / time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / r["avg_launch_us"] / 1e3) / r["achieved"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert "workload" in d["config"] and "model" not in d["config"]
