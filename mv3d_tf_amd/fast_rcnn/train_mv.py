@@ -170,6 +170,11 @@ class SolverWrapper(object):
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             spent += time.perf_counter() - t0
+            if dist is not None and (it + 1) % cfg.TRAIN.DISPLAY == 0:
+                # the logged losses are the mean over the ranks' frames (one small all-reduce per DISPLAY)
+                t = torch.as_tensor(vals, dtype=torch.float64, device=params[0].device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t)
+                vals = (t / world).cpu().numpy()
             loss_cls, loss_box, rpn_loss_cls, rpn_loss_box = vals
             history.append((rpn_loss_cls + rpn_loss_box + loss_cls + loss_box, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box))
             if (it + 1) % cfg.TRAIN.DISPLAY == 0 and rank == 0:
