@@ -660,6 +660,7 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
     __shared__ unsigned char s_nb[BW_CHUNK][BWI_PIX], s_xr[BW_CHUNK][BWI_PIX];
     __shared__ int s_off[BW_CHUNK][BWI_PIX];
     __shared__ int s_wcnt[4], s_cnt[BWI_PIX], s_base[BWI_PIX], s_run[BWI_PIX];
+    __shared__ int s_part[16][BWI_PIX];
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
@@ -777,10 +778,21 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
     for (int pass = 0; pass < npass; ++pass) {
         if (npass > 1) { nlist = build(pass); }
         __syncthreads();
-        if (threadIdx.x < BWI_PIX) {                              // per pixel: where each entry's bins go, in entry order
-            int run = s_run[threadIdx.x];
-            for (int e = 0; e < nlist; ++e) { s_off[e][threadIdx.x] = run; run += s_nb[e][threadIdx.x]; }
-            s_run[threadIdx.x] = run;
+        {   // per pixel: where each entry's bins go, in entry order = an exclusive prefix of s_nb over the entries.  16 stripes
+            // of entries per pixel (thread = (stripe, pixel)): stripe sums, a 16-step prefix over the stripes, then the
+            // stripe's own entries -- a serial walk by one thread per pixel was the slowest part of the launch on segments
+            // with a few hundred entries
+            const int sp = threadIdx.x & (BWI_PIX - 1), st = threadIdx.x / BWI_PIX;       // pixel, stripe
+            const int L = (nlist + 15) / 16, e0 = st * L, e1 = min(nlist, e0 + L);
+            int sum = 0;
+            for (int e = e0; e < e1; ++e) sum += s_nb[e][sp];
+            s_part[st][sp] = sum;
+            __syncthreads();
+            int run = s_run[sp];
+            for (int t = 0; t < st; ++t) run += s_part[t][sp];
+            for (int e = e0; e < e1; ++e) { s_off[e][sp] = run; run += s_nb[e][sp]; }
+            __syncthreads();
+            if (st == 15) s_run[sp] = run;                             // (the last stripe ends at the total)
         }
         __syncthreads();
         for (int e = q; e < nlist; e += 256 / BWI_PIX) {
