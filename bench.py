@@ -357,12 +357,12 @@ def main():
         del ring
         torch.cuda.empty_cache()
         args2 = argparse.Namespace(**vars(args))
-        r2 = Ring(args2, rank, "test", 16, 3, streams[:1])
+        r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
         dt2, _ = timed(r2, 3, max(2, args.steps // 2), 2, barrier)
         dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
         if rank == 0:
             sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
-                                           "views, one stream, eager launches, ring of 3 batches",
+                                           "views, ring of 3 batches on the step's streams (%s launches)" % args.launch,
                                "frames_per_s": round(max(2, args.steps // 2) * 3 * 16 * world / dt2, 2),
                                "roofline_kernels": roofline_entries(r2, "test", "test/b16")}
         del r2
