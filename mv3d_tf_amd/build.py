@@ -34,7 +34,9 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    # MV3D_HIPCC_FLAGS: extra compiler flags for experiment builds (e.g. -DMV3D_TUNING, which compiles the environment
+    # overrides the tools/ probes use); the shipped library is built without any
+    cmd = [hipcc] + FLAGS + os.environ.get("MV3D_HIPCC_FLAGS", "").split() + sources() + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -17,19 +17,8 @@
 #include <stdlib.h>
 #include <math.h>
 #include "common.h"
-
-struct RoiGeom { int rsw, rsh, rew, reh; };
-
-// roi_pooling_op.cc:139-143: round() (half away from zero) of the f32 product
-__device__ __forceinline__ RoiGeom roi_geom(const float *roi, float scale)
-{
-    RoiGeom g;
-    g.rsw = (int)roundf(__fmul_rn(roi[1], scale));
-    g.rsh = (int)roundf(__fmul_rn(roi[2], scale));
-    g.rew = (int)roundf(__fmul_rn(roi[3], scale));
-    g.reh = (int)roundf(__fmul_rn(roi[4], scale));
-    return g;
-}
+#include "kernels.h"
+#include "roi_geom.h"
 
 template <int VEC>
 struct VecT;
@@ -1124,6 +1113,21 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
         fast = fast && bwd_fast_ok(w.channels, pooled_height, pooled_width, w.height, w.width, w.batch_size);
     }
     if (workspace && ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    {
+        bool tiles = mv3d_roi_grad_tiles_ok(num_views, views, pooled_height, pooled_width);
+        const int *ovr = nullptr;
+#ifdef MV3D_TUNING
+        static int tune[2 * MV3D_MAX_ROI_VIEWS];
+        if (const char *e = getenv("MV3D_BWD_TILES")) {             // "th,twl,th,twl,..." per view of the call
+            int i = 0;
+            for (const char *q = e; *q && i < 2 * MV3D_MAX_ROI_VIEWS; ++i) { tune[i] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
+            for (; i < 2 * MV3D_MAX_ROI_VIEWS; ++i) tune[i] = 0;
+            ovr = tune;
+        }
+        if (getenv("MV3D_BWD_OLD")) tiles = false;
+#endif
+        if (tiles) return mv3d_launch_roi_grad_tiles(num_views, views, pooled_height, pooled_width, ovr, (hipStream_t)stream);
+    }
     if (!fast) {                                          // generic shapes: one launch of the generic kernel per view
         for (int k = 0; k < num_views; ++k) {
             const mv3d_roi_grad_view &w = views[k];
