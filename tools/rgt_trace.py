@@ -52,31 +52,14 @@ torch.cuda.synchronize()
 us = a.elapsed_time(b) * 1e3
 t = tr.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] != 0]
-blk = np.nonzero(tr.cpu().numpy().reshape(-1, 8)[:, 0])[0]
-for x in range(8):                      # the cycle counters of the 8 XCDs have their own origins: align each to its first stamp
-    m = (blk & 7) == x
-    if m.any():
-        base = t[m][:, 0].min()
-        t[m, 0] -= base; t[m, 1] -= base; t[m, 2] -= base; t[m, 7] -= base
-t0 = 0
-span = t[:, 7].max() - t0
-print("workgroups %d, event time %.1f us, stamp span %d ticks -> %.1f ticks/us" % (len(t), us, span, span / us))
-tpu = span / us
-dur = (t[:, 7] - t[:, 0]) / tpu
-g0 = (t[:, 1] - t[:, 0]) / tpu
-geo, stre, wo, nl, nbt = t[:, 3] / tpu, t[:, 4] / tpu, (t[:, 7] - t[:, 2]) / tpu, t[:, 5], t[:, 6]
-for lo, hi in ((0, 0), (1, 16), (17, 64), (65, 128), (129, 256), (257, 100000)):
-    m = (nl >= lo) & (nl <= hi)
-    if m.sum() == 0:
-        continue
-    print("records %4d..%-6d: %5d wg  total %6.2f us (max %6.2f)  roi filter %5.2f  geometry %5.2f  stream %6.2f (max %6.2f)  write-out %5.2f  batches %.1f"
-          % (lo, hi, m.sum(), dur[m].mean(), dur[m].max(), g0[m].mean(), geo[m].mean(), stre[m].mean(), stre[m].max(), wo[m].mean(), nbt[m].mean()))
-start = (t[:, 0] - t0) / tpu
-end = (t[:, 7] - t0) / tpu
-edges = np.arange(0, us + 5, 5)
-print("timeline (5 us bins): started   ", np.histogram(start, edges)[0].tolist())
-print("                      finished  ", np.histogram(end, edges)[0].tolist())
-print("                      resident  ", [int(((start <= e) & (end > e)).sum()) for e in edges[:-1]])
-late = np.argsort(end)[-8:]
-for i in late:
-    print("  late wg: start %.1f end %.1f records %d geo %.2f stream %.2f" % (start[i], end[i], nl[i], geo[i], stre[i]))
+dur = t[:, 7] - t[:, 0]
+tpu = dur.max() / us            # the longest workgroup spans (nearly) the whole launch
+print("workgroups %d, event time %.1f us, longest workgroup %d ticks -> ~%.0f ticks/us" % (len(t), us, dur.max(), tpu))
+geo, stre, nl, ntl = t[:, 3] / tpu, t[:, 4] / tpu, t[:, 5], t[:, 6]
+d = dur / tpu
+print("per workgroup: duration mean %.1f us (min %.1f max %.1f), geometry %.1f us, stream+write %.1f us, tiles %.1f, records %.0f (max %d)"
+      % (d.mean(), d.min(), d.max(), geo.mean(), stre.mean(), ntl.mean(), nl.mean(), nl.max()))
+o = np.argsort(d)
+for i in list(o[:3]) + list(o[-6:]):
+    print("   wg: %.1f us, geometry %.1f, stream %.1f, tiles %d, records %d" % (d[i], geo[i], stre[i], ntl[i], nl[i]))
+print("correlation duration ~ records: %.2f" % np.corrcoef(d, nl)[0, 1])
