@@ -56,9 +56,3 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
                      const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace,
                      hipStream_t stream, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr);
 
-// ---- RoiPoolGrad as an ordered scatter into LDS-resident map tiles (roi_grad_tiles.hip) ---------
-// ok(): same C (a power of two, 64 .. 512) for all views, pooled sizes <= 15, 16-byte aligned buffers, i32 record offsets.
-// tile_override (tuning builds only, else NULL): per view {rows, log2(columns)}, rows = 0 keeps the heuristic.
-bool mv3d_roi_grad_tiles_ok(int num_views, const mv3d_roi_grad_view *views, int PH, int PW);
-int mv3d_launch_roi_grad_tiles(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, const int *tile_override,
-                               hipStream_t stream);

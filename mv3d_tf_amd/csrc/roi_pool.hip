@@ -1113,21 +1113,6 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
         fast = fast && bwd_fast_ok(w.channels, pooled_height, pooled_width, w.height, w.width, w.batch_size);
     }
     if (workspace && ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
-    {
-        bool tiles = mv3d_roi_grad_tiles_ok(num_views, views, pooled_height, pooled_width);
-        const int *ovr = nullptr;
-#ifdef MV3D_TUNING
-        static int tune[2 * MV3D_MAX_ROI_VIEWS];
-        if (const char *e = getenv("MV3D_BWD_TILES")) {             // "th,twl,th,twl,..." per view of the call
-            int i = 0;
-            for (const char *q = e; *q && i < 2 * MV3D_MAX_ROI_VIEWS; ++i) { tune[i] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
-            for (; i < 2 * MV3D_MAX_ROI_VIEWS; ++i) tune[i] = 0;
-            ovr = tune;
-        }
-        if (getenv("MV3D_BWD_OLD")) tiles = false;
-#endif
-        if (tiles) return mv3d_launch_roi_grad_tiles(num_views, views, pooled_height, pooled_width, ovr, (hipStream_t)stream);
-    }
     if (!fast) {                                          // generic shapes: one launch of the generic kernel per view
         for (int k = 0; k < num_views; ++k) {
             const mv3d_roi_grad_view &w = views[k];
@@ -1203,7 +1188,10 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
     if (indexed) {
         size_t o = MV3D_ALIGN;
         ix.header = (int *)ws;
-        ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;   // diagnostics
+        ix.trace = nullptr;
+#ifdef MV3D_TUNING                                                     // diagnostics (tools/roi_bwd_trace.py), experiment builds only
+        ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;
+#endif
         ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
         ix.seg_ne = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
         ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
@@ -1211,8 +1199,12 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
         if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
         hipLaunchKernelGGL(roi_bwd_index_kernel<false>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
         hipLaunchKernelGGL(roi_bwd_index_kernel<true>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
-        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;   // tuning hooks
+#ifdef MV3D_TUNING                                                     // tuning hooks, experiment builds only
+        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;
         static const int cpl_env = getenv("MV3D_BWG_CPL") ? atoi(getenv("MV3D_BWG_CPL")) : 0;
+#else
+        const int groups = BWG_GROUPS, cpl_env = 0;
+#endif
         // channels per lane: 1 (64-channel slices, 256-B pieces of a record per wave) measured best on the training batch:
         // 75 us for the three launches vs 82 (2 channels, 512-B pieces) and 105 (4 channels, 1-KB pieces, 8 records in flight):
         // the walk is bound by its dependent round trips, and a lane with more channels holds fewer records in flight

@@ -11,7 +11,7 @@ from mv3d_tf_amd import build, ops, synth
 from oracle import oracle
 
 build.build()
-for (B, H, W, C, R, seed) in ((1, 9, 11, 64, 6, 1), (2, 13, 17, 64, 40, 2), (2, 20, 31, 128, 90, 3), (2, 24, 24, 512, 128, 4)):
+for (B, H, W, C, R, seed) in ((1, 9, 11, 64, 6, 1), (2, 13, 17, 64, 40, 2), (2, 20, 31, 128, 90, 3), (2, 24, 24, 512, 128, 4), (1, 9, 11, 64, 300, 5), (2, 12, 12, 64, 700, 6), (1, 40, 40, 256, 256, 7)):
     rng = np.random.RandomState(seed)
     data = synth.feature_map(seed, H, W, C, B)
     x1 = rng.uniform(-8, W * 8 - 8, R); y1 = rng.uniform(-8, H * 8 - 8, R)

@@ -55,11 +55,13 @@ t = t[t[:, 0] != 0]
 dur = t[:, 7] - t[:, 0]
 tpu = dur.max() / us            # the longest workgroup spans (nearly) the whole launch
 print("workgroups %d, event time %.1f us, longest workgroup %d ticks -> ~%.0f ticks/us" % (len(t), us, dur.max(), tpu))
-geo, stre, nl, ntl = t[:, 3] / tpu, t[:, 4] / tpu, t[:, 5], t[:, 6]
+nl, ntl, view = t[:, 5], t[:, 6], t[:, 1]
 d = dur / tpu
-print("per workgroup: duration mean %.1f us (min %.1f max %.1f), geometry %.1f us, stream+write %.1f us, tiles %.1f, records %.0f (max %d)"
-      % (d.mean(), d.min(), d.max(), geo.mean(), stre.mean(), ntl.mean(), nl.mean(), nl.max()))
+for k in sorted(set(view.tolist())):
+    m = view == k
+    print("view %d: %d workgroups, duration mean %.1f us (min %.1f max %.1f), tiles %.1f, ring entries %.0f (max %d)"
+          % (k, m.sum(), d[m].mean(), d[m].min(), d[m].max(), ntl[m].mean(), nl[m].mean(), nl[m].max()))
 o = np.argsort(d)
 for i in list(o[:3]) + list(o[-6:]):
-    print("   wg: %.1f us, geometry %.1f, stream %.1f, tiles %d, records %d" % (d[i], geo[i], stre[i], ntl[i], nl[i]))
-print("correlation duration ~ records: %.2f" % np.corrcoef(d, nl)[0, 1])
+    print("   wg (view %d): %.1f us, tiles %d, entries %d" % (view[i], d[i], ntl[i], nl[i]))
+print("correlation duration ~ entries: %.2f" % np.corrcoef(d, nl)[0, 1])
