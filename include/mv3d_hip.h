@@ -294,6 +294,24 @@ int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev
                                       float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
                                       float *const *bbox_targets_out, float *const *rois_3d_out, float *const *rois_fv_out,
                                       void *const *workspace, const size_t *workspace_bytes, void *stream);
+/* The batched entries for proposals whose NUMBER stays on the device (the `num_out_dev` of mv3d_proposal_3d): num_rois_cap[b]
+ * = the capacity of frame b's proposal blobs (sizes the workspace: mv3d_proposal_target_workspace_bytes(num_rois_cap[b],
+ * G[b])), num_rois_dev[b] -> the frame's count, read by the kernels (clamped to [0, cap]).  A training step then needs ONE
+ * host round trip -- the counts of the candidate lists the caller draws from -- instead of two. */
+int mv3d_proposal_target_stage1_batch_devn(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                           const int *num_rois_cap, const int32_t *const *num_rois_dev,
+                                           const float *const *gt_bv_dev, const float *const *gt_3d_dev, const int *G,
+                                           const mv3d_proposal_target_params *params, int32_t *const *counts_dev,
+                                           void *const *workspace, const size_t *workspace_bytes, void *stream);
+int mv3d_proposal_target_stage2_batch_devn(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                           const int *num_rois_cap, const int32_t *const *num_rois_dev,
+                                           const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                           const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
+                                           const mv3d_proposal_target_params *params, const int32_t *const *fg_pick_dev,
+                                           const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
+                                           float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
+                                           float *const *bbox_targets_out, float *const *rois_3d_out, float *const *rois_fv_out,
+                                           void *const *workspace, const size_t *workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ SURVEY §8(f) "next" rows
  * BEV rasteriser: replaces point_cloud_2_top (lib/utils/read_lidar.py:10-115, called with

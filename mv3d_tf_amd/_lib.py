@@ -79,6 +79,9 @@ _SIGS = {
     "mv3d_proposal_target_stage1_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mv3d_proposal_target_stage2_batch": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                                     _P, _P, _P]),
+    "mv3d_proposal_target_stage1_batch_devn": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv3d_proposal_target_stage2_batch_devn": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                         _P, _P, _P, _P, _P]),
     "mv3d_proposal_target_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mv3d_proposal_target_stage1": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.POINTER(ProposalTargetParams), _P, _P,
                                               C.c_size_t, _P]),

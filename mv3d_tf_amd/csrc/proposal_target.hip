@@ -22,6 +22,7 @@ struct PtDev {
     const float *rois_bv, *rois_3d;      // (R,5), (R,7)
     const float *gt_bv, *gt_3d;          // (G,5), (G,7)
     int R, G;
+    const int32_t *R_dev;                // optional: the proposals' number lives on the device (<= R = the capacity)
     float gt_frame;                      // batch column of the appended ground-truth rows (0 in the reference)
     double fg_thresh, bg_hi, bg_lo;
     double *max_ov;                      // (R+G)
@@ -45,15 +46,16 @@ struct PtBatch { PtFrame f[PT_MAX_BATCH]; };
 
 // row r of the candidate set: proposals then ground truth with a 0 batch column (:38-44); a batched caller sets
 // params.frame_index so that the ground-truth rows of frame b carry b like the frame's proposals do
-__device__ __forceinline__ void cand_bv(const PtDev &d, int r, float o[5])
+__device__ __forceinline__ int pt_num_rois(const PtDev &d) { return d.R_dev ? min(max(*d.R_dev, 0), d.R) : d.R; }
+__device__ __forceinline__ void cand_bv(const PtDev &d, const int R, int r, float o[5])
 {
-    if (r < d.R) { for (int j = 0; j < 5; ++j) o[j] = d.rois_bv[5 * r + j]; }
-    else { o[0] = d.gt_frame; for (int j = 0; j < 4; ++j) o[1 + j] = d.gt_bv[5 * (r - d.R) + j]; }
+    if (r < R) { for (int j = 0; j < 5; ++j) o[j] = d.rois_bv[5 * r + j]; }
+    else { o[0] = d.gt_frame; for (int j = 0; j < 4; ++j) o[1 + j] = d.gt_bv[5 * (r - R) + j]; }
 }
-__device__ __forceinline__ void cand_3d(const PtDev &d, int r, float o[7])
+__device__ __forceinline__ void cand_3d(const PtDev &d, const int R, int r, float o[7])
 {
-    if (r < d.R) { for (int j = 0; j < 7; ++j) o[j] = d.rois_3d[7 * r + j]; }
-    else { o[0] = d.gt_frame; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - d.R) + j]; }
+    if (r < R) { for (int j = 0; j < 7; ++j) o[j] = d.rois_3d[7 * r + j]; }
+    else { o[0] = d.gt_frame; for (int j = 0; j < 6; ++j) o[1 + j] = d.gt_3d[7 * (r - R) + j]; }
 }
 
 __global__ __launch_bounds__(256) void pt_overlap_kernel(PtBatch bt)
@@ -64,9 +66,10 @@ __global__ __launch_bounds__(256) void pt_overlap_kernel(PtBatch bt)
         for (int j = 0; j < 4; ++j) s_gt[4 * g + j] = d.gt_bv[5 * g + j];
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= d.R + d.G) return;
+    const int R = pt_num_rois(d);
+    if (r >= R + d.G) return;
     float b[5];
-    cand_bv(d, r, b);
+    cand_bv(d, R, r, b);
     const double b0 = b[1], b1 = b[2], b2 = b[3], b3 = b[4];
     double mx = 0.0;
     int am = 0;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(1024) void pt_compact_kernel(PtBatch bt)
 {
     const PtDev &d = bt.f[blockIdx.y].d;
     int32_t *counts = bt.f[blockIdx.y].counts;
-    const int n = d.R + d.G;
+    const int n = pt_num_rois(d) + d.G;
     int tot[2];
     mv3d_block_compact<2>(
         n,
@@ -128,8 +131,9 @@ __global__ __launch_bounds__(PT_EMIT_THREADS) void pt_emit_kernel(PtBatch bt)
     // labels = gt_boxes_bv[gt_assignment, 4]; labels[fg_rois_per_this_image:] = 0 (:238, :276)
     const float lab = (t < e.n_fg) ? d.gt_bv[5 * g + 4] : 0.0f;
     float b[5], q[7];
-    cand_bv(d, r, b);
-    cand_3d(d, r, q);
+    const int R = pt_num_rois(d);
+    cand_bv(d, R, r, b);
+    cand_3d(d, R, r, q);
     if (k == 0) {
         for (int j = 0; j < 5; ++j) e.rois_bv[5 * t + j] = b[j];
         for (int j = 0; j < 7; ++j) e.rois_3d[7 * t + j] = q[j];
@@ -206,7 +210,7 @@ static bool pt_layout(int R, int G, PtLayout &L)
 static void pt_fill(PtDev &d, const PtLayout &L, char *ws, const float *rois_bv, const float *rois_3d, int R,
                     const float *gt_bv, const float *gt_3d, int G, const mv3d_proposal_target_params *p)
 {
-    d.rois_bv = rois_bv; d.rois_3d = rois_3d; d.gt_bv = gt_bv; d.gt_3d = gt_3d; d.R = R; d.G = G;
+    d.rois_bv = rois_bv; d.rois_3d = rois_3d; d.gt_bv = gt_bv; d.gt_3d = gt_3d; d.R = R; d.G = G; d.R_dev = nullptr;
     d.fg_thresh = p->fg_thresh; d.bg_hi = p->bg_thresh_hi; d.bg_lo = p->bg_thresh_lo; d.gt_frame = (float)p->frame_index;
     d.max_ov = (double *)(ws + L.o_maxov); d.assign = (int32_t *)(ws + L.o_assign);
     d.fg_list = (int32_t *)(ws + L.o_fg); d.bg_list = (int32_t *)(ws + L.o_bg);
@@ -218,10 +222,10 @@ extern "C" size_t mv3d_proposal_target_workspace_bytes(int num_rois, int G)
     return pt_layout(num_rois, G, L) ? L.total : 0;
 }
 
-extern "C" int mv3d_proposal_target_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
-                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
-                                                 const int *G, const mv3d_proposal_target_params *p, int32_t *const *counts_dev,
-                                                 void *const *workspace, const size_t *workspace_bytes, void *stream)
+static int pt_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev, const int *num_rois,
+                           const int32_t *const *num_rois_dev, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                           const int *G, const mv3d_proposal_target_params *p, int32_t *const *counts_dev,
+                           void *const *workspace, const size_t *workspace_bytes, void *stream)
 {
     if (batch <= 0 || batch > PT_MAX_BATCH || !p || !rois_bv_dev || !rois_3d_dev || !num_rois || !gt_bv_dev || !gt_3d_dev || !G ||
         !counts_dev || !workspace || !workspace_bytes)
@@ -235,6 +239,7 @@ extern "C" int mv3d_proposal_target_stage1_batch(int batch, const float *const *
             return MV3D_ERR_INVALID_ARG;
         if (!workspace[b] || workspace_bytes[b] < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
         pt_fill(bt.f[b].d, L, (char *)workspace[b], rois_bv_dev[b], rois_3d_dev[b], num_rois[b], gt_bv_dev[b], gt_3d_dev[b], G[b], &p[b]);
+        bt.f[b].d.R_dev = num_rois_dev ? num_rois_dev[b] : nullptr;
         bt.f[b].counts = counts_dev[b];
         if (num_rois[b] + G[b] > most) most = num_rois[b] + G[b];
     }
@@ -242,6 +247,27 @@ extern "C" int mv3d_proposal_target_stage1_batch(int batch, const float *const *
     hipLaunchKernelGGL(pt_overlap_kernel, dim3((most + 255) / 256, batch), dim3(256), 0, s, bt);
     hipLaunchKernelGGL(pt_compact_kernel, dim3(1, batch), dim3(1024), 0, s, bt);
     return mv3d_launch_status();
+}
+
+extern "C" int mv3d_proposal_target_stage1_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                                 const int *G, const mv3d_proposal_target_params *p, int32_t *const *counts_dev,
+                                                 void *const *workspace, const size_t *workspace_bytes, void *stream)
+{
+    return pt_stage1_batch(batch, rois_bv_dev, rois_3d_dev, num_rois, nullptr, gt_bv_dev, gt_3d_dev, G, p, counts_dev, workspace,
+                           workspace_bytes, stream);
+}
+
+extern "C" int mv3d_proposal_target_stage1_batch_devn(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                      const int *num_rois_cap, const int32_t *const *num_rois_dev,
+                                                      const float *const *gt_bv_dev, const float *const *gt_3d_dev, const int *G,
+                                                      const mv3d_proposal_target_params *p, int32_t *const *counts_dev,
+                                                      void *const *workspace, const size_t *workspace_bytes, void *stream)
+{
+    if (!num_rois_dev) return MV3D_ERR_INVALID_ARG;
+    for (int b = 0; b < batch && b < PT_MAX_BATCH; ++b) if (!num_rois_dev[b]) return MV3D_ERR_INVALID_ARG;
+    return pt_stage1_batch(batch, rois_bv_dev, rois_3d_dev, num_rois_cap, num_rois_dev, gt_bv_dev, gt_3d_dev, G, p, counts_dev,
+                           workspace, workspace_bytes, stream);
 }
 
 extern "C" int mv3d_proposal_target_stage1(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
@@ -253,8 +279,8 @@ extern "C" int mv3d_proposal_target_stage1(const float *rois_bv_dev, const float
                                              &workspace, &workspace_bytes, stream);
 }
 
-extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
-                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+static int pt_stage2_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                 const int *num_rois, const int32_t *const *num_rois_dev, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
                                                  const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
                                                  const mv3d_proposal_target_params *p, const int32_t *const *fg_pick_dev,
                                                  const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
@@ -279,6 +305,7 @@ extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *
             return MV3D_ERR_INVALID_ARG;
         if (!workspace[b] || workspace_bytes[b] < L.total || ((uintptr_t)workspace[b] % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
         pt_fill(bt.f[b].d, L, (char *)workspace[b], rois_bv_dev[b], rois_3d_dev[b], num_rois[b], gt_bv_dev[b], gt_3d_dev[b], G[b], &p[b]);
+        bt.f[b].d.R_dev = num_rois_dev ? num_rois_dev[b] : nullptr;
         e.fg_pick = fg_pick_dev[b]; e.bg_pick = bg_pick_dev[b];
         e.gt_corners = gt_corners_dev[b]; e.calib = calib_dev[b];
         e.rois_bv = rois_bv_out[b]; e.rois_img = rois_img_out[b]; e.targets = bbox_targets_out[b]; e.rois_3d = rois_3d_out[b];
@@ -291,6 +318,37 @@ extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *
                        (hipStream_t)stream, bt);
     return mv3d_launch_status();
 }
+
+#define PT_S2_ARGS gt_bv_dev, gt_3d_dev, gt_corners_dev, G, calib_dev, p, fg_pick_dev, n_fg, bg_pick_dev, n_bg, rois_bv_out, rois_img_out, \
+                   labels_out, bbox_targets_out, rois_3d_out, rois_fv_out, workspace, workspace_bytes, stream
+extern "C" int mv3d_proposal_target_stage2_batch(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                 const int *num_rois, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                                 const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
+                                                 const mv3d_proposal_target_params *p, const int32_t *const *fg_pick_dev,
+                                                 const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
+                                                 float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
+                                                 float *const *bbox_targets_out, float *const *rois_3d_out,
+                                                 float *const *rois_fv_out, void *const *workspace,
+                                                 const size_t *workspace_bytes, void *stream)
+{
+    return pt_stage2_batch(batch, rois_bv_dev, rois_3d_dev, num_rois, nullptr, PT_S2_ARGS);
+}
+
+extern "C" int mv3d_proposal_target_stage2_batch_devn(int batch, const float *const *rois_bv_dev, const float *const *rois_3d_dev,
+                                                      const int *num_rois_cap, const int32_t *const *num_rois_dev,
+                                                      const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                                                      const float *const *gt_corners_dev, const int *G, const float *const *calib_dev,
+                                                      const mv3d_proposal_target_params *p, const int32_t *const *fg_pick_dev,
+                                                      const int *n_fg, const int32_t *const *bg_pick_dev, const int *n_bg,
+                                                      float *const *rois_bv_out, float *const *rois_img_out, int32_t *const *labels_out,
+                                                      float *const *bbox_targets_out, float *const *rois_3d_out,
+                                                      float *const *rois_fv_out, void *const *workspace,
+                                                      const size_t *workspace_bytes, void *stream)
+{
+    if (!num_rois_dev) return MV3D_ERR_INVALID_ARG;
+    return pt_stage2_batch(batch, rois_bv_dev, rois_3d_dev, num_rois_cap, num_rois_dev, PT_S2_ARGS);
+}
+#undef PT_S2_ARGS
 
 extern "C" int mv3d_proposal_target_stage2(const float *rois_bv_dev, const float *rois_3d_dev, int num_rois,
                                            const float *gt_bv_dev, const float *gt_3d_dev,

@@ -11,7 +11,7 @@ cfg.TRAIN.SNAPSHOT_ITERS and at the end.  `sess` / `saver` are opaque here (no T
 Data parallel (BASELINE configs[3]): when torch.distributed is initialised (one process per GPU, backend
 "nccl" = RCCL), every rank trains on its shard of the roidb (frame r, r + W, ...) and the gradients are averaged by
 `sharding.GradBucketer` (25 MB buckets, last layer first, overlapping backward) before the optimiser step; rank 0 writes
-the snapshots and prints.  `frames_per_step` > 1 accumulates that many frames per rank and step (per-GPU batch)."""
+the snapshots and prints.  `frames_per_step` > 1 = that many frames per rank and step, run as ONE batch through the graph (per-GPU batch)."""
 import os
 import time
 
@@ -77,10 +77,45 @@ def rcnn_losses(cls_score, roi_data_3d, bbox_pred, sigma=3.0):
 
 
 def total_loss(net_layers, sigma=3.0):
-    """train_mv.py:130: cross_entropy + loss_box + rpn_cross_entropy + rpn_loss_box from the train graph's layers."""
-    rpn_ce, rpn_box = rpn_losses(net_layers['rpn_cls_score_reshape'], net_layers['rpn_data'], net_layers['rpn_bbox_pred'], sigma)
-    ce, box = rcnn_losses(net_layers['cls_score'], net_layers['roi_data_3d'], net_layers['bbox_pred'], sigma)
-    return ce + box + rpn_ce + rpn_box, (ce, box, rpn_ce, rpn_box)
+    """train_mv.py:130: cross_entropy + loss_box + rpn_cross_entropy + rpn_loss_box from the train graph's layers.  For a batch
+    of B frames every loss is the mean over the frames of the reference's per-frame loss (what B single-frame steps with
+    averaged gradients give, and what the data-parallel all-reduce averages across ranks)."""
+    L = net_layers
+    rpn_data = L['rpn_data']
+    if rpn_data[0].dim() == 1:                                  # one frame: the reference's shapes
+        rpn_ce, rpn_box = rpn_losses(L['rpn_cls_score_reshape'], rpn_data, L['rpn_bbox_pred'], sigma)
+        ce, box = rcnn_losses(L['cls_score'], L['roi_data_3d'], L['bbox_pred'], sigma)
+        return ce + box + rpn_ce + rpn_box, (ce, box, rpn_ce, rpn_box)
+    B = rpn_data[0].shape[0]
+    rows = L['roi_rows']
+    parts = [0.0, 0.0, 0.0, 0.0]
+    o = 0
+    for b in range(B):
+        r_ce, r_box = rpn_losses(L['rpn_cls_score_reshape'][b], (rpn_data[0][b], rpn_data[1][b]), L['rpn_bbox_pred'][b], sigma)
+        sl = slice(o, o + rows[b])
+        o += rows[b]
+        data = L['roi_data_3d']
+        ce, box = rcnn_losses(L['cls_score'][sl], (None, None, data[2][sl], data[3][sl]), L['bbox_pred'][sl], sigma)
+        for k, v in enumerate((ce, box, r_ce, r_box)):
+            parts[k] = parts[k] + v / B
+    return parts[0] + parts[1] + parts[2] + parts[3], tuple(parts)
+
+
+def stack_blobs(frames):
+    """blobs of several frames (RoIDataLayer.forward() each) -> the feed of one batched pass: images / BEV maps stacked on
+    axis 0 (same size per batch, as KITTI crops are), im_info (B,3), calib (B,4,12), ground truth as per-frame lists."""
+    if len(frames) == 1:
+        return dict(frames[0])
+    feed = {}
+    for k in ("image_data", "lidar_bv_data", "lidar_fv_data"):
+        if k in frames[0]:
+            feed[k] = np.concatenate([np.asarray(f[k]) for f in frames], 0)
+    feed["im_info"] = np.concatenate([np.asarray(f["im_info"], np.float32).reshape(1, 3) for f in frames], 0)
+    feed["calib"] = np.stack([np.asarray(f["calib"], np.float32).reshape(4, 12) for f in frames], 0)
+    for k in ("gt_boxes", "gt_boxes_bv", "gt_boxes_3d", "gt_boxes_corners"):
+        if k in frames[0]:
+            feed[k] = [np.asarray(f[k], np.float32) for f in frames]
+    return feed
 
 
 def snapshot_filename(output_dir, iter):
@@ -91,8 +126,9 @@ def snapshot_filename(output_dir, iter):
 
 def save_weights_npy(net, path):
     """The `.npy` dict {layer: {'weights': ..., 'biases': ...}} that network.load() reads (network.py:45-64; the
-    reference writes the same structure at test_mv.py:345-372)."""
-    d = {name: {'weights': w.detach().cpu().numpy(), 'biases': b.detach().cpu().numpy()} for name, (w, b) in net.params.items()}
+    reference writes the same structure at test_mv.py:345-372): weights in the TF layouts (HWIO / [in, out]), like
+    SolverWrapper.snapshot -- save -> load is the identity."""
+    d = {name: {'weights': _tf_layout(w), 'biases': b.detach().cpu().numpy()} for name, (w, b) in net.params.items()}
     np.save(path, d, allow_pickle=True)
     return path
 
@@ -153,18 +189,16 @@ class SolverWrapper(object):
         for it in range(start_iter, max_iters):
             t0 = time.perf_counter()
             bucketer.zero_grad()
-            vals = np.zeros(4)
-            for k in range(frames_per_step):
-                blobs = data_layer.forward()                                            # get one batch (:162)
-                feed = dict(blobs, keep_prob=0.5)                                       # feed_dict (:165-173)
-                layers = self.net.forward(feed)
-                loss, parts = total_loss(layers)
-                bucketer.reset()
-                # gradients of the frames of a step add up in the flat buckets; the all-reduce starts with the LAST frame's
-                # backward pass (the hooks of the earlier frames only count)
-                bucketer.dist_enabled = (k == frames_per_step - 1)
-                (loss / frames_per_step).backward()
-                vals += np.array([float(v.detach()) for v in parts]) / frames_per_step           # (ce, box, rpn_ce, rpn_box)
+            # the frames of a step go through the graph as ONE batch (the hot-path kernels take the frame as blockIdx.y); the
+            # four losses are means over the batch's anchors / ROIs, as train_mv.py:92-130 has them for its single frame
+            feed = stack_blobs([data_layer.forward() for _ in range(frames_per_step)])   # get one batch (:162), x frames
+            feed["keep_prob"] = 0.5                                                       # feed_dict (:165-173)
+            layers = self.net.forward(feed)
+            loss, parts = total_loss(layers)
+            bucketer.reset()
+            bucketer.dist_enabled = True                       # the bucketed all-reduce overlaps this backward pass
+            loss.backward()
+            vals = np.array([float(v.detach()) for v in parts])                           # (ce, box, rpn_ce, rpn_box)
             bucketer.finish()
             self.optimizer.step()
             if torch.cuda.is_available():
@@ -254,23 +288,25 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
     rng = np.random.RandomState(100 + rank)
-    feeds = []
+    frames = []
     for k in range(frames_per_step):
         _, _, info, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(7000 + 10 * rank + k, 76, 76, "peaky", return_gt=True)
         bev = (rng.random_sample((1, 608, 608, 9)) < 0.03).astype(np.float32) * rng.uniform(0, 2.4, (1, 608, 608, 9)).astype(np.float32)
         img = rng.randint(0, 255, (1, 375, 1242, 3)).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
-        feeds.append({"lidar_bv_data": torch.as_tensor(bev).cuda(), "image_data": torch.as_tensor(img.astype(np.float32)).cuda(),
-                      "im_info": info, "calib": calib, "gt_boxes_bv": gt_bv, "gt_boxes_3d": gt_3d, "gt_boxes_corners": gt_cnr,
-                      "keep_prob": 0.5})
+        frames.append({"lidar_bv_data": bev, "image_data": img.astype(np.float32), "im_info": info, "calib": calib,
+                       "gt_boxes_bv": gt_bv, "gt_boxes_3d": gt_3d, "gt_boxes_corners": gt_cnr})
+    feed = stack_blobs(frames)
+    for k in ("lidar_bv_data", "image_data"):
+        feed[k] = torch.as_tensor(feed[k]).cuda()                # resident inputs
+    feed["keep_prob"] = 0.5
 
     def step():
         bucketer.zero_grad()
-        for k, feed in enumerate(feeds):
-            layers = net.forward(feed)
-            loss, _ = total_loss(layers)
-            bucketer.reset()
-            bucketer.dist_enabled = (k == len(feeds) - 1)
-            (loss / len(feeds)).backward()
+        layers = net.forward(feed)                               # the frames of the step as one batch
+        loss, _ = total_loss(layers)
+        bucketer.reset()
+        bucketer.dist_enabled = True
+        loss.backward()
         bucketer.finish()
         opt.step()
 

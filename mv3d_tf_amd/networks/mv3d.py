@@ -1,9 +1,16 @@
 """MV3D graphs (lib/networks/MV3D_test.py:32-123, MV3D_train.py:42-182) as data tables run
 by a small executor, with the hot-path layers bound to libmv3d_hip.so:
 
-    proposal_layer_3d / anchor_target_layer / proposal_target_layer_3d   mv3d_tf_amd.rpn_msr.*
-    roi_pool (+ gradient)                                                 mv3d_tf_amd.roi_pooling_layer
+    proposal_layer_3d                                                     mv3d_tf_amd.rpn_msr (device tensors, any batch)
+    anchor_target_layer + proposal_target_layer_3d (TRAIN)                mv3d_tf_amd.train_path.TrainPathStream: the batched
+                                                                          C entries, ONE host round trip per step for the draws
+    roi_pool of every view (+ gradient)                                   roi_pooling_layer.roi_pool_views: one launch forward, the
+                                                                          indexed RoiPoolGrad (with workspace) backward
     proposal_transform                                                    tuple element 0 ('bv') / 1 ('img')
+
+`forward(feed)` takes B >= 1 frames (B > 1: lists of per-frame ground-truth arrays, im_info (B,3), calib (B,4,12)); the ROI
+batch column is the frame index, every hot-path kernel runs once for the whole batch (blockIdx.y = frame).  The numpy-contract
+callables of mv3d_tf_amd.rpn_msr (the tf.py_func boundary of network.py:221-273) are unchanged and give the same values.
 
 Layer names, shapes and the plumbing of lib/networks/network.py:199-405 are kept (`layers`
 dict, `get_output(name)`, NHWC activations, fc on a 4-D input flattens in (c,h,w) order,
@@ -17,10 +24,8 @@ import torch
 import torch.nn.functional as F
 
 from ..fast_rcnn.config import cfg
-from ..roi_pooling_layer.roi_pooling_op import roi_pool
-from ..rpn_msr.anchor_target_layer_tf import anchor_target_layer
+from ..roi_pooling_layer.roi_pooling_op import roi_pool_views
 from ..rpn_msr.proposal_layer_tf import proposal_layer_3d
-from ..rpn_msr.proposal_target_layer_tf import proposal_target_layer_3d
 
 n_classes = 2                 # lib/networks/MV3D_train.py:4
 _feat_stride = [8, 8]         # :5
@@ -118,15 +123,37 @@ class MV3D:
         y = F.linear(x, w, b)
         return F.relu(y) if relu else y
 
+    # ---- hot-path plumbing
+    def _train_path(self, B, H, W):
+        from ..train_path import TrainPathStream
+        key = (B, H, W)
+        if getattr(self, "_tp_key", None) != key:
+            self._tp = TrainPathStream(B, H, W, self.device, num_classes=n_classes, depth=1, want_fv=(self.views == 3))
+            self._tp_key = key
+        return self._tp
+
+    @staticmethod
+    def _gt_frames(L, B):
+        """per frame (gt_boxes_bv, gt_boxes_3d, gt_boxes_corners): the feed holds arrays for one frame, lists for several"""
+        keys = ("gt_boxes_bv", "gt_boxes_3d", "gt_boxes_corners")
+        if isinstance(L[keys[0]], (list, tuple)):
+            frames = list(zip(*[L[k] for k in keys]))
+        else:
+            frames = [tuple(L[k] for k in keys)]
+        if len(frames) != B:
+            raise ValueError("ground truth for %d frames, data for %d" % (len(frames), B))
+        return frames
+
     # ---- the graph
     def forward(self, feed):
         """feed: dict with the reference's placeholder names (Appendix C of SURVEY.md); numpy or tensors."""
         L = self.layers
         L.clear()
         dev = self.device
+        to_dev = lambda a: a.to(dev) if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32)).to(dev)
         for k in _INPUTS:
             if k in feed and feed[k] is not None:
-                L[k] = torch.as_tensor(np.asarray(feed[k], np.float32)).to(dev) if not isinstance(feed[k], torch.Tensor) else feed[k].to(dev)
+                L[k] = [to_dev(a) for a in feed[k]] if isinstance(feed[k], (list, tuple)) else to_dev(feed[k])
         keep_prob = float(feed.get("keep_prob", self.keep_prob))
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
@@ -146,31 +173,60 @@ class MV3D:
         L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)   # :399-403
         L["rpn_cls_prob_reshape"] = L["rpn_cls_prob"].reshape(n, h, w, c)
         stride = _feat_stride[0]
+        B = int(n)
+        info = L["im_info"].reshape(-1, 3)
+        cal = L["calib"].reshape(-1, 4, 12)
+        if info.shape[0] == 1 and B > 1:
+            info = info.expand(B, 3)
+        if cal.shape[0] == 1 and B > 1:
+            cal = cal.expand(B, 4, 12)
+        info, cal = info.contiguous(), cal.contiguous()
+        prob = L["rpn_cls_prob_reshape"].detach().contiguous()
+        pred = L["rpn_bbox_pred"].detach().contiguous()
         if self.phase == "TRAIN":
-            L["rpn_data"] = anchor_target_layer(score.detach(), L["gt_boxes_bv"], L["gt_boxes_3d"], L["im_info"], [stride, ],
-                                                anchor_scales)                       # MV3D_train.py:88
+            # anchor_target_layer (MV3D_train.py:88) + proposal_layer_3d (:98) + proposal_target_layer_3d (:105), all frames
+            # behind one launch per kernel; the subsampling draws come from the numpy global RNG, frame by frame
+            gt = [tuple(t.reshape(-1, c).contiguous() for t, c in zip(g, (5, 7, 25))) for g in self._gt_frames(L, B)]
+            path = self._train_path(B, h, w)
+            out = path.finish(path.submit(prob, pred, info, cal, gt))
+            out = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
+                   for k, v in out.items()}                                           # (the path's buffers are reused by the next step)
+            L["roi_rows"] = out["S"]
+            bvb, imgb, b3b = out["proposals"][:3]
+            cnt = out["num_proposals"]
+            cat = lambda t: t[0, :cnt[0]].clone() if B == 1 else torch.cat([t[b, :cnt[b]] for b in range(B)], 0)
+            rois = (cat(bvb), cat(imgb), cat(b3b))
+            rois = rois + (rois[2],)                                                  # network.py:234
+            L["rpn_rois"] = rois
+            if B == 1:
+                m = int(out["n_anchors"][0].item())
+                L["rpn_data"] = (out["rpn_labels"][0], out["rpn_targets"][0], out["anchors"][0, :m], out["anchors_3d"][0, :m])
+            else:
+                L["rpn_data"] = (out["rpn_labels"], out["rpn_targets"], out["anchors"], out["anchors_3d"], out["n_anchors"])
             L["rpn-data"] = L["rpn_data"]                                             # (the Faster-RCNN spelling)
-        bv, img, b3 = proposal_layer_3d(L["rpn_cls_prob_reshape"].detach(), L["rpn_bbox_pred"].detach(), L["im_info"],
-                                        L["calib"], self.phase, [stride, ], anchor_scales)
-        rois = (bv, img, b3, b3)                                                      # network.py:234
-        L["rpn_rois" if self.phase == "TRAIN" else "rois"] = rois
-        if self.phase == "TRAIN":
-            data = proposal_target_layer_3d(rois[0], rois[3], L["gt_boxes_bv"], L["gt_boxes_3d"], L["gt_boxes_corners"],
-                                            L["calib"], n_classes)
+            data = (out["rois"]["bev"], out["rois"]["rgb"], out["labels"], out["bbox_targets"], out["rois_3d"])
             L["roi_data_3d"] = data                                                   # (rois_bv, rois_img, labels, targets, rois_3d)
             L["roi_data_bv"], L["roi_data_img"] = data[0], data[1]                    # proposal_transform (network.py:292-315)
+            r3, rois_fv = data[4], out["rois"]["fv"]
         else:
+            bv, img, b3 = proposal_layer_3d(prob, pred, info, cal, self.phase, [stride, ], anchor_scales)
+            rois = (bv, img, b3, b3)
+            L["rois"] = rois
             L["roi_data_bv"], L["roi_data_img"] = rois[0], rois[1]
-        # RoI pooling on both views + fusion head (MV3D_test.py:95-123)
-        L["pool_5"] = roi_pool(L["conv5_3"].contiguous(), L["roi_data_bv"].contiguous(), 7, 7, 1.0 / 8)[0]
-        L["pool_5_2"] = roi_pool(L["conv5_3_2"].contiguous(), L["roi_data_img"].contiguous(), 7, 7, 1.0 / 8)[0]
-        pools = [("_1", "pool_5"), ("_2", "pool_5_2")]
+            r3, rois_fv = rois[2], None
+        # RoI pooling of every view in one launch (+ the indexed gradient) and the fusion head (MV3D_test.py:95-123)
+        views = [(L["conv5_3"], L["roi_data_bv"]), (L["conv5_3_2"], L["roi_data_img"])]
+        names = ["pool_5", "pool_5_2"]
         if self.views == 3:
-            from ..utils.front_view import rois_3d_to_fv
-            r3 = data[4] if self.phase == "TRAIN" else rois[2]
-            L["roi_data_fv"] = rois_3d_to_fv(r3 if isinstance(r3, torch.Tensor) else torch.as_tensor(np.asarray(r3, np.float32)).to(dev))
-            L["pool_5_3"] = roi_pool(L["conv5_3_3"].contiguous(), L["roi_data_fv"].contiguous(), 7, 7, 1.0 / 8)[0]
-            pools.append(("_3", "pool_5_3"))
+            if rois_fv is None:
+                from ..utils.front_view import rois_3d_to_fv
+                rois_fv = rois_3d_to_fv(r3)
+            L["roi_data_fv"] = rois_fv
+            views.append((L["conv5_3_3"], rois_fv))
+            names.append("pool_5_3")
+        for name, top in zip(names, roi_pool_views([(d.contiguous(), r.contiguous()) for d, r in views], 7, 7, 1.0 / 8)):
+            L[name] = top
+        pools = list(zip(("_1", "_2", "_3"), names))
         tower = []
         for t, pool in pools:
             x = self._fc(L[pool], "fc6" + t)

@@ -32,6 +32,50 @@ class RoiPoolFunction(torch.autograd.Function):
         return grad, None, None, None, None
 
 
+class RoiPoolViewsFunction(torch.autograd.Function):
+    """The RoiPool layers of one step (`pool_5`, `pool_5_2` [, `pool_5_3`]: network.py:199-213 called once per view) behind
+    ONE launch forward (mv3d_roi_pool_forward_views) and ONE call backward (mv3d_roi_pool_backward_views with its workspace:
+    the indexed gather, roi_pooling_op.cc:319-452 for every view).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...)
+    -> (top_0, top_1, ...); gradients for the data tensors only (roi_pooling_op_grad.py:43).  A view whose output gets no
+    gradient (unused in the loss) contributes zeros, like an unconnected tf.gradients branch."""
+
+    @staticmethod
+    def forward(ctx, pooled_height, pooled_width, spatial_scale, *tensors):
+        datas = [t.contiguous() for t in tensors[0::2]]
+        rois = [t.contiguous() for t in tensors[1::2]]
+        res = ops.roi_pool_forward_views([(d, r, spatial_scale) for d, r in zip(datas, rois)], pooled_height, pooled_width)
+        ctx.save_for_backward(*rois, *[am for _, am in res])
+        ctx.meta = ([tuple(d.shape) for d in datas], pooled_height, pooled_width, spatial_scale)
+        return tuple(top for top, _ in res)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shapes, ph, pw, scale = ctx.meta
+        n = len(shapes)
+        saved = ctx.saved_tensors
+        rois, argmax = saved[:n], saved[n:]
+        views = []
+        for k in range(n):
+            g = grads[k]
+            if g is None:
+                g = torch.zeros((rois[k].shape[0], ph, pw, shapes[k][3]), dtype=torch.float32, device=rois[k].device)
+            views.append((g.contiguous(), rois[k], argmax[k], shapes[k], scale))
+        outs = ops.roi_pool_backward_views(views, ph, pw)
+        ret = [None, None, None]
+        for k in range(n):
+            ret += [outs[k], None]
+        return tuple(ret)
+
+
+def roi_pool_views(views, pooled_height, pooled_width, spatial_scale):
+    """views: [(bottom_data NHWC device tensor, bottom_rois (R,5) device tensor), ...] -> [top, ...] (autograd-aware)."""
+    flat = []
+    for d, r in views:
+        _check(d, r)
+        flat += [d, r]
+    return list(RoiPoolViewsFunction.apply(int(pooled_height), int(pooled_width), float(spatial_scale), *flat))
+
+
 def _check(bottom_data, bottom_rois):
     # OP_REQUIRES at roi_pooling_op.cc:83-88
     if bottom_data.ndim != 4:
