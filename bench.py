@@ -11,9 +11,10 @@ Default workload = BASELINE configs[2], path only (the largest single-GPU config
       mv3d_roi_pool_forward_views   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7
       mv3d_roi_pool_backward_views  the same three layers, RoiPoolGrad
 
-A "step" = one pass over `--batches-per-step` such batches (default 64 batches = 128 frames), cycling through a ring of
-`--ring` (default 16) DISTINCT batches per GPU -- distinct frames and distinct feature maps (1.1 GB of maps + 3.3 GB of
-outputs per ring), so that nothing is served from the 256 MB Infinity Cache by re-reading the previous step's frame.
+A "step" = one pass over `--batches-per-step` such batches (default 1664 batches = 3328 frames: `--steps 20` is a SUSTAINED
+~5 s timed region, not a burst), cycling through a ring of `--ring` (default 16) DISTINCT batches per GPU -- distinct frames
+and distinct feature maps (1.1 GB of maps + 3.3 GB of outputs per ring), so that nothing is served from the 256 MB Infinity
+Cache by re-reading the previous step's frame.
 Batches are enqueued round-robin on `--streams` HIP streams (a batch is a dependent chain of ~20 small launches +
 two HBM-bound RoiPool launches; independent batches overlap).  Inputs are resident in HBM before the timed region,
 including the random-subsample index lists of the two target layers, which are arguments of the C-ABI (drawn from the
@@ -30,8 +31,9 @@ timed region are the only collectives of the path-only line.
 Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel of the step (largest share of GPU time), measured live
 with HIP events on the stream it is launched on; `roofline_kernels` lists the RoiPool forward and backward launches
 separately; `cpu_baseline` = the C oracle on the same workload on the host cores (bounded sample); `secondary` holds
-the TEST-cfg (configs[1]/[4]) line and, with --with-trunk, the full training step with the torch VGG16 trunks
-and the bucketed gradient all-reduce.
+`fresh_inputs` (the same training path on NEW frames every batch: mv3d_tf_amd.train_path.TrainPathStream, host draws in the
+loop, pipelined), the TEST-cfg (configs[1]/[4]) line and `with_trunk`, the full training step with the torch VGG16 trunks and
+the bucketed gradient all-reduce (--no-trunk skips it).
 """
 import argparse
 import json
@@ -59,7 +61,7 @@ def parse():
                     help="train: BASELINE configs[2] path-only (default); test: configs[4] per-GPU path (batch 16, TEST cfg)")
     ap.add_argument("--batch", type=int, default=0, help="frames per batch per GPU (default: 2 for train, 16 for test)")
     ap.add_argument("--ring", type=int, default=0, help="distinct resident batches per GPU (default: 16 train, 4 test)")
-    ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step (default: 64 train, 8 test)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step (default: 1664 train, 208 test)")
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph: every ring batch is captured once into a hipGraph on its stream and replayed (one host call "
@@ -67,9 +69,11 @@ def parse():
                          "them once three batches are in flight); eager: plain in-order launches")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--with-trunk", action="store_true", help="add the full training step (torch VGG16 trunks + DP all-reduce)")
+    ap.add_argument("--with-trunk", action="store_true", help="(default since r03; kept for old command lines)")
+    ap.add_argument("--no-trunk", action="store_true", help="skip secondary.with_trunk (the full training step with the torch VGG16 trunks)")
+    ap.add_argument("--no-fresh", action="store_true", help="skip secondary.fresh_inputs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests)")
     return ap.parse_args()
 
@@ -149,11 +153,11 @@ def events_ms(stream, fns, rounds):
 
 
 def pmc_traffic(kernel, signature):
-    """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r02_pmc_traffic.json holds
-    the signature it was collected with); None otherwise -- never a stale number."""
+    """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r03_pmc_traffic.json: one table per
+    signature it was collected with); None otherwise -- never a stale number."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        if table.get("signature") != signature:
+        table = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["signatures"].get(signature)
+        if not table:
             return None
         keys = [k for k in table["kernels"] if kernel in k]          # RoiPoolGrad = three kernels behind one call: summed
         return int(sum(table["kernels"][k]["hbm_bytes_per_launch"] for k in keys)) if keys else None
@@ -257,6 +261,73 @@ def cpu_baseline(ring, workload, seconds):
                       % (nm, cores, dtm, n1, dt1, key, "+bwd" if workload == "train" else "", os.cpu_count())}
 
 
+def fresh_inputs_line(rank, variant, seconds=1.5):
+    """The training path on FRESH inputs: every batch brings new RPN heads / ground truth / feature maps (a pool of 8 resident
+    input batches, each processed as new: stage 1 -> counts to the host -> numpy-global-RNG draws -> index lists back -> stage
+    2 -> RoiPool forward + backward on its ROIs), batch i + 1 submitted before batch i is finished so that the device never
+    waits for the host's draws of the batch it is working on."""
+    from mv3d_tf_amd import hot_path, ops, synth
+    from mv3d_tf_amd.train_path import TrainPathStream
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, POOL = 2, 8
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    pool = []
+    for k in range(POOL):
+        frames = [synth.rpn_head(300000 * (rank + 1) + k * B + b, 76, 76, variant, return_gt=True) for b in range(B)]
+        pool.append(((t(np.concatenate([f[0] for f in frames])), t(np.concatenate([f[1] for f in frames])),
+                      t(np.concatenate([f[2] for f in frames])), t(np.stack([f[3] for f in frames])),
+                      [tuple(t(a) for a in f[4]) for f in frames]), hot_path.synth_maps(B, 900 + k, dev)))
+    path = TrainPathStream(B, 76, 76, dev, depth=2)
+    cap = B * path.roi_cap
+    g = torch.Generator(device=dev).manual_seed(5)
+    bufs = []
+    for _ in range(2):
+        d = {}
+        for v in hot_path.VIEWS:
+            H, W, Cc = hot_path.VIEW_MAPS[v]
+            d[v] = (torch.empty((cap, 7, 7, Cc), device=dev), torch.empty((cap, 7, 7, Cc), dtype=torch.int32, device=dev),
+                    torch.rand((cap, 7, 7, Cc), generator=g, device=dev) * 2.0 - 1.0, torch.empty((B, H, W, Cc), device=dev))
+        bufs.append(d)
+
+    def roi(out, maps, d):
+        St = out["rois"]["bev"].shape[0]
+        views = [(maps[v], out["rois"][v], 0.125) for v in hot_path.VIEWS]
+        res = ops.roi_pool_forward_views(views, 7, 7, outs=[(d[v][0][:St], d[v][1][:St]) for v in hot_path.VIEWS])
+        ops.roi_pool_backward_views([(d[v][2][:St], out["rois"][v], res[k][1], tuple(maps[v].shape), 0.125) for k, v in enumerate(hot_path.VIEWS)],
+                                    7, 7, outs=[d[v][3] for v in hot_path.VIEWS])
+
+    def run(nb):
+        slot = path.submit(*pool[0][0])
+        for i in range(nb):
+            nxt = path.submit(*pool[(i + 1) % POOL][0]) if i + 1 < nb else None
+            out = path.finish(slot)
+            roi(out, pool[i % POOL][1], bufs[i % 2])
+            slot = nxt
+
+    np.random.seed(7 + rank)
+    run(8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(40)
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 40
+    nb = max(40, int(seconds / per))
+    path.t_draw = path.t_wait = 0.0
+    t0 = time.perf_counter()
+    run(nb)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "the default line's training path on FRESH inputs (mv3d_tf_amd.train_path.TrainPathStream): new heads / "
+                        "ground truth / maps every batch of 2 frames, one host round trip per batch for the numpy-global-RNG "
+                        "subsampling draws (exactly the reference's, draw for draw), batch i + 1 submitted before batch i is "
+                        "finished; RoiPool fwd + bwd of the 3 views on the batch's ROIs; 1 stream, eager launches",
+            "frames_per_s": round(nb * B / dt, 2), "batches_timed": nb,
+            "host_draw_ms_per_frame": round(path.t_draw / (nb * B) * 1e3, 4),
+            "host_wait_for_device_ms_per_frame": round(path.t_wait / (nb * B) * 1e3, 4),
+            "bound": "host: the legacy RandomState.permutation of every candidate list (~21 k background anchors per frame, twice) "
+                     "is the reference's subsampling contract; one process draws for one GPU"}
+
+
 def timed(ring, nbatches, steps, warmup, barrier):
     for _ in range(warmup):
         ring.run(nbatches)
@@ -309,7 +380,7 @@ def main():
 
     wl = args.workload
     batch = args.batch or (2 if wl == "train" else 16)
-    nb = args.batches_per_step or (64 if wl == "train" else 8)
+    nb = args.batches_per_step or (1664 if wl == "train" else 208)
     ring_n = args.ring or (16 if wl == "train" else 4)
     streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     ring = Ring(args, rank, wl, batch, ring_n, streams)
@@ -333,7 +404,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": batch, "batches_per_step": nb, "frames_per_step_per_gpu": nb * batch,
-                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": args.launch == "graph",
+                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": args.launch == "graph", "timed_region_s": round(dt, 3),
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
         }
         # one batch alone on one stream: the latency of the path
@@ -356,18 +427,26 @@ def main():
         sec = {}
         del ring
         torch.cuda.empty_cache()
+        if not args.no_fresh:
+            fr = fresh_inputs_line(rank, args.variant)
+            fr["frames_per_s"] = round(sharding.sum_over_ranks(fr["frames_per_s"], dist, device="cuda" if args.dist_backend == "nccl" else "cpu"), 2)
+            if rank == 0:
+                fr["fraction_of_resident_replay"] = round(fr["frames_per_s"] / res["value"], 4)
+                sec["fresh_inputs"] = fr
+            torch.cuda.empty_cache()
         args2 = argparse.Namespace(**vars(args))
         r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
-        dt2, _ = timed(r2, 3, max(2, args.steps // 2), 2, barrier)
+        nb2, st2 = 48, max(2, args.steps // 2)
+        dt2, _ = timed(r2, nb2, st2, 1, barrier)
         dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
         if rank == 0:
             sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
                                            "views, ring of 3 batches on the step's streams (%s launches)" % args.launch,
-                               "frames_per_s": round(max(2, args.steps // 2) * 3 * 16 * world / dt2, 2),
-                               "roofline_kernels": roofline_entries(r2, "test", "test/b16")}
+                               "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
+                               "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
         del r2
         torch.cuda.empty_cache()
-        if args.with_trunk:
+        if not args.no_trunk:
             from mv3d_tf_amd.fast_rcnn import train_mv
             sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
         if rank == 0:

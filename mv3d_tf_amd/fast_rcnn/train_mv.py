@@ -165,14 +165,17 @@ class SolverWrapper(object):
         self.log('Wrote snapshot to: {:s}'.format(filename))
         return filename
 
-    def train_model(self, sess, max_iters, frames_per_step=1, start_iter=0):
+    def train_model(self, sess, max_iters, frames_per_step=1, start_iter=0, resume=None):
         """Network training loop (:87-219).  Returns the list of per-iteration loss tuples
-        (total, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box)."""
+        (total, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box).  `resume` = a snapshot written by snapshot(): its weights are
+        loaded, and -- when the `<snapshot>.optim.pt` written next to it exists -- the Adam state and the iteration counter, so
+        that training continues where it stopped (the reference can only restart from weights)."""
         from .. import sharding
         dist = _dist()
         rank = dist.get_rank() if dist is not None else 0
         world = dist.get_world_size() if dist is not None else 1
-        roidb = self.roidb if world == 1 else [self.roidb[i] for i in sharding.frame_shard(len(self.roidb), rank, world)]
+        shard = list(sharding.frame_shard(len(self.roidb), rank, world)) or [rank % len(self.roidb)]   # (fewer frames than ranks:
+        roidb = self.roidb if world == 1 else [self.roidb[i] for i in shard]        # wrap around -- no rank may sit out a collective)
         data_layer = get_data_layer(roidb, self.imdb.num_classes)
         if self.pretrained_model is not None:
             self.log('Loading pretrained model weights from {:s}'.format(self.pretrained_model))
@@ -183,6 +186,13 @@ class SolverWrapper(object):
                 dist.broadcast(p_.data, src=0)
         lr = self.LEARNING_RATE
         self.optimizer = torch.optim.Adam(params, lr=lr)       # tf.train.AdamOptimizer(lr) defaults: beta 0.9 / 0.999, eps 1e-8
+        if resume is not None:
+            self.net.load(resume, sess, self.saver, False)
+            if os.path.exists(resume + '.optim.pt'):
+                state = torch.load(resume + '.optim.pt', map_location=params[0].device)
+                self.optimizer.load_state_dict(state['optimizer'])
+                start_iter = int(state['iter'])
+            self.log('Resumed from {:s} at iteration {:d}'.format(resume, start_iter))
         bucketer = sharding.GradBucketer(params, dist)
         history, last_snapshot_iter, spent = [], -1, 0.0
         it = start_iter - 1

@@ -29,6 +29,15 @@ def max_over_ranks(value, dist=None, device="cpu"):
     return float(t.item())
 
 
+def sum_over_ranks(value, dist=None, device="cpu"):
+    """sum of a python float over all ranks (whole-job rates of per-rank secondary lines)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def gather_frame_results(local, num_frames, dist=None, device="cpu"):
     """local: dict {frame index: 1-D int64 tensor} for the frames this rank owns.  Returns on
     every rank the list of per-frame tensors in frame order (None if no process group: local only).
@@ -105,24 +114,34 @@ class GradBucketer:
         """before every backward pass (gradients are zeroed in place: the views must stay attached)"""
         for b in self.buckets:
             b["pending"], b["handle"] = len(b["params"]), None
+        self._next = 0                      # buckets are launched strictly in index order (see _arrived)
 
     def zero_grad(self):
         for b in self.buckets:
             b["flat"].zero_()
 
+    def _launch_ready(self):
+        # Collectives are matched across ranks by LAUNCH ORDER: bucket i goes out only after buckets 0 .. i - 1 have, on every
+        # rank, whatever order the hooks fire in and even if a data-dependent branch left some parameter without a gradient on
+        # one rank (its bucket then waits for finish(), and so does everything behind it).
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            b = self.buckets[self._next]
+            b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+            self._next += 1
+
     def _arrived(self, p):
         b = self.buckets[self._bucket_of[id(p)]]
         b["pending"] -= 1
         if b["pending"] == 0 and self.dist is not None and self.dist_enabled:
-            b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+            self._launch_ready()
 
     def finish(self):
-        """after backward: every bucket reduced (buckets whose parameters got no gradient this step are reduced here)"""
+        """after backward: every bucket reduced (the buckets not launched during backward go out here, in index order)"""
         if self.dist is None:
             return
-        for b in self.buckets:
-            if b["handle"] is None:
-                b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+        for b in self.buckets[self._next:]:
+            b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
+        self._next = len(self.buckets)
         for b in self.buckets:
             b["handle"].wait()
             if self.average:

@@ -22,6 +22,7 @@ With `depth` slots a caller submits batch i + 1 before it finishes batch i: the 
 `RandomState.permutation` shuffles every candidate (21 k background anchors per frame, twice) -- ~0.3 ms per frame on one
 core, which bounds a single process at ~3 k fresh frames / s whatever the device does."""
 import ctypes as C
+import time
 
 import numpy as np
 import numpy.random as npr
@@ -103,6 +104,7 @@ class TrainPathStream:
             check(1, "mv3d_proposal_3d_capacity")
         self.slots = [self._make_slot() for _ in range(int(depth))]
         self._next = 0
+        self.t_wait = self.t_draw = 0.0                  # host seconds spent waiting for stage 1 / drawing (diagnostics)
 
     # ------------------------------------------------------------------ buffers of one batch in flight
     def _make_slot(self):
@@ -202,7 +204,10 @@ class TrainPathStream:
         rois {bev, rgb, fv} (S,5) with the frame index in column 0, rois_3d (S,7), labels (S,1) i32, bbox_targets (S,24 nc),
         S (list of the frames' row counts), num_proposals (list)."""
         B, H, W, N, L = self.B, self.H, self.W, self.N, lib()
+        t0 = time.perf_counter()
         s.event.synchronize()                                          # the batch's reports are on the host
+        t1 = time.perf_counter()
+        self.t_wait += t1 - t0
         small = s.h_small.numpy()
         if int(small[:, 5].max()) & 1:
             s.busy = False
@@ -218,6 +223,7 @@ class TrainPathStream:
                 lists.append(a)
                 sizes.append(len(a))
         total = sum(sizes)
+        self.t_draw += time.perf_counter() - t1
         hl = s.h_lists.numpy()
         o, offs = 0, []
         for a, n in zip(lists, sizes):

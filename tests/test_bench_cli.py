@@ -52,9 +52,9 @@ def test_main_fails_loudly_without_a_gpu(bench, monkeypatch):
 def test_pmc_traffic_only_for_the_profiled_configuration(bench, tmp_path, monkeypatch):
     prof = tmp_path / "profiles"
     prof.mkdir()
-    (prof / "r02_pmc_traffic.json").write_text(json.dumps({"signature": "train/b2/r256/peaky", "kernels": {
+    (prof / "r03_pmc_traffic.json").write_text(json.dumps({"signatures": {"train/b2/r256/peaky": {"kernels": {
         "void roi_bwd_gather_kernel<1>": {"hbm_bytes_per_launch": 100}, "void roi_bwd_index_kernel<false>": {"hbm_bytes_per_launch": 10},
-        "void roi_pool_fwd_xcd_multi_kernel<2>": {"hbm_bytes_per_launch": 7}}}))
+        "void roi_pool_fwd_xcd_multi_kernel<2>": {"hbm_bytes_per_launch": 7}}}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("roi_bwd_", "train/b2/r256/peaky") == 110            # RoiPoolGrad = its kernels summed
     assert bench.pmc_traffic("roi_pool_fwd_xcd_multi_kernel", "train/b2/r256/peaky") == 7
@@ -83,3 +83,24 @@ def test_bench_line_contract_on_the_gpu():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
+def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
+    """`bench.py --gpus 2 --dist-backend gloo` on the 1-GPU box (both ranks share the device): the sharded path-only line, the
+    fresh-input line and the full training step WITH the trunks -- i.e. the bucketed gradient all-reduce overlapping a real
+    backward pass of the 143 M-parameter graph has run (gloo here; RCCL needs one GPU per rank)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+                          "--ring", "3", "--batches-per-step", "6", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    sec = d["secondary"]
+    fr = sec["fresh_inputs"]
+    assert fr["frames_per_s"] > 0 and fr["host_draw_ms_per_frame"] > 0 and 0 < fr["fraction_of_resident_replay"]
+    wt = sec["with_trunk"]
+    assert wt["frames_per_s"] > 0 and wt["allreduce_buckets"] >= 8 and wt["gradient_bytes_per_step"] > 500e6
+    assert sec["test_cfg"]["frames_per_s"] > 0

@@ -191,3 +191,107 @@ def test_train_net_two_iterations_and_snapshot(tmp_path, capsys):
     net2.load(os.path.join(tmp_path, pref + "_iter_3.ckpt"))
     for k in ("conv5_3", "rpn_bbox_pred", "fc6_1", "bbox_pred"):
         assert torch.equal(net2.params[k][0], net.params[k][0].detach()) and torch.equal(net2.params[k][1], net.params[k][1].detach())
+
+
+# ---------------------------------------------------------------------------------------------------- SolverWrapper under DP
+class _ToyNet:
+    """the network face SolverWrapper uses (params dict, parameters(), forward(feed) -> layers, load()) on CPU tensors"""
+
+    def __init__(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda *s: (torch.randn(*s, generator=g) * 0.3).requires_grad_(True)
+        self.params = {"conv": [mk(4, 3, 3, 3), mk(4)], "fc": [mk(3, 4), mk(3)], "unused": [mk(2, 2), mk(2)]}
+        self.loaded = None
+
+    def parameters(self):
+        return [p for wb in self.params.values() for p in wb]
+
+    def forward(self, feed):
+        import torch.nn.functional as F
+        x = torch.as_tensor(np.asarray(feed["image_data"], np.float32)).permute(0, 3, 1, 2)
+        h = F.relu(F.conv2d(x, *self.params["conv"], padding=1)).mean(dim=(2, 3))
+        return {"logits": F.linear(h, *self.params["fc"]), "n": x.shape[0]}      # ("unused" never gets a gradient)
+
+    def load(self, path, *a):
+        self.loaded = path
+
+
+class _ToyImdb:
+    num_classes = 2
+
+
+def _toy_roidb(n):
+    rng = np.random.RandomState(0)
+    return [{"image": rng.randint(0, 255, (6, 8, 3)).astype(np.uint8), "lidar_bv": np.zeros((8, 8, 9), np.float32),
+             "calib": np.zeros((4, 12), np.float32), "boxes": np.zeros((1, 4)), "k": k,
+             "max_overlaps": np.array([1.0])} for k in range(n)]
+
+
+def _solver_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.IMS_PER_BATCH = 1, 2, 1
+    np.random.seed(5)
+
+    def toy_total_loss(layers, sigma=3.0):                      # (the real losses are device kernels: not under test here)
+        loss = (layers["logits"] ** 2).mean()
+        z = loss.detach() * 0
+        return loss, (loss, z, z, z)
+
+    train_mv.total_loss = toy_total_loss
+    train_mv.get_data_layer = lambda roidb, nc: _ToyLayer(roidb)
+    net = _ToyNet(10 + rank)                                    # DIFFERENT initial weights per rank: rank 0's must win
+    sw = train_mv.SolverWrapper(None, None, net, _ToyImdb(), _toy_roidb(5), os.path.join(out_dir, "snap"))
+    lines = []
+    sw.log = lines.append
+    hist = sw.train_model(None, 3, frames_per_step=2)
+    torch.save({"w": [p.detach().clone() for p in net.parameters()], "hist": hist, "lines": lines}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+class _ToyLayer:
+    def __init__(self, roidb):
+        self.roidb, self.i = roidb, 0
+
+    def forward(self):
+        e = self.roidb[self.i % len(self.roidb)]
+        self.i += 1
+        return {"image_data": e["image"][None].astype(np.float32), "lidar_bv_data": e["lidar_bv"][None], "calib": e["calib"],
+                "im_info": np.array([[8, 8, 1]], np.float32), "gt_boxes_bv": np.zeros((1, 5), np.float32),
+                "gt_boxes_3d": np.zeros((1, 7), np.float32), "gt_boxes_corners": np.zeros((1, 25), np.float32)}
+
+
+def test_solver_wrapper_train_model_under_gloo_world2(tmp_path):
+    """SolverWrapper.train_model itself under torch.distributed (gloo, 2 ranks, 2 frames per rank and step as ONE batch):
+    rank 0's initial weights are broadcast, the weights are identical on both ranks after 3 iterations (a parameter that never
+    gets a gradient does not desynchronise the bucket order), only rank 0 logs and snapshots, the logged losses are the mean
+    over the ranks (DISPLAY all-reduce), the snapshot + .optim.pt pair is written."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_solver_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt", weights_only=False), torch.load(tmp_path / "r1.pt", weights_only=False)
+    for a, b in zip(r0["w"], r1["w"]):
+        assert torch.equal(a, b)
+    assert len(r0["hist"]) == 3 and np.allclose(np.array(r0["hist"]), np.array(r1["hist"]))     # all-reduced display values
+    assert any(l.startswith("iter: 3 / 3") for l in r0["lines"]) and any("speed:" in l for l in r0["lines"])
+    assert not r1["lines"]                                                                     # rank 0 only
+    snaps = sorted(os.listdir(tmp_path / "snap"))
+    assert any(n.endswith("_iter_2.ckpt") for n in snaps) and any(n.endswith("_iter_3.ckpt") for n in snaps)
+    assert any(n.endswith("_iter_3.ckpt.optim.pt") for n in snaps)
+
+
+def test_stack_blobs_batches_frames():
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.fast_rcnn.train_mv import stack_blobs
+    a, b = _ToyLayer(_toy_roidb(2)).forward(), _ToyLayer(_toy_roidb(2)).forward()
+    one = stack_blobs([a])
+    assert one["image_data"].shape == (1, 6, 8, 3) and one["gt_boxes_bv"].shape == (1, 5)      # one frame: the reference's feed
+    two = stack_blobs([a, b])
+    assert two["image_data"].shape == (2, 6, 8, 3) and two["im_info"].shape == (2, 3) and two["calib"].shape == (2, 4, 12)
+    assert isinstance(two["gt_boxes_3d"], list) and len(two["gt_boxes_3d"]) == 2

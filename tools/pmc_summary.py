@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; own runs).
 
-    python tools/pmc_summary.py gpurun_out/pmc1 profiles/r02_pmc_traffic [signature]
+    python tools/pmc_summary.py gpurun_out/pmc1 profiles/r03_pmc_traffic <signature>
 
-`signature` (bench.py: "<workload>/b<batch>/r<rois>/<variant>") is stored in the JSON; bench.py only quotes a traffic number
-whose signature equals the configuration it is running.
+`signature` (bench.py: "<workload>/b<batch>/r<rois>/<variant>") keys the table inside the JSON ({"signatures": {sig: {"kernels":
+...}}}: several configurations in one file); bench.py only quotes a traffic number whose signature equals the configuration
+it is running.  The .txt next to it gets one section per signature.
 
 Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB;
 on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads, so the read side is
@@ -35,9 +36,13 @@ def main(src, dst):
                                     fetch_kib_raw=f.get(k, {}), write_kib_raw=w.get(k, {}))
         lines.append("%-60s %6d %14.3f %14.3f %16.3f" % (k[:60], f.get(k, w.get(k))["calls"], rd, wr, rd + wr))
     sig = sys.argv[3] if len(sys.argv) > 3 else ""
-    open(dst + ".json", "w").write(json.dumps({"signature": sig, "kernels": out}, indent=1))
-    open(dst + ".txt", "w").write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate runs), bench.py --launch eager --streams 1 --steps 2 (tools/gpu_pmc.sh)\n"
-                                  "# FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); KiB -> MB\n" + "\n".join(lines) + "\n")
+    import os
+    table = json.load(open(dst + ".json")) if os.path.exists(dst + ".json") else {"signatures": {}}
+    table["signatures"][sig] = {"kernels": out}
+    open(dst + ".json", "w").write(json.dumps(table, indent=1))
+    open(dst + ".txt", "a").write("# signature %s\n# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate runs), bench.py --launch eager --streams 1 "
+                                  "--steps 2 --batches-per-step 64 (tools/gpu_pmc.sh)\n"
+                                  "# FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md); KiB -> MB\n" % sig + "\n".join(lines) + "\n\n")
     print("\n".join(lines))
 
 
