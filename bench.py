@@ -449,6 +449,9 @@ def main():
         if not args.no_trunk:
             from mv3d_tf_amd.fast_rcnn import train_mv
             sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
+            torch.cuda.empty_cache()
+            from mv3d_tf_amd.fast_rcnn import test_mv
+            sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
         if rank == 0:
             res["secondary"] = sec
     if rank == 0:

@@ -234,7 +234,10 @@ int mv3d_anchor_target_stage2(int H, int W, const mv3d_anchor_target_params *p,
  * entries (device pointers / counts); labels_dev (batch,N), targets_dev (batch,N,6), im_info_dev (batch,3),
  * anchors_dev (batch,cap,5), anchors_3d_dev (batch,cap,7), n_anchors_dev (batch) are contiguous over the frames; one
  * workspace per frame, each of at least workspace_bytes = mv3d_anchor_target_workspace_bytes(H, W, max_b G[b]) bytes.
- * batch <= 16.  stage2 = two launches: the three disable lists, then debug rows + final labels. */
+ * batch <= 16.  stage2 = two launches: the three disable lists, then debug rows + final labels.
+ * ONE-SHOT CONTRACT: stage 2 CONSUMES the workspace stage 1 left (the second background draw marks its anchors in the
+ * workspace's argmax array, the list look-back words are only cleared by stage 1's overlap launch): exactly one stage-2 call
+ * per stage-1 call on a workspace; to apply other disable lists, run stage 1 again.  (Same for the per-frame entries.) */
 int mv3d_anchor_target_stage1_batch(int batch, int H, int W, const float *im_info_dev, const float *const *gt_bv_dev,
                                     const float *const *gt_3d_dev, const int *G, const mv3d_anchor_target_params *p,
                                     float *labels_dev, float *targets_dev, int32_t *const *counts_dev,

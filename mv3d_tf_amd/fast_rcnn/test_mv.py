@@ -102,3 +102,43 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
     imdb.evaluate_detections(all_boxes, all_boxes_cnr, output_dir)
     return all_boxes, all_boxes_cnr
 
+
+
+def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16"), reduce_device="cuda"):
+    """Full MV3D_test forward WITH the dense layers, for bench.py's `serving_with_trunk` key (BASELINE configs[4]: batch
+    16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the torch trunks /
+    FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision; fp16 = autocast
+    of the DENSE layers only (MIOpen / rocBLAS half kernels; the hot-path layers stay f32) -- a lower precision than the
+    reference, reported next to fp32, never the headline.  No hand-written convolution is claimed."""
+    import time
+    from .. import sharding, synth
+    from ..networks import get_network
+    net = get_network("MV3D_test")
+    rng = np.random.RandomState(200 + rank)
+    bev = torch.as_tensor(((rng.random_sample((batch, 608, 608, 9)) < 0.03) * rng.uniform(0, 2.4, (batch, 608, 608, 9))).astype(np.float32)).cuda()
+    img = torch.as_tensor((rng.randint(0, 255, (batch, 375, 1242, 3)) - cfg.PIXEL_MEANS).astype(np.float32)).cuda()
+    feed = {"lidar_bv_data": bev, "image_data": img, "im_info": np.array([[608, 608, 1]] * batch, np.float32),
+            "calib": np.stack([synth.KITTI_CALIB] * batch), "keep_prob": 1.0}
+    out = {"workload": "MV3D_test full forward incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head + proposal_layer_3d (TEST cfg) + "
+                       "RoiPool x2 + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image" % batch}
+
+    def step():
+        with torch.no_grad():
+            L = net.forward(feed)
+            ops.box_detect_tail(L["rois"][2].contiguous(), L["bbox_pred"].contiguous(), n_classes)
+
+    for name in dtypes:
+        net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[name]
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1 and dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device=reduce_device)
+        out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2)}
+    out["note"] = "fp16 = autocast of the dense layers only, lower precision than the reference's fp32; the hot-path layers run in f32"
+    return out

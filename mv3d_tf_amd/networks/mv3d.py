@@ -54,6 +54,9 @@ class MV3D:
         self.device = torch.device(device or ("cuda:%d" % cfg.GPU_ID))
         self.layers = {}
         self.keep_prob = 1.0 if phase == "TEST" else 0.5          # train_mv.py:167 / test_mv.py:183
+        # optional reduced-precision DENSE layers (torch.float16 / torch.bfloat16 autocast of the VGG16 trunks, RPN convs and FC
+        # head: BASELINE configs[4] "fp16 VGG16"); the hot-path layers always get and give f32.  None = the reference's fp32.
+        self.amp_dtype = None
         self.params = {}
         g = torch.Generator().manual_seed(seed)
 
@@ -103,10 +106,14 @@ class MV3D:
                 self.params[key][1].copy_(torch.as_tensor(np.asarray(sub["biases"], np.float32)))
 
     # ---- dense layers (torch; NHWC kept as channels_last NCHW views)
+    def _amp(self):
+        return torch.autocast(device_type="cuda", dtype=self.amp_dtype or torch.float16, enabled=self.amp_dtype is not None)
+
     def _conv(self, x, name, relu=True, pad=1):
         w, b = self.params[name]
-        y = F.conv2d(x, w, b, padding=pad)
-        return F.relu(y) if relu else y
+        with self._amp():
+            y = F.conv2d(x, w, b, padding=pad)
+            return F.relu(y) if relu else y
 
     def _trunk(self, x, suffix):
         for stem, _, pool in _VGG:
@@ -114,14 +121,17 @@ class MV3D:
             self.layers[stem + suffix] = x.permute(0, 2, 3, 1)      # NHWC view, as fetched by callers
             if pool:
                 x = F.max_pool2d(x, 2, 2)
+        if x.dtype != torch.float32:                                # the feature map the RoiPool layer reads: f32 NHWC
+            self.layers[stem + suffix] = x.float().permute(0, 2, 3, 1)
         return x
 
     def _fc(self, x, name, relu=True):
         if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)
             x = x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
         w, b = self.params[name]
-        y = F.linear(x, w, b)
-        return F.relu(y) if relu else y
+        with self._amp():
+            y = F.linear(x, w, b)
+            return F.relu(y) if relu else y
 
     # ---- hot-path plumbing
     def _train_path(self, B, H, W):
@@ -165,9 +175,9 @@ class MV3D:
         # RPN (MV3D_train.py:82-103)
         rpn = self._conv(bev, "rpn_conv/3x3")
         L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
-        score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).permute(0, 2, 3, 1).contiguous()
+        score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
         L["rpn_cls_score"] = score
-        L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).permute(0, 2, 3, 1).contiguous()
+        L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
         n, h, w, c = score.shape
         L["rpn_cls_score_reshape"] = score.reshape(n, h, -1, 2)                       # reshape_layer(2) (network.py:333-341)
         L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)   # :399-403
@@ -238,7 +248,7 @@ class MV3D:
             L["fc7" + t] = x
             tower.append(x)
         fused = torch.cat(tower, dim=1)
-        L["cls_score"] = self._fc(fused, "cls_score", relu=False)
+        L["cls_score"] = self._fc(fused, "cls_score", relu=False).float()
         L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
-        L["bbox_pred"] = self._fc(fused, "bbox_pred", relu=False)
+        L["bbox_pred"] = self._fc(fused, "bbox_pred", relu=False).float()
         return L

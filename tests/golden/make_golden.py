@@ -203,7 +203,13 @@ def gen_kitti(d):
     save("kitti_label", **kw)
 
 
+ONLY_NAMES = None          # --only extra: write just these fixtures (the others are computed and left untouched on disk)
+EXTRA_R03 = ("proposal3d_75_TRAIN_peaky", "proposal3d_75_TEST_rand", "anchor_target_76_no_gt_overlap")
+
+
 def save(name, **kw):
+    if ONLY_NAMES is not None and name not in ONLY_NAMES:
+        return
     kw["numpy_version"] = np.__version__
     kw["scratch_patches"] = PATCH_NOTE
     path = os.path.join(HERE, name + ".npz")
@@ -214,7 +220,8 @@ def save(name, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep-scratch", action="store_true")
-    ap.add_argument("--only", default="", help="'kitti': regenerate only the KITTI label / calib fixture")
+    ap.add_argument("--only", default="", help="'kitti': regenerate only the KITTI label / calib fixture; 'extra': write only "
+                                               "the fixtures added in round 3 (EXTRA_R03)")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="mv3d_ref_")
     build_scratch(d)
@@ -223,6 +230,9 @@ def main():
         if not args.keep_scratch:
             shutil.rmtree(d, ignore_errors=True)
         return
+    if args.only == "extra":
+        global ONLY_NAMES
+        ONLY_NAMES = EXTRA_R03
     from fast_rcnn.config import cfg
     cfg.USE_GPU_NMS = False
     from rpn_msr.proposal_layer_tf import proposal_layer_3d
@@ -289,7 +299,8 @@ def main():
     for H, key, var, seed, full in ((76, "TRAIN", "rand", 3, True), (76, "TEST", "peaky", 4, False),
                                     (76, "TRAIN", "peaky", 5, False), (75, "TEST", "peaky", 6, True),
                                     (75, "TRAIN", "rand", 7, False), (76, "TEST", "rand", 8, False),
-                                    (20, "TRAIN", "peaky", 9, True)):
+                                    (20, "TRAIN", "peaky", 9, True),
+                                    (75, "TRAIN", "peaky", 10, False), (75, "TEST", "rand", 12, False)):   # (Appendix D leftovers, r03)
         if key == "TEST":   # experiments/cfgs/faster_rcnn_end2end.yml:15-20
             cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 6000, 300
         prob, pred, im_info, calib = synth.rpn_head(seed, H, H, var)
@@ -359,6 +370,10 @@ def main():
         at_case("many_gt", H, gtbv3, gt3d3, 5)
     gtb = np.array([[100, 100, 103, 102, 1]], np.float32)  # tiny GT: low IoU everywhere
     at_case("tiny_gt", 76, gtb, np.array([[49.8, 19.8, -0.95, 0.3, 0.4, 1.5, 1]], np.float32), 6)
+    # a ground-truth box INSIDE the map that no inside-image anchor overlaps (the map corner: every anchor that reaches it
+    # crosses the border and is filtered): its gt-argmax row is all zeros -> the zero-overlap flood, next to a normal car
+    gtc_ = np.array([[0, 0, 5, 3, 1], [300, 280, 339, 296, 1]], np.float32)
+    at_case("no_gt_overlap", 76, gtc_, np.array([[59.9, 29.9, -0.95, 0.4, 0.6, 1.5, 1], [32.0, -1.9, -0.95, 3.9, 1.6, 1.56, 1]], np.float32), 8)
 
     # ---- a17 proposal_target_layer_3d
     for name, seed, ngt in (("few", 41, 2), ("many", 42, 12)):

@@ -109,3 +109,42 @@ def test_kitti_label_and_calib_match_reference(tmp_path, oracle):
     cam, lid, b3, bv = oracle.gt_encode(box, ry, tr)
     assert _same(ann["boxes3D_cam_corners"], cam) and _same(ann["boxes_corners"], lid)
     assert _same(ann["boxes_3D"], b3) and _same(ann["boxes_bv"], bv)
+
+
+@pytest.mark.gpu
+def test_get_training_roidb_to_train_net_on_a_kitti_tree(tmp_path, capsys):
+    """the documented entry chain with the DEFAULT config (USE_FLIPPED defaulted to True and the chain raised):
+    kitti_mv3d(tree) -> get_training_roidb -> filter_roidb -> train_net, two iterations on the fixture's label / calib files
+    with synthetic BEV maps and images."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from mv3d_tf_amd import build
+    build.build()
+    from mv3d_tf_amd.datasets import kitti_mv3d
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.networks import get_network
+    assert cfg.TRAIN.USE_FLIPPED is False and cfg.TRAIN.MAX_SIZE == 2000          # lib/fast_rcnn/config.py:84,64
+    g = golden("kitti_label")
+    root, n = _tree(tmp_path, g)
+    rng = np.random.RandomState(0)
+    for i in range(n):                                                            # frames the graph can run on
+        np.save(os.path.join(root, "object/training/lidar_bv/%06d.npy" % i), (rng.random_sample((608, 608, 9)) < 0.02).astype(np.float32))
+        np.save(os.path.join(root, "object/training/image_2/%06d.npy" % i), rng.randint(0, 255, (96, 320, 3)).astype(np.uint8))
+    db = kitti_mv3d("train", root)
+    roidb = train_mv.get_training_roidb(db)
+    assert len(roidb) == n and all("max_overlaps" in e and "calib" in e for e in roidb)
+    for i, e in enumerate(roidb):                                                 # (.png placeholders of the fixture tree -> the arrays)
+        e["image_path"] = os.path.join(root, "object/training/image_2/%06d.npy" % i)
+    kept = train_mv.filter_roidb(roidb)
+    assert 0 < len(kept) < n                                                      # the frame without a known class is dropped
+    saved = (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY)
+    cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY = 1, 1
+    try:
+        np.random.seed(cfg.RNG_SEED)
+        hist = train_mv.train_net(get_network("MV3D_train"), db, roidb, str(tmp_path / "out"), max_iters=2)
+    finally:
+        cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY = saved
+    assert len(hist) == 2 and all(np.isfinite(h[0]) for h in hist)
+    assert "iter: 2 / 2, total loss: " in capsys.readouterr().out

@@ -79,7 +79,7 @@ def test_projection_matrix_and_edges(oracle):
 
 PROPOSAL_CASES = ["proposal3d_76_TRAIN_rand", "proposal3d_76_TEST_peaky", "proposal3d_76_TRAIN_peaky",
                   "proposal3d_75_TEST_peaky", "proposal3d_75_TRAIN_rand", "proposal3d_76_TEST_rand",
-                  "proposal3d_20_TRAIN_peaky"]
+                  "proposal3d_20_TRAIN_peaky", "proposal3d_75_TRAIN_peaky", "proposal3d_75_TEST_rand"]
 
 
 def proposal_case(name):
@@ -118,7 +118,7 @@ def test_proposal_layer_3d(oracle, name):
 
 AT_CASES = ["anchor_target_76_normal", "anchor_target_76_gt_outside", "anchor_target_76_many_gt",
             "anchor_target_75_normal", "anchor_target_75_gt_outside", "anchor_target_75_many_gt",
-            "anchor_target_76_tiny_gt"]
+            "anchor_target_76_tiny_gt", "anchor_target_76_no_gt_overlap"]
 
 
 @pytest.mark.parametrize("name", AT_CASES)
