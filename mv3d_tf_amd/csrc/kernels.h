@@ -56,3 +56,4 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
                      const int32_t *part_counts, int n_parts, int32_t *n_valid, void *workspace,
                      hipStream_t stream, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr);
 
+

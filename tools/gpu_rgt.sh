@@ -1,14 +1,29 @@
 #!/bin/bash
-# GPU box: tuning build of the library, parity checks of RoiPoolGrad, then sweeps with the kernel-only probe.
+# GPU box: kernel-level view of the tile-indexed RoiPoolGrad per view set (rocprofv3 kernel trace of the probe).
 set -u
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/rgt; mkdir -p $OUT
-python -m mv3d_tf_amd.build --force > /dev/null 2>&1; echo "--- product build"; timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -4 | tee $OUT/product.log
 MV3D_HIPCC_FLAGS=-DMV3D_TUNING python -m mv3d_tf_amd.build --force > $OUT/build.log 2>&1 || { tail -20 $OUT/build.log; exit 1; }
-timeout 300 python tools/rgt_debug.py 2>&1 | grep -v "^   " | tail -8
-if [ "${TESTS:-1}" = 1 ]; then timeout 900 python -m pytest tests/test_roipool_pin.py tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -5 | tee $OUT/tests.log; fi
-echo "--- new default"; timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -4 | tee $OUT/new.log
-for T in "$@"; do echo "--- tiles $T"; MV3D_BWD_TILES=$T ONLY=bev+rgb+fv timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -1 | tee -a $OUT/sweep.log; done
-for Wp in ${GROUPS_:-}; do echo "--- groups $Wp"; MV3D_RT_GROUPS=$Wp ONLY=bev+rgb+fv timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -1 | tee -a $OUT/sweep.log; done
-for Wt in ${WEIGHTS:-}; do echo "--- weights $Wt"; MV3D_RT_WEIGHTS=$Wt ONLY=bev+rgb+fv timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -1 | tee -a $OUT/sweep.log; done
-echo "--- trace all"; timeout 300 python tools/rgt_trace.py 2>&1 | tail -14 | tee $OUT/trace.log
+if [ "${TESTS:-0}" = 1 ]; then timeout 300 python tools/rgt_debug.py 2>&1 | grep -v "^   " | tail -10; timeout 900 python -m pytest tests/test_roipool_pin.py tests/test_gpu_configs.py tests/test_train_stream.py -m gpu -x -q 2>&1 | tail -5 | tee $OUT/tests.log; fi
+for V in bev+rgb+fv fv rgb; do
+  for OLD in 0 1; do
+    export ONLY=$V; if [ $OLD = 1 ]; then export MV3D_BWD_OLD=1; else unset MV3D_BWD_OLD; fi
+    echo "--- $V old=$OLD"; timeout 300 python tools/roi_bwd_probe.py 2>&1 | tail -1
+    (cd /tmp && export TMPDIR=/tmp && rm -rf $GRAFT_REPO_ROOT/$OUT/prof && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r -- python $GRAFT_REPO_ROOT/tools/roi_bwd_probe.py > /dev/null 2>&1)
+    python - $OUT/prof/r_results.db <<'PY'
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1])
+rows = c.execute("select name, end-start, grid_x from kernels order by start").fetchall()
+# the probe's last timed loop with R > 0 dominates: report per kernel the median of the longest half
+import statistics
+by = {}
+for n, d, g in rows:
+    if n.startswith("ti_") or "roi_bwd" in n or n.startswith("void ti_"):
+        by.setdefault(n.split("(")[0], []).append(d / 1e3)
+for n, v in by.items():
+    v.sort()
+    top = v[len(v) // 2:]
+    print("   %-44s calls %4d  median of upper half %7.2f us  max %7.2f" % (n[:44], len(v), statistics.median(top), v[-1]))
+PY
+  done
+done

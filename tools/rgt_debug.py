@@ -19,7 +19,7 @@ for (B, H, W, C, R, seed) in ((1, 9, 11, 64, 6, 1), (2, 13, 17, 64, 40, 2), (2, 
     top, am = oracle.roi_pool(data, rois, 7, 7, 0.125)
     grad = rng.uniform(-1, 1, top.shape).astype(np.float32)
     want = oracle.roi_pool_grad(data, rois, am, grad, 7, 7, 0.125)
-    got = ops.roi_pool_backward(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), data.shape, 7, 7, 0.125).cpu().numpy()
+    got = ops.roi_pool_backward_views([(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), tuple(data.shape), 0.125)], 7, 7)[0].cpu().numpy()   # (the workspace path)
     bad = np.argwhere(got != want)
     print("case B%d H%d W%d C%d R%d: %d of %d elements differ" % (B, H, W, C, R, len(bad), want.size))
     if len(bad):
@@ -36,7 +36,7 @@ for name in ("roipool_bev_C512", "roipool_rgb_C512"):
     g, data, rois, grad = trp.load_case(name)
     top, am = oracle.roi_pool(data, rois, 7, 7, 0.125)
     want = oracle.roi_pool_grad(data, rois, am, grad, 7, 7, 0.125)
-    got = ops.roi_pool_backward(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), data.shape, 7, 7, 0.125).cpu().numpy()
+    got = ops.roi_pool_backward_views([(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), tuple(data.shape), 0.125)], 7, 7)[0].cpu().numpy()   # (the workspace path)
     bad = np.argwhere(got != want)
     print(name, data.shape, rois.shape, "differ:", len(bad), "nan in want", np.isnan(want).sum(), "nan in got", np.isnan(got).sum())
     if len(bad):
