@@ -19,7 +19,6 @@ resident.  `run()` then replays the batch with NO host synchronisation: every la
 of the path; `top_diff` is a resident synthetic tensor.)
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -278,11 +277,6 @@ class TrainPathBatch:
         bnd.keep += [fwd, bwd]
         self.fwd_args, self.bwd_args = af, ab
         self.num_rois = St
-        if os.environ.get("MV3D_ONLY_ROI"):                    # diagnostics: replay only the two RoiPool calls
-            bnd.calls = bnd.calls[-2:]
-        if os.environ.get("MV3D_SKIP"):                        # diagnostics: drop replay calls by index (0 = proposal_3d, 1-2 anchor
-            drop = {int(x) for x in os.environ["MV3D_SKIP"].split(",")}     # targets, 3-4 proposal targets, 5 FV ROIs, 6 fwd, 7 bwd)
-            bnd.calls = [c for k, c in enumerate(bnd.calls) if k not in drop]
         self.bound = bnd
 
     # ------------------------------------------------------------------ replay, no host sync

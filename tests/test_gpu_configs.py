@@ -110,7 +110,7 @@ def test_views_entries_other_channel_widths(gpu, oracle, C):
 
 
 def test_config4_batch16_hipgraph_replay_equals_eager_equals_oracle(gpu, oracle):
-    """BASELINE configs[4] per-GPU step: 16 frames, TEST cfg, proposal_3d + both RoiPool views.  The captured hipGraph,
+    """BASELINE configs[4] per-GPU step: 16 frames, TEST cfg, proposal_3d + FV ROIs + all THREE RoiPool views.  The captured hipGraph,
     replayed twice (the second time on fresh inputs written into the same buffers), gives the eager results and the
     oracle's, frame by frame."""
     torch, ops = gpu
@@ -124,33 +124,40 @@ def test_config4_batch16_hipgraph_replay_equals_eager_equals_oracle(gpu, oracle)
 
     host = frames(2000)
     prob, pred, info, calib = (dev(torch, a) for a in host)
-    bev_h, rgb_h = synth.feature_map(81, 76, 76, 512, B), synth.feature_map(82, 46, 155, 512, B)
-    bev, rgb = dev(torch, bev_h), dev(torch, rgb_h)
+    bev_h, rgb_h, fv_h = synth.feature_map(81, 76, 76, 512, B), synth.feature_map(82, 46, 155, 512, B), synth.feature_map(83, 8, 64, 512, B)
+    bev, rgb, fvm = dev(torch, bev_h), dev(torch, rgb_h), dev(torch, fv_h)
     eager = ops.proposal_3d(prob, pred, info, calib, params)
     cap = eager[0].shape[1]
-    e_views = ops.roi_pool_forward_views([(bev, eager[0].view(-1, 5), 0.125), (rgb, eager[1].view(-1, 5), 0.125)], 7, 7)
+    e_fv = ops.rois_3d_to_fv(eager[2].view(-1, 7))                  # the third view's ROIs (zero rows -> zero boxes)
+
+    def step(o, fv_rois, outs=None):
+        ops.rois_3d_to_fv(o[2].view(-1, 7), out=fv_rois)
+        return ops.roi_pool_forward_views([(bev, o[0].view(-1, 5), 0.125), (rgb, o[1].view(-1, 5), 0.125), (fvm, fv_rois, 0.125)], 7, 7, outs=outs)
+
+    e_views = step(eager, e_fv)
     torch.cuda.synchronize()
-    e_host = [t.cpu().numpy().copy() for t in eager] + [t.cpu().numpy().copy() for pair in e_views for t in pair]
+    e_host = [t.cpu().numpy().copy() for t in eager] + [t.cpu().numpy().copy() for pair in e_views for t in pair] + [e_fv.cpu().numpy().copy()]
 
     out = tuple(torch.empty_like(t) for t in eager)
+    fv_out = torch.empty_like(e_fv)
     v_out = [(torch.empty_like(t), torch.empty_like(a)) for (t, a) in e_views]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                              # warm-up on the capture stream (workspace allocation)
         ops.proposal_3d(prob, pred, info, calib, params, out=out)
-        ops.roi_pool_forward_views([(bev, out[0].view(-1, 5), 0.125), (rgb, out[1].view(-1, 5), 0.125)], 7, 7, outs=v_out)
+        step(out, fv_out, v_out)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         ops.proposal_3d(prob, pred, info, calib, params, out=out)
-        ops.roi_pool_forward_views([(bev, out[0].view(-1, 5), 0.125), (rgb, out[1].view(-1, 5), 0.125)], 7, 7, outs=v_out)
+        step(out, fv_out, v_out)
     for t in out:
         t.zero_()
     for rep in range(2):
         graph.replay()
         torch.cuda.synchronize()
-        got = [t.cpu().numpy() for t in out] + [t.cpu().numpy() for pair in v_out for t in pair]
+        got = [t.cpu().numpy() for t in out] + [t.cpu().numpy() for pair in v_out for t in pair] + [fv_out.cpu().numpy()]
         for a, b in zip(got, e_host):
             assert np.array_equal(a, b), "replay %d differs from the eager step" % rep
     # oracle, frame by frame (every frame must reach 300 rows or fewer; rows past num_out are zero)
@@ -165,8 +172,10 @@ def test_config4_batch16_hipgraph_replay_equals_eager_equals_oracle(gpu, oracle)
         assert not got[0][b, n:].any()
     for b in (0, B - 1):                                        # RoiPool rows of the first and last frame vs the oracle
         rows = slice(b * cap, b * cap + int(num[b]))
-        for k, (fmap, blob) in enumerate(((bev_h, got[0]), (rgb_h, got[1]))):
-            o_top, o_am = oracle.roi_pool(fmap, blob.reshape(-1, 5)[rows], 7, 7, 0.125)
+        fv_rows = oracle.rois_3d_to_fv(got[2].reshape(-1, 7)[rows])
+        assert np.array_equal(got[11][rows], fv_rows)
+        for k, (fmap, blob) in enumerate(((bev_h, got[0].reshape(-1, 5)[rows]), (rgb_h, got[1].reshape(-1, 5)[rows]), (fv_h, fv_rows))):
+            o_top, o_am = oracle.roi_pool(fmap, blob, 7, 7, 0.125)
             assert np.array_equal(got[5 + 2 * k][rows], o_top) and np.array_equal(got[6 + 2 * k][rows], o_am)
     # new inputs written into the captured buffers: the replay follows them
     host2 = frames(3000)
