@@ -358,6 +358,27 @@ int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_dev, const 
                    float *losses_dev, float *d_cls_score_dev, float *d_bbox_pred_dev, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------ the VGG16 trunk's contraction (north_star "MFMA only for the
+ * VGG16 conv backbone"): Network.conv(3, 3, c_o, 1, 1) [3x3, stride 1, SAME, + bias, optional ReLU] and
+ * Network.max_pool(2, 2, 2, 2, 'VALID') of lib/networks/network.py:109-133,182-189 for the layers of
+ * lib/networks/MV3D_train.py:44-81, as an implicit GEMM on v_mfma_f32_32x32x16_f16 (f16 operands, f32 accumulate).
+ * This is the SERVING trunk (BASELINE configs[4]: fp16), lower precision than the reference's fp32 graph and not part of the
+ * bit-exact contract; tolerance vs an fp32 convolution of the same f16-rounded operands: 2e-3 relative to the map's max.
+ *   x_framed  (batch, height + 2, width + 2, c_in)  f16 NHWC with a one-pixel ZERO frame (the SAME padding, materialised)
+ *   w_packed  (c_out, 9 * c_in) f16, k = (ky * 3 + kx) * c_in + c   [TF's HWIO filter transposed to (O, H, W, I)]
+ *   bias      (c_out) f32
+ *   y         out_framed ? (batch, height + 2, width + 2, c_out) interior only (the frame is the owner's, zeroed once)
+ *                        : (batch, height, width, c_out);  f32 if out_f32 (the map a RoiPool layer reads) else f16
+ * c_in and c_out multiples of 64 (conv1_1 with its 9 / 3 input channels stays with the caller); every buffer < 2 GiB. */
+int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
+                     int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
+/* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */
+int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
+/* NHWC f32 (batch, height, width, channels) -> interior pixels, first `channels` channels of a framed f16 buffer
+ * (batch, height + 2, width + 2, channels_out >= channels) */
+int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,279 @@
+// 3x3 / stride 1 / SAME convolution + bias + ReLU of the VGG16 trunks as an implicit GEMM on the gfx950 matrix cores
+// (v_mfma_f32_32x32x16_f16: f16 operands, f32 accumulate), and the 2x2 max pool between the stages.
+//
+// What it stands in for: Network.conv(3, 3, c_o, 1, 1) / Network.max_pool(2, 2, 2, 2, 'VALID') of
+// lib/networks/network.py:109-133,182-189 for the layer list of lib/networks/MV3D_train.py:44-81 (conv1_2 .. conv5_3 of the
+// BEV and RGB trunks, rpn_conv/3x3).  Lower precision than the reference's fp32 graph: this is the serving trunk
+// (BASELINE configs[4] says fp16), never the parity contract; the hot-path layers that consume its maps stay f32.
+//
+// Data layout (HBM): activations NHWC f16 with a one-pixel zero frame, (B, H + 2, W + 2, C): a tap (dy, dx) of the filter is
+// then a plain address offset and no load in the K loop needs a bounds test.  Weights (Cout, 9 * Cin) f16, k = tap * Cin + c.
+// GEMM view: D[cout][pixel] = sum_k Wt[cout][k] * X[pixel][k], pixels = B*H*W output positions, k = 9 * Cin.
+//
+// One workgroup = BM pixels x BN couts; a K step is 64 channels of one tap (128 B per pixel / per cout row).  Both operands are
+// staged HBM/L2 -> LDS by buffer_load ... lds (16 B per lane, no VGPR round trip) into two LDS stages; the rows are stored with
+// their 16-byte k-groups XOR-swizzled by (row >> 1) & 7 (applied on the SOURCE address: the DMA image is lane-linear), which
+// makes the ds_read_b128 of the MFMA operands (32 consecutive rows, one k-group) bank-conflict-free per 16 lanes.
+// Accumulators go back through LDS so that every global store is a full 16-byte piece of a pixel's channel row.
+#include "common.h"
+
+namespace mv3d_conv {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct ConvArgs {
+    const void *x;
+    const void *w;
+    const float *bias;
+    void *y;
+    int H, W, Cin, Cout, M, HW;
+    int out_pad, relu;
+    unsigned x_bytes, w_bytes;
+    int m_tiles, n_tiles;
+};
+
+constexpr int BK_BYTES = 128;     // 64 f16 channels of one tap
+
+template <int BM, int BN, int WP, int WC, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
+{
+#if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
+    constexpr int NW = WP * WC, NT = NW * 64;
+    constexpr int TP = BM / WP, TC = BN / WC, FP = TP / 32, FC = TC / 32;
+    constexpr int STAGE = (BM + BN) * BK_BYTES;
+    constexpr int XCH = BM / 8 / NW, WCH = BN / 8 / NW;          // 8-row DMA pieces per wave and stage
+    constexpr int ESZ = OUT_F32 ? 4 : 2;
+    constexpr int OUT_BYTES = BM * BN * ESZ;
+    constexpr int LDS_BYTES = (2 * STAGE > OUT_BYTES ? 2 * STAGE : OUT_BYTES) + BM * 4;
+    static_assert(NT == 256 && NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TP % 32 == 0 && TC % 32 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    unsigned *const s_pix = (unsigned *)(lds + LDS_BYTES - BM * 4);
+
+    // ---- workgroup -> tile: the n-tiles of one m-tile run back to back on ONE XCD (they share the activation rows in its L2)
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int mt = (local / a.n_tiles) * 8 + xcd, nt = local % a.n_tiles;
+    if (mt >= a.m_tiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K2 = 9 * a.Cin * 2;                                 // bytes of one weight row
+    const int Wp = a.W + 2;
+
+    // ---- output address of every pixel of the tile (epilogue)
+    for (int p = tid; p < BM; p += NT) {
+        const int m = m0 + p;
+        unsigned off = 0xFFFFFFFFu;
+        if (m < a.M) {
+            const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
+            const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
+            off = (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ);
+        }
+        s_pix[p] = off;
+    }
+
+    // ---- DMA source addresses: lane -> (row = lane >> 3 of the 8-row piece, 16-byte k-group (lane & 7) ^ swizzle(row))
+    const int gsel = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    int xoff[XCH];
+#pragma unroll
+    for (int j = 0; j < XCH; ++j) {
+        int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
+        m = m < a.M ? m : a.M - 1;
+        const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
+        xoff[j] = ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 + gsel * 16;
+    }
+    const int woff = (lane >> 3) * K2 + gsel * 16;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+    const int wrow0 = (n0 + wave * 8) * K2;                       // + j * NW * 8 * K2 per piece
+
+    // K-step state (scalar): tap (ty, tx) and the 64-channel slice cc of it
+    const int cpt = a.Cin >> 6, KT = 9 * cpt;
+    int ty = 0, tx = 0, cc = 0;
+    auto issue = [&](const int kt, const int stage) __attribute__((always_inline)) {
+        const int sx = ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
+        const int sw = wrow0 + kt * BK_BYTES;
+        char *const base = lds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < XCH; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + (j * NW + wave) * 1024), 16, xoff[j], sx, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WCH; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t *)(base + BM * BK_BYTES + (j * NW + wave) * 1024), 16, woff,
+                                                     sw + j * NW * 8 * K2, 0, 0);
+        if (++cc == cpt) { cc = 0; if (++tx == 3) { tx = 0; ++ty; } }
+    };
+
+    // ---- MFMA operand reads: lane -> fragment row lane & 31, k-group 2 * ks + (lane >> 5), un-swizzled by (row >> 1) & 7
+    const int wp = wave % WP, wc = wave / WP;
+    const int h = lane >> 5, sw7 = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (lane & 31) * BK_BYTES + (((ks * 2 + h) ^ sw7) << 4);
+    const int x_lds = wp * TP * BK_BYTES, w_lds = BM * BK_BYTES + wc * TC * BK_BYTES;
+
+    f32x16 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage kt have landed ...
+        __builtin_amdgcn_s_barrier();                             // ... everyone's have, and stage kt - 1 has been consumed
+        if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+        const char *const st = lds + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 fw[FC], fx[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) fw[i] = *(const half8 *)(st + w_lds + i * 32 * BK_BYTES + koff[ks]);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) fx[j] = *(const half8 *)(st + x_lds + j * 32 * BK_BYTES + koff[ks]);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
+
+    // ---- epilogue: + bias, ReLU, -> LDS tile [pixel][cout] (16-byte slots XOR-swizzled by the pixel), -> 16-byte global stores
+    // D layout of the 32x32 MFMA: lane holds column (= pixel) lane & 31, rows (= couts) 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2
+    constexpr int ROWB = BN * ESZ, SLOTS = ROWB / 16;
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = wc * TC + i * 32 + 8 * q + 4 * h;
+            const f32x4 bv = *(const f32x4 *)(a.bias + n0 + c0);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int P = wp * TP + j * 32 + (lane & 31);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][4 * q + e] + bv[e];
+                    if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                if (OUT_F32) {
+                    *(f32x4 *)(lds + P * ROWB + ((((c0 >> 2)) ^ (P & (SLOTS - 1))) << 4)) = v;
+                } else {
+                    half4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
+                    *(half4 *)(lds + P * ROWB + (((c0 >> 3) ^ (P & (SLOTS - 1))) << 4) + (c0 & 7) * 2) = hv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    char *const yb = (char *)a.y + (size_t)n0 * ESZ;
+#pragma unroll 4
+    for (int u = tid; u < BM * SLOTS; u += NT) {
+        const int P = u / SLOTS, s = u % SLOTS;
+        const unsigned off = s_pix[P];
+        const u32x4 v = *(const u32x4 *)(lds + P * ROWB + ((s ^ (P & (SLOTS - 1))) << 4));
+        if (off != 0xFFFFFFFFu) *(u32x4 *)(yb + off + s * 16) = v;
+    }
+#endif
+}
+
+// 2x2 / stride 2 max pool, VALID (floor), framed NHWC f16 -> framed NHWC f16; one thread = 8 channels of one output pixel
+__global__ __launch_bounds__(256) void maxpool2x2_f16_kernel(const half8 *__restrict__ x, half8 *__restrict__ y, int B, int H, int W, int C8,
+                                                              int Ho, int Wo)
+{
+    const long total = (long)B * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long r = i / C8;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho), b = (int)(r / Ho);
+        const half8 *p = x + (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C8 + c;
+        const half8 v0 = p[0], v1 = p[C8], v2 = p[(long)(W + 2) * C8], v3 = p[(long)(W + 2) * C8 + C8];
+        y[(((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C8 + c] =
+            __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3));
+    }
+}
+
+// NHWC f32 (B,H,W,C) -> framed NHWC f16 (B,H+2,W+2,Co), Co >= C: interior pixels, first C channels only (the frame and the
+// padding channels are zeroed once by the owner of the buffer)
+__global__ __launch_bounds__(256) void frame_f32_to_f16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int B, int H, int W, int C,
+                                                                int Co)
+{
+    const long total = (long)B * H * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int xx = (int)(r % W);
+        r /= W;
+        const int yy = (int)(r % H), b = (int)(r / H);
+        y[(((long)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Co + c] = (_Float16)x[i];
+    }
+}
+
+template <int BM, int BN, int WP, int WC>
+int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
+{
+    ConvArgs b = a;
+    b.m_tiles = (a.M + BM - 1) / BM;
+    b.n_tiles = a.Cout / BN;
+    const int grid = (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
+    if (out_f32)
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, true>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+    else
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, false>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+    return mv3d_launch_status();
+}
+
+}  // namespace mv3d_conv
+using namespace mv3d_conv;
+
+extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
+                                int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream)
+{
+    if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
+    if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 2, wb = (size_t)c_out * 9 * c_in * 2;
+    const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * (out_f32 ? 4 : 2);
+    if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
+    ConvArgs a;
+    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y;
+    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width;
+    a.out_pad = out_framed != 0; a.relu = relu != 0;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.m_tiles = a.n_tiles = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2>(a, out_f32, s);
+    return launch_conv<128, 64, 2, 2>(a, out_f32, s);
+}
+
+extern "C" int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
+{
+    if (!x_framed || !y_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
+    const int Ho = height / 2, Wo = width / 2;
+    const long total = (long)batch * Ho * Wo * (channels / 8);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(maxpool2x2_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half8 *)x_framed, (half8 *)y_framed, batch,
+                       height, width, channels / 8, Ho, Wo);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
+                                   void *stream)
+{
+    if (!x_nhwc || !y_framed || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || channels_out < channels) return MV3D_ERR_INVALID_ARG;
+    const long total = (long)batch * height * width * channels;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(frame_f32_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nhwc, (_Float16 *)y_framed, batch, height, width,
+                       channels, channels_out);
+    return mv3d_launch_status();
+}

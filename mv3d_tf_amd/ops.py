@@ -380,3 +380,49 @@ def rcnn_loss(cls_score, labels, bbox_pred, bbox_targets, sigma=3.0, want_grad=T
     return _loss_call(lib().mv3d_rcnn_loss, "mv3d_rcnn_loss", cls_score, labels, bbox_pred, bbox_targets,
                       (cls_score.shape[1], bbox_pred.shape[1]), sigma, want_grad)
 
+
+
+# ------------------------------------------------------------------ the serving trunk's contraction (f16 MFMA)
+def pack_conv3x3_weights(w_oihw, c_in_pad=None):
+    """torch (O, I, 3, 3) f32 -> (O, 9 * I') f16 with k = (ky * 3 + kx) * I' + c, I' = I zero-padded to c_in_pad."""
+    O, I = w_oihw.shape[:2]
+    Ip = c_in_pad or I
+    w = torch.zeros((O, 3, 3, Ip), dtype=torch.float16, device=w_oihw.device)
+    w[..., :I] = w_oihw.detach().permute(0, 2, 3, 1).to(torch.float16)
+    return w.reshape(O, 9 * Ip).contiguous()
+
+
+def framed_buffer(B, H, W, C, device):
+    """zeroed (B, H + 2, W + 2, C) f16: the kernels below only ever write its interior, so the SAME-padding frame stays 0"""
+    return torch.zeros((B, H + 2, W + 2, C), dtype=torch.float16, device=device)
+
+
+def frame_nhwc_f16(x_nhwc, out):
+    """(B, H, W, C) f32 -> interior / first C channels of the framed f16 buffer `out` (B, H + 2, W + 2, C' >= C)"""
+    B, H, W, Cc = x_nhwc.shape
+    check(lib().mv3d_frame_nhwc_f16(_ptr(x_nhwc), _ptr(out), B, H, W, Cc, out.shape[3], _stream()), "mv3d_frame_nhwc_f16")
+    return out
+
+
+def conv3x3_f16(x_framed, w_packed, bias, out=None, out_framed=True, out_f32=False, relu=True):
+    """x_framed (B, H + 2, W + 2, Cin) f16, w_packed (Cout, 9 Cin) f16, bias (Cout) f32 -> framed f16 (default), or the bare
+    (B, H, W, Cout) map in f16 / f32."""
+    B, Hp, Wp, cin = x_framed.shape
+    H, W, cout = Hp - 2, Wp - 2, w_packed.shape[0]
+    if out is None:
+        if out_framed:
+            out = framed_buffer(B, H, W, cout, x_framed.device)
+        else:
+            out = torch.empty((B, H, W, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x_framed.device)
+    check(lib().mv3d_conv3x3_f16(_ptr(x_framed), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, cin, cout, int(out_framed), int(out_f32),
+                                 int(relu), _stream()), "mv3d_conv3x3_f16")
+    return out
+
+
+def maxpool2x2_f16(x_framed, out=None):
+    B, Hp, Wp, Cc = x_framed.shape
+    H, W = Hp - 2, Wp - 2
+    if out is None:
+        out = framed_buffer(B, H // 2, W // 2, Cc, x_framed.device)
+    check(lib().mv3d_maxpool2x2_f16(_ptr(x_framed), _ptr(out), B, H, W, Cc, _stream()), "mv3d_maxpool2x2_f16")
+    return out

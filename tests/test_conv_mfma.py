@@ -1,0 +1,90 @@
+"""-m gpu numerics of the serving trunk's contraction (mv3d_conv3x3_f16 / mv3d_maxpool2x2_f16, csrc/conv3x3_mfma.hip) against
+a plain PyTorch fp32 convolution of the SAME f16-rounded operands.
+
+Tolerance: the kernel multiplies f16 operands exactly and accumulates in f32 (MFMA), so against the fp32 reference it differs by
+the f32 accumulation order (~1e-6 relative) plus, for f16 outputs, one rounding to f16 (2^-11 relative): |got - want| <=
+2e-3 * max|want| for f16 maps, 2e-5 * max|want| for f32 maps.  Operands are asymmetric random values, so a transposed
+fragment / tap / channel mapping cannot pass."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from mv3d_tf_amd import build
+    build.build()
+    return torch
+
+
+def _reference(torch, x, w, b, relu):
+    """fp32 conv of f16-rounded operands; x (B,H,W,Cin), w (O,I,3,3) -> (B,H,W,O)"""
+    y = torch.nn.functional.conv2d(x.half().float().permute(0, 3, 1, 2), w.half().float(), b, padding=1)
+    if relu:
+        y = torch.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,out_f32,relu,framed", [
+    (2, 76, 76, 512, 512, False, True, True),        # conv4_2 / conv5_x of the BEV trunk
+    (1, 46, 155, 512, 512, True, True, False),       # conv5_3_2 (RGB), the f32 map RoiPool reads; M % 128 != 0
+    (1, 20, 36, 64, 64, False, True, True),          # conv1_2 shape class (64-cout tile)
+    (1, 33, 17, 64, 128, False, False, True),        # conv2_1 class, odd sizes, no ReLU
+    (1, 19, 23, 128, 256, True, False, False),
+    (1, 8, 64, 256, 512, False, True, False),        # FV trunk conv4_1
+])
+def test_conv3x3_matches_fp32_reference(gpu, B, H, W, cin, cout, out_f32, relu, framed):
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 7 + cin)
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), device="cuda", generator=g)
+    want = _reference(torch, x, w, b, relu)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, x.device))
+    assert float(xf[:, 0].abs().max()) == 0 and float(xf[:, :, -1].abs().max()) == 0
+    got = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w), b, out_framed=framed, out_f32=out_f32, relu=relu)
+    torch.cuda.synchronize()
+    if framed:
+        assert got.shape == (B, H + 2, W + 2, cout)
+        assert float(got[:, 0].abs().max()) == 0 and float(got[:, -1].abs().max()) == 0            # the frame is never written
+        assert float(got[:, :, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0
+        got = got[:, 1:-1, 1:-1]
+    assert got.dtype == (torch.float32 if out_f32 else torch.float16)
+    scale = float(want.abs().max())
+    err = float((got.float() - want).abs().max())
+    assert err <= (2e-5 if out_f32 else 2e-3) * scale, (err, scale)
+
+
+def test_maxpool_and_two_layer_chain(gpu):
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, H, W = 2, 37, 50
+    x = torch.randn((B, H, W, 64), device="cuda", generator=g)
+    w1 = torch.randn((64, 64, 3, 3), device="cuda", generator=g) * 0.06
+    w2 = torch.randn((128, 64, 3, 3), device="cuda", generator=g) * 0.06
+    b1, b2 = torch.randn(64, device="cuda", generator=g), torch.randn(128, device="cuda", generator=g)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 64, x.device))
+    y1 = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w1), b1)
+    p1 = ops.maxpool2x2_f16(y1)
+    y2 = ops.conv3x3_f16(p1, ops.pack_conv3x3_weights(w2), b2, out_framed=False, out_f32=True)
+    torch.cuda.synchronize()
+    # pool: exact on the f16 values (VALID / floor: the odd last row is dropped)
+    want_p = torch.nn.functional.max_pool2d(y1[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert p1.shape == (B, H // 2 + 2, W // 2 + 2, 64) and torch.equal(p1[:, 1:-1, 1:-1].float(), want_p)
+    assert float(p1[:, 0].abs().max()) == 0 and float(p1[:, :, -1].abs().max()) == 0
+    want = _reference(torch, want_p, w2, b2, True)
+    assert float((y2 - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_bad_arguments_are_refused(gpu):
+    torch = gpu
+    from mv3d_tf_amd import _lib, ops
+    xf = ops.framed_buffer(1, 8, 8, 48, "cuda")
+    with pytest.raises(_lib.Mv3dError):
+        ops.conv3x3_f16(xf, torch.zeros((64, 9 * 48), dtype=torch.float16, device="cuda"), torch.zeros(64, device="cuda"))

@@ -1,0 +1,48 @@
+"""Times mv3d_conv3x3_f16 on the trunk's layer shapes against torch's (MIOpen) f16 convolution: TFLOP/s per layer.
+    python tools/conv_probe.py [batch]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from mv3d_tf_amd import build, ops  # noqa: E402
+
+build.build()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+SHAPES = [("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
+          ("bev conv4_1", 76, 76, 256, 512), ("bev conv4_2", 76, 76, 512, 512),
+          ("rgb conv1_2", 375, 1242, 64, 64), ("rgb conv2_2", 187, 621, 128, 128), ("rgb conv3_2", 93, 310, 256, 256),
+          ("rgb conv4_2", 46, 155, 512, 512)]
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for name, H, W, cin, cout in SHAPES:
+    x = torch.randn((B, H, W, cin), device="cuda")
+    w = torch.randn((cout, cin, 3, 3), device="cuda") * 0.02
+    b = torch.zeros(cout, device="cuda")
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, "cuda"))
+    wp = ops.pack_conv3x3_weights(w)
+    out = ops.framed_buffer(B, H, W, cout, "cuda")
+    ms = timed(lambda: ops.conv3x3_f16(xf, wp, b, out=out))
+    xh = x.half().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    wh = w.half().contiguous(memory_format=torch.channels_last)
+    bh = b.half()
+    ms_t = timed(lambda: torch.relu_(torch.nn.functional.conv2d(xh, wh, bh, padding=1)))
+    xn, wn = x.half().permute(0, 3, 1, 2).contiguous(), w.half()
+    ms_n = timed(lambda: torch.relu_(torch.nn.functional.conv2d(xn, wn, bh, padding=1)))
+    fl = 2.0 * B * H * W * cout * 9 * cin
+    print("%-12s B=%d  mfma %.3f ms %.0f TF/s | torch nhwc %.3f ms %.0f TF/s | torch nchw %.3f ms %.0f TF/s" % (
+        name, B, ms, fl / ms / 1e9, ms_t, fl / ms_t / 1e9, ms_n, fl / ms_n / 1e9), flush=True)
+    del x, xf, out, xh, xn
