@@ -37,9 +37,11 @@ struct ConvArgs {
     int m_tiles, n_tiles;
 };
 
-constexpr int BK_BYTES = 128;     // 64 f16 channels of one tap
+#define BK_BYTES 128     // 64 f16 channels of one tap
 
-template <int BM, int BN, int WP, int WC, bool OUT_F32>
+// FIRST: the layer fed by the network input (conv1_1: 9 / 3 channels zero-padded to 16 = 32 B per pixel): a K step is FOUR taps
+// x 16 channels (12 tap slots, the last 3 with zero weights), so K = 3 steps instead of 9 x 64 mostly-zero channels.
+template <int BM, int BN, int WP, int WC, bool OUT_F32, bool FIRST>
 __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
 {
 #if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
     constexpr int XCH = BM / 8 / NW, WCH = BN / 8 / NW;          // 8-row DMA pieces per wave and stage
     constexpr int ESZ = OUT_F32 ? 4 : 2;
     constexpr int OUT_BYTES = BM * BN * ESZ;
-    constexpr int LDS_BYTES = (2 * STAGE > OUT_BYTES ? 2 * STAGE : OUT_BYTES) + BM * 4;
+    constexpr int LDS_BYTES = 2 * STAGE > OUT_BYTES + BM * 4 ? 2 * STAGE : OUT_BYTES + BM * 4;
     static_assert(NT == 256 && NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TP % 32 == 0 && TC % 32 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    unsigned *const s_pix = (unsigned *)(lds + LDS_BYTES - BM * 4);
+    unsigned *const s_pix = (unsigned *)(lds + OUT_BYTES);        // (filled after the K loop: the stages may cover it)
 
     // ---- workgroup -> tile: the n-tiles of one m-tile run back to back on ONE XCD (they share the activation rows in its L2)
     const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
@@ -61,20 +63,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K2 = 9 * a.Cin * 2;                                 // bytes of one weight row
+    const int K2 = FIRST ? 3 * BK_BYTES : 9 * a.Cin * 2;          // bytes of one weight row
     const int Wp = a.W + 2;
-
-    // ---- output address of every pixel of the tile (epilogue)
-    for (int p = tid; p < BM; p += NT) {
-        const int m = m0 + p;
-        unsigned off = 0xFFFFFFFFu;
-        if (m < a.M) {
-            const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
-            const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
-            off = (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ);
-        }
-        s_pix[p] = off;
-    }
 
     // ---- DMA source addresses: lane -> (row = lane >> 3 of the 8-row piece, 16-byte k-group (lane & 7) ^ swizzle(row))
     const int gsel = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
@@ -84,7 +74,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
         int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
         m = m < a.M ? m : a.M - 1;
         const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
-        xoff[j] = ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 + gsel * 16;
+        xoff[j] = ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 + (FIRST ? (gsel & 1) : gsel) * 16;
     }
     const int woff = (lane >> 3) * K2 + gsel * 16;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
@@ -92,15 +82,20 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
     const int wrow0 = (n0 + wave * 8) * K2;                       // + j * NW * 8 * K2 per piece
 
     // K-step state (scalar): tap (ty, tx) and the 64-channel slice cc of it
-    const int cpt = a.Cin >> 6, KT = 9 * cpt;
+    const int cpt = a.Cin >> 6, KT = FIRST ? 3 : 9 * cpt;
     int ty = 0, tx = 0, cc = 0;
     auto issue = [&](const int kt, const int stage) __attribute__((always_inline)) {
-        const int sx = ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
+        const int sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
         const int sw = wrow0 + kt * BK_BYTES;
         char *const base = lds + stage * STAGE;
+        int tapv = 0;                                             // FIRST: this lane's tap of the step (per lane, not per step)
+        if (FIRST) {
+            const int t = kt * 4 + (gsel >> 1), t9 = t < 9 ? t : 0, tyy = t9 / 3;
+            tapv = (tyy * Wp + (t9 - tyy * 3)) * a.Cin * 2;
+        }
 #pragma unroll
         for (int j = 0; j < XCH; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + (j * NW + wave) * 1024), 16, xoff[j], sx, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + (j * NW + wave) * 1024), 16, xoff[j] + tapv, sx, 0, 0);
 #pragma unroll
         for (int j = 0; j < WCH; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t *)(base + BM * BK_BYTES + (j * NW + wave) * 1024), 16, woff,
@@ -144,6 +139,16 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
         }
     }
     __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
+    for (int p = tid; p < BM; p += NT) {                          // output address of every pixel of the tile
+        const int m = m0 + p;
+        unsigned off = 0xFFFFFFFFu;
+        if (m < a.M) {
+            const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
+            const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
+            off = (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ);
+        }
+        s_pix[p] = off;
+    }
 
     // ---- epilogue: + bias, ReLU, -> LDS tile [pixel][cout] (16-byte slots XOR-swizzled by the pixel), -> 16-byte global stores
     // D layout of the 32x32 MFMA: lane holds column (= pixel) lane & 31, rows (= couts) 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void frame_f32_to_f16_kernel(const float *__re
     }
 }
 
-template <int BM, int BN, int WP, int WC>
+template <int BM, int BN, int WP, int WC, bool FIRST>
 int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
 {
     ConvArgs b = a;
@@ -228,9 +233,9 @@ int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
     b.n_tiles = a.Cout / BN;
     const int grid = (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
     if (out_f32)
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, true>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, true, FIRST>), dim3(grid), dim3(256), 0, s, b);
     else
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, false>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, false, FIRST>), dim3(grid), dim3(256), 0, s, b);
     return mv3d_launch_status();
 }
 
@@ -241,8 +246,9 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
                                 int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream)
 {
     if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
-    if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
-    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 2, wb = (size_t)c_out * 9 * c_in * 2;
+    const bool first = c_in == 16;                                // the input layer's packing (see the header)
+    if (c_in <= 0 || (c_in % 64 && !first) || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 2, wb = (size_t)c_out * (first ? 192 : 9 * c_in) * 2;
     const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * (out_f32 ? 4 : 2);
     if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
     ConvArgs a;
@@ -252,8 +258,9 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.m_tiles = a.n_tiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2>(a, out_f32, s);
-    return launch_conv<128, 64, 2, 2>(a, out_f32, s);
+    if (first) return c_out % 128 == 0 ? launch_conv<128, 128, 2, 2, true>(a, out_f32, s) : launch_conv<256, 64, 4, 1, true>(a, out_f32, s);
+    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2, false>(a, out_f32, s);
+    return launch_conv<256, 64, 4, 1, false>(a, out_f32, s);
 }
 
 extern "C" int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)

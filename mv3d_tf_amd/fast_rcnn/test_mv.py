@@ -104,12 +104,14 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
 
 
 
-def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16"), reduce_device="cuda"):
+def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16", "fp16_mfma"), reduce_device="cuda"):
     """Full MV3D_test forward WITH the dense layers, for bench.py's `serving_with_trunk` key (BASELINE configs[4]: batch
-    16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the torch trunks /
-    FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision; fp16 = autocast
-    of the DENSE layers only (MIOpen / rocBLAS half kernels; the hot-path layers stay f32) -- a lower precision than the
-    reference, reported next to fp32, never the headline.  No hand-written convolution is claimed."""
+    16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the trunks /
+    FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision (torch: MIOpen /
+    rocBLAS); fp16 = autocast of the DENSE layers only (MIOpen / rocBLAS half kernels); fp16_mfma = the 27 3x3 convolutions
+    on this repository's MFMA kernel (mv3d_conv3x3_f16, mv3d_tf_amd.trunk), the FC head still autocast rocBLAS.  The hot-path
+    layers stay f32 in every variant; the f16 variants are a lower precision than the reference, reported next to fp32, never
+    the headline."""
     import time
     from .. import sharding, synth
     from ..networks import get_network
@@ -119,7 +121,7 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
     img = torch.as_tensor((rng.randint(0, 255, (batch, 375, 1242, 3)) - cfg.PIXEL_MEANS).astype(np.float32)).cuda()
     feed = {"lidar_bv_data": bev, "image_data": img, "im_info": np.array([[608, 608, 1]] * batch, np.float32),
             "calib": np.stack([synth.KITTI_CALIB] * batch), "keep_prob": 1.0}
-    out = {"workload": "MV3D_test full forward incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head + proposal_layer_3d (TEST cfg) + "
+    out = {"workload": "MV3D_test full forward incl. VGG16 trunks + FC head + proposal_layer_3d (TEST cfg) + "
                        "RoiPool x2 + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image" % batch}
 
     def step():
@@ -128,7 +130,8 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
             ops.box_detect_tail(L["rois"][2].contiguous(), L["bbox_pred"].contiguous(), n_classes)
 
     for name in dtypes:
-        net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[name]
+        net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16}[name]
+        net.mfma_trunk = name == "fp16_mfma"
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -140,5 +143,6 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
         torch.cuda.synchronize()
         dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device=reduce_device)
         out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2)}
-    out["note"] = "fp16 = autocast of the dense layers only, lower precision than the reference's fp32; the hot-path layers run in f32"
+    out["note"] = ("fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
+                   "(f32 accumulate), FC head autocast; both lower precision than the reference's fp32; the hot-path layers run in f32")
     return out

@@ -57,6 +57,11 @@ class MV3D:
         # optional reduced-precision DENSE layers (torch.float16 / torch.bfloat16 autocast of the VGG16 trunks, RPN convs and FC
         # head: BASELINE configs[4] "fp16 VGG16"); the hot-path layers always get and give f32.  None = the reference's fp32.
         self.amp_dtype = None
+        # serve the 3x3 convolutions (trunks + rpn_conv/3x3) through the hand-written f16 MFMA kernel (mv3d_tf_amd.trunk): forward
+        # only, f16 operands / f32 accumulation, the serving configuration next to amp_dtype = torch.float16
+        self.mfma_trunk = False
+        self._mfma = None
+        self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
 
@@ -125,7 +130,50 @@ class MV3D:
             self.layers[stem + suffix] = x.float().permute(0, 2, 3, 1)
         return x
 
+    def _mfma_trunks(self, L):
+        """trunks + RPN head with every 3x3 convolution on mv3d_conv3x3_f16; returns (rpn_cls_score, rpn_bbox_pred) f32 NHWC"""
+        if torch.is_grad_enabled() and self.trainable:
+            raise RuntimeError("mfma_trunk is the forward-only serving trunk: run it under torch.no_grad() (or trainable=False)")
+        if self._mfma is None:
+            from ..trunk import MfmaTrunks
+            self._mfma = MfmaTrunks(self, _VGG)
+        bev = self._mfma.trunk(L["lidar_bv_data"], "", last_framed=True)
+        L["conv5_3"] = bev[:, 1:-1, 1:-1].float()                    # the f32 NHWC map the RoiPool layer reads
+        self._mfma.trunk(L["image_data"], "_2", last_framed=False)
+        if self.views == 3:
+            self._mfma.trunk(L["lidar_fv_data"], "_3", last_framed=False)
+        rpn = self._mfma.rpn_conv(bev)                               # (B, H, W, 512) f16
+        L["rpn_conv/3x3"] = rpn
+        heads = []
+        for name in ("rpn_cls_score", "rpn_bbox_pred"):               # 1x1 convolutions = a matmul over the channel axis
+            w, b = self.params[name]
+            heads.append(F.linear(rpn, w.reshape(w.shape[0], -1).half(), b.half()).float().contiguous())
+        return heads
+
+    def _serving_weights(self, name, nhwc_from=None):
+        """Inference-only view of a layer's parameters, cached until the fp32 parameter changes: cast once to amp_dtype (autocast
+        would re-cast the 100 M fc6 weights on every call) and, for a layer fed by a 4-D NHWC blob, with the input axis
+        re-ordered from the reference's (c,h,w) flattening to (h,w,c) so that the blob is used as it lies in memory."""
+        w, b = self.params[name]
+        key = (name, self.amp_dtype, nhwc_from)
+        ver = (w._version, b._version)
+        hit = self._wcache.get(key)
+        if hit is None or hit[0] != ver:
+            wd = w.detach()
+            if nhwc_from is not None:
+                h_, w_, c_ = nhwc_from
+                wd = wd.reshape(w.shape[0], c_, h_, w_).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+            dt = self.amp_dtype or torch.float32
+            hit = (ver, wd.to(dt).contiguous(), b.detach().to(dt))
+            self._wcache[key] = hit
+        return hit[1], hit[2]
+
     def _fc(self, x, name, relu=True):
+        if not torch.is_grad_enabled():                             # serving: cached weights, no flattening copy
+            nhwc = tuple(x.shape[1:]) if x.ndim == 4 else None
+            w, b = self._serving_weights(name, nhwc)
+            y = F.linear(x.reshape(x.shape[0], -1).to(w.dtype), w, b)
+            return F.relu(y) if relu else y
         if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)
             x = x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
         w, b = self.params[name]
@@ -168,16 +216,19 @@ class MV3D:
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
-        bev = self._trunk(to_nchw(L["lidar_bv_data"]), "")
-        rgb = self._trunk(to_nchw(L["image_data"]), "_2")
-        if self.views == 3:
-            self._trunk(to_nchw(L["lidar_fv_data"]), "_3")
-        # RPN (MV3D_train.py:82-103)
-        rpn = self._conv(bev, "rpn_conv/3x3")
-        L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
-        score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
+        if self.mfma_trunk:
+            score, L["rpn_bbox_pred"] = self._mfma_trunks(L)
+        else:
+            bev = self._trunk(to_nchw(L["lidar_bv_data"]), "")
+            self._trunk(to_nchw(L["image_data"]), "_2")
+            if self.views == 3:
+                self._trunk(to_nchw(L["lidar_fv_data"]), "_3")
+            # RPN (MV3D_train.py:82-103)
+            rpn = self._conv(bev, "rpn_conv/3x3")
+            L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
+            score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
+            L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
         L["rpn_cls_score"] = score
-        L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
         n, h, w, c = score.shape
         L["rpn_cls_score_reshape"] = score.reshape(n, h, -1, 2)                       # reshape_layer(2) (network.py:333-341)
         L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)   # :399-403

@@ -295,10 +295,11 @@ def box_detect_tail(rois_3d, bbox_pred, num_classes):
     return cnr, pr, bv, bvr
 
 
-def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_maps=False):
+def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_maps=False, want_argmax=True):
     """views: list of (data (B,H,W,C), rois (R,5), spatial_scale); one launch for all of them.
     Returns [(top, argmax), ...]; pass `outs` (same structure) to reuse output tensors.  cold_maps: the maps are not
-    cache-resident (mv3d_roi_pool_forward_views_cold: same results, prefetch workgroups in front of the launch)."""
+    cache-resident (mv3d_roi_pool_forward_views_cold: same results, prefetch workgroups in front of the launch).
+    want_argmax=False (inference): argmax_data = NULL, the entries are (top, None)."""
     arr = (RoiView * len(views))()
     res = []
     for k, (data, rois, scale) in enumerate(views):
@@ -308,8 +309,8 @@ def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_m
             top, am = outs[k]
         else:
             top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.float32, device=data.device)
-            am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device)
-        arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, R, H, W, Cc)
+            am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device) if want_argmax else None
+        arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr() if am is not None else None, float(scale), B, R, H, W, Cc)
         res.append((top, am))
     fn = lib().mv3d_roi_pool_forward_views_cold if cold_maps else lib().mv3d_roi_pool_forward_views
     check(fn(len(views), arr, pooled_height, pooled_width, _stream()), "mv3d_roi_pool_forward_views")
@@ -390,6 +391,14 @@ def pack_conv3x3_weights(w_oihw, c_in_pad=None):
     w = torch.zeros((O, 3, 3, Ip), dtype=torch.float16, device=w_oihw.device)
     w[..., :I] = w_oihw.detach().permute(0, 2, 3, 1).to(torch.float16)
     return w.reshape(O, 9 * Ip).contiguous()
+
+
+def pack_conv3x3_weights_input_layer(w_oihw):
+    """the input layer's packing (c_in <= 16, see mv3d_conv3x3_f16): (O, I, 3, 3) f32 -> (O, 12 * 16) f16, k = 16 * tap + c"""
+    O, I = w_oihw.shape[:2]
+    w = torch.zeros((O, 12, 16), dtype=torch.float16, device=w_oihw.device)
+    w[:, :9, :I] = w_oihw.detach().permute(0, 2, 3, 1).reshape(O, 9, I).to(torch.float16)
+    return w.reshape(O, 192).contiguous()
 
 
 def framed_buffer(B, H, W, C, device):

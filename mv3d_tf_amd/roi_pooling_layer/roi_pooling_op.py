@@ -73,6 +73,11 @@ def roi_pool_views(views, pooled_height, pooled_width, spatial_scale):
     for d, r in views:
         _check(d, r)
         flat += [d, r]
+    if not (torch.is_grad_enabled() and any(d.requires_grad for d, _ in views)):
+        # inference: no gradient will be asked for, so the argmax planes (as many bytes again as the pooled output) are not written
+        res = ops.roi_pool_forward_views([(d.contiguous(), r.contiguous(), float(spatial_scale)) for d, r in views], int(pooled_height),
+                                         int(pooled_width), want_argmax=False)
+        return [top for top, _ in res]
     return list(RoiPoolViewsFunction.apply(int(pooled_height), int(pooled_width), float(spatial_scale), *flat))
 
 

@@ -60,6 +60,22 @@ def test_conv3x3_matches_fp32_reference(gpu, B, H, W, cin, cout, out_f32, relu, 
     assert err <= (2e-5 if out_f32 else 2e-3) * scale, (err, scale)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 40, 52, 9, 64), (1, 31, 45, 3, 64), (1, 16, 16, 9, 128)])
+def test_input_layer_variant(gpu, B, H, W, cin, cout):
+    """conv1_1: 9 / 3 input channels zero-padded to 16, K steps of 4 taps x 16 channels"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(H + cin)
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * 0.3
+    b = torch.randn((cout,), device="cuda", generator=g)
+    want = _reference(torch, x, w, b, True)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 16, x.device))
+    got = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights_input_layer(w), b)[:, 1:-1, 1:-1]
+    torch.cuda.synchronize()
+    assert float((got.float() - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
 def test_maxpool_and_two_layer_chain(gpu):
     torch = gpu
     from mv3d_tf_amd import ops
@@ -88,3 +104,42 @@ def test_bad_arguments_are_refused(gpu):
     xf = ops.framed_buffer(1, 8, 8, 48, "cuda")
     with pytest.raises(_lib.Mv3dError):
         ops.conv3x3_f16(xf, torch.zeros((64, 9 * 48), dtype=torch.float16, device="cuda"), torch.zeros(64, device="cuda"))
+
+
+def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu):
+    """MV3D_test forward with mfma_trunk = True against the same graph on torch's autocast f16 convolutions (He-scaled weights
+    so that 13 layers keep O(1) activations): conv5_3 maps within 2 % of their max (two different f16 pipelines, 13 roundings
+    deep), the same proposal count, finite detections."""
+    torch = gpu
+    import numpy as np
+    from mv3d_tf_amd import synth
+    from mv3d_tf_amd.networks import get_network
+    net = get_network("MV3D_test")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    with torch.no_grad():
+        for name, (w, b) in net.params.items():
+            if w.ndim == 4:
+                w.copy_(torch.randn(w.shape, device="cuda", generator=g) * (2.0 / (w.shape[1] * w.shape[2] * w.shape[3])) ** 0.5)
+                b.copy_(torch.randn(b.shape, device="cuda", generator=g) * 0.05)
+    rng = np.random.RandomState(4)
+    B = 2
+    feed = {"lidar_bv_data": ((rng.random_sample((B, 608, 608, 9)) < 0.05) * rng.uniform(0, 2.4, (B, 608, 608, 9))).astype(np.float32),
+            "image_data": rng.uniform(-1, 1, (B, 96, 320, 3)).astype(np.float32),
+            "im_info": np.array([[608, 608, 1]] * B, np.float32), "calib": np.stack([synth.KITTI_CALIB] * B)}
+    outs = {}
+    for mfma in (False, True):
+        net.amp_dtype, net.mfma_trunk = torch.float16, mfma
+        with torch.no_grad():
+            L = net.forward(feed)
+        torch.cuda.synchronize()
+        outs[mfma] = {k: L[k].float().clone() for k in ("conv5_3", "conv5_3_2", "rpn_cls_score", "rpn_bbox_pred", "cls_prob", "bbox_pred")}
+        outs[mfma]["n"] = L["rois"][0].shape[0]
+        assert L["conv5_3"].dtype == torch.float32 and L["conv5_3"].shape == (B, 76, 76, 512) and L["conv5_3_2"].shape == (B, 12, 40, 512)
+    a, b = outs[False], outs[True]
+    for k in ("conv5_3", "conv5_3_2", "rpn_cls_score", "rpn_bbox_pred"):
+        scale = float(a[k].abs().max())
+        assert scale > 1e-3 and float((a[k] - b[k]).abs().max()) <= 0.02 * scale, (k, scale, float((a[k] - b[k]).abs().max()))
+    assert torch.isfinite(b["cls_prob"]).all() and torch.isfinite(b["bbox_pred"]).all() and b["n"] > 0
+    net.mfma_trunk = True
+    with pytest.raises(RuntimeError):
+        net.forward(feed)                                  # grad mode + trainable parameters: the serving trunk refuses

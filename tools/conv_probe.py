@@ -1,16 +1,18 @@
 """Times mv3d_conv3x3_f16 on the trunk's layer shapes against torch's (MIOpen) f16 convolution: TFLOP/s per layer.
-    python tools/conv_probe.py [batch]"""
+    python tools/conv_probe.py [batch] [--no-torch]"""
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mv3d_tf_amd import build, ops  # noqa: E402
 
 build.build()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-SHAPES = [("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
+TORCH = "--no-torch" not in sys.argv
+SHAPES = [("bev conv1_1", 608, 608, 9, 64), ("rgb conv1_1", 375, 1242, 3, 64), ("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
           ("bev conv4_1", 76, 76, 256, 512), ("bev conv4_2", 76, 76, 512, 512),
           ("rgb conv1_2", 375, 1242, 64, 64), ("rgb conv2_2", 187, 621, 128, 128), ("rgb conv3_2", 93, 310, 256, 256),
           ("rgb conv4_2", 46, 155, 512, 512)]
@@ -32,10 +34,14 @@ for name, H, W, cin, cout in SHAPES:
     x = torch.randn((B, H, W, cin), device="cuda")
     w = torch.randn((cout, cin, 3, 3), device="cuda") * 0.02
     b = torch.zeros(cout, device="cuda")
-    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, "cuda"))
-    wp = ops.pack_conv3x3_weights(w)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 16 if cin < 16 else cin, "cuda"))
+    wp = ops.pack_conv3x3_weights_input_layer(w) if cin < 16 else ops.pack_conv3x3_weights(w)
     out = ops.framed_buffer(B, H, W, cout, "cuda")
     ms = timed(lambda: ops.conv3x3_f16(xf, wp, b, out=out))
+    fl = 2.0 * B * H * W * cout * 9 * cin
+    if not TORCH:
+        print("%-12s B=%d  mfma %.3f ms %.0f TF/s" % (name, B, ms, fl / ms / 1e9), flush=True)
+        continue
     xh = x.half().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
     wh = w.half().contiguous(memory_format=torch.channels_last)
     bh = b.half()

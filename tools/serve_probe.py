@@ -1,0 +1,11 @@
+"""One serving configuration of bench_serve_step on its own (for rocprofv3):  python tools/serve_probe.py fp16_mfma [steps]"""
+import json
+import sys
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mv3d_tf_amd.fast_rcnn.test_mv import bench_serve_step  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "fp16_mfma"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+print(json.dumps(bench_serve_step(0, 1, None, steps=steps, warmup=2, dtypes=(name,))))
