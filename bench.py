@@ -452,6 +452,14 @@ def main():
             torch.cuda.empty_cache()
             from mv3d_tf_amd.fast_rcnn import test_mv
             sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
+            torch.cuda.empty_cache()
+            if rank == 0:
+                # the hand-written MFMA convolution against the dense f16 matrix-core peak (rank 0 only: a per-kernel figure)
+                from mv3d_tf_amd import trunk
+                from mv3d_tf_amd.networks.mv3d import _VGG
+                sec["serving_with_trunk"]["roofline_kernels"] = [trunk.bench_conv_layers(_VGG)]
+            if dist is not None:
+                dist.barrier()
         if rank == 0:
             res["secondary"] = sec
     if rank == 0:

@@ -41,8 +41,9 @@ struct ConvArgs {
 
 // FIRST: the layer fed by the network input (conv1_1: 9 / 3 channels zero-padded to 16 = 32 B per pixel): a K step is FOUR taps
 // x 16 channels (12 tap slots, the last 3 with zero weights), so K = 3 steps instead of 9 x 64 mostly-zero channels.
-template <int BM, int BN, int WP, int WC, bool OUT_F32, bool FIRST>
-__global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
+// STAGES: LDS stages of the operand pipeline; the DMA of K step kt + STAGES - 1 is issued while step kt is multiplied.
+template <int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
+__global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArgs a)
 {
 #if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
     constexpr int NW = WP * WC, NT = NW * 64;
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
     constexpr int XCH = BM / 8 / NW, WCH = BN / 8 / NW;          // 8-row DMA pieces per wave and stage
     constexpr int ESZ = OUT_F32 ? 4 : 2;
     constexpr int OUT_BYTES = BM * BN * ESZ;
-    constexpr int LDS_BYTES = 2 * STAGE > OUT_BYTES + BM * 4 ? 2 * STAGE : OUT_BYTES + BM * 4;
-    static_assert(NT == 256 && NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TP % 32 == 0 && TC % 32 == 0, "tile shape");
+    constexpr int LDS_BYTES = STAGES * STAGE > OUT_BYTES + BM * 4 ? STAGES * STAGE : OUT_BYTES + BM * 4;
+    static_assert(LDS_BYTES <= 160 * 1024 && (STAGES == 2 || STAGES == 3) && NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TP % 32 == 0 && TC % 32 == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     unsigned *const s_pix = (unsigned *)(lds + OUT_BYTES);        // (filled after the K loop: the stages may cover it)
 
@@ -84,24 +85,31 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
     // K-step state (scalar): tap (ty, tx) and the 64-channel slice cc of it
     const int cpt = a.Cin >> 6, KT = FIRST ? 3 : 9 * cpt;
     int ty = 0, tx = 0, cc = 0;
-    auto issue = [&](const int kt, const int stage) __attribute__((always_inline)) {
-        const int sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
-        const int sw = wrow0 + kt * BK_BYTES;
-        char *const base = lds + stage * STAGE;
-        int tapv = 0;                                             // FIRST: this lane's tap of the step (per lane, not per step)
-        if (FIRST) {
+    int sx = 0, sw = 0, tapv = 0;                                 // source offsets of the step being fetched (next())
+    char *dst = lds;
+    auto next = [&](const int kt) __attribute__((always_inline)) {
+        sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
+        sw = wrow0 + kt * BK_BYTES;
+        dst = lds + (kt % STAGES) * STAGE;
+        if (FIRST) {                                              // this lane's tap of the step (per lane, not per step)
             const int t = kt * 4 + (gsel >> 1), t9 = t < 9 ? t : 0, tyy = t9 / 3;
             tapv = (tyy * Wp + (t9 - tyy * 3)) * a.Cin * 2;
         }
-#pragma unroll
-        for (int j = 0; j < XCH; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + (j * NW + wave) * 1024), 16, xoff[j] + tapv, sx, 0, 0);
-#pragma unroll
-        for (int j = 0; j < WCH; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t *)(base + BM * BK_BYTES + (j * NW + wave) * 1024), 16, woff,
-                                                     sw + j * NW * 8 * K2, 0, 0);
         if (++cc == cpt) { cc = 0; if (++tx == 3) { tx = 0; ++ty; } }
     };
+    // pieces [q0, q1) of the step's XCH + WCH DMA pieces of this wave
+    auto issue = [&](const int q0, const int q1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < XCH + WCH; ++q) {
+            if (q < q0 || q >= q1) continue;
+            if (q < XCH)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(dst + (q * NW + wave) * 1024), 16, xoff[q < XCH ? q : 0] + tapv, sx, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t *)(dst + BM * BK_BYTES + ((q - XCH) * NW + wave) * 1024), 16, woff,
+                                                         sw + (q - XCH) * NW * 8 * K2, 0, 0);
+        }
+    };
+    constexpr int NQ = XCH + WCH;
 
     // ---- MFMA operand reads: lane -> fragment row lane & 31, k-group 2 * ks + (lane >> 5), un-swizzled by (row >> 1) & 7
     const int wp = wave % WP, wc = wave / WP;
@@ -119,12 +127,19 @@ __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const ConvArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue(0, 0);
+    constexpr int D = STAGES - 1;                                 // prefetch distance in K steps
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+        if (p < KT) { next(p); issue(0, NQ); }
     for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage kt have landed ...
+        // this wave's pieces of stage kt have landed (the D - 1 younger stages in flight may stay outstanding) ...
+        if (D >= 2 && kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NQ) : "memory");   // (D <= 2 supported)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // ... everyone's have, and stage kt - 1 has been consumed
-        if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
-        const char *const st = lds + (kt & 1) * STAGE;
+        const bool more = kt + D < KT;
+        if (more) next(kt + D);
+        if (more) issue(0, NQ);        // (all pieces up front: spreading them between the MFMAs measured 3-7 % slower)
+        const char *const st = lds + (kt % STAGES) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             half8 fw[FC], fx[FP];
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void frame_f32_to_f16_kernel(const float *__re
     }
 }
 
-template <int BM, int BN, int WP, int WC, bool FIRST>
+template <int BM, int BN, int WP, int WC, int STAGES, bool FIRST>
 int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
 {
     ConvArgs b = a;
@@ -233,9 +248,9 @@ int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
     b.n_tiles = a.Cout / BN;
     const int grid = (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
     if (out_f32)
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, true, FIRST>), dim3(grid), dim3(256), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
     else
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, false, FIRST>), dim3(grid), dim3(256), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, STAGES, false, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
     return mv3d_launch_status();
 }
 
@@ -258,9 +273,11 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.m_tiles = a.n_tiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (first) return c_out % 128 == 0 ? launch_conv<128, 128, 2, 2, true>(a, out_f32, s) : launch_conv<256, 64, 4, 1, true>(a, out_f32, s);
-    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2, false>(a, out_f32, s);
-    return launch_conv<256, 64, 4, 1, false>(a, out_f32, s);
+    if (first) return c_out % 128 == 0 ? launch_conv<128, 128, 2, 2, 2, true>(a, out_f32, s) : launch_conv<256, 64, 4, 1, 2, true>(a, out_f32, s);
+    // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
+    // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
+    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2, 2, false>(a, out_f32, s);
+    return launch_conv<256, 64, 4, 1, 2, false>(a, out_f32, s);
 }
 
 extern "C" int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)

@@ -121,13 +121,19 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
     img = torch.as_tensor((rng.randint(0, 255, (batch, 375, 1242, 3)) - cfg.PIXEL_MEANS).astype(np.float32)).cuda()
     feed = {"lidar_bv_data": bev, "image_data": img, "im_info": np.array([[608, 608, 1]] * batch, np.float32),
             "calib": np.stack([synth.KITTI_CALIB] * batch), "keep_prob": 1.0}
-    out = {"workload": "MV3D_test full forward incl. VGG16 trunks + FC head + proposal_layer_3d (TEST cfg) + "
+    # BASELINE configs[4]: "300 proposals/frame" = the 6000 -> 300 TEST setting the reference's config.py keeps as a comment
+    # (lib/fast_rcnn/config.py:186-190; its live default is 12000 -> 2000)
+    saved = (cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N)
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 6000, 300
+    out = {"workload": "MV3D_test full forward incl. VGG16 trunks + FC head + proposal_layer_3d (TEST cfg 6000 -> 300) + "
                        "RoiPool x2 + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image" % batch}
+    rois = [0]
 
     def step():
         with torch.no_grad():
             L = net.forward(feed)
             ops.box_detect_tail(L["rois"][2].contiguous(), L["bbox_pred"].contiguous(), n_classes)
+            rois[0] = int(L["rois"][2].shape[0])
 
     for name in dtypes:
         net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16}[name]
@@ -142,7 +148,9 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
             step()
         torch.cuda.synchronize()
         dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device=reduce_device)
-        out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2)}
+        out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
+                     "rois_per_step": rois[0]}
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
     out["note"] = ("fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
                    "(f32 accumulate), FC head autocast; both lower precision than the reference's fp32; the hot-path layers run in f32")
     return out

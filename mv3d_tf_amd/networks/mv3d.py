@@ -172,6 +172,7 @@ class MV3D:
         if not torch.is_grad_enabled():                             # serving: cached weights, no flattening copy
             nhwc = tuple(x.shape[1:]) if x.ndim == 4 else None
             w, b = self._serving_weights(name, nhwc)
+            # (a plain GEMM: rocBLAS / hipBLASLt.  The convolution kernel run without taps measured 617 vs 943 TFLOP/s on fc6.)
             y = F.linear(x.reshape(x.shape[0], -1).to(w.dtype), w, b)
             return F.relu(y) if relu else y
         if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)

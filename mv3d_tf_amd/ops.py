@@ -435,3 +435,4 @@ def maxpool2x2_f16(x_framed, out=None):
         out = framed_buffer(B, H // 2, W // 2, Cc, x_framed.device)
     check(lib().mv3d_maxpool2x2_f16(_ptr(x_framed), _ptr(out), B, H, W, Cc, _stream()), "mv3d_maxpool2x2_f16")
     return out
+

@@ -66,3 +66,53 @@ class MfmaTrunks:
         """rpn_conv/3x3 (MV3D_test.py:82-84) on the framed BEV conv5_3 -> (B, H, W, 512) f16 NHWC"""
         wp, bias = self._packed("rpn_conv/3x3")
         return ops.conv3x3_f16(conv5_3_framed, wp, bias, out_framed=False, out_f32=False)
+
+
+def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3))):
+    """[(name, H, W, c_in, c_out)] of every 3x3 convolution of the serving graph on KITTI-shaped inputs (+ rpn_conv/3x3)"""
+    rows = []
+    for suffix, H, W, c in inputs:
+        for stem, cout, pool in vgg:
+            rows.append((stem + suffix, H, W, c, cout))
+            c = cout
+            if pool:
+                H, W = H // 2, W // 2
+        if suffix == "":
+            rows.append(("rpn_conv/3x3", H, W, c, 512))
+    return rows
+
+
+def bench_conv_layers(vgg, batch=16, reps=3):
+    """Roofline entry of the convolution kernel for bench.py: every 3x3 layer of the serving graph (27 launches: BEV trunk,
+    rpn_conv/3x3, RGB trunk) at `batch` frames, each timed with HIP events on the launch stream over `reps` launches after one
+    warm-up.  achieved = ALGORITHMIC flops (2 * B*H*W * c_out * 9 * c_in with the true c_in, i.e. conv1_1's zero padding is not
+    counted) / time; peak = the dense f16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s)."""
+    dev = torch.device("cuda")
+    tot_fl, tot_ms, per = 0.0, 0.0, {}
+    for name, H, W, cin, cout in serving_layers(vgg):
+        first = cin < 16
+        x = ops.framed_buffer(batch, H, W, 16 if first else cin, dev)
+        x[:, 1:-1, 1:-1, :cin] = torch.randn((batch, H, W, cin), device=dev, dtype=torch.float16)
+        w = torch.randn((cout, cin, 3, 3), device=dev) * (2.0 / (9 * cin)) ** 0.5
+        wp = ops.pack_conv3x3_weights_input_layer(w) if first else ops.pack_conv3x3_weights(w)
+        b = torch.zeros(cout, device=dev)
+        out = ops.framed_buffer(batch, H, W, cout, dev)
+        ops.conv3x3_f16(x, wp, b, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv3x3_f16(x, wp, b, out=out)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * batch * H * W * cout * 9 * cin
+        tot_fl += fl
+        tot_ms += ms
+        per[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+        del x, out
+    ach = tot_fl / tot_ms / 1e9
+    best = max(per.items(), key=lambda kv: kv[1]["tflops"])
+    return {"kernel": "conv3x3_f16_kernel (v_mfma_f32_32x32x16_f16; the 27 3x3 convolutions of the serving graph, batch %d)" % batch,
+            "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": 27 * reps,
+            "best_layer": {"name": best[0], **best[1]}, "traffic": None}

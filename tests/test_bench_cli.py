@@ -104,3 +104,7 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     wt = sec["with_trunk"]
     assert wt["frames_per_s"] > 0 and wt["allreduce_buckets"] >= 8 and wt["gradient_bytes_per_step"] > 500e6
     assert sec["test_cfg"]["frames_per_s"] > 0
+    sv = sec["serving_with_trunk"]
+    assert sv["fp32"]["frames_per_s"] > 0 and sv["fp16_mfma"]["frames_per_s"] > 0 and sv["fp16_mfma"]["rois_per_step"] > 0
+    rk = sv["roofline_kernels"][0]
+    assert rk["bound"] == "mfma" and rk["peak"] == 2500.0 and 0 < rk["frac"] < 1 and abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-3

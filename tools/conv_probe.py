@@ -7,9 +7,13 @@ import torch
 
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mv3d_tf_amd import build, ops  # noqa: E402
+from mv3d_tf_amd import _lib, build, ops  # noqa: E402
 
-build.build()
+if "--lib" in sys.argv:                      # an experiment build of the library (tools only)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+else:
+    build.build()
+ONLY = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 TORCH = "--no-torch" not in sys.argv
 SHAPES = [("bev conv1_1", 608, 608, 9, 64), ("rgb conv1_1", 375, 1242, 3, 64), ("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
@@ -31,6 +35,8 @@ def timed(fn, n=10):
 
 
 for name, H, W, cin, cout in SHAPES:
+    if ONLY and not any(o in name for o in ONLY):
+        continue
     x = torch.randn((B, H, W, cin), device="cuda")
     w = torch.randn((cout, cin, 3, 3), device="cuda") * 0.02
     b = torch.zeros(cout, device="cuda")
