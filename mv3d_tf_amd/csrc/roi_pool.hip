@@ -666,7 +666,9 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
     const int j = threadIdx.x & (BWI_PIX - 1), q = threadIdx.x / BWI_PIX;      // pixel of the segment, entry stripe
     const int npass = (R + BW_CHUNK - 1) / BW_CHUNK;
     const long long pix0 = ((long long)n * H + h) * W + w0;
-    if (!FILL) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have candidates): the
+    if (FILL == ((h & 1) != 0)) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have
+        // candidates); even rows by the sizing launch, odd rows by the list launch: each launch is a chain of barriers and LDS
+        // round trips with the memory system idle, so half of the 55 MB of streaming stores hides under each.  The
         // segment's npx * C floats are contiguous
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
