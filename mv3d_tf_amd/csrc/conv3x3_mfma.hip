@@ -57,9 +57,12 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     unsigned *const s_pix = (unsigned *)(lds + OUT_BYTES);        // (filled after the K loop: the stages may cover it)
 
-    // ---- workgroup -> tile: the n-tiles of one m-tile run back to back on ONE XCD (they share the activation rows in its L2)
+    // ---- workgroup -> tile: XCD x (= id & 7) owns a contiguous band of m-tiles (image rows: the tiles above / below a tile --
+    // whose taps re-read two of its three input rows -- run on the SAME XCD at about the same time and hit its L2), and the
+    // n-tiles of one m-tile run back to back (they share the activation rows).  Round-robin m-tiles over the XCDs instead:
+    // conv1_2 6-8 % slower, the rest equal.
     const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
-    const int mt = (local / a.n_tiles) * 8 + xcd, nt = local % a.n_tiles;
+    const int mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles, nt = local % a.n_tiles;
     if (mt >= a.m_tiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;

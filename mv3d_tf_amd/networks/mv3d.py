@@ -61,6 +61,7 @@ class MV3D:
         # only, f16 operands / f32 accumulation, the serving configuration next to amp_dtype = torch.float16
         self.mfma_trunk = False
         self._mfma = None
+        self._side = None
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -137,12 +138,23 @@ class MV3D:
         if self._mfma is None:
             from ..trunk import MfmaTrunks
             self._mfma = MfmaTrunks(self, _VGG)
+        # the image (and front-view) trunk on a side stream: the trunks are independent chains of chip-filling launches, and
+        # the last, partly filled round of workgroups of a layer of one trunk overlaps the start of a layer of the other
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._mfma.trunk(L["image_data"], "_2", last_framed=False)
+            if self.views == 3:
+                self._mfma.trunk(L["lidar_fv_data"], "_3", last_framed=False)
         bev = self._mfma.trunk(L["lidar_bv_data"], "", last_framed=True)
         L["conv5_3"] = bev[:, 1:-1, 1:-1].float()                    # the f32 NHWC map the RoiPool layer reads
-        self._mfma.trunk(L["image_data"], "_2", last_framed=False)
-        if self.views == 3:
-            self._mfma.trunk(L["lidar_fv_data"], "_3", last_framed=False)
         rpn = self._mfma.rpn_conv(bev)                               # (B, H, W, 512) f16
+        main.wait_stream(self._side)
+        for k in ("conv5_3_2", "conv5_3_3"):
+            if k in L:
+                L[k].record_stream(main)
         L["rpn_conv/3x3"] = rpn
         heads = []
         for name in ("rpn_cls_score", "rpn_bbox_pred"):               # 1x1 convolutions = a matmul over the channel axis
