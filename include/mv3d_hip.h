@@ -370,7 +370,8 @@ int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_dev, const 
  *   y         out_framed ? (batch, height + 2, width + 2, c_out) interior only (the frame is the owner's, zeroed once)
  *                        : (batch, height, width, c_out);  f32 if out_f32 (the map a RoiPool layer reads) else f16
  * c_in and c_out multiples of 64, or c_in == 16 = the input layer (conv1_1: 9 / 3 channels zero-padded to 16), whose weights are
- * packed (c_out, 192): k = 16 * tap + c for the 9 taps, zero for tap slots 9..11.  Every buffer < 2 GiB. */
+ * packed (c_out, 192): k = 16 * tap + c for the 9 taps, zero for tap slots 9..11.  Every buffer < 2 GiB (32-bit buffer
+ * offsets: split the batch above that) and 16-byte aligned; MV3D_ERR_INVALID_ARG otherwise, before any launch. */
 int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
                      int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
 /* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */

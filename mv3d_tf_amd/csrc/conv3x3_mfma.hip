@@ -264,6 +264,7 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
                                 int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream)
 {
     if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
+    if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;   // 16-byte pieces
     const bool first = c_in == 16;                                // the input layer's packing (see the header)
     if (c_in <= 0 || (c_in % 64 && !first) || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
     const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 2, wb = (size_t)c_out * (first ? 192 : 9 * c_in) * 2;
@@ -286,6 +287,7 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
 extern "C" int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
 {
     if (!x_framed || !y_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
+    if ((((uintptr_t)x_framed | (uintptr_t)y_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
     const int Ho = height / 2, Wo = width / 2;
     const long total = (long)batch * Ho * Wo * (channels / 8);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);

@@ -104,7 +104,7 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
 
 
 
-def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16", "fp16_mfma"), reduce_device="cuda"):
+def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16", "fp16_mfma"), reduce_device="cuda", views=3):
     """Full MV3D_test forward WITH the dense layers, for bench.py's `serving_with_trunk` key (BASELINE configs[4]: batch
     16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the trunks /
     FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision (torch: MIOpen /
@@ -115,18 +115,21 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
     import time
     from .. import sharding, synth
     from ..networks import get_network
-    net = get_network("MV3D_test")
+    net = get_network("MV3D_test_3view" if views == 3 else "MV3D_test")     # configs[4] serves the full 3-view model
     rng = np.random.RandomState(200 + rank)
     bev = torch.as_tensor(((rng.random_sample((batch, 608, 608, 9)) < 0.03) * rng.uniform(0, 2.4, (batch, 608, 608, 9))).astype(np.float32)).cuda()
     img = torch.as_tensor((rng.randint(0, 255, (batch, 375, 1242, 3)) - cfg.PIXEL_MEANS).astype(np.float32)).cuda()
     feed = {"lidar_bv_data": bev, "image_data": img, "im_info": np.array([[608, 608, 1]] * batch, np.float32),
             "calib": np.stack([synth.KITTI_CALIB] * batch), "keep_prob": 1.0}
+    if views == 3:
+        feed["lidar_fv_data"] = torch.as_tensor(rng.uniform(0, 1, (batch, 64, 512, 3)).astype(np.float32)).cuda()
     # BASELINE configs[4]: "300 proposals/frame" = the 6000 -> 300 TEST setting the reference's config.py keeps as a comment
     # (lib/fast_rcnn/config.py:186-190; its live default is 12000 -> 2000)
     saved = (cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N)
     cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 6000, 300
-    out = {"workload": "MV3D_test full forward incl. VGG16 trunks + FC head + proposal_layer_3d (TEST cfg 6000 -> 300) + "
-                       "RoiPool x2 + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image" % batch}
+    out = {"workload": "MV3D_test%s full forward incl. VGG16 trunks + FC head + proposal_layer_3d (TEST cfg 6000 -> 300) + "
+                       "RoiPool x%d + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image%s"
+                       % ("_3view" if views == 3 else "", views, batch, " + 64x512x3 front view" if views == 3 else "")}
     rois = [0]
 
     def step():

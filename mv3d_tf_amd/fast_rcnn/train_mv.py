@@ -284,7 +284,7 @@ def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters
     return history
 
 
-def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0):
+def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3):
     """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
     VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
     frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
@@ -293,7 +293,8 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     from .. import sharding, synth
     from ..networks import get_network
     np.random.seed(cfg.RNG_SEED + rank)
-    net = get_network("MV3D_train")
+    net = get_network("MV3D_train_3view" if views == 3 else "MV3D_train")   # configs[2]: "full 3-view MV3D -- BEV/FV/RGB VGG16"
+    net.amp_dtype = amp                                          # None = the reference's fp32; torch.bfloat16: autocast dense layers
     params = net.parameters()
     opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
@@ -303,11 +304,15 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
         _, _, info, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(7000 + 10 * rank + k, 76, 76, "peaky", return_gt=True)
         bev = (rng.random_sample((1, 608, 608, 9)) < 0.03).astype(np.float32) * rng.uniform(0, 2.4, (1, 608, 608, 9)).astype(np.float32)
         img = rng.randint(0, 255, (1, 375, 1242, 3)).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
-        frames.append({"lidar_bv_data": bev, "image_data": img.astype(np.float32), "im_info": info, "calib": calib,
+        fv = rng.uniform(0, 1, (1, 64, 512, 3)).astype(np.float32)
+        frames.append({"lidar_bv_data": bev, "image_data": img.astype(np.float32), "lidar_fv_data": fv, "im_info": info, "calib": calib,
                        "gt_boxes_bv": gt_bv, "gt_boxes_3d": gt_3d, "gt_boxes_corners": gt_cnr})
     feed = stack_blobs(frames)
-    for k in ("lidar_bv_data", "image_data"):
-        feed[k] = torch.as_tensor(feed[k]).cuda()                # resident inputs
+    if views != 3:
+        feed.pop("lidar_fv_data", None)
+    for k in ("lidar_bv_data", "image_data", "lidar_fv_data"):
+        if k in feed:
+            feed[k] = torch.as_tensor(feed[k]).cuda()            # resident inputs
     feed["keep_prob"] = 0.5
 
     def step():
@@ -335,8 +340,9 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cuda")
     nparam = sum(p.numel() for p in params)
-    out = {"workload": "MV3D_train full step incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head: %d frames / GPU / step, "
-                       "608x608x9 BEV + 375x1242x3 image, fp32, Adam" % frames_per_step,
+    out = {"workload": "MV3D_train%s full step incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head: %d frames / GPU / step, "
+                       "608x608x9 BEV + 375x1242x3 image%s, %s, Adam" % ("_3view" if views == 3 else "", frames_per_step,
+                                                                       " + 64x512x3 front view" if views == 3 else "", "fp32" if amp is None else "dense layers autocast to %s (fp32 master weights, f32 hot path)" % str(amp).split(".")[-1]),
            "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 2),
            "parameters": nparam, "gradient_bytes_per_step": bucketer.total_bytes(), "allreduce_buckets": len(bucketer.buckets),
            "allreduce": "RCCL, 25 MB buckets, last layer first, overlapping backward" if world > 1 else "none (1 GPU)"}

@@ -423,8 +423,13 @@ def conv3x3_f16(x_framed, w_packed, bias, out=None, out_framed=True, out_f32=Fal
             out = framed_buffer(B, H, W, cout, x_framed.device)
         else:
             out = torch.empty((B, H, W, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x_framed.device)
-    check(lib().mv3d_conv3x3_f16(_ptr(x_framed), _ptr(w_packed), _ptr(bias), _ptr(out), B, H, W, cin, cout, int(out_framed), int(out_f32),
-                                 int(relu), _stream()), "mv3d_conv3x3_f16")
+    # the kernel addresses each buffer with 32-bit offsets: frames are independent, so a larger batch goes in chunks
+    per_frame = max(Hp * Wp * cin * 2, out[0].numel() * out.element_size())
+    step = max(1, min(B, (2 ** 31 - 1) // per_frame))
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        check(lib().mv3d_conv3x3_f16(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout,
+                                     int(out_framed), int(out_f32), int(relu), _stream()), "mv3d_conv3x3_f16")
     return out
 
 

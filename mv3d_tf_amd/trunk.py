@@ -32,6 +32,11 @@ class MfmaTrunks:
             self._w[name] = hit
         return hit[1], hit[2]
 
+    def clear(self):
+        """drop the cached framed buffers and packed weights (e.g. after serving a different batch size)"""
+        self._w.clear()
+        self._buf.clear()
+
     def _framed(self, tag, B, H, W, C, dev):
         key = (tag, B, H, W, C)
         buf = self._buf.get(key)
@@ -68,7 +73,7 @@ class MfmaTrunks:
         return ops.conv3x3_f16(conv5_3_framed, wp, bias, out_framed=False, out_f32=False)
 
 
-def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3))):
+def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3), ("_3", 64, 512, 3))):
     """[(name, H, W, c_in, c_out)] of every 3x3 convolution of the serving graph on KITTI-shaped inputs (+ rpn_conv/3x3)"""
     rows = []
     for suffix, H, W, c in inputs:
@@ -83,8 +88,8 @@ def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3))):
 
 
 def bench_conv_layers(vgg, batch=16, reps=3):
-    """Roofline entry of the convolution kernel for bench.py: every 3x3 layer of the serving graph (27 launches: BEV trunk,
-    rpn_conv/3x3, RGB trunk) at `batch` frames, each timed with HIP events on the launch stream over `reps` launches after one
+    """Roofline entry of the convolution kernel for bench.py: every 3x3 layer of the 3-view serving graph (40 launches: BEV
+    trunk, rpn_conv/3x3, RGB trunk, front-view trunk) at `batch` frames, each timed with HIP events on the launch stream over `reps` launches after one
     warm-up.  achieved = ALGORITHMIC flops (2 * B*H*W * c_out * 9 * c_in with the true c_in, i.e. conv1_1's zero padding is not
     counted) / time; peak = the dense f16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s)."""
     dev = torch.device("cuda")
@@ -112,7 +117,7 @@ def bench_conv_layers(vgg, batch=16, reps=3):
         del x, out
     ach = tot_fl / tot_ms / 1e9
     best = max(per.items(), key=lambda kv: kv[1]["tflops"])
-    return {"kernel": "conv3x3_f16_kernel (v_mfma_f32_32x32x16_f16; the 27 3x3 convolutions of the serving graph, batch %d)" % batch,
+    return {"kernel": "conv3x3_f16_kernel (v_mfma_f32_32x32x16_f16; the %d 3x3 convolutions of the 3-view serving graph, batch %d)" % (len(per), batch),
             "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-            "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": 27 * reps,
+            "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": len(per) * reps,
             "best_layer": {"name": best[0], **best[1]}, "traffic": None}

@@ -52,6 +52,15 @@ def test_workspace_queries_and_argument_validation(hiplib):
                               None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_roi_pool_forward(None, 0.125, 1, 4, 8, 8, 16, 7, 7, None, None, None, None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_nms_device(None, 10, 0.7, 0, None, None, None, None, 0, None) == hiplib.ERR_INVALID_ARG
+    # the MFMA convolution: NULL / misaligned pointers, channel counts the tiles do not cover, buffers beyond 32-bit offsets
+    A = 4096                                                             # a non-NULL, 16-byte aligned "pointer" (never dereferenced)
+    assert L.mv3d_conv3x3_f16(None, A, A, A, 1, 8, 8, 64, 64, 1, 0, 1, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_f16(A + 2, A, A, A, 1, 8, 8, 64, 64, 1, 0, 1, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_f16(A, A, A, A, 1, 8, 8, 48, 64, 1, 0, 1, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_f16(A, A, A, A, 1, 8, 8, 64, 96, 1, 0, 1, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_f16(A, A, A, A, 64, 608, 608, 64, 64, 1, 0, 1, None) == hiplib.ERR_INVALID_ARG    # 3 GB of activations
+    assert L.mv3d_maxpool2x2_f16(A, A, 1, 8, 8, 12, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_frame_nhwc_f16(A, A, 1, 8, 8, 9, 8, None) == hiplib.ERR_INVALID_ARG
 
 
 def test_missing_library_fails_loudly(hiplib, monkeypatch, tmp_path):

@@ -98,6 +98,26 @@ def test_maxpool_and_two_layer_chain(gpu):
     assert float((y2 - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+def test_large_batches_are_split_into_chunks(gpu, monkeypatch):
+    """buffers beyond the kernel's 32-bit offsets: the wrapper runs the frames in chunks (here forced by a tiny limit)"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randn((5, 12, 20, 64), device="cuda", generator=g)
+    w = torch.randn((64, 64, 3, 3), device="cuda", generator=g) * 0.06
+    b = torch.randn(64, device="cuda", generator=g)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(5, 12, 20, 64, x.device))
+    want = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w), b)
+    calls = []
+    real = ops.lib().mv3d_conv3x3_f16
+    monkeypatch.setattr(ops.lib(), "mv3d_conv3x3_f16", lambda *a: calls.append(a[4]) or real(*a))
+    import builtins
+    monkeypatch.setattr(ops, "max", lambda *a: 2 ** 30 if len(a) == 2 and a[0] == 14 * 22 * 64 * 2 else builtins.max(*a), raising=False)
+    got = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w), b)
+    torch.cuda.synchronize()
+    assert calls == [1, 1, 1, 1, 1] and torch.equal(got, want)
+
+
 def test_bad_arguments_are_refused(gpu):
     torch = gpu
     from mv3d_tf_amd import _lib, ops
