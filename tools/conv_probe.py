@@ -19,7 +19,10 @@ TORCH = "--no-torch" not in sys.argv
 SHAPES = [("bev conv1_1", 608, 608, 9, 64), ("rgb conv1_1", 375, 1242, 3, 64), ("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
           ("bev conv4_1", 76, 76, 256, 512), ("bev conv4_2", 76, 76, 512, 512),
           ("rgb conv1_2", 375, 1242, 64, 64), ("rgb conv2_2", 187, 621, 128, 128), ("rgb conv3_2", 93, 310, 256, 256),
-          ("rgb conv4_2", 46, 155, 512, 512)]
+          ("rgb conv4_2", 46, 155, 512, 512),
+          # fixed cost per workgroup: the same tiles with 2x / 4x the K steps (time(2K) - time(K) = K steps of pure loop)
+          ("fix c1_2 k18", 608, 608, 128, 64), ("fix c1_2 k36", 608, 608, 256, 64), ("fix c2_2 k36", 304, 304, 256, 128),
+          ("fix c4_2 k36", 76, 76, 256, 512)]
 
 
 def timed(fn, n=10):
