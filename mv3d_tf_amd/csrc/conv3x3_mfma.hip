@@ -31,7 +31,7 @@ struct ConvArgs {
     const void *w;
     const float *bias;
     void *y;
-    int H, W, Cin, Cout, M, HW;
+    int H, W, Cin, Cout, M, HW, Bn;
     int out_pad, relu;
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
@@ -72,13 +72,20 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
 
     // ---- DMA source addresses: lane -> (row = lane >> 3 of the 8-row piece, 16-byte k-group (lane & 7) ^ swizzle(row))
     const int gsel = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    // (one pair of integer divisions per lane, the other pieces' pixels by walking NW * 8 pixels on: sixteen runtime divisions
+    // per lane were a visible part of a short-K workgroup's life)
     int xoff[XCH];
+    {
+        int m = m0 + wave * 8 + (lane >> 3);
+        int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
+        const int last = ((a.Bn * (a.H + 2) - 3) * Wp + a.W - 1) * a.Cin * 2;      // pixel M - 1: rows past the end read it (never stored)
 #pragma unroll
-    for (int j = 0; j < XCH; ++j) {
-        int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
-        m = m < a.M ? m : a.M - 1;
-        const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
-        xoff[j] = ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 + (FIRST ? (gsel & 1) : gsel) * 16;
+        for (int j = 0; j < XCH; ++j) {
+            xoff[j] = (m < a.M ? ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 : last) + (FIRST ? (gsel & 1) : gsel) * 16;
+            m += NW * 8;
+            xx += NW * 8;
+            while (xx >= a.W) { xx -= a.W; if (++yy == a.H) { yy = 0; ++b; } }
+        }
     }
     const int woff = (lane >> 3) * K2 + gsel * 16;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
@@ -157,15 +164,14 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
         }
     }
     __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
-    for (int p = tid; p < BM; p += NT) {                          // output address of every pixel of the tile
-        const int m = m0 + p;
-        unsigned off = 0xFFFFFFFFu;
-        if (m < a.M) {
-            const int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
-            const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
-            off = (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ);
+    {   // output address of every pixel of the tile: the tile's first pixel by division (wave-uniform), the others by walking
+        const int b0 = m0 / a.HW, r0 = m0 - b0 * a.HW, y0 = r0 / a.W, x0 = r0 - y0 * a.W;
+        const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
+        for (int p = tid; p < BM; p += NT) {
+            int b = b0, yy = y0, xx = x0 + p;
+            while (xx >= a.W) { xx -= a.W; if (++yy == a.H) { yy = 0; ++b; } }
+            s_pix[p] = m0 + p < a.M ? (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ) : 0xFFFFFFFFu;
         }
-        s_pix[p] = off;
     }
 
     // ---- epilogue: + bias, ReLU, -> LDS tile [pixel][cout] (16-byte slots XOR-swizzled by the pixel), -> 16-byte global stores
@@ -272,7 +278,7 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
     if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
     ConvArgs a;
     a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y;
-    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width;
+    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width; a.Bn = batch;
     a.out_pad = out_framed != 0; a.relu = relu != 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.m_tiles = a.n_tiles = 0;
