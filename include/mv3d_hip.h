@@ -374,6 +374,25 @@ int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_dev, const 
  * offsets: split the batch above that) and 16-byte aligned; MV3D_ERR_INVALID_ARG otherwise, before any launch. */
 int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
                      int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
+/* The same three entries on bfloat16 activations / weights (v_mfma_f32_32x32x16_bf16, f32 accumulate): the TRAINING trunk's
+ * forward and data-gradient convolutions (mv3d_tf_amd/trunk_train.py) -- f16's 5-bit exponent would need loss scaling. */
+int mv3d_conv3x3_bf16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
+                      int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
+int mv3d_maxpool2x2_bf16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
+int mv3d_frame_nhwc_bf16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
+                         void *stream);
+/* Gradient of ReLU + max_pool(2, 2, 2, 2, 'VALID') for the training trunk: y_framed = the pre-pool map (a ReLU output),
+ * g_pooled_framed = gradient w.r.t. the pooled map -> gy_framed = gradient w.r.t. y's pre-activation (first maximum of the
+ * window gets the gradient if it is > 0).  All framed bf16; rows / columns the pool dropped are left untouched (zero). */
+int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
+                             int channels, void *stream);
+/* Weight gradient of that convolution (csrc/conv3x3_wgrad.hip): dw[co][tap][ci] (c_out, 9, c_in) f32 = sum over the pixels of the
+ * batch of dy[pixel][co] * x[pixel + tap][ci]; x_framed (batch, height + 2, width + 2, c_in) bf16 = the layer's input,
+ * dy_framed (.., c_out) bf16 = the gradient w.r.t. its pre-activation with a ZERO frame; c_in, c_out multiples of 64.
+ * workspace: >= mv3d_conv3x3_wgrad_workspace_bytes(...) bytes, 16-byte aligned (split-K partial sums, folded in a fixed order). */
+size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out);
+int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, int batch, int height, int width, int c_in,
+                            int c_out, void *workspace, size_t workspace_bytes, void *stream);
 /* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */
 int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
 /* NHWC f32 (batch, height, width, channels) -> interior pixels, first `channels` channels of a framed f16 buffer

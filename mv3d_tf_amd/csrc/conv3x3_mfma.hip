@@ -19,8 +19,8 @@
 
 namespace mv3d_conv {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Vec { typedef T v8 __attribute__((ext_vector_type(8))); typedef T v4 __attribute__((ext_vector_type(4))); };
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -42,7 +42,8 @@ struct ConvArgs {
 // FIRST: the layer fed by the network input (conv1_1: 9 / 3 channels zero-padded to 16 = 32 B per pixel): a K step is FOUR taps
 // x 16 channels (12 tap slots, the last 3 with zero weights), so K = 3 steps instead of 9 x 64 mostly-zero channels.
 // STAGES: LDS stages of the operand pipeline; the DMA of K step kt + STAGES - 1 is issued while step kt is multiplied.
-template <int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
+// T: the 16-bit operand / activation type, _Float16 (serving) or __bf16 (the training trunk: f16's 5-bit exponent would need loss scaling)
+template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
 __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArgs a)
 {
 #if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
@@ -152,15 +153,18 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
         const char *const st = lds + (kt % STAGES) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            half8 fw[FC], fx[FP];
+            typename Vec<T>::v8 fw[FC], fx[FP];
 #pragma unroll
-            for (int i = 0; i < FC; ++i) fw[i] = *(const half8 *)(st + w_lds + i * 32 * BK_BYTES + koff[ks]);
+            for (int i = 0; i < FC; ++i) fw[i] = *(const typename Vec<T>::v8 *)(st + w_lds + i * 32 * BK_BYTES + koff[ks]);
 #pragma unroll
-            for (int j = 0; j < FP; ++j) fx[j] = *(const half8 *)(st + x_lds + j * 32 * BK_BYTES + koff[ks]);
+            for (int j = 0; j < FP; ++j) fx[j] = *(const typename Vec<T>::v8 *)(st + x_lds + j * 32 * BK_BYTES + koff[ks]);
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
-                for (int j = 0; j < FP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FP; ++j) {
+                    if constexpr (sizeof(T) == 2 && __is_same(T, _Float16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
     __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
@@ -195,10 +199,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
                 if (OUT_F32) {
                     *(f32x4 *)(lds + P * ROWB + ((((c0 >> 2)) ^ (P & (SLOTS - 1))) << 4)) = v;
                 } else {
-                    half4 hv;
+                    typename Vec<T>::v4 hv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[e] = (_Float16)v[e];
-                    *(half4 *)(lds + P * ROWB + (((c0 >> 3) ^ (P & (SLOTS - 1))) << 4) + (c0 & 7) * 2) = hv;
+                    for (int e = 0; e < 4; ++e) hv[e] = (T)v[e];
+                    *(typename Vec<T>::v4 *)(lds + P * ROWB + (((c0 >> 3) ^ (P & (SLOTS - 1))) << 4) + (c0 & 7) * 2) = hv;
                 }
             }
         }
@@ -215,10 +219,12 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
 #endif
 }
 
-// 2x2 / stride 2 max pool, VALID (floor), framed NHWC f16 -> framed NHWC f16; one thread = 8 channels of one output pixel
-__global__ __launch_bounds__(256) void maxpool2x2_f16_kernel(const half8 *__restrict__ x, half8 *__restrict__ y, int B, int H, int W, int C8,
-                                                              int Ho, int Wo)
+// 2x2 / stride 2 max pool, VALID (floor), framed NHWC -> framed NHWC; one thread = 8 channels of one output pixel
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const typename Vec<T>::v8 *__restrict__ x, typename Vec<T>::v8 *__restrict__ y, int B, int H,
+                                                          int W, int C8, int Ho, int Wo)
 {
+    typedef typename Vec<T>::v8 V;
     const long total = (long)B * Ho * Wo * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C8);
@@ -226,17 +232,54 @@ __global__ __launch_bounds__(256) void maxpool2x2_f16_kernel(const half8 *__rest
         const int xo = (int)(r % Wo);
         r /= Wo;
         const int yo = (int)(r % Ho), b = (int)(r / Ho);
-        const half8 *p = x + (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C8 + c;
-        const half8 v0 = p[0], v1 = p[C8], v2 = p[(long)(W + 2) * C8], v3 = p[(long)(W + 2) * C8 + C8];
-        y[(((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C8 + c] =
-            __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3));
+        const V *p = x + (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C8 + c;
+        const V v0 = p[0], v1 = p[C8], v2 = p[(long)(W + 2) * C8], v3 = p[(long)(W + 2) * C8 + C8];
+        V o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                 // (through f32: exact for a maximum, and there is no packed bf16 max)
+            const float m0 = fmaxf((float)v0[e], (float)v1[e]), m1 = fmaxf((float)v2[e], (float)v3[e]);
+            o[e] = (T)fmaxf(m0, m1);
+        }
+        y[(((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C8 + c] = o;
+    }
+}
+
+// Gradient of (ReLU ->) 2x2 max pool: y = the framed pre-pool map (a ReLU output), g = framed gradient w.r.t. the pooled map ->
+// gy = framed gradient w.r.t. the PRE-ACTIVATION of y: the window's FIRST maximum (row-major, torch's / MIOpen's choice) gets
+// the pooled gradient if it is > 0 (the ReLU mask), the other three positions 0.  Rows / columns the VALID pool drops are not
+// written (the owner zeroed the buffer once).  One thread = 8 channels of one pooled pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const typename Vec<T>::v8 *__restrict__ y, const typename Vec<T>::v8 *__restrict__ g,
+                                                              typename Vec<T>::v8 *__restrict__ gy, int B, int H, int W, int C8, int Ho, int Wo)
+{
+    typedef typename Vec<T>::v8 V;
+    const long total = (long)B * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long r = i / C8;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho), b = (int)(r / Ho);
+        const long base = (((long)b * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C8 + c, row = (long)(W + 2) * C8;
+        const V v0 = y[base], v1 = y[base + C8], v2 = y[base + row], v3 = y[base + row + C8];
+        const V gv = g[(((long)b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C8 + c];
+        V o0, o1, o2, o3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a0 = (float)v0[e], a1 = (float)v1[e], a2 = (float)v2[e], a3 = (float)v3[e];
+            const float m = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+            const T gg = m > 0.f ? gv[e] : (T)0.f, z = (T)0.f;
+            const int k = a0 == m ? 0 : (a1 == m ? 1 : (a2 == m ? 2 : 3));
+            o0[e] = k == 0 ? gg : z; o1[e] = k == 1 ? gg : z; o2[e] = k == 2 ? gg : z; o3[e] = k == 3 ? gg : z;
+        }
+        gy[base] = o0; gy[base + C8] = o1; gy[base + row] = o2; gy[base + row + C8] = o3;
     }
 }
 
 // NHWC f32 (B,H,W,C) -> framed NHWC f16 (B,H+2,W+2,Co), Co >= C: interior pixels, first C channels only (the frame and the
 // padding channels are zeroed once by the owner of the buffer)
-__global__ __launch_bounds__(256) void frame_f32_to_f16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int B, int H, int W, int C,
-                                                                int Co)
+template <typename T>
+__global__ __launch_bounds__(256) void frame_f32_kernel(const float *__restrict__ x, T *__restrict__ y, int B, int H, int W, int C, int Co)
 {
     const long total = (long)B * H * W * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -245,11 +288,11 @@ __global__ __launch_bounds__(256) void frame_f32_to_f16_kernel(const float *__re
         const int xx = (int)(r % W);
         r /= W;
         const int yy = (int)(r % H), b = (int)(r / H);
-        y[(((long)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Co + c] = (_Float16)x[i];
+        y[(((long)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * Co + c] = (T)x[i];
     }
 }
 
-template <int BM, int BN, int WP, int WC, int STAGES, bool FIRST>
+template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool FIRST>
 int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
 {
     ConvArgs b = a;
@@ -257,17 +300,18 @@ int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
     b.n_tiles = a.Cout / BN;
     const int grid = (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
     if (out_f32)
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
     else
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WP, WC, STAGES, false, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+        hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, false, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
     return mv3d_launch_status();
 }
 
 }  // namespace mv3d_conv
 using namespace mv3d_conv;
 
-extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
-                                int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream)
+template <typename T>
+static int conv3x3_entry(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
+                         int c_out, int out_framed, int out_f32, int relu, void *stream)
 {
     if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;   // 16-byte pieces
@@ -283,32 +327,73 @@ extern "C" int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, cons
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.m_tiles = a.n_tiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (first) return c_out % 128 == 0 ? launch_conv<128, 128, 2, 2, 2, true>(a, out_f32, s) : launch_conv<256, 64, 4, 1, 2, true>(a, out_f32, s);
+    if (first) return c_out % 128 == 0 ? launch_conv<T, 128, 128, 2, 2, 2, true>(a, out_f32, s) : launch_conv<T, 256, 64, 4, 1, 2, true>(a, out_f32, s);
     // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
     // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
-    if (c_out % 128 == 0) return launch_conv<128, 128, 2, 2, 2, false>(a, out_f32, s);
-    return launch_conv<256, 64, 4, 1, 2, false>(a, out_f32, s);
+    if (c_out % 128 == 0) return launch_conv<T, 128, 128, 2, 2, 2, false>(a, out_f32, s);
+    return launch_conv<T, 256, 64, 4, 1, 2, false>(a, out_f32, s);
 }
 
-extern "C" int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
+template <typename T>
+static int maxpool_entry(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
 {
     if (!x_framed || !y_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)x_framed | (uintptr_t)y_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
     const int Ho = height / 2, Wo = width / 2;
     const long total = (long)batch * Ho * Wo * (channels / 8);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(maxpool2x2_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const half8 *)x_framed, (half8 *)y_framed, batch,
-                       height, width, channels / 8, Ho, Wo);
+    hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const typename Vec<T>::v8 *)x_framed,
+                       (typename Vec<T>::v8 *)y_framed, batch, height, width, channels / 8, Ho, Wo);
     return mv3d_launch_status();
 }
 
-extern "C" int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
-                                   void *stream)
+template <typename T>
+static int frame_entry(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out, void *stream)
 {
     if (!x_nhwc || !y_framed || batch <= 0 || height <= 0 || width <= 0 || channels <= 0 || channels_out < channels) return MV3D_ERR_INVALID_ARG;
     const long total = (long)batch * height * width * channels;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(frame_f32_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nhwc, (_Float16 *)y_framed, batch, height, width,
-                       channels, channels_out);
+    hipLaunchKernelGGL(frame_f32_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_nhwc, (T *)y_framed, batch, height, width, channels,
+                       channels_out);
     return mv3d_launch_status();
+}
+
+extern "C" int mv3d_conv3x3_f16(const void *x, const void *w, const float *bias, void *y, int batch, int height, int width, int c_in, int c_out,
+                                int out_framed, int out_f32, int relu, void *stream)
+{
+    return conv3x3_entry<_Float16>(x, w, bias, y, batch, height, width, c_in, c_out, out_framed, out_f32, relu, stream);
+}
+extern "C" int mv3d_conv3x3_bf16(const void *x, const void *w, const float *bias, void *y, int batch, int height, int width, int c_in, int c_out,
+                                 int out_framed, int out_f32, int relu, void *stream)
+{
+    return conv3x3_entry<__bf16>(x, w, bias, y, batch, height, width, c_in, c_out, out_framed, out_f32, relu, stream);
+}
+extern "C" int mv3d_maxpool2x2_f16(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
+{
+    return maxpool_entry<_Float16>(x, y, batch, height, width, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_bf16(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
+{
+    return maxpool_entry<__bf16>(x, y, batch, height, width, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
+                                        int channels, void *stream)
+{
+    if (!y_framed || !g_pooled_framed || !gy_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
+    if ((((uintptr_t)y_framed | (uintptr_t)g_pooled_framed | (uintptr_t)gy_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
+    typedef Vec<__bf16>::v8 V;
+    const int Ho = height / 2, Wo = width / 2;
+    const long total = (long)batch * Ho * Wo * (channels / 8);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const V *)y_framed, (const V *)g_pooled_framed,
+                       (V *)gy_framed, batch, height, width, channels / 8, Ho, Wo);
+    return mv3d_launch_status();
+}
+extern "C" int mv3d_frame_nhwc_f16(const float *x, void *y, int batch, int height, int width, int channels, int channels_out, void *stream)
+{
+    return frame_entry<_Float16>(x, y, batch, height, width, channels, channels_out, stream);
+}
+extern "C" int mv3d_frame_nhwc_bf16(const float *x, void *y, int batch, int height, int width, int channels, int channels_out, void *stream)
+{
+    return frame_entry<__bf16>(x, y, batch, height, width, channels, channels_out, stream);
 }

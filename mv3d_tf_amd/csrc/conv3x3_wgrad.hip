@@ -1,0 +1,211 @@
+// Weight gradient of the 3x3 / stride 1 / SAME convolution for the training trunk (mv3d_tf_amd/trunk_train.py), on the gfx950
+// matrix cores: dW[co][tap][ci] = sum over pixels q of dY[q][co] * X[q + shift(tap)][ci], bf16 operands, f32 accumulation.
+// What it stands in for: the filter gradient TensorFlow computes for Network.conv (lib/networks/network.py:109-133) when
+// lib/fast_rcnn/train_mv.py:138-219 minimises the loss -- here in the mixed-precision trunk, never the fp32 parity contract.
+//
+// Both operands are the FRAMED NHWC maps of conv3x3_mfma.hip: q runs over the framed pixel index of the whole batch, the zero
+// frame of dY makes frame pixels contribute nothing, and a tap is the row shift (dy - 1) * (W + 2) + (dx - 1) of X.
+// The contraction index is the PIXEL, which NHWC stores strided; the MFMA wants 8 consecutive k per lane.  So both operand
+// tiles are staged as they lie in memory ([pixel][channel] rows, buffer_load ... lds) and read with ds_read_b64_tr_b16: 16 lanes
+// fetch a 4-pixel x 16-channel block and each receives ONE channel's 4 pixels (tools/tr_read_probe.hip shows the mapping).
+// For X the tap's dx is just a row offset of the read (+ dx rows), so one staged tile of 64 + 2 rows serves the three taps of a
+// filter row.
+//
+// Workgroup = (co tile of 128 | 64) x (64 input channels) x (filter row dy: 3 taps = 192 GEMM columns) x (a range of K steps of
+// 64 pixels); 4 waves = 2 (co halves) x 2 (column halves: 3 fragments of 32 columns each).  Partial sums of the K ranges go to
+// part[split][co][tap][ci] (f32) and are folded in split order by conv3x3_wgrad_reduce_kernel: deterministic, no atomics.
+#include "common.h"
+
+namespace mv3d_wgrad {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+struct WgradArgs {
+    const void *x, *dy;
+    float *part;
+    int Wp, Cin, Cout, Q, steps, steps_per_split, splits, ci_tiles;
+    unsigned x_bytes, dy_bytes;
+};
+
+#define WG_PIX 64              // pixels per K step
+#define WG_XROWS 72            // staged X rows per step: 64 + 2 (dx = 0..2), padded to 9 pieces of 8 rows
+#define WG_OOB 0x7ffffff0      // a byte offset beyond every buffer: the load returns zeros
+
+template <int BMC>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
+{
+#if __HIP_DEVICE_COMPILE__
+    constexpr int RB = BMC * 2;                                   // bytes of a dY tile row
+    constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WG_PIX / RPP;   // lanes per row, rows per 1-KB piece, dY pieces
+    constexpr int DY_BYTES = WG_PIX * RB, X_BYTES = WG_XROWS * 128, STAGE = DY_BYTES + X_BYTES;
+    constexpr int NP = DYP + 9;                                   // DMA pieces per step
+    constexpr int FA = BMC / 64;                                  // 32-co fragments per wave
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wb = wave >> 1;
+    // workgroup -> (split, dy, ci tile, co tile)
+    int id = blockIdx.x;
+    const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
+    const int dyr = id % 3; id /= 3;
+    const int split = id % a.splits;
+    const int co_t = id / a.splits;
+    const int co0 = co_t * BMC, ci0 = ci_t * 64;
+    const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    // per-lane parts of the DMA source offsets (everything in the vector offset: negative / past-the-end rows must fail the
+    // buffer's range check and read as zeros)
+    const int dyv = (lane / LPR) * a.Cout * 2 + (lane % LPR) * 16 + co0 * 2;
+    const int xv = (lane >> 3) * a.Cin * 2 + (lane & 7) * 16 + ci0 * 2;
+    const int xshift = (dyr - 1) * a.Wp - 1;
+    auto issue = [&](const int step, const int st) __attribute__((always_inline)) {
+        const int q0 = step * WG_PIX;
+        char *const base = lds + st * STAGE;
+#pragma unroll
+        for (int p0 = 0; p0 < (NP + 3) / 4; ++p0) {
+            const int p = p0 * 4 + wave;
+            if (p < DYP) {
+                const long long off = (long long)(q0 + p * RPP) * a.Cout * 2 + dyv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_t *)(base + p * 1024), 16, off < (long long)a.dy_bytes ? (int)off : WG_OOB, 0, 0, 0);
+            } else if (p < NP) {
+                const long long off = (long long)(q0 + xshift + (p - DYP) * 8) * a.Cin * 2 + xv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + DY_BYTES + (p - DYP) * 1024), 16,
+                                                         (off >= 0 && off < (long long)a.x_bytes) ? (int)off : WG_OOB, 0, 0, 0);
+            }
+        }
+    };
+
+    // transposing reads: lane (t = lane & 15, G = (lane >> 4) & 1, kg = lane >> 5) supplies row 8 kg + 4 h + (t >> 2), channels
+    // 16 G + 4 (t & 3) .. + 3 of the block and receives channel 16 G + t, pixels 8 kg + 4 h .. + 3: an MFMA operand (row / column
+    // lane & 31, k = 8 (lane >> 5) + 0..7) is two such reads (h = 0, 1)
+    const int t = lane & 15, G = (lane >> 4) & 1, kg = lane >> 5;
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * kg + 4 * h + (t >> 2), ch = 16 * G + 4 * (t & 3);
+        aoff[h] = row * RB + (wa * (BMC / 2) + ch) * 2;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n0 = 96 * wb + 32 * j;                      // GEMM column of the fragment: tap dx = n0 / 64, channel n0 % 64
+            boff[j][h] = DY_BYTES + (row + n0 / 64) * 128 + (n0 % 64 + ch) * 2;
+        }
+    }
+
+    f32x16 acc[FA][3];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < s1) issue(s + 1, (s + 1 - s0) & 1);
+        const char *const st = lds + ((s - s0) & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[FA], fb[3];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + i * 64 + aoff[0]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + i * 64 + aoff[1]));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fa[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * 128 + boff[j][0]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * 128 + boff[j][1]));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fb[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // partial sums: D layout = lane holds column (GEMM column n) lane & 31, rows (co) 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2
+    float *const out = a.part + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n0 = 96 * wb + 32 * j, tap = 3 * dyr + n0 / 64, ci = ci0 + n0 % 64 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                out[((size_t)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+#endif
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = part[i];
+        for (int k = 1; k < splits; ++k) s += part[(long)k * n + i];
+        dw[i] = s;
+    }
+}
+
+}  // namespace mv3d_wgrad
+using namespace mv3d_wgrad;
+
+static int wgrad_splits(int tiles, int steps)
+{
+    int ks = (1024 + tiles - 1) / tiles;                          // ~1024 workgroups: four per CU
+    if (ks > steps / 4) ks = steps / 4;                           // ... of at least 4 K steps each
+    return ks < 1 ? 1 : ks;
+}
+
+extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out)
+{
+    if (batch <= 0 || height <= 0 || width <= 0 || c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return 0;
+    const int bmc = c_out % 128 == 0 ? 128 : 64;
+    const int steps = (batch * (height + 2) * (width + 2) + WG_PIX - 1) / WG_PIX;
+    return (size_t)wgrad_splits((c_out / bmc) * (c_in / 64) * 3, steps) * c_out * 9 * c_in * 4;
+}
+
+extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, int batch, int height, int width, int c_in,
+                                       int c_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x_framed || !dy_framed || !dw || !workspace || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
+    if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    if ((((uintptr_t)x_framed | (uintptr_t)dy_framed | (uintptr_t)dw | (uintptr_t)workspace) & 15) != 0) return MV3D_ERR_INVALID_ARG;
+    const size_t need = mv3d_conv3x3_wgrad_workspace_bytes(batch, height, width, c_in, c_out);
+    if (workspace_bytes < need) return MV3D_ERR_WORKSPACE;
+    const size_t q = (size_t)batch * (height + 2) * (width + 2);
+    if (q * c_in * 2 >= 0x7fffff00u || q * c_out * 2 >= 0x7fffff00u) return MV3D_ERR_INVALID_ARG;    // 32-bit buffer offsets
+    const int bmc = c_out % 128 == 0 ? 128 : 64;
+    WgradArgs a;
+    a.x = x_framed; a.dy = dy_framed; a.part = (float *)workspace;
+    a.Wp = width + 2; a.Cin = c_in; a.Cout = c_out; a.Q = (int)q;
+    a.steps = (int)((q + WG_PIX - 1) / WG_PIX);
+    a.ci_tiles = c_in / 64;
+    const int tiles = (c_out / bmc) * a.ci_tiles * 3;
+    a.splits = wgrad_splits(tiles, a.steps);
+    a.steps_per_split = (a.steps + a.splits - 1) / a.splits;
+    a.x_bytes = (unsigned)(q * c_in * 2); a.dy_bytes = (unsigned)(q * c_out * 2);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = tiles * a.splits;
+    if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+    const long n = (long)c_out * 9 * c_in;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, a.part, dw, n,
+                       a.splits);
+    return mv3d_launch_status();
+}

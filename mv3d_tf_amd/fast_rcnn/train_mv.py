@@ -284,7 +284,7 @@ def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters
     return history
 
 
-def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3):
+def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False):
     """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
     VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
     frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
@@ -295,6 +295,7 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     np.random.seed(cfg.RNG_SEED + rank)
     net = get_network("MV3D_train_3view" if views == 3 else "MV3D_train")   # configs[2]: "full 3-view MV3D -- BEV/FV/RGB VGG16"
     net.amp_dtype = amp                                          # None = the reference's fp32; torch.bfloat16: autocast dense layers
+    net.mfma_trunk = bool(mfma)                                  # trunks' forward + backward on the bf16 MFMA kernel (trunk_train.py)
     params = net.parameters()
     opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
@@ -342,7 +343,8 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     nparam = sum(p.numel() for p in params)
     out = {"workload": "MV3D_train%s full step incl. torch (MIOpen / rocBLAS) VGG16 trunks + FC head: %d frames / GPU / step, "
                        "608x608x9 BEV + 375x1242x3 image%s, %s, Adam" % ("_3view" if views == 3 else "", frames_per_step,
-                                                                       " + 64x512x3 front view" if views == 3 else "", "fp32" if amp is None else "dense layers autocast to %s (fp32 master weights, f32 hot path)" % str(amp).split(".")[-1]),
+                                                                       " + 64x512x3 front view" if views == 3 else "", ("fp32" if amp is None else "dense layers autocast to %s (fp32 master weights, f32 hot path)" % str(amp).split(".")[-1])
+                                                                       + (", trunk convolutions forward + backward on the bf16 MFMA kernel" if mfma else "")),
            "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 2),
            "parameters": nparam, "gradient_bytes_per_step": bucketer.total_bytes(), "allreduce_buckets": len(bucketer.buckets),
            "allreduce": "RCCL, 25 MB buckets, last layer first, overlapping backward" if world > 1 else "none (1 GPU)"}

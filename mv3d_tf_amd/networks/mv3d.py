@@ -57,8 +57,9 @@ class MV3D:
         # optional reduced-precision DENSE layers (torch.float16 / torch.bfloat16 autocast of the VGG16 trunks, RPN convs and FC
         # head: BASELINE configs[4] "fp16 VGG16"); the hot-path layers always get and give f32.  None = the reference's fp32.
         self.amp_dtype = None
-        # serve the 3x3 convolutions (trunks + rpn_conv/3x3) through the hand-written f16 MFMA kernel (mv3d_tf_amd.trunk): forward
-        # only, f16 operands / f32 accumulation, the serving configuration next to amp_dtype = torch.float16
+        # the 3x3 convolutions on the hand-written MFMA kernel.  TEST graph / no_grad: trunks + rpn_conv/3x3 in f16 (mv3d_tf_amd.trunk,
+        # forward only, next to amp_dtype = torch.float16).  TRAIN graph with gradients: the trunks' forward AND backward in bf16
+        # with fp32 master weights (mv3d_tf_amd.trunk_train, next to amp_dtype = torch.bfloat16 for the other dense layers).
         self.mfma_trunk = False
         self._mfma = None
         self._side = None
@@ -229,7 +230,19 @@ class MV3D:
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
-        if self.mfma_trunk:
+        if self.mfma_trunk and self.phase == "TRAIN" and torch.is_grad_enabled():
+            # mixed-precision training trunks: forward and backward convolutions on the bf16 MFMA kernel (mv3d_tf_amd.trunk_train)
+            from ..trunk_train import trunk as mfma_train_trunk
+            bev_nhwc = mfma_train_trunk(_VGG, L["lidar_bv_data"], self.params, "")
+            L["conv5_3"] = bev_nhwc
+            L["conv5_3_2"] = mfma_train_trunk(_VGG, L["image_data"], self.params, "_2")
+            if self.views == 3:
+                L["conv5_3_3"] = mfma_train_trunk(_VGG, L["lidar_fv_data"], self.params, "_3")
+            rpn = self._conv(bev_nhwc.permute(0, 3, 1, 2), "rpn_conv/3x3")
+            L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
+            score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
+            L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
+        elif self.mfma_trunk:
             score, L["rpn_bbox_pred"] = self._mfma_trunks(L)
         else:
             bev = self._trunk(to_nchw(L["lidar_bv_data"]), "")

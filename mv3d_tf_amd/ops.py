@@ -384,52 +384,66 @@ def rcnn_loss(cls_score, labels, bbox_pred, bbox_targets, sigma=3.0, want_grad=T
 
 
 # ------------------------------------------------------------------ the serving trunk's contraction (f16 MFMA)
-def pack_conv3x3_weights(w_oihw, c_in_pad=None):
-    """torch (O, I, 3, 3) f32 -> (O, 9 * I') f16 with k = (ky * 3 + kx) * I' + c, I' = I zero-padded to c_in_pad."""
+# (the `_f16` functions take float16 or bfloat16 tensors and pick the C entry by the tensor's dtype: f16 = the serving trunk,
+# bf16 = the training trunk)
+def _half_entry(stem, dtype):
+    if dtype == torch.float16:
+        return getattr(lib(), stem + "_f16"), stem + "_f16"
+    if dtype == torch.bfloat16:
+        return getattr(lib(), stem + "_bf16"), stem + "_bf16"
+    raise TypeError("float16 or bfloat16 tensors expected, got %s" % dtype)
+
+
+def pack_conv3x3_weights(w_oihw, c_in_pad=None, dtype=torch.float16):
+    """torch (O, I, 3, 3) f32 -> (O, 9 * I') f16 / bf16 with k = (ky * 3 + kx) * I' + c, I' = I zero-padded to c_in_pad."""
     O, I = w_oihw.shape[:2]
     Ip = c_in_pad or I
-    w = torch.zeros((O, 3, 3, Ip), dtype=torch.float16, device=w_oihw.device)
-    w[..., :I] = w_oihw.detach().permute(0, 2, 3, 1).to(torch.float16)
+    w = torch.zeros((O, 3, 3, Ip), dtype=dtype, device=w_oihw.device)
+    w[..., :I] = w_oihw.detach().permute(0, 2, 3, 1).to(dtype)
     return w.reshape(O, 9 * Ip).contiguous()
 
 
-def pack_conv3x3_weights_input_layer(w_oihw):
-    """the input layer's packing (c_in <= 16, see mv3d_conv3x3_f16): (O, I, 3, 3) f32 -> (O, 12 * 16) f16, k = 16 * tap + c"""
+def pack_conv3x3_weights_input_layer(w_oihw, dtype=torch.float16):
+    """the input layer's packing (c_in <= 16, see mv3d_conv3x3_f16): (O, I, 3, 3) f32 -> (O, 12 * 16), k = 16 * tap + c"""
     O, I = w_oihw.shape[:2]
-    w = torch.zeros((O, 12, 16), dtype=torch.float16, device=w_oihw.device)
-    w[:, :9, :I] = w_oihw.detach().permute(0, 2, 3, 1).reshape(O, 9, I).to(torch.float16)
+    w = torch.zeros((O, 12, 16), dtype=dtype, device=w_oihw.device)
+    w[:, :9, :I] = w_oihw.detach().permute(0, 2, 3, 1).reshape(O, 9, I).to(dtype)
     return w.reshape(O, 192).contiguous()
 
 
-def framed_buffer(B, H, W, C, device):
-    """zeroed (B, H + 2, W + 2, C) f16: the kernels below only ever write its interior, so the SAME-padding frame stays 0"""
-    return torch.zeros((B, H + 2, W + 2, C), dtype=torch.float16, device=device)
+def framed_buffer(B, H, W, C, device, dtype=torch.float16):
+    """zeroed (B, H + 2, W + 2, C): the kernels below only ever write its interior, so the SAME-padding frame stays 0"""
+    return torch.zeros((B, H + 2, W + 2, C), dtype=dtype, device=device)
 
 
 def frame_nhwc_f16(x_nhwc, out):
-    """(B, H, W, C) f32 -> interior / first C channels of the framed f16 buffer `out` (B, H + 2, W + 2, C' >= C)"""
+    """(B, H, W, C) f32 -> interior / first C channels of the framed f16 / bf16 buffer `out` (B, H + 2, W + 2, C' >= C)"""
     B, H, W, Cc = x_nhwc.shape
-    check(lib().mv3d_frame_nhwc_f16(_ptr(x_nhwc), _ptr(out), B, H, W, Cc, out.shape[3], _stream()), "mv3d_frame_nhwc_f16")
+    fn, name = _half_entry("mv3d_frame_nhwc", out.dtype)
+    check(fn(_ptr(x_nhwc), _ptr(out), B, H, W, Cc, out.shape[3], _stream()), name)
     return out
 
 
 def conv3x3_f16(x_framed, w_packed, bias, out=None, out_framed=True, out_f32=False, relu=True):
-    """x_framed (B, H + 2, W + 2, Cin) f16, w_packed (Cout, 9 Cin) f16, bias (Cout) f32 -> framed f16 (default), or the bare
-    (B, H, W, Cout) map in f16 / f32."""
+    """x_framed (B, H + 2, W + 2, Cin) f16 / bf16, w_packed (Cout, 9 Cin) same type, bias (Cout) f32 -> framed map of that type
+    (default), or the bare (B, H, W, Cout) map in that type / f32."""
     B, Hp, Wp, cin = x_framed.shape
     H, W, cout = Hp - 2, Wp - 2, w_packed.shape[0]
+    if w_packed.dtype != x_framed.dtype:
+        raise TypeError("activations %s, weights %s" % (x_framed.dtype, w_packed.dtype))
+    fn, name = _half_entry("mv3d_conv3x3", x_framed.dtype)
     if out is None:
         if out_framed:
-            out = framed_buffer(B, H, W, cout, x_framed.device)
+            out = framed_buffer(B, H, W, cout, x_framed.device, x_framed.dtype)
         else:
-            out = torch.empty((B, H, W, cout), dtype=torch.float32 if out_f32 else torch.float16, device=x_framed.device)
+            out = torch.empty((B, H, W, cout), dtype=torch.float32 if out_f32 else x_framed.dtype, device=x_framed.device)
     # the kernel addresses each buffer with 32-bit offsets: frames are independent, so a larger batch goes in chunks
     per_frame = max(Hp * Wp * cin * 2, out[0].numel() * out.element_size())
     step = max(1, min(B, (2 ** 31 - 1) // per_frame))
     for b0 in range(0, B, step):
         nb = min(step, B - b0)
-        check(lib().mv3d_conv3x3_f16(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout,
-                                     int(out_framed), int(out_f32), int(relu), _stream()), "mv3d_conv3x3_f16")
+        check(fn(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout, int(out_framed),
+                 int(out_f32), int(relu), _stream()), name)
     return out
 
 
@@ -437,7 +451,30 @@ def maxpool2x2_f16(x_framed, out=None):
     B, Hp, Wp, Cc = x_framed.shape
     H, W = Hp - 2, Wp - 2
     if out is None:
-        out = framed_buffer(B, H // 2, W // 2, Cc, x_framed.device)
-    check(lib().mv3d_maxpool2x2_f16(_ptr(x_framed), _ptr(out), B, H, W, Cc, _stream()), "mv3d_maxpool2x2_f16")
+        out = framed_buffer(B, H // 2, W // 2, Cc, x_framed.device, x_framed.dtype)
+    fn, name = _half_entry("mv3d_maxpool2x2", x_framed.dtype)
+    check(fn(_ptr(x_framed), _ptr(out), B, H, W, Cc, _stream()), name)
     return out
 
+
+
+def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
+    """gradient of ReLU + 2x2 max pool into the zero-initialised framed bf16 buffer `out` (same shape as y_framed)"""
+    B, Hp, Wp, Cc = y_framed.shape
+    check(lib().mv3d_maxpool2x2_bwd_bf16(_ptr(y_framed), _ptr(g_pooled_framed), _ptr(out), B, Hp - 2, Wp - 2, Cc, _stream()),
+          "mv3d_maxpool2x2_bwd_bf16")
+    return out
+
+
+def conv3x3_wgrad_bf16(x_framed, dy_framed):
+    """x_framed (B, H + 2, W + 2, Cin) bf16, dy_framed (B, H + 2, W + 2, Cout) bf16 with a zero frame -> (Cout, 9, Cin) f32"""
+    B, Hp, Wp, cin = x_framed.shape
+    cout = dy_framed.shape[3]
+    need = lib().mv3d_conv3x3_wgrad_workspace_bytes(B, Hp - 2, Wp - 2, cin, cout)
+    if need == 0:
+        raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, "mv3d_conv3x3_wgrad_workspace_bytes")
+    ws = torch.empty(need, dtype=torch.uint8, device=x_framed.device)
+    dw = torch.empty((cout, 9, cin), dtype=torch.float32, device=x_framed.device)
+    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), B, Hp - 2, Wp - 2, cin, cout, _ptr(ws), need, _stream()),
+          "mv3d_conv3x3_wgrad_bf16")
+    return dw

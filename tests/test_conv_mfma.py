@@ -98,6 +98,37 @@ def test_maxpool_and_two_layer_chain(gpu):
     assert float((y2 - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+def test_bf16_entries_match_fp32_reference(gpu):
+    """the training trunk's type: bf16 operands (8 mantissa bits), f32 accumulate; vs torch fp32 on the bf16-rounded operands:
+    <= 1e-2 x max|want| for bf16 maps (one output rounding, 2^-8), 2e-5 for f32 maps; pool exact"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(77)
+    bf = torch.bfloat16
+    B, H, W, cin, cout = 2, 38, 50, 128, 256
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), device="cuda", generator=g)
+    want = torch.relu(torch.nn.functional.conv2d(x.to(bf).float().permute(0, 3, 1, 2), w.to(bf).float(), b, padding=1)).permute(0, 2, 3, 1)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, x.device, bf))
+    y16 = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w, dtype=bf), b)
+    y32 = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w, dtype=bf), b, out_framed=False, out_f32=True)
+    p16 = ops.maxpool2x2_f16(y16)
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    assert y16.dtype == bf and float((y16[:, 1:-1, 1:-1].float() - want).abs().max()) <= 1e-2 * scale
+    assert float((y32 - want).abs().max()) <= 2e-5 * scale
+    wp = torch.nn.functional.max_pool2d(y16[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert p16.dtype == bf and torch.equal(p16[:, 1:-1, 1:-1].float(), wp)
+    # the input-layer variant
+    x9 = torch.randn((1, 20, 24, 9), device="cuda", generator=g)
+    w9 = torch.randn((64, 9, 3, 3), device="cuda", generator=g) * 0.3
+    b9 = torch.zeros(64, device="cuda")
+    want9 = torch.relu(torch.nn.functional.conv2d(x9.to(bf).float().permute(0, 3, 1, 2), w9.to(bf).float(), b9, padding=1)).permute(0, 2, 3, 1)
+    got9 = ops.conv3x3_f16(ops.frame_nhwc_f16(x9, ops.framed_buffer(1, 20, 24, 16, "cuda", bf)), ops.pack_conv3x3_weights_input_layer(w9, bf), b9)
+    assert float((got9[:, 1:-1, 1:-1].float() - want9).abs().max()) <= 1e-2 * float(want9.abs().max())
+
+
 def test_large_batches_are_split_into_chunks(gpu, monkeypatch):
     """buffers beyond the kernel's 32-bit offsets: the wrapper runs the frames in chunks (here forced by a tiny limit)"""
     torch = gpu
@@ -163,3 +194,57 @@ def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu):
     net.mfma_trunk = True
     with pytest.raises(RuntimeError):
         net.forward(feed)                                  # grad mode + trainable parameters: the serving trunk refuses
+
+
+def _torch_trunk(torch, layers, x_nhwc, params, amp=False):
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+        x = x_nhwc.permute(0, 3, 1, 2)
+        for name, _, pool in layers:
+            w, b = params[name]
+            x = torch.relu(torch.nn.functional.conv2d(x, w, b, padding=1))
+            if pool:
+                x = torch.nn.functional.max_pool2d(x, 2, 2)
+        return x.permute(0, 2, 3, 1).float()
+
+
+@pytest.mark.parametrize("wgrad", ["torch", "mfma"])
+def test_training_trunk_gradients_match_torch_autograd(gpu, wgrad):
+    """mv3d_tf_amd.trunk_train.TrunkFunction (bf16 activations / gradients, f32 accumulation) against torch autograd of the same
+    trunk (5 layers, 2 pools) in fp32.  A bf16 pipeline differs from fp32 by more than rounding: ReLU masks and pool routes of
+    near-ties flip, so even torch's own bf16 autocast only reaches cosine 0.988 - 0.999 per gradient tensor here
+    (tools/trunk_grad_debug.py).  The bar: every weight / bias gradient has cosine >= 0.98 with the fp32 gradient AND is no
+    further from it than torch's bf16 autocast gradient is (cosine within 0.003); a wrong tap flip / channel swap / pool routing
+    gives a cosine near 0."""
+    torch = gpu
+    from mv3d_tf_amd import trunk_train
+    if wgrad == "mfma" and not hasattr(trunk_train, "wgrad_mfma"):
+        pytest.skip("weight gradient on the MFMA kernel not built")
+    layers = [("a", 64, False), ("b", 64, True), ("c", 128, False), ("d", 128, True), ("e", 256, False)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    params, cin = {}, 9
+    for name, cout, _ in layers:
+        w = (torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5).requires_grad_(True)
+        b = (torch.randn((cout,), device="cuda", generator=g) * 0.1).requires_grad_(True)
+        params[name] = [w, b]
+        cin = cout
+    x = torch.randn((2, 42, 54, 9), device="cuda", generator=g)            # 42 x 54 -> 21 x 27 -> 10 x 13 (an odd size is dropped)
+    R = torch.randn((2, 10, 13, 256), device="cuda", generator=g)
+
+    def grads(fn):
+        for v in params.values():
+            v[0].grad = v[1].grad = None
+        out = fn()
+        (out * R).sum().backward()
+        return out.detach(), {k: (v[0].grad.clone().float(), v[1].grad.clone().float()) for k, v in params.items()}
+
+    o32, g32 = grads(lambda: _torch_trunk(torch, layers, x, params))
+    _, gam = grads(lambda: _torch_trunk(torch, layers, x, params, amp=True))
+    fn = trunk_train._wgrad_torch if wgrad == "torch" else trunk_train.wgrad_mfma
+    out, got = grads(lambda: trunk_train.trunk(layers, x, params, "", wgrad=fn))
+    torch.cuda.synchronize()
+    assert out.shape == o32.shape and float((out - o32).abs().max()) <= 0.04 * float(o32.abs().max())
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))
+    for name, _, _ in layers:
+        for k in (0, 1):
+            c_mine, c_amp = cos(got[name][k], g32[name][k]), cos(gam[name][k], g32[name][k])
+            assert c_mine >= 0.98 and c_mine >= c_amp - 0.003, (name, k, c_mine, c_amp)
