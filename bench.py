@@ -450,6 +450,18 @@ def main():
             from mv3d_tf_amd.fast_rcnn import train_mv
             sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
             torch.cuda.empty_cache()
+            # the same step with the trunks' forward AND backward convolutions on this library's bf16 MFMA kernels (mixed precision:
+            # a lower precision than the reference's fp32 training, reported next to it)
+            mp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=torch.bfloat16, mfma=True)
+            torch.cuda.empty_cache()
+            if rank == 0:
+                from mv3d_tf_amd import trunk_train
+                from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
+                sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
+                                                         "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.empty_cache()
             from mv3d_tf_amd.fast_rcnn import test_mv
             sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
             torch.cuda.empty_cache()

@@ -63,6 +63,7 @@ class MV3D:
         self.mfma_trunk = False
         self._mfma = None
         self._side = None
+        self._train_pool = None
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -232,12 +233,14 @@ class MV3D:
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
         if self.mfma_trunk and self.phase == "TRAIN" and torch.is_grad_enabled():
             # mixed-precision training trunks: forward and backward convolutions on the bf16 MFMA kernel (mv3d_tf_amd.trunk_train)
-            from ..trunk_train import trunk as mfma_train_trunk
-            bev_nhwc = mfma_train_trunk(_VGG, L["lidar_bv_data"], self.params, "")
+            from ..trunk_train import BufferPool, trunk as mfma_train_trunk
+            if self._train_pool is None:
+                self._train_pool = BufferPool()         # (one forward / backward pair per network in flight)
+            bev_nhwc = mfma_train_trunk(_VGG, L["lidar_bv_data"], self.params, "", pool=self._train_pool)
             L["conv5_3"] = bev_nhwc
-            L["conv5_3_2"] = mfma_train_trunk(_VGG, L["image_data"], self.params, "_2")
+            L["conv5_3_2"] = mfma_train_trunk(_VGG, L["image_data"], self.params, "_2", pool=self._train_pool)
             if self.views == 3:
-                L["conv5_3_3"] = mfma_train_trunk(_VGG, L["lidar_fv_data"], self.params, "_3")
+                L["conv5_3_3"] = mfma_train_trunk(_VGG, L["lidar_fv_data"], self.params, "_3", pool=self._train_pool)
             rpn = self._conv(bev_nhwc.permute(0, 3, 1, 2), "rpn_conv/3x3")
             L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
             score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()

@@ -31,49 +31,71 @@ def _dgrad_weights(w_oihw):
 
 
 def _wgrad_torch(x_framed, dy_framed, c_in):
-    """weight gradient through torch (MIOpen): (O, c_in, 3, 3) f32"""
+    """weight gradient through torch (MIOpen): (O, c_in, 3, 3) f32 -- the yardstick of tests / tools, not the product path"""
     x = x_framed[:, 1:-1, 1:-1, :c_in].permute(0, 3, 1, 2)
     dy = dy_framed[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
     return torch.nn.grad.conv2d_weight(x, (dy.shape[1], c_in, 3, 3), dy, padding=1).float()
 
 
 def wgrad_mfma(x_framed, dy_framed, c_in):
-    """weight gradient on the MFMA kernel (csrc/conv3x3_wgrad.hip); the input layer (9 / 3 channels, 0.1 % of the trunk's
-    flops, a K dimension the 64-channel tiles do not cover) stays with torch"""
-    if x_framed.shape[3] % 64:
-        return _wgrad_torch(x_framed, dy_framed, c_in)
+    """weight gradient on the MFMA kernel (csrc/conv3x3_wgrad.hip): (O, c_in, 3, 3) f32.  (The input layer's 9 / 3 channels sit
+    in a 64-channel framed buffer during training, so it goes through the same kernel; its padding channels are cut off here.)"""
     dw = ops.conv3x3_wgrad_bf16(x_framed, dy_framed)                 # (O, 9, I) f32
-    return dw.reshape(dw.shape[0], 3, 3, dw.shape[2]).permute(0, 3, 1, 2)
+    return dw.reshape(dw.shape[0], 3, 3, dw.shape[2])[..., :c_in].permute(0, 3, 1, 2)
+
+
+class BufferPool:
+    """Framed buffers of a training trunk, kept across steps (their zero frames are written once).  ONE forward / backward pair
+    per pool may be in flight: the next forward overwrites the activations the backward pass reads."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, tag, B, H, W, C, dev):
+        key = (tag, B, H, W, C)
+        buf = self._buf.get(key)
+        if buf is None:
+            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev, BF)
+        return buf
+
+
+class _NoPool:
+    @staticmethod
+    def get(tag, B, H, W, C, dev):
+        return ops.framed_buffer(B, H, W, C, dev, BF)
 
 
 class TrunkFunction(torch.autograd.Function):
-    """apply(layers, wgrad, x_nhwc_f32, w_0, b_0, ..., w_12, b_12) -> conv5_3 (B, H', W', 512) f32;
-    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> (O, c_in, 3, 3) f32"""
+    """apply(layers, wgrad, pool, x_nhwc_f32, w_0, b_0, ..., w_12, b_12) -> conv5_3 (B, H', W', 512) f32;
+    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> (O, c_in, 3, 3) f32,
+    pool = (BufferPool | None, tag)"""
 
     @staticmethod
-    def forward(ctx, layers, wgrad, x_nhwc, *wb):
+    def forward(ctx, layers, wgrad, pool_tag, x_nhwc, *wb):
         B, H, W, c0 = x_nhwc.shape
         dev = x_nhwc.device
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), ops.framed_buffer(B, H, W, 16, dev, BF))
+        bufs, tag = (pool_tag[0] or _NoPool), pool_tag[1]
+        # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
+        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, 64, dev))
         saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
         n = len(layers)
         out = None
         for i, (_, cout, pool) in enumerate(layers):
             w, b = wb[2 * i], wb[2 * i + 1]
-            wp = ops.pack_conv3x3_weights_input_layer(w, BF) if i == 0 else ops.pack_conv3x3_weights(w, dtype=BF)
+            wp = ops.pack_conv3x3_weights(w, 64 if i == 0 else None, dtype=BF)
             bias = b.detach().float().contiguous()
             if i == n - 1:
                 out = ops.conv3x3_f16(x, wp, bias, out_framed=False, out_f32=True)
                 saved.append((x, None, H, W))
                 break
-            y = ops.conv3x3_f16(x, wp, bias)
+            y = ops.conv3x3_f16(x, wp, bias, out=bufs.get("%s/y%d" % (tag, i), B, H, W, cout, dev))
             saved.append((x, y, H, W))
             if pool:
                 H, W = H // 2, W // 2
-                x = ops.maxpool2x2_f16(y)
+                x = ops.maxpool2x2_f16(y, out=bufs.get("%s/p%d" % (tag, i), B, H, W, cout, dev))
             else:
                 x = y
-        ctx.layers, ctx.wgrad, ctx.saved, ctx.c0 = layers, wgrad, saved, c0
+        ctx.layers, ctx.wgrad, ctx.saved, ctx.c0, ctx.bufs, ctx.tag = layers, wgrad, saved, c0, bufs, tag
         ctx.weights = [wb[2 * i] for i in range(n)]
         ctx.save_for_backward(out)
         return out
@@ -87,28 +109,70 @@ class TrunkFunction(torch.autograd.Function):
         dev = g.device
         grads = [None] * (2 * n)
         # gradient w.r.t. conv5_3's pre-activation, framed
+        bufs, tag = ctx.bufs, ctx.tag
         x_last, _, H, W = saved[n - 1]
-        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), ops.framed_buffer(B, H, W, layers[n - 1][1], dev, BF))
+        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev))
+        zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
         for i in range(n - 1, -1, -1):
             x_in, _, H, W = saved[i]
             c_in = ctx.c0 if i == 0 else layers[i - 1][1]
             grads[2 * i] = ctx.wgrad(x_in, dy, c_in)
-            grads[2 * i + 1] = dy[:, 1:-1, 1:-1].float().sum((0, 1, 2))
+            grads[2 * i + 1] = dy.sum((0, 1, 2), dtype=torch.float32)            # (the frame is zero)
             if i == 0:
                 break
-            zero_bias = torch.zeros(c_in, dtype=torch.float32, device=dev)
-            dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, relu=False)      # framed bf16, c_in channels
+            # two gradient buffers per resolution alternate (dy of layer i is read while dx = dy of layer i - 1 is written)
+            dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, relu=False,
+                                 out=bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev))          # framed bf16, c_in channels
             _, y_prev, Hp, Wp_ = saved[i - 1]
             if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i
-                dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, ops.framed_buffer(B, Hp, Wp_, c_in, dev, BF))
+                dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev))
             else:
                 dy = dx.mul_(y_prev > 0)               # ReLU mask (the frame of both is zero)
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
-def trunk(layers, x_nhwc, params, suffix, wgrad=wgrad_mfma):
-    """conv1_1<suffix> .. conv5_3<suffix> of a TRAIN graph: params = {name: [w, b]} (fp32, OIHW)"""
+def trunk(layers, x_nhwc, params, suffix, wgrad=wgrad_mfma, pool=None):
+    """conv1_1<suffix> .. conv5_3<suffix> of a TRAIN graph: params = {name: [w, b]} (fp32, OIHW); pool: a BufferPool that keeps
+    the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call"""
     wb = []
     for stem, _, _ in layers:
         wb += list(params[stem + suffix])
-    return TrunkFunction.apply(layers, wgrad, x_nhwc, *wb)
+    return TrunkFunction.apply(layers, wgrad, (pool, "trunk" + suffix), x_nhwc, *wb)
+
+
+def bench_wgrad_layers(vgg, batch=2, reps=3):
+    """Roofline entry of the weight-gradient kernel for bench.py: every trunk layer of the 3-view TRAIN graph it serves (conv1_2 ..
+    conv5_3 of the three trunks; the 64-channel-padded input layers are left out of the flop count) at the training batch, each
+    timed with HIP events on the launch stream over `reps` launches (kernel + its split-K reduce) after one warm-up.
+    achieved = 2 * B*H*W * c_out * 9 * c_in / time; peak = the dense bf16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s)."""
+    from .trunk import serving_layers
+    dev = torch.device("cuda")
+    tot_fl, tot_ms, n = 0.0, 0.0, 0
+    best = (None, 0.0, 0.0)
+    for name, H, W, cin, cout in serving_layers(vgg):
+        if cin < 64 or name.startswith("rpn_conv"):
+            continue
+        x = ops.framed_buffer(batch, H, W, cin, dev, BF)
+        x[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cin), device=dev, dtype=BF)
+        dy = ops.framed_buffer(batch, H, W, cout, dev, BF)
+        dy[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cout), device=dev, dtype=BF)
+        ops.conv3x3_wgrad_bf16(x, dy)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv3x3_wgrad_bf16(x, dy)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * batch * H * W * cout * 9 * cin
+        tot_fl += fl
+        tot_ms += ms
+        n += 1
+        if fl / ms / 1e9 > best[1]:
+            best = (name, fl / ms / 1e9, ms)
+    ach = tot_fl / tot_ms / 1e9
+    return {"kernel": "conv3x3_wgrad_kernel + reduce (v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16; the %d weight gradients of the "
+                      "3-view training trunks, batch %d)" % (n, batch),
+            "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": n * reps,
+            "best_layer": {"name": best[0], "tflops": round(best[1], 1), "ms": round(best[2], 4)}, "traffic": None}
