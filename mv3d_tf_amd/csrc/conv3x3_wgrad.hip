@@ -63,8 +63,14 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.dy_bytes, 0x00020000);
     // per-lane parts of the DMA source offsets (everything in the vector offset: negative / past-the-end rows must fail the
     // buffer's range check and read as zeros)
-    const int dyv = (lane / LPR) * a.Cout * 2 + (lane % LPR) * 16 + co0 * 2;
-    const int xv = (lane >> 3) * a.Cin * 2 + (lane & 7) * 16 + ci0 * 2;
+    // LDS image: rows of RB bytes whose 64-byte granules are XOR-swizzled by the row (applied HERE, on the source column: the DMA
+    // image is lane-linear), so that the 4 rows x 64 B a transposing read touches per pass fall into the four 64-byte bank groups:
+    // 256-byte rows: granule ^= row & 3; 128-byte rows: granule ^= (row >> 1) & 1.  Unswizzled the reads measured 64 % conflict cycles.
+    const int dy_col = RB == 256 ? ((((lane & 15) >> 2) ^ (lane >> 4)) << 6) | ((lane & 3) << 4)
+                                 : ((((lane & 7) >> 2) ^ ((lane >> 4) & 1)) << 6) | ((lane & 3) << 4);
+    const int x_col = ((((lane & 7) >> 2) ^ ((lane >> 4) & 1)) << 6) | ((lane & 3) << 4);
+    const int dyv = (lane / LPR) * a.Cout * 2 + dy_col + co0 * 2;
+    const int xv = (lane >> 3) * a.Cin * 2 + x_col + ci0 * 2;
     const int xshift = (dyr - 1) * a.Wp - 1;
     auto issue = [&](const int step, const int st) __attribute__((always_inline)) {
         const int q0 = step * WG_PIX;
@@ -87,15 +93,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
     // 16 G + 4 (t & 3) .. + 3 of the block and receives channel 16 G + t, pixels 8 kg + 4 h .. + 3: an MFMA operand (row / column
     // lane & 31, k = 8 (lane >> 5) + 0..7) is two such reads (h = 0, 1)
     const int t = lane & 15, G = (lane >> 4) & 1, kg = lane >> 5;
-    int aoff[2], boff[3][2];
+    auto phys = [](const int row, const int b, const int rb) __attribute__((always_inline)) {      // swizzled byte offset of (row, byte column b)
+        const int f = rb == 256 ? (row & 3) : ((row >> 1) & 1);
+        return row * rb + ((((b >> 6) ^ f) << 6) | (b & 63));
+    };
+    int aoff[FA][2], boff[3][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int row = 8 * kg + 4 * h + (t >> 2), ch = 16 * G + 4 * (t & 3);
-        aoff[h] = row * RB + (wa * (BMC / 2) + ch) * 2;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) aoff[i][h] = phys(row, (wa * (BMC / 2) + 32 * i + ch) * 2, RB);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int n0 = 96 * wb + 32 * j;                      // GEMM column of the fragment: tap dx = n0 / 64, channel n0 % 64
-            boff[j][h] = DY_BYTES + (row + n0 / 64) * 128 + (n0 % 64 + ch) * 2;
+            boff[j][h] = DY_BYTES + phys(row + n0 / 64, (n0 % 64 + ch) * 2, 128);
         }
     }
 
@@ -118,8 +129,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
             bf16x8 fa[FA], fb[3];
 #pragma unroll
             for (int i = 0; i < FA; ++i) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + i * 64 + aoff[0]));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + i * 64 + aoff[1]));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + aoff[i][0]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(st + ks * 16 * RB + aoff[i][1]));
                 const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 fa[i] = __builtin_bit_cast(bf16x8, v);
             }
