@@ -378,6 +378,11 @@ int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bi
  * forward and data-gradient convolutions (mv3d_tf_amd/trunk_train.py) -- f16's 5-bit exponent would need loss scaling. */
 int mv3d_conv3x3_bf16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
                       int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
+/* y = (conv3x3(x) + bias) where gate > 0, else 0: the data-gradient step of the training trunk in one launch (x = the framed gradient
+ * of the layer above, w = that layer's filter flipped with its channel axes swapped, gate_framed = this layer's framed ReLU
+ * output (batch, height + 2, width + 2, c_out) bf16); framed bf16 output, no ReLU of its own. */
+int mv3d_conv3x3_gated_bf16(const void *x_framed, const void *w_packed, const float *bias, const void *gate_framed, void *y,
+                            int batch, int height, int width, int c_in, int c_out, void *stream);
 int mv3d_maxpool2x2_bf16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
 int mv3d_frame_nhwc_bf16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
                          void *stream);

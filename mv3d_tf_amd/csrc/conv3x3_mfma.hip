@@ -30,6 +30,7 @@ struct ConvArgs {
     const void *x;
     const void *w;
     const float *bias;
+    const void *mask;             // optional, same layout as a framed 16-bit y: y = 0 where mask <= 0 (a ReLU's gradient gate)
     void *y;
     int H, W, Cin, Cout, M, HW, Bn;
     int out_pad, relu;
@@ -213,8 +214,17 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     for (int u = tid; u < BM * SLOTS; u += NT) {
         const int P = u / SLOTS, s = u % SLOTS;
         const unsigned off = s_pix[P];
-        const u32x4 v = *(const u32x4 *)(lds + P * ROWB + ((s ^ (P & (SLOTS - 1))) << 4));
-        if (off != 0xFFFFFFFFu) *(u32x4 *)(yb + off + s * 16) = v;
+        u32x4 v = *(const u32x4 *)(lds + P * ROWB + ((s ^ (P & (SLOTS - 1))) << 4));
+        if (off == 0xFFFFFFFFu) continue;
+        if (!OUT_F32 && a.mask) {                                 // gate by the sign of the masking map's 8 values of this piece
+            typedef typename Vec<T>::v8 V8;
+            const V8 m = *(const V8 *)((const char *)a.mask + (size_t)n0 * ESZ + off + s * 16);
+            V8 o = __builtin_bit_cast(V8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)m[e] > 0.f ? o[e] : (T)0.f;
+            v = __builtin_bit_cast(u32x4, o);
+        }
+        *(u32x4 *)(yb + off + s * 16) = v;
     }
 #endif
 }
@@ -311,8 +321,9 @@ using namespace mv3d_conv;
 
 template <typename T>
 static int conv3x3_entry(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
-                         int c_out, int out_framed, int out_f32, int relu, void *stream)
+                         int c_out, int out_framed, int out_f32, int relu, void *stream, const void *mask = nullptr)
 {
+    if (mask && (!out_framed || out_f32 || ((uintptr_t)mask & 15))) return MV3D_ERR_INVALID_ARG;
     if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;   // 16-byte pieces
     const bool first = c_in == 16;                                // the input layer's packing (see the header)
@@ -321,7 +332,7 @@ static int conv3x3_entry(const void *x_framed, const void *w_packed, const float
     const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * (out_f32 ? 4 : 2);
     if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
     ConvArgs a;
-    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y;
+    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y; a.mask = mask;
     a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width; a.Bn = batch;
     a.out_pad = out_framed != 0; a.relu = relu != 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
@@ -367,6 +378,12 @@ extern "C" int mv3d_conv3x3_bf16(const void *x, const void *w, const float *bias
                                  int out_framed, int out_f32, int relu, void *stream)
 {
     return conv3x3_entry<__bf16>(x, w, bias, y, batch, height, width, c_in, c_out, out_framed, out_f32, relu, stream);
+}
+extern "C" int mv3d_conv3x3_gated_bf16(const void *x, const void *w, const float *bias, const void *gate_framed, void *y, int batch, int height,
+                                       int width, int c_in, int c_out, void *stream)
+{
+    if (!gate_framed) return MV3D_ERR_INVALID_ARG;
+    return conv3x3_entry<__bf16>(x, w, bias, y, batch, height, width, c_in, c_out, 1, 0, 0, stream, gate_framed);
 }
 extern "C" int mv3d_maxpool2x2_f16(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
 {

@@ -241,10 +241,15 @@ class MV3D:
             L["conv5_3_2"] = mfma_train_trunk(_VGG, L["image_data"], self.params, "_2", pool=self._train_pool)
             if self.views == 3:
                 L["conv5_3_3"] = mfma_train_trunk(_VGG, L["lidar_fv_data"], self.params, "_3", pool=self._train_pool)
-            rpn = self._conv(bev_nhwc.permute(0, 3, 1, 2), "rpn_conv/3x3")
-            L["rpn_conv/3x3"] = rpn.permute(0, 2, 3, 1)
-            score = self._conv(rpn, "rpn_cls_score", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
-            L["rpn_bbox_pred"] = self._conv(rpn, "rpn_bbox_pred", relu=False, pad=0).float().permute(0, 2, 3, 1).contiguous()
+            from ..trunk_train import conv_relu
+            rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"])           # (B, H, W, 512) f32, same kernels
+            L["rpn_conv/3x3"] = rpn_nhwc
+            heads = []
+            for name in ("rpn_cls_score", "rpn_bbox_pred"):                       # 1x1 convolutions = a matmul over the channel axis
+                w, b = self.params[name]
+                with self._amp():
+                    heads.append(F.linear(rpn_nhwc, w.reshape(w.shape[0], -1), b).float().contiguous())
+            score, L["rpn_bbox_pred"] = heads
         elif self.mfma_trunk:
             score, L["rpn_bbox_pred"] = self._mfma_trunks(L)
         else:

@@ -478,3 +478,12 @@ def conv3x3_wgrad_bf16(x_framed, dy_framed):
     check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), B, Hp - 2, Wp - 2, cin, cout, _ptr(ws), need, _stream()),
           "mv3d_conv3x3_wgrad_bf16")
     return dw
+
+
+def conv3x3_gated_bf16(x_framed, w_packed, bias, gate_framed, out):
+    """(conv3x3(x) + bias) gated by gate > 0 into the framed bf16 buffer `out` (the training trunk's data gradient + ReLU mask)"""
+    B, Hp, Wp, cin = x_framed.shape
+    cout = w_packed.shape[0]
+    check(lib().mv3d_conv3x3_gated_bf16(_ptr(x_framed), _ptr(w_packed), _ptr(bias), _ptr(gate_framed), _ptr(out), B, Hp - 2, Wp - 2, cin, cout,
+                                        _stream()), "mv3d_conv3x3_gated_bf16")
+    return out

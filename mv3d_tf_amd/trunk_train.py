@@ -121,14 +121,44 @@ class TrunkFunction(torch.autograd.Function):
             if i == 0:
                 break
             # two gradient buffers per resolution alternate (dy of layer i is read while dx = dy of layer i - 1 is written)
-            dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, relu=False,
-                                 out=bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev))          # framed bf16, c_in channels
             _, y_prev, Hp, Wp_ = saved[i - 1]
-            if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i
+            out_buf = bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev)
+            if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i: route through it (mask fused)
+                dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, relu=False, out=out_buf)
                 dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev))
-            else:
-                dy = dx.mul_(y_prev > 0)               # ReLU mask (the frame of both is zero)
+            else:                                      # data gradient and the ReLU mask of layer i - 1's output in one launch
+                dy = ops.conv3x3_gated_bf16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, y_prev, out_buf)
         return (None, None, None, None) + tuple(grads)
+
+
+class ConvReluFunction(torch.autograd.Function):
+    """One 3x3 + ReLU layer between f32 NHWC maps (rpn_conv/3x3 on conv5_3, MV3D_train.py:84-86) on the same three kernels:
+    apply(wgrad, x_nhwc_f32, w, b) -> (B, H, W, c_out) f32."""
+
+    @staticmethod
+    def forward(ctx, wgrad, x_nhwc, w, b):
+        B, H, W, cin = x_nhwc.shape
+        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), ops.framed_buffer(B, H, W, cin, x_nhwc.device, BF))
+        out = ops.conv3x3_f16(x, ops.pack_conv3x3_weights(w, dtype=BF), b.detach().float().contiguous(), out_framed=False, out_f32=True)
+        ctx.wgrad, ctx.x, ctx.w = wgrad, x, w
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        B, H, W, cout = g.shape
+        cin = ctx.x.shape[3]
+        dev = g.device
+        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), ops.framed_buffer(B, H, W, cout, dev, BF))
+        gw = ctx.wgrad(ctx.x, dy, cin)
+        gb = dy.sum((0, 1, 2), dtype=torch.float32)
+        dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.w), torch.zeros(cin, dtype=torch.float32, device=dev), relu=False, out_framed=False, out_f32=True)
+        return None, dx, gw, gb
+
+
+def conv_relu(x_nhwc, w, b, wgrad=wgrad_mfma):
+    return ConvReluFunction.apply(wgrad, x_nhwc, w, b)
 
 
 def trunk(layers, x_nhwc, params, suffix, wgrad=wgrad_mfma, pool=None):
