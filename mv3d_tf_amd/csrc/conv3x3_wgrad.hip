@@ -164,12 +164,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
 #endif
 }
 
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits)
+// folds the split-K partial sums in split order and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3),
+// dropping the padding channels of the input layer (c_in_real <= c_in)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits, int c_in,
+                                                                    int c_in_real)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c_in);
+        if (ci >= c_in_real) continue;
+        const long r = i / c_in;                                  // co * 9 + tap
         float s = part[i];
         for (int k = 1; k < splits; ++k) s += part[(long)k * n + i];
-        dw[i] = s;
+        dw[((r / 9) * c_in_real + ci) * 9 + r % 9] = s;
     }
 }
 
@@ -178,7 +184,7 @@ using namespace mv3d_wgrad;
 
 static int wgrad_splits(int tiles, int steps)
 {
-    int ks = (1024 + tiles - 1) / tiles;                          // ~1024 workgroups: four per CU
+    int ks = (768 + tiles - 1) / tiles;                           // ~768 workgroups = the three per CU the LDS allows (1024: 5-10 % slower, more partials)
     if (ks > steps / 4) ks = steps / 4;                           // ... of at least 4 K steps each
     return ks < 1 ? 1 : ks;
 }
@@ -192,8 +198,9 @@ extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int 
 }
 
 extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, int batch, int height, int width, int c_in,
-                                       int c_out, void *workspace, size_t workspace_bytes, void *stream)
+                                       int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (c_in_real <= 0 || c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
     if (!x_framed || !dy_framed || !dw || !workspace || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
     if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)x_framed | (uintptr_t)dy_framed | (uintptr_t)dw | (uintptr_t)workspace) & 15) != 0) return MV3D_ERR_INVALID_ARG;
@@ -217,6 +224,6 @@ extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_fram
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
     const long n = (long)c_out * 9 * c_in;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, a.part, dw, n,
-                       a.splits);
+                       a.splits, c_in, c_in_real);
     return mv3d_launch_status();
 }

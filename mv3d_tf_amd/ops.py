@@ -466,17 +466,19 @@ def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
     return out
 
 
-def conv3x3_wgrad_bf16(x_framed, dy_framed):
-    """x_framed (B, H + 2, W + 2, Cin) bf16, dy_framed (B, H + 2, W + 2, Cout) bf16 with a zero frame -> (Cout, 9, Cin) f32"""
+def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None):
+    """x_framed (B, H + 2, W + 2, Cin) bf16, dy_framed (B, H + 2, W + 2, Cout) bf16 with a zero frame -> the filter gradient
+    (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped)"""
     B, Hp, Wp, cin = x_framed.shape
     cout = dy_framed.shape[3]
+    creal = cin if c_in_real is None else int(c_in_real)
     need = lib().mv3d_conv3x3_wgrad_workspace_bytes(B, Hp - 2, Wp - 2, cin, cout)
     if need == 0:
         raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, "mv3d_conv3x3_wgrad_workspace_bytes")
     ws = torch.empty(need, dtype=torch.uint8, device=x_framed.device)
-    dw = torch.empty((cout, 9, cin), dtype=torch.float32, device=x_framed.device)
-    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), B, Hp - 2, Wp - 2, cin, cout, _ptr(ws), need, _stream()),
-          "mv3d_conv3x3_wgrad_bf16")
+    dw = torch.empty((cout, creal, 3, 3), dtype=torch.float32, device=x_framed.device)
+    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), B, Hp - 2, Wp - 2, cin, creal, cout, _ptr(ws), need,
+                                        _stream()), "mv3d_conv3x3_wgrad_bf16")
     return dw
 
 

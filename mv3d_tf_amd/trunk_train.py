@@ -39,9 +39,8 @@ def _wgrad_torch(x_framed, dy_framed, c_in):
 
 def wgrad_mfma(x_framed, dy_framed, c_in):
     """weight gradient on the MFMA kernel (csrc/conv3x3_wgrad.hip): (O, c_in, 3, 3) f32.  (The input layer's 9 / 3 channels sit
-    in a 64-channel framed buffer during training, so it goes through the same kernel; its padding channels are cut off here.)"""
-    dw = ops.conv3x3_wgrad_bf16(x_framed, dy_framed)                 # (O, 9, I) f32
-    return dw.reshape(dw.shape[0], 3, 3, dw.shape[2])[..., :c_in].permute(0, 3, 1, 2)
+    in a 64-channel framed buffer during training, so it goes through the same kernel; its padding channels are cut off by it.)"""
+    return ops.conv3x3_wgrad_bf16(x_framed, dy_framed, c_in)
 
 
 class BufferPool:
