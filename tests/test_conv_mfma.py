@@ -295,3 +295,62 @@ def test_train_graph_on_the_mfma_trunk(gpu):
     before = net.params["conv4_1"][0].detach().clone()
     opt.step()
     assert not torch.equal(before, net.params["conv4_1"][0])
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,creal", [(2, 38, 50, 128, 256, None), (1, 21, 33, 64, 64, 9), (2, 12, 40, 256, 512, None)])
+def test_weight_gradient_kernel_matches_torch(gpu, B, H, W, cin, cout, creal):
+    """mv3d_conv3x3_wgrad_bf16 against torch's conv2d_weight in fp32 on the SAME bf16-rounded operands: the kernel multiplies
+    bf16 exactly and accumulates in f32 (per split, then over the splits), so only the summation order differs: <= 1e-4 of the
+    largest entry.  Asymmetric random operands: a wrong tap / transposed-read mapping cannot pass."""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B + H + cin)
+    bf = torch.bfloat16
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g).to(bf)
+    dy = torch.randn((B, H, W, cout), device="cuda", generator=g).to(bf)
+    xf = ops.framed_buffer(B, H, W, cin, "cuda", bf)
+    xf[:, 1:-1, 1:-1] = x
+    dyf = ops.framed_buffer(B, H, W, cout, "cuda", bf)
+    dyf[:, 1:-1, 1:-1] = dy
+    got = ops.conv3x3_wgrad_bf16(xf, dyf, creal)
+    want = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
+    if creal:
+        want = want[:, :creal]
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and got.is_contiguous()
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_gated_data_gradient_and_pool_backward(gpu):
+    """mv3d_conv3x3_gated_bf16 = convolution, then zero where the gate map is <= 0; mv3d_maxpool2x2_bwd_bf16 = torch's max_pool2d
+    backward (first maximum of the window) times the ReLU mask -- both exact on the bf16 values"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(12)
+    bf = torch.bfloat16
+    B, H, W, cin, cout = 2, 21, 30, 128, 64
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * 0.03
+    zero = torch.zeros(cout, device="cuda")
+    gate = torch.randn((B, H, W, cout), device="cuda", generator=g).to(bf)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, "cuda", bf))
+    gf = ops.framed_buffer(B, H, W, cout, "cuda", bf)
+    gf[:, 1:-1, 1:-1] = gate
+    wp = ops.pack_conv3x3_weights(w, dtype=bf)
+    plain = ops.conv3x3_f16(xf, wp, zero, relu=False)
+    gated = ops.conv3x3_gated_bf16(xf, wp, zero, gf, ops.framed_buffer(B, H, W, cout, "cuda", bf))
+    torch.cuda.synchronize()
+    assert torch.equal(gated, torch.where(gf > 0, plain, torch.zeros_like(plain)))
+    # pool backward on a ReLU output with ties at 0
+    y = torch.relu(torch.randn((B, H, W, cout), device="cuda", generator=g)).to(bf)
+    yf = ops.framed_buffer(B, H, W, cout, "cuda", bf)
+    yf[:, 1:-1, 1:-1] = y
+    gp = torch.randn((B, H // 2, W // 2, cout), device="cuda", generator=g).to(bf)
+    gpf = ops.framed_buffer(B, H // 2, W // 2, cout, "cuda", bf)
+    gpf[:, 1:-1, 1:-1] = gp
+    got = ops.maxpool2x2_bwd_bf16(yf, gpf, ops.framed_buffer(B, H, W, cout, "cuda", bf))[:, 1:-1, 1:-1].float()
+    yy = y.float().permute(0, 3, 1, 2).requires_grad_(True)
+    torch.nn.functional.max_pool2d(yy, 2, 2).backward(gp.float().permute(0, 3, 1, 2))
+    want = (yy.grad * (yy > 0)).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
