@@ -34,7 +34,11 @@ cfg.TRAIN = _section(
     RPN_BATCHSIZE=128, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
     HAS_RPN=False, BBOX_NORMALIZE_TARGETS_PRECOMPUTED=False, PROPOSAL_METHOD='selective_search',
     DISPLAY=10, SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='VGGnet_fast_rcnn', SNAPSHOT_INFIX='', DEBUG_TIMELINE=False,
-    SCALES=(600,), MAX_SIZE=2000, USE_FLIPPED=False, LEARNING_RATE=0.001)
+    SCALES=(600,), MAX_SIZE=2000, USE_FLIPPED=False, LEARNING_RATE=0.001,
+    # (not in the reference) True: SolverWrapper trains in mixed precision -- the trunks' forward / data-gradient / weight-gradient
+    # convolutions on the bf16 MFMA kernels (mv3d_tf_amd/trunk_train.py), the other dense layers under bf16 autocast, fp32 master
+    # weights and Adam.  False = the reference's fp32 training.
+    MIXED_PRECISION=False)
 cfg.TEST = _section(
     NMS=0.5, HAS_RPN=True, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
     DEBUG_TIMELINE=False)

@@ -180,6 +180,9 @@ class SolverWrapper(object):
         if self.pretrained_model is not None:
             self.log('Loading pretrained model weights from {:s}'.format(self.pretrained_model))
             self.net.load(self.pretrained_model, sess, self.saver, True)
+        if cfg.TRAIN.get("MIXED_PRECISION", False) and hasattr(self.net, "mfma_trunk"):
+            self.net.mfma_trunk, self.net.amp_dtype = True, torch.bfloat16
+            self.log('Mixed precision: bf16 MFMA trunks, fp32 master weights')
         params = self.net.parameters()
         if dist is not None:                                   # identical replicas: rank 0's weights everywhere
             for p_ in params:
