@@ -393,12 +393,17 @@ int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, 
                              int channels, void *stream);
 /* Weight gradient of that convolution (csrc/conv3x3_wgrad.hip): dw (c_out, c_in_real, 3, 3) f32 [the OIHW filter layout; TF's
  * HWIO is its transpose(2, 3, 1, 0)], dw[co][ci][tap] = sum over the pixels of the batch of dy[pixel][co] * x[pixel + tap][ci],
- * for the first c_in_real <= c_in channels (the input layer's buffer is padded to 64 channels); x_framed (batch, height + 2, width + 2, c_in) bf16 = the layer's input,
+ * for the first c_in_real <= c_in channels (the input layer's buffer is padded to 64 channels); db (c_out) f32 (may be NULL) =
+ * the bias gradient, the sum of dy over the pixels, from the same launch; x_framed (batch, height + 2, width + 2, c_in) bf16 = the layer's input,
  * dy_framed (.., c_out) bf16 = the gradient w.r.t. its pre-activation with a ZERO frame; c_in, c_out multiples of 64.
  * workspace: >= mv3d_conv3x3_wgrad_workspace_bytes(...) bytes, 16-byte aligned (split-K partial sums, folded in a fixed order). */
 size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out);
-int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, int batch, int height, int width, int c_in,
-                            int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream);
+int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
+                            int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream);
+/* fp32 OIHW filter (c_out, c_in, 3, 3) -> the packed bf16 forms of one training step in one launch: fwd_packed (c_out, 9 * c_in_pad)
+ * [zero-initialised by the caller when c_in_pad > c_in] for mv3d_conv3x3_bf16, dgrad_packed (c_in, 9 * c_out) (may be NULL) for
+ * the data-gradient convolution: the filter flipped by 180 degrees with its channel axes swapped. */
+int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, void *dgrad_packed, int c_out, int c_in, int c_in_pad, void *stream);
 /* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */
 int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
 /* NHWC f32 (batch, height, width, channels) -> interior pixels, first `channels` channels of a framed f16 buffer

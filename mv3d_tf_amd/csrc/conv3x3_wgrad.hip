@@ -27,7 +27,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
 struct WgradArgs {
     const void *x, *dy;
-    float *part;
+    float *part, *bpart;          // split-K partial sums: filter [splits][Cout][9][Cin]; bias [splits][Cout] (or nullptr)
     int Wp, Cin, Cout, Q, steps, steps_per_split, splits, ci_tiles;
     unsigned x_bytes, dy_bytes;
 };
@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // bias gradient (sum over the pixels of dY): the workgroups of input-channel tile 0 / filter row 0 multiply their dY
+    // fragments by an all-ones operand as well -- every column of that product is the column sum
+    const bool do_bias = a.bpart != nullptr && ci_t == 0 && dyr == 0 && wb == 0;       // (wave-uniform)
+    f32x16 accb[FA];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
     if (s0 < s1) issue(s0, 0);
     for (int s = s0; s < s1; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -145,9 +157,20 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
             for (int i = 0; i < FA; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < FA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
+            }
         }
     }
 
+    if (do_bias && (lane & 31) == 0) {                            // column 0 of the ones-product: rows (co) 8 q + 4 (lane >> 5) + {0..3}
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = accb[i][r];
+    }
     // partial sums: D layout = lane holds column (GEMM column n) lane & 31, rows (co) 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2
     float *const out = a.part + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll
@@ -167,15 +190,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
 // folds the split-K partial sums in split order and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3),
 // dropping the padding channels of the input layer (c_in_real <= c_in)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits, int c_in,
-                                                                    int c_in_real)
+                                                                    int c_in_real, const float *__restrict__ bpart, float *__restrict__ db, int c_out)
 {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long total = n + (db ? c_out : 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i >= n) {                                             // the bias gradient's partial sums
+            const int co = (int)(i - n);
+            float s = bpart[co];
+            for (int k = 1; k < splits; ++k) s += bpart[(long)k * c_out + co];
+            db[co] = s;
+            continue;
+        }
         const int ci = (int)(i % c_in);
         if (ci >= c_in_real) continue;
         const long r = i / c_in;                                  // co * 9 + tap
         float s = part[i];
         for (int k = 1; k < splits; ++k) s += part[(long)k * n + i];
         dw[((r / 9) * c_in_real + ci) * 9 + r % 9] = s;
+    }
+}
+
+// fp32 OIHW filter -> the two packed bf16 forms the trunk's step needs, in one launch: fwd (O, 9 * Ipad), k = tap * Ipad + i (the
+// forward convolution) and dgrad (I, 9 * O), W'[i][tap'][o] = W[o][i][8 - tap'] (the data-gradient convolution; nullptr = skip)
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const float *__restrict__ w, __bf16 *__restrict__ fwd, __bf16 *__restrict__ dgrad, int O, int I,
+                                                            int Ipad)
+{
+    const long n = (long)O * I * 9;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9);
+        const long r = i / 9;
+        const int ci = (int)(r % I), o = (int)(r / I);
+        const __bf16 v = (__bf16)w[i];
+        fwd[((long)o * 9 + tap) * Ipad + ci] = v;
+        if (dgrad) dgrad[((long)ci * 9 + (8 - tap)) * O + o] = v;
     }
 }
 
@@ -194,11 +241,12 @@ extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int 
     if (batch <= 0 || height <= 0 || width <= 0 || c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return 0;
     const int bmc = c_out % 128 == 0 ? 128 : 64;
     const int steps = (batch * (height + 2) * (width + 2) + WG_PIX - 1) / WG_PIX;
-    return (size_t)wgrad_splits((c_out / bmc) * (c_in / 64) * 3, steps) * c_out * 9 * c_in * 4;
+    const size_t ks = (size_t)wgrad_splits((c_out / bmc) * (c_in / 64) * 3, steps);
+    return ks * c_out * 9 * c_in * 4 + ks * c_out * 4;             // filter partials + bias partials
 }
 
-extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, int batch, int height, int width, int c_in,
-                                       int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
+                                       int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (c_in_real <= 0 || c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
     if (!x_framed || !dy_framed || !dw || !workspace || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
@@ -211,6 +259,7 @@ extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_fram
     const int bmc = c_out % 128 == 0 ? 128 : 64;
     WgradArgs a;
     a.x = x_framed; a.dy = dy_framed; a.part = (float *)workspace;
+    a.bpart = nullptr;
     a.Wp = width + 2; a.Cin = c_in; a.Cout = c_out; a.Q = (int)q;
     a.steps = (int)((q + WG_PIX - 1) / WG_PIX);
     a.ci_tiles = c_in / 64;
@@ -218,12 +267,22 @@ extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_fram
     a.splits = wgrad_splits(tiles, a.steps);
     a.steps_per_split = (a.steps + a.splits - 1) / a.splits;
     a.x_bytes = (unsigned)(q * c_in * 2); a.dy_bytes = (unsigned)(q * c_out * 2);
+    if (db) a.bpart = a.part + (size_t)a.splits * c_out * 9 * c_in;
     hipStream_t s = (hipStream_t)stream;
     const int grid = tiles * a.splits;
     if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
     const long n = (long)c_out * 9 * c_in;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, a.part, dw, n,
-                       a.splits, c_in, c_in_real);
+                       a.splits, c_in, c_in_real, a.bpart, db, c_out);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, void *dgrad_packed, int c_out, int c_in, int c_in_pad, void *stream)
+{
+    if (!w_oihw || !fwd_packed || c_out <= 0 || c_in <= 0 || c_in_pad < c_in) return MV3D_ERR_INVALID_ARG;
+    const long n = (long)c_out * c_in * 9;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                       (__bf16 *)fwd_packed, (__bf16 *)dgrad_packed, c_out, c_in, c_in_pad);
     return mv3d_launch_status();
 }

@@ -466,9 +466,9 @@ def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
     return out
 
 
-def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None):
+def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None, want_bias=False):
     """x_framed (B, H + 2, W + 2, Cin) bf16, dy_framed (B, H + 2, W + 2, Cout) bf16 with a zero frame -> the filter gradient
-    (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped)"""
+    (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped) [, the bias gradient (Cout) f32]"""
     B, Hp, Wp, cin = x_framed.shape
     cout = dy_framed.shape[3]
     creal = cin if c_in_real is None else int(c_in_real)
@@ -477,9 +477,21 @@ def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None):
         raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, "mv3d_conv3x3_wgrad_workspace_bytes")
     ws = torch.empty(need, dtype=torch.uint8, device=x_framed.device)
     dw = torch.empty((cout, creal, 3, 3), dtype=torch.float32, device=x_framed.device)
-    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), B, Hp - 2, Wp - 2, cin, creal, cout, _ptr(ws), need,
+    db = torch.empty((cout,), dtype=torch.float32, device=x_framed.device) if want_bias else None
+    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), _ptr(db), B, Hp - 2, Wp - 2, cin, creal, cout, _ptr(ws), need,
                                         _stream()), "mv3d_conv3x3_wgrad_bf16")
-    return dw
+    return (dw, db) if want_bias else dw
+
+
+def pack_conv3x3_train_bf16(w_oihw, c_in_pad=None, want_dgrad=True):
+    """fp32 (O, I, 3, 3) -> (forward packing (O, 9 * I') bf16, data-gradient packing (I, 9 * O) bf16 | None) in one launch"""
+    O, I = w_oihw.shape[:2]
+    Ip = c_in_pad or I
+    w = w_oihw.detach().contiguous()
+    fwd = (torch.zeros if Ip > I else torch.empty)((O, 9 * Ip), dtype=torch.bfloat16, device=w.device)
+    dg = torch.empty((I, 9 * O), dtype=torch.bfloat16, device=w.device) if want_dgrad else None
+    check(lib().mv3d_conv3x3_pack_bf16(_ptr(w), _ptr(fwd), _ptr(dg), O, I, Ip, _stream()), "mv3d_conv3x3_pack_bf16")
+    return fwd, dg
 
 
 def conv3x3_gated_bf16(x_framed, w_packed, bias, gate_framed, out):

@@ -13,8 +13,8 @@ One `torch.autograd.Function` per trunk (conv1_1 .. conv5_3 of lib/networks/MV3D
   backward   per layer, last to first:
              dY   = gradient w.r.t. the layer's pre-activation, framed bf16 with a ZERO frame (= dX of the layer above times the
                     ReLU mask; through a pool: mv3d_maxpool2x2_bwd_bf16, mask included)
-             dW   = sum over pixels of dY[p][co] * X[p + tap][ci]      (weight gradient)
-             db   = sum over pixels of dY
+             dW   = sum over pixels of dY[p][co] * X[p + tap][ci]      (weight gradient: mv3d_conv3x3_wgrad_bf16)
+             db   = sum over pixels of dY                              (from the same launch: dY times an all-ones operand)
              dX   = mv3d_conv3x3_bf16(dY, W flipped by 180 degrees with its channel axes swapped): the data gradient of a
                     3x3 / stride 1 / SAME convolution IS such a convolution, and the zero frame of dY is its padding.
 """
@@ -25,22 +25,19 @@ from . import ops
 BF = torch.bfloat16
 
 
-def _dgrad_weights(w_oihw):
-    """(O, I, 3, 3) -> packed bf16 weights of the data-gradient convolution: (I, 9 * O), W'[i][ky][kx][o] = W[o][i][2-ky][2-kx]"""
-    return ops.pack_conv3x3_weights(w_oihw.detach().flip(2, 3).transpose(0, 1), dtype=BF)
-
-
 def _wgrad_torch(x_framed, dy_framed, c_in):
-    """weight gradient through torch (MIOpen): (O, c_in, 3, 3) f32 -- the yardstick of tests / tools, not the product path"""
+    """weight / bias gradient through torch (MIOpen): ((O, c_in, 3, 3) f32, (O,) f32) -- the yardstick of tests / tools, not the
+    product path"""
     x = x_framed[:, 1:-1, 1:-1, :c_in].permute(0, 3, 1, 2)
     dy = dy_framed[:, 1:-1, 1:-1].permute(0, 3, 1, 2)
-    return torch.nn.grad.conv2d_weight(x, (dy.shape[1], c_in, 3, 3), dy, padding=1).float()
+    return torch.nn.grad.conv2d_weight(x, (dy.shape[1], c_in, 3, 3), dy, padding=1).float(), dy_framed.sum((0, 1, 2), dtype=torch.float32)
 
 
 def wgrad_mfma(x_framed, dy_framed, c_in):
-    """weight gradient on the MFMA kernel (csrc/conv3x3_wgrad.hip): (O, c_in, 3, 3) f32.  (The input layer's 9 / 3 channels sit
-    in a 64-channel framed buffer during training, so it goes through the same kernel; its padding channels are cut off by it.)"""
-    return ops.conv3x3_wgrad_bf16(x_framed, dy_framed, c_in)
+    """weight AND bias gradient on the MFMA kernel (csrc/conv3x3_wgrad.hip): ((O, c_in, 3, 3) f32, (O,) f32).  (The input layer's
+    9 / 3 channels sit in a 64-channel framed buffer during training, so it goes through the same kernel; its padding channels
+    are cut off by it.)"""
+    return ops.conv3x3_wgrad_bf16(x_framed, dy_framed, c_in, want_bias=True)
 
 
 class BufferPool:
@@ -66,7 +63,7 @@ class _NoPool:
 
 class TrunkFunction(torch.autograd.Function):
     """apply(layers, wgrad, pool, x_nhwc_f32, w_0, b_0, ..., w_12, b_12) -> conv5_3 (B, H', W', 512) f32;
-    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> (O, c_in, 3, 3) f32,
+    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> ((O, c_in, 3, 3) f32, (O,) f32),
     pool = (BufferPool | None, tag)"""
 
     @staticmethod
@@ -77,11 +74,13 @@ class TrunkFunction(torch.autograd.Function):
         # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
         x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, 64, dev))
         saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
+        packed_dgrad = []
         n = len(layers)
         out = None
         for i, (_, cout, pool) in enumerate(layers):
             w, b = wb[2 * i], wb[2 * i + 1]
-            wp = ops.pack_conv3x3_weights(w, 64 if i == 0 else None, dtype=BF)
+            wp, wd = ops.pack_conv3x3_train_bf16(w, 64 if i == 0 else None, want_dgrad=i > 0)   # (both packings in one launch)
+            packed_dgrad.append(wd)
             bias = b.detach().float().contiguous()
             if i == n - 1:
                 out = ops.conv3x3_f16(x, wp, bias, out_framed=False, out_f32=True)
@@ -95,7 +94,7 @@ class TrunkFunction(torch.autograd.Function):
             else:
                 x = y
         ctx.layers, ctx.wgrad, ctx.saved, ctx.c0, ctx.bufs, ctx.tag = layers, wgrad, saved, c0, bufs, tag
-        ctx.weights = [wb[2 * i] for i in range(n)]
+        ctx.packed_dgrad = packed_dgrad
         ctx.save_for_backward(out)
         return out
 
@@ -115,18 +114,17 @@ class TrunkFunction(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             x_in, _, H, W = saved[i]
             c_in = ctx.c0 if i == 0 else layers[i - 1][1]
-            grads[2 * i] = ctx.wgrad(x_in, dy, c_in)
-            grads[2 * i + 1] = dy.sum((0, 1, 2), dtype=torch.float32)            # (the frame is zero)
+            grads[2 * i], grads[2 * i + 1] = ctx.wgrad(x_in, dy, c_in)
             if i == 0:
                 break
             # two gradient buffers per resolution alternate (dy of layer i is read while dx = dy of layer i - 1 is written)
             _, y_prev, Hp, Wp_ = saved[i - 1]
             out_buf = bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev)
             if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i: route through it (mask fused)
-                dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, relu=False, out=out_buf)
+                dx = ops.conv3x3_f16(dy, ctx.packed_dgrad[i], zero_bias, relu=False, out=out_buf)
                 dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev))
             else:                                      # data gradient and the ReLU mask of layer i - 1's output in one launch
-                dy = ops.conv3x3_gated_bf16(dy, _dgrad_weights(ctx.weights[i]), zero_bias, y_prev, out_buf)
+                dy = ops.conv3x3_gated_bf16(dy, ctx.packed_dgrad[i], zero_bias, y_prev, out_buf)
         return (None, None, None, None) + tuple(grads)
 
 
@@ -138,8 +136,9 @@ class ConvReluFunction(torch.autograd.Function):
     def forward(ctx, wgrad, x_nhwc, w, b):
         B, H, W, cin = x_nhwc.shape
         x = ops.frame_nhwc_f16(x_nhwc.contiguous(), ops.framed_buffer(B, H, W, cin, x_nhwc.device, BF))
-        out = ops.conv3x3_f16(x, ops.pack_conv3x3_weights(w, dtype=BF), b.detach().float().contiguous(), out_framed=False, out_f32=True)
-        ctx.wgrad, ctx.x, ctx.w = wgrad, x, w
+        wp, wd = ops.pack_conv3x3_train_bf16(w)
+        out = ops.conv3x3_f16(x, wp, b.detach().float().contiguous(), out_framed=False, out_f32=True)
+        ctx.wgrad, ctx.x, ctx.wd = wgrad, x, wd
         ctx.save_for_backward(out)
         return out
 
@@ -150,9 +149,8 @@ class ConvReluFunction(torch.autograd.Function):
         cin = ctx.x.shape[3]
         dev = g.device
         dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), ops.framed_buffer(B, H, W, cout, dev, BF))
-        gw = ctx.wgrad(ctx.x, dy, cin)
-        gb = dy.sum((0, 1, 2), dtype=torch.float32)
-        dx = ops.conv3x3_f16(dy, _dgrad_weights(ctx.w), torch.zeros(cin, dtype=torch.float32, device=dev), relu=False, out_framed=False, out_f32=True)
+        gw, gb = ctx.wgrad(ctx.x, dy, cin)
+        dx = ops.conv3x3_f16(dy, ctx.wd, torch.zeros(cin, dtype=torch.float32, device=dev), relu=False, out_framed=False, out_f32=True)
         return None, dx, gw, gb
 
 

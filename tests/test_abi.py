@@ -63,8 +63,9 @@ def test_workspace_queries_and_argument_validation(hiplib):
     assert L.mv3d_conv3x3_gated_bf16(A, A, A, None, A, 1, 8, 8, 64, 64, None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_conv3x3_wgrad_workspace_bytes(2, 76, 76, 512, 512) >= 512 * 9 * 512 * 4
     assert L.mv3d_conv3x3_wgrad_workspace_bytes(2, 76, 76, 48, 512) == 0
-    assert L.mv3d_conv3x3_wgrad_bf16(A, A, A, 2, 76, 76, 512, 512, 512, A, 16, None) == hiplib.ERR_WORKSPACE
-    assert L.mv3d_conv3x3_wgrad_bf16(A, A, A, 2, 76, 76, 512, 600, 512, A, 1 << 30, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_wgrad_bf16(A, A, A, None, 2, 76, 76, 512, 512, 512, A, 16, None) == hiplib.ERR_WORKSPACE
+    assert L.mv3d_conv3x3_wgrad_bf16(A, A, A, None, 2, 76, 76, 512, 600, 512, A, 1 << 30, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_conv3x3_pack_bf16(None, A, A, 64, 64, 64, None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_maxpool2x2_bwd_bf16(A, A, None, 1, 8, 8, 64, None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_maxpool2x2_f16(A, A, 1, 8, 8, 12, None) == hiplib.ERR_INVALID_ARG
     assert L.mv3d_frame_nhwc_f16(A, A, 1, 8, 8, 9, 8, None) == hiplib.ERR_INVALID_ARG

@@ -312,13 +312,29 @@ def test_weight_gradient_kernel_matches_torch(gpu, B, H, W, cin, cout, creal):
     xf[:, 1:-1, 1:-1] = x
     dyf = ops.framed_buffer(B, H, W, cout, "cuda", bf)
     dyf[:, 1:-1, 1:-1] = dy
-    got = ops.conv3x3_wgrad_bf16(xf, dyf, creal)
+    got, got_b = ops.conv3x3_wgrad_bf16(xf, dyf, creal, want_bias=True)
+    want_b = dy.float().sum((0, 1, 2))
+    assert float((got_b - want_b).abs().max()) <= 1e-4 * float(want_b.abs().max())
     want = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
     if creal:
         want = want[:, :creal]
     torch.cuda.synchronize()
     assert got.shape == want.shape and got.is_contiguous()
     assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_one_launch_weight_packing(gpu):
+    """mv3d_conv3x3_pack_bf16 = the torch packing of the forward filter and of the flipped / channel-swapped data-gradient filter"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn((128, 64, 3, 3), device="cuda", generator=g)
+    fwd, dg = ops.pack_conv3x3_train_bf16(w)
+    assert torch.equal(fwd, ops.pack_conv3x3_weights(w, dtype=torch.bfloat16))
+    assert torch.equal(dg, ops.pack_conv3x3_weights(w.flip(2, 3).transpose(0, 1), dtype=torch.bfloat16))
+    w9 = torch.randn((64, 9, 3, 3), device="cuda", generator=g)
+    fwd9, none = ops.pack_conv3x3_train_bf16(w9, 64, want_dgrad=False)
+    assert none is None and torch.equal(fwd9, ops.pack_conv3x3_weights(w9, 64, dtype=torch.bfloat16))
 
 
 def test_gated_data_gradient_and_pool_backward(gpu):
