@@ -64,6 +64,7 @@ class MV3D:
         self._mfma = None
         self._side = None
         self._train_pool = None
+        self._train_streams = []
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -236,11 +237,32 @@ class MV3D:
             from ..trunk_train import BufferPool, trunk as mfma_train_trunk
             if self._train_pool is None:
                 self._train_pool = BufferPool()         # (one forward / backward pair per network in flight)
+            # the image / front-view trunks on side streams: at a training batch of 2 their launches do not fill the chip, so the
+            # trunks' kernels overlap -- forward here, and backward too (autograd runs a Function's backward on its forward's stream)
+            # Single process only: under data parallelism the gradient buckets go on the wire from post-accumulate hooks, and a
+            # bucket whose gradients were produced on different streams would need cross-stream fences the bucketer does not have.
+            import torch.distributed as tdist
+            main = torch.cuda.current_stream()
+            side_in = [("_2", "image_data", "conv5_3_2")] + ([("_3", "lidar_fv_data", "conv5_3_3")] if self.views == 3 else [])
+            multi = not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
+            if multi and not self._train_streams:
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)     # (the mismatch is the point)
+            while multi and len(self._train_streams) < len(side_in):
+                self._train_streams.append(torch.cuda.Stream(device=self.device))
+            for k, (sfx, key, out) in enumerate(side_in):
+                if not multi:
+                    L[out] = mfma_train_trunk(_VGG, L[key], self.params, sfx, pool=self._train_pool)
+                    continue
+                st = self._train_streams[k]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    L[out] = mfma_train_trunk(_VGG, L[key], self.params, sfx, pool=self._train_pool)
             bev_nhwc = mfma_train_trunk(_VGG, L["lidar_bv_data"], self.params, "", pool=self._train_pool)
             L["conv5_3"] = bev_nhwc
-            L["conv5_3_2"] = mfma_train_trunk(_VGG, L["image_data"], self.params, "_2", pool=self._train_pool)
-            if self.views == 3:
-                L["conv5_3_3"] = mfma_train_trunk(_VGG, L["lidar_fv_data"], self.params, "_3", pool=self._train_pool)
+            for k, (sfx, key, out) in enumerate(side_in):
+                if multi:
+                    main.wait_stream(self._train_streams[k])
+                    L[out].record_stream(main)
             from ..trunk_train import conv_relu
             rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"])           # (B, H, W, 512) f32, same kernels
             L["rpn_conv/3x3"] = rpn_nhwc
