@@ -110,3 +110,18 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     assert sv["fp32"]["frames_per_s"] > 0 and sv["fp16_mfma"]["frames_per_s"] > 0 and sv["fp16_mfma"]["rois_per_step"] > 0
     rk = sv["roofline_kernels"][0]
     assert rk["bound"] == "mfma" and rk["peak"] == 2500.0 and 0 < rk["frac"] < 1 and abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-3
+
+
+def test_conv_roofline_accounting():
+    """the layer table behind bench.py's MFMA roofline entries (host logic): 40 3x3 convolutions in the 3-view serving graph, the
+    reference's shapes (lib/networks/MV3D_train.py:44-84), 11.2 TFLOP algorithmic at batch 16"""
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.networks.mv3d import _VGG
+    from mv3d_tf_amd.trunk import serving_layers
+    rows = serving_layers(_VGG)
+    assert len(rows) == 40 and sum(1 for r in rows if r[0] == "rpn_conv/3x3") == 1
+    by = {r[0]: r for r in rows}
+    assert by["conv1_1"][1:] == (608, 608, 9, 64) and by["conv5_3"][1:] == (76, 76, 512, 512) and by["rpn_conv/3x3"][1:] == (76, 76, 512, 512)
+    assert by["conv5_3_2"][1:] == (46, 155, 512, 512) and by["conv4_1_3"][1:] == (8, 64, 256, 512) and by["conv1_2_3"][1:] == (64, 512, 64, 64)
+    flop = sum(2.0 * 16 * H * W * cout * 9 * cin for _, H, W, cin, cout in rows)
+    assert abs(flop - 11.2e12) < 0.05e12
