@@ -138,9 +138,10 @@ class MV3D:
         """trunks + RPN head with every 3x3 convolution on mv3d_conv3x3_f16; returns (rpn_cls_score, rpn_bbox_pred) f32 NHWC"""
         if torch.is_grad_enabled() and self.trainable:
             raise RuntimeError("mfma_trunk is the forward-only serving trunk: run it under torch.no_grad() (or trainable=False)")
-        if self._mfma is None:
+        half = torch.bfloat16 if self.amp_dtype == torch.bfloat16 else torch.float16
+        if self._mfma is None or self._mfma.dtype != half:
             from ..trunk import MfmaTrunks
-            self._mfma = MfmaTrunks(self, _VGG)
+            self._mfma = MfmaTrunks(self, _VGG, dtype=half)
         # the image (and front-view) trunk on a side stream: the trunks are independent chains of chip-filling launches, and
         # the last, partly filled round of workgroups of a layer of one trunk overlaps the start of a layer of the other
         main = torch.cuda.current_stream()
@@ -162,7 +163,7 @@ class MV3D:
         heads = []
         for name in ("rpn_cls_score", "rpn_bbox_pred"):               # 1x1 convolutions = a matmul over the channel axis
             w, b = self.params[name]
-            heads.append(F.linear(rpn, w.reshape(w.shape[0], -1).half(), b.half()).float().contiguous())
+            heads.append(F.linear(rpn, w.reshape(w.shape[0], -1).to(half), b.to(half)).float().contiguous())
         return heads
 
     def _serving_weights(self, name, nhwc_from=None):

@@ -1,8 +1,8 @@
 """The serving graph's VGG16 trunks on the hand-written MFMA convolution (csrc/conv3x3_mfma.hip).
 
 `MfmaTrunks(net)` runs the 3x3 convolutions + 2x2 pools of lib/networks/MV3D_test.py:34-78 (conv1_1 .. conv5_3 of every view,
-rpn_conv/3x3) through mv3d_conv3x3_f16 / mv3d_maxpool2x2_f16: f16 operands, f32 accumulation, activations kept in HBM as
-framed NHWC f16 (one-pixel zero frame = the SAME padding, written once when a buffer is made).  Forward only, lower precision
+rpn_conv/3x3) through mv3d_conv3x3_f16 / mv3d_maxpool2x2_f16 (or their _bf16 twins when the graph's amp_dtype is bfloat16):
+16-bit operands, f32 accumulation, activations kept in HBM as framed NHWC f16 / bf16 (one-pixel zero frame = the SAME padding, written once when a buffer is made).  Forward only, lower precision
 than the reference's fp32 graph (BASELINE configs[4] "fp16 VGG16"): never the parity contract; the maps the hot-path layers
 read (conv5_3*) are handed over as f32 NHWC, as those layers require.
 
@@ -16,9 +16,10 @@ from . import ops
 
 
 class MfmaTrunks:
-    def __init__(self, net, vgg):
+    def __init__(self, net, vgg, dtype=torch.float16):
         self.net = net
         self.vgg = vgg                       # [(stem, c_out, pool_after)]
+        self.dtype = dtype                   # float16 (default) or bfloat16 (f16's range is the usual worry with raw-pixel inputs)
         self._w = {}                         # name -> (version, packed f16 weights, f32 bias)
         self._buf = {}                       # (tag, B, H, W, C) -> framed f16 buffer (frame stays zero: only interiors are written)
 
@@ -28,7 +29,7 @@ class MfmaTrunks:
         hit = self._w.get(name)
         if hit is None or hit[0] != ver:
             pack = ops.pack_conv3x3_weights_input_layer if input_layer else ops.pack_conv3x3_weights
-            hit = (ver, pack(w), b.detach().float().contiguous())
+            hit = (ver, pack(w, dtype=self.dtype), b.detach().float().contiguous())
             self._w[name] = hit
         return hit[1], hit[2]
 
@@ -41,7 +42,7 @@ class MfmaTrunks:
         key = (tag, B, H, W, C)
         buf = self._buf.get(key)
         if buf is None:
-            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev)
+            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev, self.dtype)
         return buf
 
     def trunk(self, x_nhwc, suffix, last_framed):

@@ -157,7 +157,8 @@ def test_bad_arguments_are_refused(gpu):
         ops.conv3x3_f16(xf, torch.zeros((64, 9 * 48), dtype=torch.float16, device="cuda"), torch.zeros(64, device="cuda"))
 
 
-def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu):
+@pytest.mark.parametrize("half", ["float16", "bfloat16"])
+def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu, half):
     """MV3D_test forward with mfma_trunk = True against the same graph on torch's autocast f16 convolutions (He-scaled weights
     so that 13 layers keep O(1) activations): conv5_3 maps within 2 % of their max (two different f16 pipelines, 13 roundings
     deep), the same proposal count, finite detections."""
@@ -178,8 +179,10 @@ def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu):
             "image_data": rng.uniform(-1, 1, (B, 96, 320, 3)).astype(np.float32),
             "im_info": np.array([[608, 608, 1]] * B, np.float32), "calib": np.stack([synth.KITTI_CALIB] * B)}
     outs = {}
+    dt = getattr(torch, half)
+    tol = 0.02 if half == "float16" else 0.12            # (bf16: 8 mantissa bits, 13 layers deep, two different pipelines)
     for mfma in (False, True):
-        net.amp_dtype, net.mfma_trunk = torch.float16, mfma
+        net.amp_dtype, net.mfma_trunk = dt, mfma
         with torch.no_grad():
             L = net.forward(feed)
         torch.cuda.synchronize()
@@ -189,7 +192,7 @@ def test_serving_graph_on_the_mfma_trunk_matches_the_torch_f16_trunk(gpu):
     a, b = outs[False], outs[True]
     for k in ("conv5_3", "conv5_3_2", "rpn_cls_score", "rpn_bbox_pred"):
         scale = float(a[k].abs().max())
-        assert scale > 1e-3 and float((a[k] - b[k]).abs().max()) <= 0.02 * scale, (k, scale, float((a[k] - b[k]).abs().max()))
+        assert scale > 1e-3 and float((a[k] - b[k]).abs().max()) <= tol * scale, (k, scale, float((a[k] - b[k]).abs().max()))
     assert torch.isfinite(b["cls_prob"]).all() and torch.isfinite(b["bbox_pred"]).all() and b["n"] > 0
     net.mfma_trunk = True
     with pytest.raises(RuntimeError):
