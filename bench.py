@@ -469,7 +469,8 @@ def main():
                 # the hand-written MFMA convolution against the dense f16 matrix-core peak (rank 0 only: a per-kernel figure)
                 from mv3d_tf_amd import trunk
                 from mv3d_tf_amd.networks.mv3d import _VGG
-                sec["serving_with_trunk"]["roofline_kernels"] = [trunk.bench_conv_layers(_VGG)]
+                import torch as _t
+                sec["serving_with_trunk"]["roofline_kernels"] = [trunk.bench_conv_layers(_VGG), trunk.bench_conv_layers(_VGG, dtype=_t.float32)]
             if dist is not None:
                 dist.barrier()
         if rank == 0:

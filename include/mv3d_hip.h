@@ -374,6 +374,14 @@ int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_dev, const 
  * offsets: split the batch above that) and 16-byte aligned; MV3D_ERR_INVALID_ARG otherwise, before any launch. */
 int mv3d_conv3x3_f16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,
                      int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream);
+/* The same convolution in the REFERENCE'S precision: f32 framed maps (c_in a multiple of 32; the input layer's 9 / 3 channels padded to
+ * 32), f32 packed weights (c_out, 9 * c_in), f32 output (framed or not), exact f32 products and sums on v_mfma_f32_32x32x2_f32 -- only
+ * the summation order differs from any other fp32 convolution.  MFMA-bound at the f32 matrix rate (157 TFLOP/s peak). */
+int mv3d_conv3x3_f32(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
+                     int c_out, int out_framed, int relu, void *stream);
+int mv3d_maxpool2x2_f32(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
+int mv3d_frame_nhwc_f32(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
+                        void *stream);
 /* The same three entries on bfloat16 activations / weights (v_mfma_f32_32x32x16_bf16, f32 accumulate): the TRAINING trunk's
  * forward and data-gradient convolutions (mv3d_tf_amd/trunk_train.py) -- f16's 5-bit exponent would need loss scaling. */
 int mv3d_conv3x3_bf16(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width,

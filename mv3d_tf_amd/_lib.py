@@ -99,6 +99,9 @@ _SIGS = {
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),
     "mv3d_gt_encode": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mv3d_conv3x3_f16": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_maxpool2x2_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_frame_nhwc_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_maxpool2x2_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

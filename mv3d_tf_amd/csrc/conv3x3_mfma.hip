@@ -20,6 +20,9 @@
 namespace mv3d_conv {
 
 template <typename T> struct Vec { typedef T v8 __attribute__((ext_vector_type(8))); typedef T v4 __attribute__((ext_vector_type(4))); };
+// the 16-byte piece of a row an MFMA operand read fetches: 8 f16 / bf16 values, or 4 f32 (the exact-f32 variant: v_mfma_f32_32x32x2_f32)
+template <typename T> struct OpVec { typedef typename Vec<T>::v8 type; };
+template <> struct OpVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,12 +41,14 @@ struct ConvArgs {
     int m_tiles, n_tiles;
 };
 
-#define BK_BYTES 128     // 64 f16 channels of one tap
+#define BK_BYTES 128     // one K step = 128 bytes of channels of one tap: 64 f16 / bf16 values or 32 f32
 
 // FIRST: the layer fed by the network input (conv1_1: 9 / 3 channels zero-padded to 16 = 32 B per pixel): a K step is FOUR taps
 // x 16 channels (12 tap slots, the last 3 with zero weights), so K = 3 steps instead of 9 x 64 mostly-zero channels.
 // STAGES: LDS stages of the operand pipeline; the DMA of K step kt + STAGES - 1 is issued while step kt is multiplied.
-// T: the 16-bit operand / activation type, _Float16 (serving) or __bf16 (the training trunk: f16's 5-bit exponent would need loss scaling)
+// T: the operand / activation type: _Float16 (serving), __bf16 (the training trunk: f16's 5-bit exponent would need loss scaling), or
+// float = the reference's precision on v_mfma_f32_32x32x2_f32 (exact f32 products and sums at the f32 matrix rate, 1/16 of f16's):
+// K steps of 32 channels, f32 maps in and out, MFMA-bound by a wide margin (8x the matrix time per staged byte).
 template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
 __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArgs a)
 {
@@ -52,6 +57,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     constexpr int TP = BM / WP, TC = BN / WC, FP = TP / 32, FC = TC / 32;
     constexpr int STAGE = (BM + BN) * BK_BYTES;
     constexpr int XCH = BM / 8 / NW, WCH = BN / 8 / NW;          // 8-row DMA pieces per wave and stage
+    constexpr int ES = sizeof(T), CPS = BK_BYTES / ES;            // element size, channels per K step
+    static_assert(ES == 2 || (OUT_F32 && !FIRST), "f32 operands: f32 maps, no input-layer packing");
     constexpr int ESZ = OUT_F32 ? 4 : 2;
     constexpr int OUT_BYTES = BM * BN * ESZ;
     constexpr int LDS_BYTES = STAGES * STAGE > OUT_BYTES + BM * 4 ? STAGES * STAGE : OUT_BYTES + BM * 4;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K2 = FIRST ? 3 * BK_BYTES : 9 * a.Cin * 2;          // bytes of one weight row
+    const int K2 = FIRST ? 3 * BK_BYTES : 9 * a.Cin * ES;         // bytes of one weight row
     const int Wp = a.W + 2;
 
     // ---- DMA source addresses: lane -> (row = lane >> 3 of the 8-row piece, 16-byte k-group (lane & 7) ^ swizzle(row))
@@ -80,10 +87,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     {
         int m = m0 + wave * 8 + (lane >> 3);
         int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
-        const int last = ((a.Bn * (a.H + 2) - 3) * Wp + a.W - 1) * a.Cin * 2;      // pixel M - 1: rows past the end read it (never stored)
+        const int last = ((a.Bn * (a.H + 2) - 3) * Wp + a.W - 1) * a.Cin * ES;     // pixel M - 1: rows past the end read it (never stored)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
-            xoff[j] = (m < a.M ? ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * 2 : last) + (FIRST ? (gsel & 1) : gsel) * 16;
+            xoff[j] = (m < a.M ? ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * ES : last) + (FIRST ? (gsel & 1) : gsel) * 16;
             m += NW * 8;
             xx += NW * 8;
             while (xx >= a.W) { xx -= a.W; if (++yy == a.H) { yy = 0; ++b; } }
@@ -95,17 +102,17 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     const int wrow0 = (n0 + wave * 8) * K2;                       // + j * NW * 8 * K2 per piece
 
     // K-step state (scalar): tap (ty, tx) and the 64-channel slice cc of it
-    const int cpt = a.Cin >> 6, KT = FIRST ? 3 : 9 * cpt;
+    const int cpt = a.Cin / CPS, KT = FIRST ? 3 : 9 * cpt;
     int ty = 0, tx = 0, cc = 0;
     int sx = 0, sw = 0, tapv = 0;                                 // source offsets of the step being fetched (next())
     char *dst = lds;
     auto next = [&](const int kt) __attribute__((always_inline)) {
-        sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * 64) * 2;
+        sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * CPS) * ES;
         sw = wrow0 + kt * BK_BYTES;
         dst = lds + (kt % STAGES) * STAGE;
         if (FIRST) {                                              // this lane's tap of the step (per lane, not per step)
             const int t = kt * 4 + (gsel >> 1), t9 = t < 9 ? t : 0, tyy = t9 / 3;
-            tapv = (tyy * Wp + (t9 - tyy * 3)) * a.Cin * 2;
+            tapv = (tyy * Wp + (t9 - tyy * 3)) * a.Cin * ES;
         }
         if (++cc == cpt) { cc = 0; if (++tx == 3) { tx = 0; ++ty; } }
     };
@@ -154,17 +161,21 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
         const char *const st = lds + (kt % STAGES) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            typename Vec<T>::v8 fw[FC], fx[FP];
+            typename OpVec<T>::type fw[FC], fx[FP];
 #pragma unroll
-            for (int i = 0; i < FC; ++i) fw[i] = *(const typename Vec<T>::v8 *)(st + w_lds + i * 32 * BK_BYTES + koff[ks]);
+            for (int i = 0; i < FC; ++i) fw[i] = *(const typename OpVec<T>::type *)(st + w_lds + i * 32 * BK_BYTES + koff[ks]);
 #pragma unroll
-            for (int j = 0; j < FP; ++j) fx[j] = *(const typename Vec<T>::v8 *)(st + x_lds + j * 32 * BK_BYTES + koff[ks]);
+            for (int j = 0; j < FP; ++j) fx[j] = *(const typename OpVec<T>::type *)(st + x_lds + j * 32 * BK_BYTES + koff[ks]);
 #pragma unroll
             for (int i = 0; i < FC; ++i)
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
-                    if constexpr (sizeof(T) == 2 && __is_same(T, _Float16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    if constexpr (__is_same(T, _Float16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    else if constexpr (__is_same(T, __bf16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    else {                                        // element e of both 4-vectors is one k (lane half h: channel 8 m + 4 h + e)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[i][e], fx[j][e], acc[i][j], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
                     v[e] = acc[i][j][4 * q + e] + bv[e];
                     if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 }
-                if (OUT_F32) {
+                if constexpr (OUT_F32) {
                     *(f32x4 *)(lds + P * ROWB + ((((c0 >> 2)) ^ (P & (SLOTS - 1))) << 4)) = v;
                 } else {
                     typename Vec<T>::v4 hv;
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
         const unsigned off = s_pix[P];
         u32x4 v = *(const u32x4 *)(lds + P * ROWB + ((s ^ (P & (SLOTS - 1))) << 4));
         if (off == 0xFFFFFFFFu) continue;
-        if (!OUT_F32 && a.mask) {                                 // gate by the sign of the masking map's 8 values of this piece
+        if constexpr (!OUT_F32) if (a.mask) {                     // gate by the sign of the masking map's 8 values of this piece
             typedef typename Vec<T>::v8 V8;
             const V8 m = *(const V8 *)((const char *)a.mask + (size_t)n0 * ESZ + off + s * 16);
             V8 o = __builtin_bit_cast(V8, v);
@@ -345,6 +356,32 @@ static int conv3x3_entry(const void *x_framed, const void *w_packed, const float
     return launch_conv<T, 256, 64, 4, 1, 2, false>(a, out_f32, s);
 }
 
+// exact-f32 variant: f32 framed activations (c_in a multiple of 32), f32 packed weights, f32 output
+static int conv3x3_f32_entry(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
+                             int c_out, int out_framed, int relu, void *stream)
+{
+    if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
+    if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;
+    if (c_in <= 0 || c_in % 32 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 4, wb = (size_t)c_out * 9 * c_in * 4;
+    const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * 4;
+    if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
+    ConvArgs a;
+    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y; a.mask = nullptr;
+    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width; a.Bn = batch;
+    a.out_pad = out_framed != 0; a.relu = relu != 0;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    hipStream_t s = (hipStream_t)stream;
+    if (c_out % 128 == 0) {
+        a.m_tiles = (a.M + 127) / 128; a.n_tiles = c_out / 128;
+        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 128, 128, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
+    } else {
+        a.m_tiles = (a.M + 127) / 128; a.n_tiles = c_out / 64;
+        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 128, 64, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
+    }
+    return mv3d_launch_status();
+}
+
 template <typename T>
 static int maxpool_entry(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
 {
@@ -384,6 +421,19 @@ extern "C" int mv3d_conv3x3_gated_bf16(const void *x, const void *w, const float
 {
     if (!gate_framed) return MV3D_ERR_INVALID_ARG;
     return conv3x3_entry<__bf16>(x, w, bias, y, batch, height, width, c_in, c_out, 1, 0, 0, stream, gate_framed);
+}
+extern "C" int mv3d_conv3x3_f32(const void *x, const void *w, const float *bias, void *y, int batch, int height, int width, int c_in, int c_out,
+                                int out_framed, int relu, void *stream)
+{
+    return conv3x3_f32_entry(x, w, bias, y, batch, height, width, c_in, c_out, out_framed, relu, stream);
+}
+extern "C" int mv3d_maxpool2x2_f32(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
+{
+    return maxpool_entry<float>(x, y, batch, height, width, channels, stream);
+}
+extern "C" int mv3d_frame_nhwc_f32(const float *x, void *y, int batch, int height, int width, int channels, int channels_out, void *stream)
+{
+    return frame_entry<float>(x, y, batch, height, width, channels, channels_out, stream);
 }
 extern "C" int mv3d_maxpool2x2_f16(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
 {

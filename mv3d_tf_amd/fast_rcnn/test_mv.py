@@ -104,7 +104,7 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
 
 
 
-def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp16", "fp16_mfma"), reduce_device="cuda", views=3):
+def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp32_mfma", "fp16", "fp16_mfma"), reduce_device="cuda", views=3):
     """Full MV3D_test forward WITH the dense layers, for bench.py's `serving_with_trunk` key (BASELINE configs[4]: batch
     16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the trunks /
     FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision (torch: MIOpen /
@@ -139,8 +139,8 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
             rois[0] = int(L["rois"][2].shape[0])
 
     for name in dtypes:
-        net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16}[name]
-        net.mfma_trunk = name == "fp16_mfma"
+        net.amp_dtype = {"fp32": None, "fp32_mfma": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16}[name]
+        net.mfma_trunk = name.endswith("_mfma")
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -154,6 +154,7 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
         out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
                      "rois_per_step": rois[0]}
     cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
-    out["note"] = ("fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
+    out["note"] = ("fp32_mfma = the reference's precision with the 3x3 convolutions on this library's exact-f32 MFMA kernel; "
+                   "fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
                    "(f32 accumulate), FC head autocast; both lower precision than the reference's fp32; the hot-path layers run in f32")
     return out

@@ -138,7 +138,7 @@ class MV3D:
         """trunks + RPN head with every 3x3 convolution on mv3d_conv3x3_f16; returns (rpn_cls_score, rpn_bbox_pred) f32 NHWC"""
         if torch.is_grad_enabled() and self.trainable:
             raise RuntimeError("mfma_trunk is the forward-only serving trunk: run it under torch.no_grad() (or trainable=False)")
-        half = torch.bfloat16 if self.amp_dtype == torch.bfloat16 else torch.float16
+        half = self.amp_dtype or torch.float32                       # amp_dtype None: the reference's fp32, on the f32 MFMA
         if self._mfma is None or self._mfma.dtype != half:
             from ..trunk import MfmaTrunks
             self._mfma = MfmaTrunks(self, _VGG, dtype=half)
@@ -153,7 +153,7 @@ class MV3D:
             if self.views == 3:
                 self._mfma.trunk(L["lidar_fv_data"], "_3", last_framed=False)
         bev = self._mfma.trunk(L["lidar_bv_data"], "", last_framed=True)
-        L["conv5_3"] = bev[:, 1:-1, 1:-1].float()                    # the f32 NHWC map the RoiPool layer reads
+        L["conv5_3"] = bev[:, 1:-1, 1:-1].float().contiguous()       # the f32 NHWC map the RoiPool layer reads
         rpn = self._mfma.rpn_conv(bev)                               # (B, H, W, 512) f16
         main.wait_stream(self._side)
         for k in ("conv5_3_2", "conv5_3_3"):

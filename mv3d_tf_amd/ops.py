@@ -384,14 +384,16 @@ def rcnn_loss(cls_score, labels, bbox_pred, bbox_targets, sigma=3.0, want_grad=T
 
 
 # ------------------------------------------------------------------ the serving trunk's contraction (f16 MFMA)
-# (the `_f16` functions take float16 or bfloat16 tensors and pick the C entry by the tensor's dtype: f16 = the serving trunk,
-# bf16 = the training trunk)
+# (the `_f16` functions take float16, bfloat16 or float32 tensors and pick the C entry by the tensor's dtype: f16 = the serving trunk,
+# bf16 = the training trunk, f32 = the serving trunk in the reference's precision)
 def _half_entry(stem, dtype):
     if dtype == torch.float16:
         return getattr(lib(), stem + "_f16"), stem + "_f16"
     if dtype == torch.bfloat16:
         return getattr(lib(), stem + "_bf16"), stem + "_bf16"
-    raise TypeError("float16 or bfloat16 tensors expected, got %s" % dtype)
+    if dtype == torch.float32:
+        return getattr(lib(), stem + "_f32"), stem + "_f32"
+    raise TypeError("float16, bfloat16 or float32 tensors expected, got %s" % dtype)
 
 
 def pack_conv3x3_weights(w_oihw, c_in_pad=None, dtype=torch.float16):
@@ -432,18 +434,25 @@ def conv3x3_f16(x_framed, w_packed, bias, out=None, out_framed=True, out_f32=Fal
     if w_packed.dtype != x_framed.dtype:
         raise TypeError("activations %s, weights %s" % (x_framed.dtype, w_packed.dtype))
     fn, name = _half_entry("mv3d_conv3x3", x_framed.dtype)
+    f32 = x_framed.dtype == torch.float32
+    if f32:
+        out_f32 = True                                            # f32 maps in, f32 maps out
     if out is None:
         if out_framed:
             out = framed_buffer(B, H, W, cout, x_framed.device, x_framed.dtype)
         else:
             out = torch.empty((B, H, W, cout), dtype=torch.float32 if out_f32 else x_framed.dtype, device=x_framed.device)
     # the kernel addresses each buffer with 32-bit offsets: frames are independent, so a larger batch goes in chunks
-    per_frame = max(Hp * Wp * cin * 2, out[0].numel() * out.element_size())
+    per_frame = max(Hp * Wp * cin * x_framed.element_size(), out[0].numel() * out.element_size())
     step = max(1, min(B, (2 ** 31 - 1) // per_frame))
     for b0 in range(0, B, step):
         nb = min(step, B - b0)
-        check(fn(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout, int(out_framed),
-                 int(out_f32), int(relu), _stream()), name)
+        if f32:
+            check(fn(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout, int(out_framed), int(relu),
+                     _stream()), name)
+        else:
+            check(fn(_ptr(x_framed[b0:b0 + nb]), _ptr(w_packed), _ptr(bias), _ptr(out[b0:b0 + nb]), nb, H, W, cin, cout, int(out_framed),
+                     int(out_f32), int(relu), _stream()), name)
     return out
 
 

@@ -19,7 +19,8 @@ class MfmaTrunks:
     def __init__(self, net, vgg, dtype=torch.float16):
         self.net = net
         self.vgg = vgg                       # [(stem, c_out, pool_after)]
-        self.dtype = dtype                   # float16 (default) or bfloat16 (f16's range is the usual worry with raw-pixel inputs)
+        self.dtype = dtype                   # float16 (default), bfloat16 (f16's range is the usual worry with raw-pixel inputs) or
+                                             # float32 = the reference's precision on the f32 MFMA
         self._w = {}                         # name -> (version, packed f16 weights, f32 bias)
         self._buf = {}                       # (tag, B, H, W, C) -> framed f16 buffer (frame stays zero: only interiors are written)
 
@@ -28,8 +29,11 @@ class MfmaTrunks:
         ver = (w._version, b._version)
         hit = self._w.get(name)
         if hit is None or hit[0] != ver:
-            pack = ops.pack_conv3x3_weights_input_layer if input_layer else ops.pack_conv3x3_weights
-            hit = (ver, pack(w, dtype=self.dtype), b.detach().float().contiguous())
+            if input_layer and self.dtype == torch.float32:      # (f32: the input layer's channels padded to one 32-channel K step)
+                packed = ops.pack_conv3x3_weights(w, 32, dtype=self.dtype)
+            else:
+                packed = (ops.pack_conv3x3_weights_input_layer if input_layer else ops.pack_conv3x3_weights)(w, dtype=self.dtype)
+            hit = (ver, packed, b.detach().float().contiguous())
             self._w[name] = hit
         return hit[1], hit[2]
 
@@ -51,7 +55,7 @@ class MfmaTrunks:
         B, H, W, c = x_nhwc.shape
         dev = x_nhwc.device
         L = self.net.layers
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), self._framed("in" + suffix, B, H, W, 16, dev))
+        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), self._framed("in" + suffix, B, H, W, 32 if self.dtype == torch.float32 else 16, dev))
         n = len(self.vgg)
         for i, (stem, cout, pool) in enumerate(self.vgg):
             name = stem + suffix
@@ -69,7 +73,7 @@ class MfmaTrunks:
         return x
 
     def rpn_conv(self, conv5_3_framed):
-        """rpn_conv/3x3 (MV3D_test.py:82-84) on the framed BEV conv5_3 -> (B, H, W, 512) f16 NHWC"""
+        """rpn_conv/3x3 (MV3D_test.py:82-84) on the framed BEV conv5_3 -> (B, H, W, 512) NHWC of the trunk's type"""
         wp, bias = self._packed("rpn_conv/3x3")
         return ops.conv3x3_f16(conv5_3_framed, wp, bias, out_framed=False, out_f32=False)
 
@@ -88,21 +92,28 @@ def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3), ("_3", 
     return rows
 
 
-def bench_conv_layers(vgg, batch=16, reps=3):
+def bench_conv_layers(vgg, batch=16, reps=3, dtype=torch.float16):
     """Roofline entry of the convolution kernel for bench.py: every 3x3 layer of the 3-view serving graph (40 launches: BEV
     trunk, rpn_conv/3x3, RGB trunk, front-view trunk) at `batch` frames, each timed with HIP events on the launch stream over `reps` launches after one
     warm-up.  achieved = ALGORITHMIC flops (2 * B*H*W * c_out * 9 * c_in with the true c_in, i.e. conv1_1's zero padding is not
-    counted) / time; peak = the dense f16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s)."""
+    counted) / time; peak = the dense MFMA peak of MI355X_MICROARCH.md for the operand type (f16 / bf16: 2.5 PFLOP/s; f32 on
+    v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s)."""
     dev = torch.device("cuda")
+    f32 = dtype == torch.float32
+    peak = 157.3 if f32 else 2500.0
     tot_fl, tot_ms, per = 0.0, 0.0, {}
     for name, H, W, cin, cout in serving_layers(vgg):
         first = cin < 16
-        x = ops.framed_buffer(batch, H, W, 16 if first else cin, dev)
-        x[:, 1:-1, 1:-1, :cin] = torch.randn((batch, H, W, cin), device=dev, dtype=torch.float16)
+        cpad = (32 if f32 else 16) if first else cin
+        x = ops.framed_buffer(batch, H, W, cpad, dev, dtype)
+        x[:, 1:-1, 1:-1, :cin] = torch.randn((batch, H, W, cin), device=dev, dtype=dtype)
         w = torch.randn((cout, cin, 3, 3), device=dev) * (2.0 / (9 * cin)) ** 0.5
-        wp = ops.pack_conv3x3_weights_input_layer(w) if first else ops.pack_conv3x3_weights(w)
+        if first and not f32:
+            wp = ops.pack_conv3x3_weights_input_layer(w, dtype=dtype)
+        else:
+            wp = ops.pack_conv3x3_weights(w, cpad, dtype=dtype)
         b = torch.zeros(cout, device=dev)
-        out = ops.framed_buffer(batch, H, W, cout, dev)
+        out = ops.framed_buffer(batch, H, W, cout, dev, dtype)
         ops.conv3x3_f16(x, wp, b, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -118,7 +129,9 @@ def bench_conv_layers(vgg, batch=16, reps=3):
         del x, out
     ach = tot_fl / tot_ms / 1e9
     best = max(per.items(), key=lambda kv: kv[1]["tflops"])
-    return {"kernel": "conv3x3_f16_kernel (v_mfma_f32_32x32x16_f16; the %d 3x3 convolutions of the 3-view serving graph, batch %d)" % (len(per), batch),
-            "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+    mfma = "v_mfma_f32_32x32x2_f32 (exact f32)" if f32 else "v_mfma_f32_32x32x16_%s" % ("f16" if dtype == torch.float16 else "bf16")
+    return {"kernel": "conv3x3_f16_kernel<%s> (%s; the %d 3x3 convolutions of the 3-view serving graph, batch %d)"
+                      % (str(dtype).split(".")[-1], mfma, len(per), batch),
+            "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": len(per) * reps,
             "best_layer": {"name": best[0], **best[1]}, "traffic": None}

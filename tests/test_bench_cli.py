@@ -108,8 +108,11 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     assert mp["frames_per_s"] > wt["frames_per_s"] and mp["roofline_kernels"][0]["bound"] == "mfma" and 0 < mp["roofline_kernels"][0]["frac"] < 1
     sv = sec["serving_with_trunk"]
     assert sv["fp32"]["frames_per_s"] > 0 and sv["fp16_mfma"]["frames_per_s"] > 0 and sv["fp16_mfma"]["rois_per_step"] > 0
+    assert sv["fp32_mfma"]["frames_per_s"] > 0
     rk = sv["roofline_kernels"][0]
     assert rk["bound"] == "mfma" and rk["peak"] == 2500.0 and 0 < rk["frac"] < 1 and abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-3
+    r32 = sv["roofline_kernels"][1]
+    assert r32["peak"] == 157.3 and 0 < r32["frac"] < 1
 
 
 def test_conv_roofline_accounting():

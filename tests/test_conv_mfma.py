@@ -414,3 +414,64 @@ def test_mixed_precision_training_converges_like_fp32(gpu):
     assert all(np.isfinite(b)) and abs(a[0] - b[0]) <= 0.01 * a[0]
     assert a[-1] < 0.4 * a[0] and b[-1] < 0.4 * b[0], (a, b)
     assert abs(a[-1] - b[-1]) <= 0.3 * max(a[-1], b[-1]), (a, b)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,relu,framed", [(2, 38, 50, 128, 256, True, True), (1, 21, 33, 32, 64, False, False),
+                                                        (1, 46, 155, 512, 512, True, False)])
+def test_exact_f32_convolution(gpu, B, H, W, cin, cout, relu, framed):
+    """mv3d_conv3x3_f32 (v_mfma_f32_32x32x2_f32: exact f32 products and sums) against torch's fp32 convolution: only the summation
+    order differs -> <= 2e-5 of the map's largest value; the f32 pool is exact"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B + H + cout)
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), device="cuda", generator=g)
+    prev = torch.backends.cudnn.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    torch.backends.cudnn.allow_tf32 = prev
+    if relu:
+        want = torch.relu(want)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cin, "cuda", torch.float32))
+    got = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights(w, dtype=torch.float32), b, out_framed=framed, relu=relu)
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32
+    if framed:
+        assert float(got[:, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0
+        p = ops.maxpool2x2_f16(got)
+        assert torch.equal(p[:, 1:-1, 1:-1], torch.nn.functional.max_pool2d(got[:, 1:-1, 1:-1].permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1))
+        got = got[:, 1:-1, 1:-1]
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_serving_graph_in_reference_precision_on_the_f32_mfma_trunk(gpu):
+    """MV3D_test with mfma_trunk = True and amp_dtype = None (fp32) against the torch / MIOpen fp32 graph: the conv5_3 maps and the
+    RPN head agree to 1e-4 of their largest value (13 layers of re-ordered f32 sums), the detections' shapes match"""
+    torch = gpu
+    import numpy as np
+    from mv3d_tf_amd import synth
+    from mv3d_tf_amd.networks import get_network
+    net = get_network("MV3D_test")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    with torch.no_grad():
+        for name, (w, b) in net.params.items():
+            if w.ndim == 4:
+                w.copy_(torch.randn(w.shape, device="cuda", generator=g) * (2.0 / (w.shape[1] * w.shape[2] * w.shape[3])) ** 0.5)
+                b.copy_(torch.randn(b.shape, device="cuda", generator=g) * 0.05)
+    rng = np.random.RandomState(4)
+    B = 2
+    feed = {"lidar_bv_data": ((rng.random_sample((B, 608, 608, 9)) < 0.05) * rng.uniform(0, 2.4, (B, 608, 608, 9))).astype(np.float32),
+            "image_data": rng.uniform(-1, 1, (B, 96, 320, 3)).astype(np.float32),
+            "im_info": np.array([[608, 608, 1]] * B, np.float32), "calib": np.stack([synth.KITTI_CALIB] * B)}
+    outs = {}
+    for mfma in (False, True):
+        net.amp_dtype, net.mfma_trunk = None, mfma
+        with torch.no_grad():
+            L = net.forward(feed)
+        torch.cuda.synchronize()
+        outs[mfma] = {k: L[k].float().clone() for k in ("conv5_3", "conv5_3_2", "rpn_cls_score", "rpn_bbox_pred")}
+        assert L["conv5_3"].dtype == torch.float32 and (L["conv5_3"].is_contiguous() or not mfma)
+    for k in outs[True]:
+        scale = float(outs[False][k].abs().max())
+        assert float((outs[False][k] - outs[True][k]).abs().max()) <= 1e-4 * scale, (k, scale)
