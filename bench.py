@@ -454,9 +454,13 @@ def main():
             # a lower precision than the reference's fp32 training, reported next to it)
             mp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=torch.bfloat16, mfma=True)
             torch.cuda.empty_cache()
+            # ... and in the reference's fp32 with the trunks' forward / data-gradient convolutions on the exact-f32 MFMA kernel
+            fp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=None, mfma=True)
+            torch.cuda.empty_cache()
             if rank == 0:
                 from mv3d_tf_amd import trunk_train
                 from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
+                sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"]}
                 sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
                                                          "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
             if dist is not None:

@@ -399,6 +399,8 @@ int mv3d_frame_nhwc_bf16(const float *x_nhwc, void *y_framed, int batch, int hei
  * window gets the gradient if it is > 0).  All framed bf16; rows / columns the pool dropped are left untouched (zero). */
 int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
                              int channels, void *stream);
+int mv3d_maxpool2x2_bwd_f32(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
+                            int channels, void *stream);      /* the same on f32 maps (the fp32 training trunk) */
 /* Weight gradient of that convolution (csrc/conv3x3_wgrad.hip): dw (c_out, c_in_real, 3, 3) f32 [the OIHW filter layout; TF's
  * HWIO is its transpose(2, 3, 1, 0)], dw[co][ci][tap] = sum over the pixels of the batch of dy[pixel][co] * x[pixel + tap][ci],
  * for the first c_in_real <= c_in channels (the input layer's buffer is padded to 64 channels); db (c_out) f32 (may be NULL) =

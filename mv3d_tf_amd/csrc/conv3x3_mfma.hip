@@ -443,18 +443,27 @@ extern "C" int mv3d_maxpool2x2_bf16(const void *x, void *y, int batch, int heigh
 {
     return maxpool_entry<__bf16>(x, y, batch, height, width, channels, stream);
 }
-extern "C" int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
-                                        int channels, void *stream)
+template <typename T>
+static int maxpool_bwd_entry(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width, int channels,
+                             void *stream)
 {
     if (!y_framed || !g_pooled_framed || !gy_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)y_framed | (uintptr_t)g_pooled_framed | (uintptr_t)gy_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    typedef Vec<__bf16>::v8 V;
+    typedef typename Vec<T>::v8 V;
     const int Ho = height / 2, Wo = width / 2;
     const long total = (long)batch * Ho * Wo * (channels / 8);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const V *)y_framed, (const V *)g_pooled_framed,
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const V *)y_framed, (const V *)g_pooled_framed,
                        (V *)gy_framed, batch, height, width, channels / 8, Ho, Wo);
     return mv3d_launch_status();
+}
+extern "C" int mv3d_maxpool2x2_bwd_bf16(const void *y, const void *g, void *gy, int batch, int height, int width, int channels, void *stream)
+{
+    return maxpool_bwd_entry<__bf16>(y, g, gy, batch, height, width, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_bwd_f32(const void *y, const void *g, void *gy, int batch, int height, int width, int channels, void *stream)
+{
+    return maxpool_bwd_entry<float>(y, g, gy, batch, height, width, channels, stream);
 }
 extern "C" int mv3d_frame_nhwc_f16(const float *x, void *y, int batch, int height, int width, int channels, int channels_out, void *stream)
 {

@@ -235,7 +235,9 @@ class MV3D:
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
         if self.mfma_trunk and self.phase == "TRAIN" and torch.is_grad_enabled():
             # mixed-precision training trunks: forward and backward convolutions on the bf16 MFMA kernel (mv3d_tf_amd.trunk_train)
-            from ..trunk_train import BufferPool, trunk as mfma_train_trunk
+            from ..trunk_train import BufferPool, trunk as _trunk_fn
+            tdt = torch.bfloat16 if self.amp_dtype is not None else torch.float32     # amp_dtype None: the reference's fp32, exact-f32 MFMA
+            mfma_train_trunk = lambda *a_, **k_: _trunk_fn(*a_, dtype=tdt, **k_)
             if self._train_pool is None:
                 self._train_pool = BufferPool()         # (one forward / backward pair per network in flight)
             # the image / front-view trunks on side streams: at a training batch of 2 their launches do not fill the chip, so the
@@ -265,7 +267,7 @@ class MV3D:
                     main.wait_stream(self._train_streams[k])
                     L[out].record_stream(main)
             from ..trunk_train import conv_relu
-            rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"])           # (B, H, W, 512) f32, same kernels
+            rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"], dtype=tdt)   # (B, H, W, 512) f32, same kernels
             L["rpn_conv/3x3"] = rpn_nhwc
             heads = []
             for name in ("rpn_cls_score", "rpn_bbox_pred"):                       # 1x1 convolutions = a matmul over the channel axis

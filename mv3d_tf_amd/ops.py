@@ -468,10 +468,12 @@ def maxpool2x2_f16(x_framed, out=None):
 
 
 def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
-    """gradient of ReLU + 2x2 max pool into the zero-initialised framed bf16 buffer `out` (same shape as y_framed)"""
+    """gradient of ReLU + 2x2 max pool into the zero-initialised framed buffer `out` (same shape / type as y_framed: bf16 or f32)"""
     B, Hp, Wp, Cc = y_framed.shape
-    check(lib().mv3d_maxpool2x2_bwd_bf16(_ptr(y_framed), _ptr(g_pooled_framed), _ptr(out), B, Hp - 2, Wp - 2, Cc, _stream()),
-          "mv3d_maxpool2x2_bwd_bf16")
+    if y_framed.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("bfloat16 or float32 maps expected")
+    fn, name = _half_entry("mv3d_maxpool2x2_bwd", y_framed.dtype)
+    check(fn(_ptr(y_framed), _ptr(g_pooled_framed), _ptr(out), B, Hp - 2, Wp - 2, Cc, _stream()), name)
     return out
 
 

@@ -47,53 +47,62 @@ class BufferPool:
     def __init__(self):
         self._buf = {}
 
-    def get(self, tag, B, H, W, C, dev):
-        key = (tag, B, H, W, C)
+    def get(self, tag, B, H, W, C, dev, dtype=BF):
+        key = (tag, B, H, W, C, dtype)
         buf = self._buf.get(key)
         if buf is None:
-            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev, BF)
+            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev, dtype)
         return buf
 
 
 class _NoPool:
     @staticmethod
-    def get(tag, B, H, W, C, dev):
-        return ops.framed_buffer(B, H, W, C, dev, BF)
+    def get(tag, B, H, W, C, dev, dtype=BF):
+        return ops.framed_buffer(B, H, W, C, dev, dtype)
+
+
+def _pack_pair(w, c_in_pad, want_dgrad, dtype):
+    """(forward packing, data-gradient packing | None) of an fp32 OIHW filter in the trunk's type"""
+    if dtype == BF:
+        return ops.pack_conv3x3_train_bf16(w, c_in_pad, want_dgrad=want_dgrad)
+    fwd = ops.pack_conv3x3_weights(w, c_in_pad, dtype=dtype)
+    return fwd, (ops.pack_conv3x3_weights(w.detach().flip(2, 3).transpose(0, 1), dtype=dtype) if want_dgrad else None)
 
 
 class TrunkFunction(torch.autograd.Function):
     """apply(layers, wgrad, pool, x_nhwc_f32, w_0, b_0, ..., w_12, b_12) -> conv5_3 (B, H', W', 512) f32;
     layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> ((O, c_in, 3, 3) f32, (O,) f32),
-    pool = (BufferPool | None, tag)"""
+    pool = (BufferPool | None, tag, dtype)"""
 
     @staticmethod
     def forward(ctx, layers, wgrad, pool_tag, x_nhwc, *wb):
         B, H, W, c0 = x_nhwc.shape
         dev = x_nhwc.device
-        bufs, tag = (pool_tag[0] or _NoPool), pool_tag[1]
-        # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, 64, dev))
+        bufs, tag, dt = (pool_tag[0] or _NoPool), pool_tag[1], pool_tag[2]
+        # (the input layer's channels zero-padded to 64 -- 32 in f32: the same kernels as every other layer, forward and gradients)
+        cpad0 = 32 if dt == torch.float32 else 64
+        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, cpad0, dev, dt))
         saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
         packed_dgrad = []
         n = len(layers)
         out = None
         for i, (_, cout, pool) in enumerate(layers):
             w, b = wb[2 * i], wb[2 * i + 1]
-            wp, wd = ops.pack_conv3x3_train_bf16(w, 64 if i == 0 else None, want_dgrad=i > 0)   # (both packings in one launch)
+            wp, wd = _pack_pair(w, cpad0 if i == 0 else None, i > 0, dt)              # (bf16: both packings in one launch)
             packed_dgrad.append(wd)
             bias = b.detach().float().contiguous()
             if i == n - 1:
                 out = ops.conv3x3_f16(x, wp, bias, out_framed=False, out_f32=True)
                 saved.append((x, None, H, W))
                 break
-            y = ops.conv3x3_f16(x, wp, bias, out=bufs.get("%s/y%d" % (tag, i), B, H, W, cout, dev))
+            y = ops.conv3x3_f16(x, wp, bias, out=bufs.get("%s/y%d" % (tag, i), B, H, W, cout, dev, dt))
             saved.append((x, y, H, W))
             if pool:
                 H, W = H // 2, W // 2
-                x = ops.maxpool2x2_f16(y, out=bufs.get("%s/p%d" % (tag, i), B, H, W, cout, dev))
+                x = ops.maxpool2x2_f16(y, out=bufs.get("%s/p%d" % (tag, i), B, H, W, cout, dev, dt))
             else:
                 x = y
-        ctx.layers, ctx.wgrad, ctx.saved, ctx.c0, ctx.bufs, ctx.tag = layers, wgrad, saved, c0, bufs, tag
+        ctx.layers, ctx.wgrad, ctx.saved, ctx.c0, ctx.bufs, ctx.tag, ctx.dt = layers, wgrad, saved, c0, bufs, tag, dt
         ctx.packed_dgrad = packed_dgrad
         ctx.save_for_backward(out)
         return out
@@ -107,9 +116,9 @@ class TrunkFunction(torch.autograd.Function):
         dev = g.device
         grads = [None] * (2 * n)
         # gradient w.r.t. conv5_3's pre-activation, framed
-        bufs, tag = ctx.bufs, ctx.tag
+        bufs, tag, dt = ctx.bufs, ctx.tag, ctx.dt
         x_last, _, H, W = saved[n - 1]
-        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev))
+        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev, dt))
         zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
         for i in range(n - 1, -1, -1):
             x_in, _, H, W = saved[i]
@@ -119,12 +128,14 @@ class TrunkFunction(torch.autograd.Function):
                 break
             # two gradient buffers per resolution alternate (dy of layer i is read while dx = dy of layer i - 1 is written)
             _, y_prev, Hp, Wp_ = saved[i - 1]
-            out_buf = bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev)
+            out_buf = bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev, dt)
             if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i: route through it (mask fused)
                 dx = ops.conv3x3_f16(dy, ctx.packed_dgrad[i], zero_bias, relu=False, out=out_buf)
-                dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev))
-            else:                                      # data gradient and the ReLU mask of layer i - 1's output in one launch
+                dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev, dt))
+            elif dt == BF:                             # data gradient and the ReLU mask of layer i - 1's output in one launch
                 dy = ops.conv3x3_gated_bf16(dy, ctx.packed_dgrad[i], zero_bias, y_prev, out_buf)
+            else:
+                dy = ops.conv3x3_f16(dy, ctx.packed_dgrad[i], zero_bias, relu=False, out=out_buf).mul_(y_prev > 0)
         return (None, None, None, None) + tuple(grads)
 
 
@@ -133,12 +144,13 @@ class ConvReluFunction(torch.autograd.Function):
     apply(wgrad, x_nhwc_f32, w, b) -> (B, H, W, c_out) f32."""
 
     @staticmethod
-    def forward(ctx, wgrad, x_nhwc, w, b):
+    def forward(ctx, wgrad_dt, x_nhwc, w, b):
+        wgrad, dt = wgrad_dt
         B, H, W, cin = x_nhwc.shape
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), ops.framed_buffer(B, H, W, cin, x_nhwc.device, BF))
-        wp, wd = ops.pack_conv3x3_train_bf16(w)
+        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), ops.framed_buffer(B, H, W, cin, x_nhwc.device, dt))
+        wp, wd = _pack_pair(w, None, True, dt)
         out = ops.conv3x3_f16(x, wp, b.detach().float().contiguous(), out_framed=False, out_f32=True)
-        ctx.wgrad, ctx.x, ctx.wd = wgrad, x, wd
+        ctx.wgrad, ctx.x, ctx.wd, ctx.dt = wgrad, x, wd, dt
         ctx.save_for_backward(out)
         return out
 
@@ -148,23 +160,30 @@ class ConvReluFunction(torch.autograd.Function):
         B, H, W, cout = g.shape
         cin = ctx.x.shape[3]
         dev = g.device
-        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), ops.framed_buffer(B, H, W, cout, dev, BF))
+        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), ops.framed_buffer(B, H, W, cout, dev, ctx.dt))
         gw, gb = ctx.wgrad(ctx.x, dy, cin)
         dx = ops.conv3x3_f16(dy, ctx.wd, torch.zeros(cin, dtype=torch.float32, device=dev), relu=False, out_framed=False, out_f32=True)
         return None, dx, gw, gb
 
 
-def conv_relu(x_nhwc, w, b, wgrad=wgrad_mfma):
-    return ConvReluFunction.apply(wgrad, x_nhwc, w, b)
+def _default_wgrad(dtype):
+    # f32: the weight gradient stays with torch / MIOpen (the transposing LDS read the MFMA kernel needs is a 16-bit instruction)
+    return wgrad_mfma if dtype == BF else _wgrad_torch
 
 
-def trunk(layers, x_nhwc, params, suffix, wgrad=wgrad_mfma, pool=None):
+def conv_relu(x_nhwc, w, b, wgrad=None, dtype=BF):
+    return ConvReluFunction.apply((wgrad or _default_wgrad(dtype), dtype), x_nhwc, w, b)
+
+
+def trunk(layers, x_nhwc, params, suffix, wgrad=None, pool=None, dtype=BF):
     """conv1_1<suffix> .. conv5_3<suffix> of a TRAIN graph: params = {name: [w, b]} (fp32, OIHW); pool: a BufferPool that keeps
-    the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call"""
+    the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call.  dtype = bfloat16:
+    mixed precision, all three convolutions of a layer on the MFMA kernels; float32: the reference's precision -- forward and data
+    gradient on the exact-f32 MFMA kernel, the weight gradient through torch / MIOpen."""
     wb = []
     for stem, _, _ in layers:
         wb += list(params[stem + suffix])
-    return TrunkFunction.apply(layers, wgrad, (pool, "trunk" + suffix), x_nhwc, *wb)
+    return TrunkFunction.apply(layers, wgrad or _default_wgrad(dtype), (pool, "trunk" + suffix, dtype), x_nhwc, *wb)
 
 
 def bench_wgrad_layers(vgg, batch=2, reps=3):

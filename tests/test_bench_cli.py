@@ -104,6 +104,7 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     wt = sec["with_trunk"]
     assert wt["frames_per_s"] > 0 and wt["allreduce_buckets"] >= 8 and wt["gradient_bytes_per_step"] > 500e6
     assert sec["test_cfg"]["frames_per_s"] > 0
+    assert wt["fp32_mfma_trunk"]["frames_per_s"] > 0
     mp = wt["bf16_mfma_trunk"]
     assert mp["frames_per_s"] > wt["frames_per_s"] and mp["roofline_kernels"][0]["bound"] == "mfma" and 0 < mp["roofline_kernels"][0]["frac"] < 1
     sv = sec["serving_with_trunk"]

@@ -475,3 +475,37 @@ def test_serving_graph_in_reference_precision_on_the_f32_mfma_trunk(gpu):
     for k in outs[True]:
         scale = float(outs[False][k].abs().max())
         assert float((outs[False][k] - outs[True][k]).abs().max()) <= 1e-4 * scale, (k, scale)
+
+
+def test_fp32_training_trunk_matches_torch_autograd(gpu):
+    """trunk_train.trunk(dtype=float32): forward and data gradient on the exact-f32 MFMA kernel, weight gradient through torch --
+    the reference's precision, so against torch fp32 autograd of the same trunk the gradients agree to 1e-3 of their largest entry
+    (re-ordered f32 sums through 5 layers and 2 pools; no ReLU / pool-route flips as in the 16-bit trunks) with cosine >= 0.99999"""
+    torch = gpu
+    from mv3d_tf_amd import trunk_train
+    layers = [("a", 64, False), ("b", 64, True), ("c", 128, False), ("d", 128, True), ("e", 256, False)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    params, cin = {}, 9
+    for name, cout, _ in layers:
+        params[name] = [(torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * (2.0 / (9 * cin)) ** 0.5).requires_grad_(True),
+                        (torch.randn((cout,), device="cuda", generator=g) * 0.1).requires_grad_(True)]
+        cin = cout
+    x = torch.randn((2, 42, 54, 9), device="cuda", generator=g)
+    R = torch.randn((2, 10, 13, 256), device="cuda", generator=g)
+
+    def grads(fn):
+        for v in params.values():
+            v[0].grad = v[1].grad = None
+        out = fn()
+        (out * R).sum().backward()
+        return out.detach(), {k: (v[0].grad.clone().float(), v[1].grad.clone().float()) for k, v in params.items()}
+
+    o32, g32 = grads(lambda: _torch_trunk(torch, layers, x, params))
+    out, got = grads(lambda: trunk_train.trunk(layers, x, params, "", dtype=torch.float32))
+    torch.cuda.synchronize()
+    assert float((out - o32).abs().max()) <= 1e-4 * float(o32.abs().max())
+    cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))
+    for name, _, _ in layers:
+        for k in (0, 1):
+            assert cos(got[name][k], g32[name][k]) >= 0.99999, (name, k, cos(got[name][k], g32[name][k]))
+            assert float((got[name][k] - g32[name][k]).abs().max()) <= 1e-3 * float(g32[name][k].abs().max()), (name, k)
