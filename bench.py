@@ -460,7 +460,8 @@ def main():
             if rank == 0:
                 from mv3d_tf_amd import trunk_train
                 from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
-                sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"]}
+                sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"],
+                                                         "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers, dtype=torch.float32)]}
                 sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
                                                          "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
             if dist is not None:

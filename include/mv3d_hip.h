@@ -410,6 +410,11 @@ int mv3d_maxpool2x2_bwd_f32(const void *y_framed, const void *g_pooled_framed, v
 size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out);
 int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
                             int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream);
+/* The same on f32 maps (the fp32 training trunk; csrc/conv3x3_wgrad.hip, v_mfma_f32_32x32x2_f32: one ds_read_b32 per operand, no
+ * transposing read): exact f32 products and sums, only the summation order differs from any other fp32 weight gradient. */
+size_t mv3d_conv3x3_wgrad_f32_workspace_bytes(int batch, int height, int width, int c_in, int c_out);
+int mv3d_conv3x3_wgrad_f32(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
+                           int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream);
 /* fp32 OIHW filter (c_out, c_in, 3, 3) -> the packed bf16 forms of one training step in one launch: fwd_packed (c_out, 9 * c_in_pad)
  * [zero-initialised by the caller when c_in_pad > c_in] for mv3d_conv3x3_bf16, dgrad_packed (c_in, 9 * c_out) (may be NULL) for
  * the data-gradient convolution: the filter flipped by 180 degrees with its channel axes swapped. */

@@ -107,6 +107,8 @@ _SIGS = {
     "mv3d_frame_nhwc_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mv3d_conv3x3_wgrad_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_conv3x3_wgrad_f32_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mv3d_conv3x3_wgrad_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_conv3x3_pack_bf16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_gated_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_maxpool2x2_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -187,6 +187,133 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
 #endif
 }
 
+// The same weight gradient on f32 maps (the fp32 training trunk): v_mfma_f32_32x32x2_f32 takes ONE f32 per lane and operand
+// (row / column lane & 31, k = lane >> 5), so a lane simply reads its (pixel, channel) element of the [pixel][channel] tile with a
+// ds_read_b32 -- no transposing read is needed (nor exists for 32-bit elements).  K steps of 32 pixels; lanes 0..31 read one pixel
+// row's 32 consecutive channels (128 B), lanes 32..63 the next pixel's: the 128-byte granules of odd rows are XOR-swizzled so that the
+// two rows fall on different bank halves.  MFMA-bound by a wide margin (64 matrix cycles per pair of 4-byte LDS reads).
+#define WGF_PIX 32
+#define WGF_XROWS 40
+template <int BMC>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradArgs a)
+{
+#if __HIP_DEVICE_COMPILE__
+    constexpr int RB = BMC * 4;                                   // bytes of a dY tile row (512 | 256)
+    constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WGF_PIX / RPP;
+    constexpr int XRB = 256, XRPP = 4, XPCS = WGF_XROWS / XRPP;   // activation rows: 64 channels x 4 B, 4 rows per 1-KB piece
+    constexpr int DY_BYTES = WGF_PIX * RB, X_BYTES = WGF_XROWS * XRB, STAGE = DY_BYTES + X_BYTES;
+    constexpr int NP = DYP + XPCS;
+    constexpr int FA = BMC / 64;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wb = wave >> 1;
+    int id = blockIdx.x;
+    const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
+    const int dyr = id % 3; id /= 3;
+    const int split = id % a.splits;
+    const int co_t = id / a.splits;
+    const int co0 = co_t * BMC, ci0 = ci_t * 64;
+    const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    // DMA lane -> (row of the piece, 16-byte column); the source column's 128-byte granule is XORed with the row's parity
+    const int dy_row = lane / LPR, dy_c = (lane % LPR) * 16;
+    const int dy_col = (((dy_c >> 7) ^ (dy_row & 1)) << 7) | (dy_c & 127);          // (a piece starts on an even row)
+    const int x_row = lane >> 4, x_c = (lane & 15) * 16;
+    const int x_col = (((x_c >> 7) ^ (x_row & 1)) << 7) | (x_c & 127);
+    const int dyv = dy_row * a.Cout * 4 + dy_col + co0 * 4;
+    const int xv = x_row * a.Cin * 4 + x_col + ci0 * 4;
+    const int xshift = (dyr - 1) * a.Wp - 1;
+    auto issue = [&](const int step, const int st) __attribute__((always_inline)) {
+        const int q0 = step * WGF_PIX;
+        char *const base = lds + st * STAGE;
+#pragma unroll
+        for (int p0 = 0; p0 < (NP + 3) / 4; ++p0) {
+            const int p = p0 * 4 + wave;
+            if (p < DYP) {
+                const long long off = (long long)(q0 + p * RPP) * a.Cout * 4 + dyv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_t *)(base + p * 1024), 16, off < (long long)a.dy_bytes ? (int)off : WG_OOB, 0, 0, 0);
+            } else if (p < NP) {
+                const long long off = (long long)(q0 + xshift + (p - DYP) * XRPP) * a.Cin * 4 + xv;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(base + DY_BYTES + (p - DYP) * 1024), 16,
+                                                         (off >= 0 && off < (long long)a.x_bytes) ? (int)off : WG_OOB, 0, 0, 0);
+            }
+        }
+    };
+
+    // operand element of a lane: pixel row 2 u + h (+ dx for the activations), channel (lane & 31) of the fragment
+    const int h = lane >> 5, c = lane & 31;
+    auto phys = [](const int row, const int b, const int rb) __attribute__((always_inline)) { return row * rb + ((((b >> 7) ^ (row & 1)) << 7) | (b & 127)); };
+    int aoff[FA], boff[3];
+#pragma unroll
+    for (int i = 0; i < FA; ++i) aoff[i] = phys(h, (wa * (BMC / 2) + 32 * i + c) * 4, RB);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n0 = 96 * wb + 32 * j;
+        boff[j] = DY_BYTES + phys(h + n0 / 64, (n0 % 64 + c) * 4, XRB);          // (2 u rows further per substep: the parity stays)
+    }
+
+    f32x16 acc[FA][3], accb[FA];
+#pragma unroll
+    for (int i = 0; i < FA; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    const bool do_bias = a.bpart != nullptr && ci_t == 0 && dyr == 0 && wb == 0;
+
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < s1) issue(s + 1, (s + 1 - s0) & 1);
+        const char *const st = lds + ((s - s0) & 1) * STAGE;
+#pragma unroll 4
+        for (int u = 0; u < WGF_PIX / 2; ++u) {
+            float fa[FA], fb[3];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) fa[i] = *(const float *)(st + 2 * u * RB + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) fb[j] = *(const float *)(st + 2 * u * XRB + boff[j]);
+#pragma unroll
+            for (int i = 0; i < FA; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < FA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], 1.0f, accb[i], 0, 0, 0);
+            }
+        }
+    }
+
+    if (do_bias && (lane & 31) == 0) {
+#pragma unroll
+        for (int i = 0; i < FA; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = accb[i][r];
+    }
+    float *const out = a.part + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n0 = 96 * wb + 32 * j, tap = 3 * dyr + n0 / 64, ci = ci0 + n0 % 64 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                out[((size_t)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+#endif
+}
+
 // folds the split-K partial sums in split order and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3),
 // dropping the padding channels of the input layer (c_in_real <= c_in)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits, int c_in,
@@ -236,46 +363,72 @@ static int wgrad_splits(int tiles, int steps)
     return ks < 1 ? 1 : ks;
 }
 
-extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out)
+static size_t wgrad_ws_bytes(int batch, int height, int width, int c_in, int c_out, int pix)
 {
     if (batch <= 0 || height <= 0 || width <= 0 || c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return 0;
     const int bmc = c_out % 128 == 0 ? 128 : 64;
-    const int steps = (batch * (height + 2) * (width + 2) + WG_PIX - 1) / WG_PIX;
+    const int steps = (batch * (height + 2) * (width + 2) + pix - 1) / pix;
     const size_t ks = (size_t)wgrad_splits((c_out / bmc) * (c_in / 64) * 3, steps);
     return ks * c_out * 9 * c_in * 4 + ks * c_out * 4;             // filter partials + bias partials
 }
 
-extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
-                                       int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out)
+{
+    return wgrad_ws_bytes(batch, height, width, c_in, c_out, WG_PIX);
+}
+extern "C" size_t mv3d_conv3x3_wgrad_f32_workspace_bytes(int batch, int height, int width, int c_in, int c_out)
+{
+    return wgrad_ws_bytes(batch, height, width, c_in, c_out, WGF_PIX);
+}
+
+static int wgrad_entry(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width, int c_in, int c_in_real,
+                       int c_out, void *workspace, size_t workspace_bytes, void *stream, int es)
 {
     if (c_in_real <= 0 || c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
     if (!x_framed || !dy_framed || !dw || !workspace || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
     if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
     if ((((uintptr_t)x_framed | (uintptr_t)dy_framed | (uintptr_t)dw | (uintptr_t)workspace) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    const size_t need = mv3d_conv3x3_wgrad_workspace_bytes(batch, height, width, c_in, c_out);
+    const int pix = es == 2 ? WG_PIX : WGF_PIX;
+    const size_t need = wgrad_ws_bytes(batch, height, width, c_in, c_out, pix);
     if (workspace_bytes < need) return MV3D_ERR_WORKSPACE;
     const size_t q = (size_t)batch * (height + 2) * (width + 2);
-    if (q * c_in * 2 >= 0x7fffff00u || q * c_out * 2 >= 0x7fffff00u) return MV3D_ERR_INVALID_ARG;    // 32-bit buffer offsets
+    if (q * c_in * es >= 0x7fffff00u || q * c_out * es >= 0x7fffff00u) return MV3D_ERR_INVALID_ARG;    // 32-bit buffer offsets
     const int bmc = c_out % 128 == 0 ? 128 : 64;
     WgradArgs a;
     a.x = x_framed; a.dy = dy_framed; a.part = (float *)workspace;
     a.bpart = nullptr;
     a.Wp = width + 2; a.Cin = c_in; a.Cout = c_out; a.Q = (int)q;
-    a.steps = (int)((q + WG_PIX - 1) / WG_PIX);
+    a.steps = (int)((q + pix - 1) / pix);
     a.ci_tiles = c_in / 64;
     const int tiles = (c_out / bmc) * a.ci_tiles * 3;
     a.splits = wgrad_splits(tiles, a.steps);
     a.steps_per_split = (a.steps + a.splits - 1) / a.splits;
-    a.x_bytes = (unsigned)(q * c_in * 2); a.dy_bytes = (unsigned)(q * c_out * 2);
+    a.x_bytes = (unsigned)(q * c_in * es); a.dy_bytes = (unsigned)(q * c_out * es);
     if (db) a.bpart = a.part + (size_t)a.splits * c_out * 9 * c_in;
     hipStream_t s = (hipStream_t)stream;
     const int grid = tiles * a.splits;
-    if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+    if (es == 2) {
+        if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<128>, dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+    }
     const long n = (long)c_out * 9 * c_in;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, a.part, dw, n,
                        a.splits, c_in, c_in_real, a.bpart, db, c_out);
     return mv3d_launch_status();
+}
+
+extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
+                                       int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return wgrad_entry(x_framed, dy_framed, dw, db, batch, height, width, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, 2);
+}
+extern "C" int mv3d_conv3x3_wgrad_f32(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
+                                      int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return wgrad_entry(x_framed, dy_framed, dw, db, batch, height, width, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, 4);
 }
 
 extern "C" int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, void *dgrad_packed, int c_out, int c_in, int c_in_pad, void *stream)

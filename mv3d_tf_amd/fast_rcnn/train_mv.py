@@ -348,8 +348,8 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     nparam = sum(p.numel() for p in params)
     dense = (("the trunks' 3x3 convolutions forward + backward on this library's bf16 MFMA kernels (mv3d_tf_amd/trunk_train.py), rpn convs / FC "
               "head through torch autocast bf16, fp32 master weights, f32 hot path") if amp is not None else
-             ("fp32 throughout: the trunks' forward and data-gradient convolutions on this library's exact-f32 MFMA kernel, weight gradients "
-              "and FC head through torch (MIOpen / rocBLAS)")) if mfma else (
+             ("fp32 throughout: the trunks' forward, data-gradient and weight-gradient convolutions on this library's exact-f32 MFMA "
+              "kernels (v_mfma_f32_32x32x2_f32), FC head through torch (rocBLAS)")) if mfma else (
         "torch (MIOpen / rocBLAS) VGG16 trunks + FC head, " + ("fp32" if amp is None else "autocast to %s (fp32 master weights, f32 hot path)"
                                                                  % str(amp).split(".")[-1]))
     out = {"workload": "MV3D_train%s full step: %d frames / GPU / step, 608x608x9 BEV + 375x1242x3 image%s; %s; Adam (fused)"

@@ -478,19 +478,24 @@ def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
 
 
 def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None, want_bias=False):
-    """x_framed (B, H + 2, W + 2, Cin) bf16, dy_framed (B, H + 2, W + 2, Cout) bf16 with a zero frame -> the filter gradient
-    (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped) [, the bias gradient (Cout) f32]"""
+    """x_framed (B, H + 2, W + 2, Cin), dy_framed (B, H + 2, W + 2, Cout) with a zero frame, both bf16 or both f32 -> the filter
+    gradient (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped) [, the bias gradient
+    (Cout) f32]"""
     B, Hp, Wp, cin = x_framed.shape
     cout = dy_framed.shape[3]
+    if x_framed.dtype != dy_framed.dtype or x_framed.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("bfloat16 or float32 maps of one type expected, got %s / %s" % (x_framed.dtype, dy_framed.dtype))
+    f32 = x_framed.dtype == torch.float32
+    ws_fn = lib().mv3d_conv3x3_wgrad_f32_workspace_bytes if f32 else lib().mv3d_conv3x3_wgrad_workspace_bytes
+    fn, name = (lib().mv3d_conv3x3_wgrad_f32, "mv3d_conv3x3_wgrad_f32") if f32 else (lib().mv3d_conv3x3_wgrad_bf16, "mv3d_conv3x3_wgrad_bf16")
     creal = cin if c_in_real is None else int(c_in_real)
-    need = lib().mv3d_conv3x3_wgrad_workspace_bytes(B, Hp - 2, Wp - 2, cin, cout)
+    need = ws_fn(B, Hp - 2, Wp - 2, cin, cout)
     if need == 0:
-        raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, "mv3d_conv3x3_wgrad_workspace_bytes")
+        raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, name + "_workspace_bytes")
     ws = torch.empty(need, dtype=torch.uint8, device=x_framed.device)
     dw = torch.empty((cout, creal, 3, 3), dtype=torch.float32, device=x_framed.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x_framed.device) if want_bias else None
-    check(lib().mv3d_conv3x3_wgrad_bf16(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), _ptr(db), B, Hp - 2, Wp - 2, cin, creal, cout, _ptr(ws), need,
-                                        _stream()), "mv3d_conv3x3_wgrad_bf16")
+    check(fn(_ptr(x_framed), _ptr(dy_framed), _ptr(dw), _ptr(db), B, Hp - 2, Wp - 2, cin, creal, cout, _ptr(ws), need, _stream()), name)
     return (dw, db) if want_bias else dw
 
 

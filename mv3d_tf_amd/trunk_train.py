@@ -79,8 +79,8 @@ class TrunkFunction(torch.autograd.Function):
         B, H, W, c0 = x_nhwc.shape
         dev = x_nhwc.device
         bufs, tag, dt = (pool_tag[0] or _NoPool), pool_tag[1], pool_tag[2]
-        # (the input layer's channels zero-padded to 64 -- 32 in f32: the same kernels as every other layer, forward and gradients)
-        cpad0 = 32 if dt == torch.float32 else 64
+        # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
+        cpad0 = 64
         x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, cpad0, dev, dt))
         saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
         packed_dgrad = []
@@ -167,8 +167,7 @@ class ConvReluFunction(torch.autograd.Function):
 
 
 def _default_wgrad(dtype):
-    # f32: the weight gradient stays with torch / MIOpen (the transposing LDS read the MFMA kernel needs is a 16-bit instruction)
-    return wgrad_mfma if dtype == BF else _wgrad_torch
+    return wgrad_mfma                         # (bf16: transposing LDS reads; f32: one ds_read_b32 per operand -- csrc/conv3x3_wgrad.hip)
 
 
 def conv_relu(x_nhwc, w, b, wgrad=None, dtype=BF):
@@ -178,19 +177,20 @@ def conv_relu(x_nhwc, w, b, wgrad=None, dtype=BF):
 def trunk(layers, x_nhwc, params, suffix, wgrad=None, pool=None, dtype=BF):
     """conv1_1<suffix> .. conv5_3<suffix> of a TRAIN graph: params = {name: [w, b]} (fp32, OIHW); pool: a BufferPool that keeps
     the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call.  dtype = bfloat16:
-    mixed precision, all three convolutions of a layer on the MFMA kernels; float32: the reference's precision -- forward and data
-    gradient on the exact-f32 MFMA kernel, the weight gradient through torch / MIOpen."""
+    mixed precision; float32: the reference's precision on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32) -- forward, data
+    gradient and weight gradient alike."""
     wb = []
     for stem, _, _ in layers:
         wb += list(params[stem + suffix])
     return TrunkFunction.apply(layers, wgrad or _default_wgrad(dtype), (pool, "trunk" + suffix, dtype), x_nhwc, *wb)
 
 
-def bench_wgrad_layers(vgg, batch=2, reps=3):
+def bench_wgrad_layers(vgg, batch=2, reps=3, dtype=BF):
     """Roofline entry of the weight-gradient kernel for bench.py: every trunk layer of the 3-view TRAIN graph it serves (conv1_2 ..
     conv5_3 of the three trunks; the 64-channel-padded input layers are left out of the flop count) at the training batch, each
     timed with HIP events on the launch stream over `reps` launches (kernel + its split-K reduce) after one warm-up.
-    achieved = 2 * B*H*W * c_out * 9 * c_in / time; peak = the dense bf16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s)."""
+    achieved = 2 * B*H*W * c_out * 9 * c_in / time; peak = the dense MFMA peak of MI355X_MICROARCH.md for the operand type (bf16:
+    2.5 PFLOP/s; f32: 157.3 TFLOP/s)."""
     from .trunk import serving_layers
     dev = torch.device("cuda")
     tot_fl, tot_ms, n = 0.0, 0.0, 0
@@ -198,10 +198,10 @@ def bench_wgrad_layers(vgg, batch=2, reps=3):
     for name, H, W, cin, cout in serving_layers(vgg):
         if cin < 64 or name.startswith("rpn_conv"):
             continue
-        x = ops.framed_buffer(batch, H, W, cin, dev, BF)
-        x[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cin), device=dev, dtype=BF)
-        dy = ops.framed_buffer(batch, H, W, cout, dev, BF)
-        dy[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cout), device=dev, dtype=BF)
+        x = ops.framed_buffer(batch, H, W, cin, dev, dtype)
+        x[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cin), device=dev, dtype=dtype)
+        dy = ops.framed_buffer(batch, H, W, cout, dev, dtype)
+        dy[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cout), device=dev, dtype=dtype)
         ops.conv3x3_wgrad_bf16(x, dy)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -217,8 +217,11 @@ def bench_wgrad_layers(vgg, batch=2, reps=3):
         if fl / ms / 1e9 > best[1]:
             best = (name, fl / ms / 1e9, ms)
     ach = tot_fl / tot_ms / 1e9
-    return {"kernel": "conv3x3_wgrad_kernel + reduce (v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16; the %d weight gradients of the "
-                      "3-view training trunks, batch %d)" % (n, batch),
-            "bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+    f32 = dtype == torch.float32
+    peak = 157.3 if f32 else 2500.0
+    how = "conv3x3_wgrad_f32_kernel + reduce (v_mfma_f32_32x32x2_f32, exact f32" if f32 else \
+        "conv3x3_wgrad_kernel + reduce (v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16"
+    return {"kernel": "%s; the %d weight gradients of the 3-view training trunks, batch %d)" % (how, n, batch),
+            "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": n * reps,
             "best_layer": {"name": best[0], "tflops": round(best[1], 1), "ms": round(best[2], 4)}, "traffic": None}

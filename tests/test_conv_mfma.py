@@ -301,6 +301,29 @@ def test_train_graph_on_the_mfma_trunk(gpu):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,creal", [(2, 38, 50, 128, 256, None), (1, 21, 33, 64, 64, 9), (2, 12, 40, 256, 512, None)])
+def test_f32_weight_gradient_kernel_matches_torch(gpu, B, H, W, cin, cout, creal):
+    """mv3d_conv3x3_wgrad_f32 (exact f32 on v_mfma_f32_32x32x2_f32) against torch's fp32 conv2d_weight: <= 2e-5 of the largest entry"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B + H + cin + 1)
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    dy = torch.randn((B, H, W, cout), device="cuda", generator=g)
+    xf = ops.framed_buffer(B, H, W, cin, "cuda", torch.float32)
+    xf[:, 1:-1, 1:-1] = x
+    dyf = ops.framed_buffer(B, H, W, cout, "cuda", torch.float32)
+    dyf[:, 1:-1, 1:-1] = dy
+    got, got_b = ops.conv3x3_wgrad_bf16(xf, dyf, creal, want_bias=True)
+    want = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.permute(0, 3, 1, 2), padding=1)
+    if creal:
+        want = want[:, :creal]
+    want_b = dy.sum((0, 1, 2))
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((got_b - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,creal", [(2, 38, 50, 128, 256, None), (1, 21, 33, 64, 64, 9), (2, 12, 40, 256, 512, None)])
 def test_weight_gradient_kernel_matches_torch(gpu, B, H, W, cin, cout, creal):
     """mv3d_conv3x3_wgrad_bf16 against torch's conv2d_weight in fp32 on the SAME bf16-rounded operands: the kernel multiplies
     bf16 exactly and accumulates in f32 (per split, then over the splits), so only the summation order differs: <= 1e-4 of the
@@ -478,8 +501,8 @@ def test_serving_graph_in_reference_precision_on_the_f32_mfma_trunk(gpu):
 
 
 def test_fp32_training_trunk_matches_torch_autograd(gpu):
-    """trunk_train.trunk(dtype=float32): forward and data gradient on the exact-f32 MFMA kernel, weight gradient through torch --
-    the reference's precision, so against torch fp32 autograd of the same trunk the gradients agree to 1e-3 of their largest entry
+    """trunk_train.trunk(dtype=float32): forward, data gradient and weight gradient on the exact-f32 MFMA kernels -- the reference's
+    precision, so against torch fp32 autograd of the same trunk the gradients agree to 1e-3 of their largest entry
     (re-ordered f32 sums through 5 layers and 2 pools; no ReLU / pool-route flips as in the 16-bit trunks) with cosine >= 0.99999"""
     torch = gpu
     from mv3d_tf_amd import trunk_train

@@ -12,7 +12,7 @@ if "--lib" in sys.argv:
 else:
     build.build()
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2
-BF = torch.bfloat16
+BF = torch.float32 if "--f32" in sys.argv else torch.bfloat16
 SHAPES = [("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
           ("bev conv4_1", 76, 76, 256, 512), ("bev conv4_2", 76, 76, 512, 512), ("rgb conv1_2", 375, 1242, 64, 64),
           ("rgb conv3_2", 93, 310, 256, 256), ("rgb conv4_2", 46, 155, 512, 512)]
