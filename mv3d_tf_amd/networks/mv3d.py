@@ -40,6 +40,20 @@ _INPUTS = ("lidar_bv_data", "image_data", "lidar_fv_data", "im_info", "calib", "
            "gt_boxes_corners")
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    """the process's side streams of a device, made ONCE: every torch.cuda.Stream() takes the next slot of torch's stream pool, and
+    which hardware queue a slot lands on decides whether the trunks really overlap -- streams made per network gave a training
+    step that was 46.5 or 53 ms depending on how many networks had been built before"""
+    key = str(device)
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 class MV3D:
     """One class for both graphs; `phase` is 'TEST' (MV3D_test) or 'TRAIN' (MV3D_train)."""
 
@@ -146,7 +160,7 @@ class MV3D:
         # the last, partly filled round of workgroups of a layer of one trunk overlaps the start of a layer of the other
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = _side_streams(self.device, 1)[0]
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self._mfma.trunk(L["image_data"], "_2", last_framed=False)
@@ -250,8 +264,8 @@ class MV3D:
             multi = not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
             if multi and not self._train_streams:
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)     # (the mismatch is the point)
-            while multi and len(self._train_streams) < len(side_in):
-                self._train_streams.append(torch.cuda.Stream(device=self.device))
+            if multi:
+                self._train_streams = _side_streams(self.device, len(side_in))
             for k, (sfx, key, out) in enumerate(side_in):
                 if not multi:
                     L[out] = mfma_train_trunk(_VGG, L[key], self.params, sfx, pool=self._train_pool)
