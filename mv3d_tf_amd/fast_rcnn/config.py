@@ -38,10 +38,16 @@ cfg.TRAIN = _section(
     # (not in the reference) True: SolverWrapper trains in mixed precision -- the trunks' forward / data-gradient / weight-gradient
     # convolutions on the bf16 MFMA kernels (mv3d_tf_amd/trunk_train.py), the other dense layers under bf16 autocast, fp32 master
     # weights and Adam.  False = the reference's fp32 training.
-    MIXED_PRECISION=False)
+    MIXED_PRECISION=False,
+    # (not in the reference) True: the trunks' convolutions on this library's MFMA kernels in the precision MIXED_PRECISION selects --
+    # with MIXED_PRECISION False that is the exact-f32 kernels (v_mfma_f32_32x32x2_f32): the reference's precision, 52.9 -> 47.6 ms.
+    MFMA_TRUNK=False)
 cfg.TEST = _section(
     NMS=0.5, HAS_RPN=True, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
-    DEBUG_TIMELINE=False)
+    DEBUG_TIMELINE=False,
+    # (not in the reference) test_net serves the 3x3 convolutions through this library's MFMA kernels: MFMA_TRUNK True with
+    # PRECISION "fp32" (exact f32, the reference's precision), "fp16" or "bf16" (dense layers autocast as well)
+    MFMA_TRUNK=False, PRECISION="fp32")
 cfg.PIXEL_MEANS = np.array([[[95.8814, 98.7743, 93.8549]]])
 cfg.RNG_SEED = 3
 cfg.EPS = 1e-14

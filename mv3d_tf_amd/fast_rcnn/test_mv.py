@@ -71,6 +71,9 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
     imdb.evaluate_detections.  `imdb` is duck-typed: image_index, num_classes, name, calib_at(i), evaluate_detections,
     and either image_at(i) / bv_at(i) (arrays) or image_path_at(i) / lidar_path_at(i) (files: .npy for the BEV, an
     image readable by numpy / PIL).  As in the reference the `thresh` argument is shadowed by 0.05 (:421)."""
+    if hasattr(net, "mfma_trunk") and (cfg.TEST.get("MFMA_TRUNK", False) or cfg.TEST.get("PRECISION", "fp32") != "fp32"):
+        net.amp_dtype = {"fp32": None, "fp16": torch.float16, "bf16": torch.bfloat16}[cfg.TEST.get("PRECISION", "fp32")]
+        net.mfma_trunk = bool(cfg.TEST.get("MFMA_TRUNK", False))
     num_images = len(imdb.image_index)
     all_boxes = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]
     all_boxes_cnr = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]

@@ -183,6 +183,9 @@ class SolverWrapper(object):
         if cfg.TRAIN.get("MIXED_PRECISION", False) and hasattr(self.net, "mfma_trunk"):
             self.net.mfma_trunk, self.net.amp_dtype = True, torch.bfloat16
             self.log('Mixed precision: bf16 MFMA trunks, fp32 master weights')
+        elif cfg.TRAIN.get("MFMA_TRUNK", False) and hasattr(self.net, "mfma_trunk"):
+            self.net.mfma_trunk, self.net.amp_dtype = True, None
+            self.log('fp32 trunks on the exact-f32 MFMA kernels')
         params = self.net.parameters()
         if dist is not None:                                   # identical replicas: rank 0's weights everywhere
             for p_ in params:

@@ -146,7 +146,7 @@ def test_data_layer_and_roidb_host_logic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "fp32_mfma"])
 def test_train_net_two_iterations_and_snapshot(tmp_path, capsys, mixed):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -172,7 +172,8 @@ def test_train_net_two_iterations_and_snapshot(tmp_path, capsys, mixed):
                       "max_overlaps": np.ones(len(gt_bv))})
     saved = (cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS)
     cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = 1, 1, 2
-    cfg.TRAIN.MIXED_PRECISION = mixed                          # True: the trunks on the bf16 MFMA kernels (trunk_train.py)
+    cfg.TRAIN.MIXED_PRECISION = mixed is True                  # True: the trunks on the bf16 MFMA kernels (trunk_train.py)
+    cfg.TRAIN.MFMA_TRUNK = mixed == "fp32_mfma"                # the reference's fp32 on the exact-f32 MFMA kernels
     try:
         np.random.seed(cfg.RNG_SEED)
         net = get_network("MV3D_train")
@@ -180,12 +181,12 @@ def test_train_net_two_iterations_and_snapshot(tmp_path, capsys, mixed):
         hist = train_mv.train_net(net, Imdb(), roidb, str(tmp_path), max_iters=3)
     finally:
         cfg.TRAIN.IMS_PER_BATCH, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = saved
-        cfg.TRAIN.MIXED_PRECISION = False
-    assert net.mfma_trunk == mixed
+        cfg.TRAIN.MIXED_PRECISION = cfg.TRAIN.MFMA_TRUNK = False
+    assert net.mfma_trunk == bool(mixed)
     assert len(hist) == 3 and all(np.isfinite(h[0]) for h in hist)
     assert not torch.equal(before, net.params["rpn_bbox_pred"][0].detach())     # Adam moved the weights
     out = capsys.readouterr().out
-    assert ("Mixed precision" in out) == mixed
+    assert ("Mixed precision" in out) == (mixed is True) and ("exact-f32" in out) == (mixed == "fp32_mfma")
     assert "iter: 1 / 3, total loss: " in out and "rpn_loss_cls: " in out and ", lr: 0.000010" in out
     assert "speed: " in out and "s / iter" in out and "Wrote snapshot to: " in out and "done solving" in out
     files = sorted(os.listdir(tmp_path))
