@@ -372,7 +372,13 @@ static int conv3x3_f32_entry(const void *x_framed, const void *w_packed, const f
     a.out_pad = out_framed != 0; a.relu = relu != 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     hipStream_t s = (hipStream_t)stream;
-    if (c_out % 128 == 0) {
+    if (c_out % 128 == 0 && ((a.M + 127) / 128) * (c_out / 128) < 1024) {
+        // few tiles (a training batch): the f32 kernel is MFMA-bound even with one wave per SIMD, so a CU that holds two workgroups
+        // just takes twice as long -- 364 tiles on 256 CUs cost two rounds.  Half-size tiles balance that (724 tiles: 1.5 rounds):
+        // the single-stream (data-parallel) fp32 training step 58.7 -> 56 ms; with the trunks on three streams it is a wash (46 ms).
+        a.m_tiles = (a.M + 63) / 64; a.n_tiles = c_out / 128;
+        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 64, 128, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
+    } else if (c_out % 128 == 0) {
         a.m_tiles = (a.M + 127) / 128; a.n_tiles = c_out / 128;
         hipLaunchKernelGGL((conv3x3_f16_kernel<float, 128, 128, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
     } else {

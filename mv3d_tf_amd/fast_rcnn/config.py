@@ -40,7 +40,8 @@ cfg.TRAIN = _section(
     # weights and Adam.  False = the reference's fp32 training.
     MIXED_PRECISION=False,
     # (not in the reference) True: the trunks' convolutions on this library's MFMA kernels in the precision MIXED_PRECISION selects --
-    # with MIXED_PRECISION False that is the exact-f32 kernels (v_mfma_f32_32x32x2_f32): the reference's precision, 52.9 -> 47.6 ms.
+    # with MIXED_PRECISION False that is the exact-f32 kernels (v_mfma_f32_32x32x2_f32): the reference's precision, 52.9 -> 47.6 ms
+    # in a single process (under data parallelism the trunks share one stream and MIOpen's fp32 kernels are the faster choice).
     MFMA_TRUNK=False)
 cfg.TEST = _section(
     NMS=0.5, HAS_RPN=True, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=5,
