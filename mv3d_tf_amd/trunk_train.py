@@ -1,9 +1,12 @@
 """The TRAINING graph's VGG16 trunks with forward AND backward convolutions on the hand-written MFMA kernel.
 
-Mixed precision, opt-in (`MV3D.mfma_trunk = True` on a TRAIN graph): bfloat16 activations / gradients / weight copies, f32
-accumulation in the matrix cores, fp32 master weights and optimiser -- a lower precision than the reference's fp32 training
-(lib/fast_rcnn/train_mv.py:138-219), reported next to it, never instead of it.  bfloat16 rather than float16: the gradients of a
-13-layer trunk span more than f16's 5-bit exponent and would need loss scaling.
+Opt-in (`MV3D.mfma_trunk = True` on a TRAIN graph), in one of two precisions (`dtype`):
+  bfloat16  mixed precision: bf16 activations / gradients / weight copies, f32 accumulation in the matrix cores, fp32 master weights
+            and optimiser -- a lower precision than the reference's fp32 training (lib/fast_rcnn/train_mv.py:138-219), reported next
+            to it, never instead of it.  bf16 rather than f16: the gradients of a 13-layer trunk span more than f16's 5-bit exponent
+            and would need loss scaling.  (The kernel names below are this variant's.)
+  float32   the reference's precision: f32 framed maps, the same three convolutions on the exact-f32 instantiations
+            (mv3d_conv3x3_f32, mv3d_conv3x3_wgrad_f32, mv3d_maxpool2x2_bwd_f32: v_mfma_f32_32x32x2_f32, f32 products and sums).
 
 One `torch.autograd.Function` per trunk (conv1_1 .. conv5_3 of lib/networks/MV3D_train.py:44-81):
 
