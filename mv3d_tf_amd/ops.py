@@ -517,3 +517,11 @@ def conv3x3_gated_bf16(x_framed, w_packed, bias, gate_framed, out):
     check(lib().mv3d_conv3x3_gated_bf16(_ptr(x_framed), _ptr(w_packed), _ptr(bias), _ptr(gate_framed), _ptr(out), B, Hp - 2, Wp - 2, cin, cout,
                                         _stream()), "mv3d_conv3x3_gated_bf16")
     return out
+
+
+# type-neutral names (the `_f16` / `_bf16` suffixes above are historical: each function picks the C entry by its tensors' dtype)
+frame_nhwc = frame_nhwc_f16
+conv3x3 = conv3x3_f16
+maxpool2x2 = maxpool2x2_f16
+maxpool2x2_bwd = maxpool2x2_bwd_bf16
+conv3x3_wgrad = conv3x3_wgrad_bf16

@@ -122,7 +122,7 @@ class TrunkFunction(torch.autograd.Function):
         bufs, tag, dt = ctx.bufs, ctx.tag, ctx.dt
         x_last, _, H, W = saved[n - 1]
         dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev, dt))
-        zero_bias = torch.zeros(512, dtype=torch.float32, device=dev)
+        zero_bias = torch.zeros(max(c for _, c, _ in layers), dtype=torch.float32, device=dev)      # (the data-gradient convolutions add no bias)
         for i in range(n - 1, -1, -1):
             x_in, _, H, W = saved[i]
             c_in = ctx.c0 if i == 0 else layers[i - 1][1]
