@@ -16,6 +16,8 @@ else:
 ONLY = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 TORCH = "--no-torch" not in sys.argv
+F32 = "--f32" in sys.argv                    # the exact-f32 instantiation (f32 framed maps)
+DT = torch.float32 if F32 else torch.float16
 SHAPES = [("bev conv1_1", 608, 608, 9, 64), ("rgb conv1_1", 375, 1242, 3, 64), ("bev conv1_2", 608, 608, 64, 64), ("bev conv2_2", 304, 304, 128, 128), ("bev conv3_2", 152, 152, 256, 256),
           ("bev conv4_1", 76, 76, 256, 512), ("bev conv4_2", 76, 76, 512, 512),
           ("rgb conv1_2", 375, 1242, 64, 64), ("rgb conv2_2", 187, 621, 128, 128), ("rgb conv3_2", 93, 310, 256, 256),
@@ -43,9 +45,10 @@ for name, H, W, cin, cout in SHAPES:
     x = torch.randn((B, H, W, cin), device="cuda")
     w = torch.randn((cout, cin, 3, 3), device="cuda") * 0.02
     b = torch.zeros(cout, device="cuda")
-    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 16 if cin < 16 else cin, "cuda"))
-    wp = ops.pack_conv3x3_weights_input_layer(w) if cin < 16 else ops.pack_conv3x3_weights(w)
-    out = ops.framed_buffer(B, H, W, cout, "cuda")
+    cpad = (32 if F32 else 16) if cin < 16 else cin
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, cpad, "cuda", DT))
+    wp = ops.pack_conv3x3_weights_input_layer(w) if (cin < 16 and not F32) else ops.pack_conv3x3_weights(w, cpad, dtype=DT)
+    out = ops.framed_buffer(B, H, W, cout, "cuda", DT)
     ms = timed(lambda: ops.conv3x3_f16(xf, wp, b, out=out))
     fl = 2.0 * B * H * W * cout * 9 * cin
     if not TORCH:
