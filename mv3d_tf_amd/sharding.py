@@ -75,7 +75,7 @@ class GradBucketer:
     * a post-accumulate hook per parameter counts arrivals; when a bucket is complete its all-reduce (sum) is launched
       asynchronously (`async_op=True`: RCCL runs it on its own stream while backward continues).
     * `finish()` waits for the handles and divides by the world size (mean gradient = what a single process would compute
-      on the concatenated batch).  With no process group the class is a no-op apart from the flat gradient views.
+      on the concatenated batch).  With no process group the class is a no-op: `zero_grad()` then simply drops the gradients.
 
     Pure torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests); no data-path collective of the
     hot path itself is involved -- frames are independent."""
@@ -117,6 +117,13 @@ class GradBucketer:
         self._next = 0                      # buckets are launched strictly in index order (see _arrived)
 
     def zero_grad(self):
+        if self.dist is None:
+            # single process: nothing goes on a wire, so the gradients need not live in the flat buffers -- dropping them lets
+            # autograd STORE each gradient instead of adding it to a zeroed view (one read + one write of every parameter's
+            # gradient less per step: ~1 ms of the 14 ms mixed-precision step of the 214 M-parameter graph)
+            for p in self.params:
+                p.grad = None
+            return
         for b in self.buckets:
             b["flat"].zero_()
 
