@@ -305,6 +305,7 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
     net.amp_dtype = amp                                          # None = the reference's fp32; torch.bfloat16: autocast dense layers
     net.mfma_trunk = bool(mfma)                                  # trunks' forward + backward on the bf16 MFMA kernel (trunk_train.py)
     net.trunk_streams = bool(trunk_streams)
+    net.trunk_streams_dp = trunk_streams == "dp"                 # (experiment switch: side streams under data parallelism too)
     params = net.parameters()
     opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE, fused=True)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)

@@ -79,7 +79,8 @@ class MV3D:
         self._side = None
         self._train_pool = None
         self._train_streams = []
-        self.trunk_streams = True          # training: the image / front-view trunks on side streams (single process only)
+        self.trunk_streams = True          # training: the image / front-view trunks on side streams (single process only ...
+        self.trunk_streams_dp = False      # ... unless this is set: GradBucketer fences every bucket by its gradients' stream events)
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -262,7 +263,8 @@ class MV3D:
             import torch.distributed as tdist
             main = torch.cuda.current_stream()
             side_in = [("_2", "image_data", "conv5_3_2")] + ([("_3", "lidar_fv_data", "conv5_3_3")] if self.views == 3 else [])
-            multi = self.trunk_streams and not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
+            multi = self.trunk_streams and (self.trunk_streams_dp or
+                                            not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1))
             if multi and not self._train_streams:
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)     # (the mismatch is the point)
             if multi:

@@ -108,12 +108,12 @@ class GradBucketer:
             p.grad = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
             self._bucket_of[id(p)] = len(self.buckets)
-        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "handle": None})
+        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "handle": None, "events": []})
 
     def reset(self):
         """before every backward pass (gradients are zeroed in place: the views must stay attached)"""
         for b in self.buckets:
-            b["pending"], b["handle"] = len(b["params"]), None
+            b["pending"], b["handle"], b["events"] = len(b["params"]), None, []
         self._next = 0                      # buckets are launched strictly in index order (see _arrived)
 
     def zero_grad(self):
@@ -133,12 +133,26 @@ class GradBucketer:
         # one rank (its bucket then waits for finish(), and so does everything behind it).
         while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
             b = self.buckets[self._next]
+            self._fence(b)
             b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
             self._next += 1
+
+    def _fence(self, b):
+        # the collective is ordered after the stream it is launched from; gradients of the bucket that were accumulated on OTHER
+        # streams (a network may run independent branches of its backward pass on side streams) are fenced in by their events
+        if b["events"]:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)
+            b["events"] = []
 
     def _arrived(self, p):
         b = self.buckets[self._bucket_of[id(p)]]
         b["pending"] -= 1
+        if self.dist is not None and p.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(p.device))       # the stream this gradient was accumulated on
+            b["events"].append(ev)
         if b["pending"] == 0 and self.dist is not None and self.dist_enabled:
             self._launch_ready()
 
@@ -147,6 +161,7 @@ class GradBucketer:
         if self.dist is None:
             return
         for b in self.buckets[self._next:]:
+            self._fence(b)
             b["handle"] = self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True)
         self._next = len(self.buckets)
         for b in self.buckets:

@@ -1,6 +1,7 @@
 """Training entry points (SURVEY.md §8(b) "Entry points kept", §8(e) multi-GPU): CPU tests of the data-parallel gradient
 exchange (world_size-2 gloo) and of the host logic; `gpu` tests of train_net / SolverWrapper on a synthetic imdb."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -301,3 +302,17 @@ def test_stack_blobs_batches_frames():
     two = stack_blobs([a, b])
     assert two["image_data"].shape == (2, 6, 8, 3) and two["im_info"].shape == (2, 3) and two["calib"].shape == (2, 4, 12)
     assert isinstance(two["gt_boxes_3d"], list) and len(two["gt_boxes_3d"]) == 2
+
+
+@pytest.mark.gpu
+def test_side_streams_under_data_parallelism_give_the_same_gradients():
+    """two gloo ranks sharing the GPU: the mixed-precision training graph with its trunks on side streams (`trunk_streams_dp`, the
+    GradBucketer fencing every bucket by its gradients' stream events) all-reduces the same bits as with the trunks on one stream"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29633", os.path.join(ROOT, "tools", "dp_streams_probe.py"), "--no-timing"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "averaged gradients bit-identical: True" in out.stdout, out.stdout[-1000:]
