@@ -118,6 +118,20 @@ def stack_blobs(frames):
     return feed
 
 
+def group_frames_by_shape(frames):
+    """frames of a step -> sub-batches whose images / maps have ONE size each (order kept).  KITTI images come in several
+    sizes (375 x 1242, 370 x 1224, 374 x 1238, 376 x 1241) and the reference's data layer neither resizes nor crops
+    (lib/roi_data_layer/minibatch_mv3d.py:17-76), so the frames of a step can only be stacked when their sizes agree."""
+    groups, index = [], {}
+    for f in frames:
+        key = tuple(tuple(np.asarray(f[k]).shape) for k in ("image_data", "lidar_bv_data", "lidar_fv_data") if k in f)
+        if key not in index:
+            index[key] = len(groups)
+            groups.append([])
+        groups[index[key]].append(f)
+    return groups
+
+
 def snapshot_filename(output_dir, iter):
     """train_mv.py:56-61: <output_dir>/<SNAPSHOT_PREFIX>[_<SNAPSHOT_INFIX>]_iter_<iter+1>.ckpt"""
     infix = ('_' + cfg.TRAIN.SNAPSHOT_INFIX if cfg.TRAIN.SNAPSHOT_INFIX != '' else '')
@@ -209,14 +223,21 @@ class SolverWrapper(object):
             bucketer.zero_grad()
             # the frames of a step go through the graph as ONE batch (the hot-path kernels take the frame as blockIdx.y); the
             # four losses are means over the batch's anchors / ROIs, as train_mv.py:92-130 has them for its single frame
-            feed = stack_blobs([data_layer.forward() for _ in range(frames_per_step)])   # get one batch (:162), x frames
-            feed["keep_prob"] = 0.5                                                       # feed_dict (:165-173)
-            layers = self.net.forward(feed)
-            loss, parts = total_loss(layers)
-            bucketer.reset()
-            bucketer.dist_enabled = True                       # the bucketed all-reduce overlaps this backward pass
-            loss.backward()
-            vals = np.array([float(v.detach()) for v in parts])                           # (ce, box, rpn_ce, rpn_box)
+            # Frames of different image sizes cannot be stacked: they go through as one sub-batch per size, their gradients
+            # accumulated with the weight (frames of the sub-batch / frames of the step) -- the step's loss is the same mean
+            # over its frames either way; the all-reduce starts with the LAST sub-batch's backward pass.
+            groups = group_frames_by_shape([data_layer.forward() for _ in range(frames_per_step)])   # get one batch (:162), x frames
+            vals = np.zeros(4)
+            for gi, grp in enumerate(groups):
+                feed = stack_blobs(grp)
+                feed["keep_prob"] = 0.5                                                   # feed_dict (:165-173)
+                layers = self.net.forward(feed)
+                loss, parts = total_loss(layers)
+                share = len(grp) / float(frames_per_step)
+                bucketer.reset()
+                bucketer.dist_enabled = (gi == len(groups) - 1)  # the bucketed all-reduce overlaps the last backward pass
+                (loss if len(groups) == 1 else loss * share).backward()
+                vals += share * np.array([float(v.detach()) for v in parts])              # (ce, box, rpn_ce, rpn_box)
             bucketer.finish()
             self.optimizer.step()
             if torch.cuda.is_available():

@@ -126,9 +126,15 @@ class MV3D:
                 continue
             w = torch.as_tensor(np.asarray(sub["weights"], np.float32))
             w = w.permute(3, 2, 0, 1) if w.ndim == 4 else w.t()
+            b = torch.as_tensor(np.asarray(sub["biases"], np.float32))
+            want_w, want_b = self.params[key]
+            if tuple(w.shape) != tuple(want_w.shape) or tuple(b.shape) != tuple(want_b.shape):
+                # (the reference's tf.assign refuses a mismatching shape as well; a silent reshape would scramble a filter)
+                raise ValueError("%s: checkpoint weights %s / biases %s do not fit the variables %s / %s"
+                                 % (key, tuple(w.shape), tuple(b.shape), tuple(want_w.shape), tuple(want_b.shape)))
             with torch.no_grad():
-                self.params[key][0].copy_(w.reshape(self.params[key][0].shape))
-                self.params[key][1].copy_(torch.as_tensor(np.asarray(sub["biases"], np.float32)))
+                want_w.copy_(w)
+                want_b.copy_(b)
 
     # ---- dense layers (torch; NHWC kept as channels_last NCHW views)
     def _amp(self):
@@ -215,12 +221,19 @@ class MV3D:
             return F.relu(y) if relu else y
 
     # ---- hot-path plumbing
-    def _train_path(self, B, H, W):
+    def _train_path(self, B, H, W, max_gt=1):
+        """The batched target-layer path for B frames of an H x W head.  Two slots alternate, so the tensors a step's layers
+        dict holds stay valid until the step after the next one starts (no per-step copies); the slots are rebuilt when the
+        batch / grid changes or a frame brings more ground-truth boxes than they were sized for (a dense frame
+        must not abort training) -- capacities grow in powers of two from 64."""
         from ..train_path import TrainPathStream
-        key = (B, H, W)
+        cap = getattr(self, "_tp_max_gt", 64)
+        while cap < max_gt:
+            cap *= 2
+        key = (B, H, W, cap)
         if getattr(self, "_tp_key", None) != key:
-            self._tp = TrainPathStream(B, H, W, self.device, num_classes=n_classes, depth=1, want_fv=(self.views == 3))
-            self._tp_key = key
+            self._tp = TrainPathStream(B, H, W, self.device, num_classes=n_classes, depth=2, max_gt=cap, want_fv=(self.views == 3))
+            self._tp_key, self._tp_max_gt = key, cap
         return self._tp
 
     @staticmethod
@@ -266,7 +279,9 @@ class MV3D:
             multi = self.trunk_streams and (self.trunk_streams_dp or
                                             not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1))
             if multi and not self._train_streams:
-                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)     # (the mismatch is the point)
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)   # (torch >= 2.9)
+                if quiet is not None:
+                    quiet(False)                                                            # (the mismatch is the point)
             if multi:
                 self._train_streams = _side_streams(self.device, len(side_in))
             for k, (sfx, key, out) in enumerate(side_in):
@@ -324,14 +339,12 @@ class MV3D:
             # anchor_target_layer (MV3D_train.py:88) + proposal_layer_3d (:98) + proposal_target_layer_3d (:105), all frames
             # behind one launch per kernel; the subsampling draws come from the numpy global RNG, frame by frame
             gt = [tuple(t.reshape(-1, c).contiguous() for t, c in zip(g, (5, 7, 25))) for g in self._gt_frames(L, B)]
-            path = self._train_path(B, h, w)
-            out = path.finish(path.submit(prob, pred, info, cal, gt))
-            out = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
-                   for k, v in out.items()}                                           # (the path's buffers are reused by the next step)
+            path = self._train_path(B, h, w, max(int(g[0].shape[0]) for g in gt))
+            out = path.finish(path.submit(prob, pred, info, cal, gt))                 # (views of the slot's buffers: valid for two steps)
             L["roi_rows"] = out["S"]
             bvb, imgb, b3b = out["proposals"][:3]
             cnt = out["num_proposals"]
-            cat = lambda t: t[0, :cnt[0]].clone() if B == 1 else torch.cat([t[b, :cnt[b]] for b in range(B)], 0)
+            cat = lambda t: t[0, :cnt[0]] if B == 1 else torch.cat([t[b, :cnt[b]] for b in range(B)], 0)
             rois = (cat(bvb), cat(imgb), cat(b3b))
             rois = rois + (rois[2],)                                                  # network.py:234
             L["rpn_rois"] = rois

@@ -80,7 +80,7 @@ class GradBucketer:
     Pure torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests); no data-path collective of the
     hot path itself is involved -- frames are independent."""
 
-    def __init__(self, params, dist=None, bucket_bytes=25 << 20, average=True):
+    def __init__(self, params, dist=None, bucket_bytes=25 << 20, average=True, allocate=None):
         self.dist = dist if (dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist is not None else 1
         self.average = average
@@ -88,6 +88,13 @@ class GradBucketer:
         self.buckets = []                   # dict(flat, params, pending, handle)
         self._bucket_of = {}
         cur, size = [], 0
+        if self.dist is None and not allocate:
+            # single process: nothing goes on a wire -- no flat buffers (one f32 copy of every parameter, 856 MB for the 3-view
+            # graph, would sit unused: zero_grad() drops the gradients instead of zeroing views).  allocate=True builds the
+            # buckets anyway (tests of the packing)
+            self._hooks = []
+            self.dist_enabled = False
+            return
         for p in reversed(self.params):     # last layer first: its gradient is ready first
             nbytes = p.numel() * p.element_size()
             if cur and (size + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
@@ -121,6 +128,9 @@ class GradBucketer:
             # single process: nothing goes on a wire, so the gradients need not live in the flat buffers -- dropping them lets
             # autograd STORE each gradient instead of adding it to a zeroed view (one read + one write of every parameter's
             # gradient less per step: ~1 ms of the 14 ms mixed-precision step of the 214 M-parameter graph)
+            # (A parameter that receives no gradient in a step then has grad None and Adam SKIPS it -- moments frozen -- whereas
+            # under data parallelism its zeroed bucket view makes Adam decay its moments; every parameter of the MV3D graphs
+            # receives a gradient every step, so the two paths take the same updates.)
             for p in self.params:
                 p.grad = None
             return

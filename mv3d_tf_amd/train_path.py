@@ -171,7 +171,11 @@ class TrainPathStream:
         st = self._sid()
         G = [int(g[0].shape[0]) for g in gt]
         if max(G) > self.max_gt or min(G) <= 0:
-            raise ValueError("TrainPathStream: 1 .. max_gt = %d ground-truth boxes per frame" % self.max_gt)
+            # (no box at all: the reference's anchor_target_layer takes argmax over an empty axis and raises as well --
+            # filter_roidb keeps such frames out of training; more than max_gt: build the stream with a larger `max_gt`, as
+            # networks/mv3d.py does on demand)
+            s.busy = False
+            raise ValueError("TrainPathStream: 1 .. max_gt = %d ground-truth boxes per frame, got %s" % (self.max_gt, G))
         # torch's cfg thresholds may have changed since the slot was built (cfg_from_file): refresh the parameter structs
         for b in range(B):
             s.tpar[b].fg_thresh, s.tpar[b].bg_thresh_hi, s.tpar[b].bg_thresh_lo = (float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),

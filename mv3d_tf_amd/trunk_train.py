@@ -45,16 +45,33 @@ def wgrad_mfma(x_framed, dy_framed, c_in):
 
 class BufferPool:
     """Framed buffers of a training trunk, kept across steps (their zero frames are written once).  ONE forward / backward pair
-    per pool may be in flight: the next forward overwrites the activations the backward pass reads."""
+    per trunk (tag prefix) may be in flight: the next forward overwrites the activations the backward pass reads -- every forward
+    takes a new generation number and a backward pass that finds a newer one raises instead of computing wrong gradients.
+    Per tag at most `max_shapes` buffer shapes stay alive (least recently used first out: KITTI images come in four sizes)."""
 
-    def __init__(self):
-        self._buf = {}
+    def __init__(self, max_shapes=4):
+        self._buf = {}                     # tag -> {shape key: buffer}, insertion order = recency
+        self._gen = {}
+        self.max_shapes = int(max_shapes)
+
+    def begin(self, trunk_tag):
+        g = self._gen[trunk_tag] = self._gen.get(trunk_tag, 0) + 1
+        return g
+
+    def check(self, trunk_tag, generation):
+        if self._gen.get(trunk_tag) != generation:
+            raise RuntimeError("BufferPool: trunk %r ran forward again before this backward pass (its saved activations are "
+                               "overwritten); use one pool per forward / backward pair in flight, or pool=None" % trunk_tag)
 
     def get(self, tag, B, H, W, C, dev, dtype=BF):
-        key = (tag, B, H, W, C, dtype)
-        buf = self._buf.get(key)
+        key = (B, H, W, C, dtype, str(dev))
+        per = self._buf.setdefault(tag, {})
+        buf = per.pop(key, None)
         if buf is None:
-            buf = self._buf[key] = ops.framed_buffer(B, H, W, C, dev, dtype)
+            buf = ops.framed_buffer(B, H, W, C, dev, dtype)
+            while len(per) >= self.max_shapes:
+                per.pop(next(iter(per)))
+        per[key] = buf                     # (re-inserted: most recently used last)
         return buf
 
 
@@ -62,6 +79,14 @@ class _NoPool:
     @staticmethod
     def get(tag, B, H, W, C, dev, dtype=BF):
         return ops.framed_buffer(B, H, W, C, dev, dtype)
+
+    @staticmethod
+    def begin(trunk_tag):
+        return 0
+
+    @staticmethod
+    def check(trunk_tag, generation):
+        pass
 
 
 def _pack_pair(w, c_in_pad, want_dgrad, dtype):
@@ -84,6 +109,7 @@ class TrunkFunction(torch.autograd.Function):
         bufs, tag, dt = (pool_tag[0] or _NoPool), pool_tag[1], pool_tag[2]
         # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
         cpad0 = 64
+        ctx.gen = bufs.begin(tag)
         x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, cpad0, dev, dt))
         saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
         packed_dgrad = []
@@ -120,6 +146,7 @@ class TrunkFunction(torch.autograd.Function):
         grads = [None] * (2 * n)
         # gradient w.r.t. conv5_3's pre-activation, framed
         bufs, tag, dt = ctx.bufs, ctx.tag, ctx.dt
+        bufs.check(tag, ctx.gen)
         x_last, _, H, W = saved[n - 1]
         dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev, dt))
         zero_bias = torch.zeros(max(c for _, c, _ in layers), dtype=torch.float32, device=dev)      # (the data-gradient convolutions add no bias)

@@ -93,7 +93,7 @@ def test_bucketing_of_the_mv3d_parameter_list():
     params = [torch.empty(s, device="meta", requires_grad=True) for s in shapes]
     nbytes = sum(int(np.prod(s)) for s in shapes) * 4
     assert 130e6 * 4 < nbytes < 150e6 * 4                     # ~143 M fp32
-    b = sharding.GradBucketer(params, None)
+    b = sharding.GradBucketer(params, None, allocate=True)
     assert b.total_bytes() == nbytes
     assert b.buckets[0]["params"][0] is params[-1] and b.buckets[-1]["params"][-1] is params[0]
     small = [x for x in b.buckets if x["flat"].numel() * 4 <= (25 << 20)]
@@ -316,3 +316,48 @@ def test_side_streams_under_data_parallelism_give_the_same_gradients():
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "averaged gradients bit-identical: True" in out.stdout, out.stdout[-1000:]
+
+
+def test_train_model_with_mixed_image_sizes_in_one_step(tmp_path):
+    """KITTI images come in several sizes and the data layer does not resize, so the frames of a step cannot always
+    be stacked.  train_model(frames_per_step=2) then runs one sub-batch per size and accumulates: the update equals one Adam
+    step on the mean of the two frames' losses."""
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.fast_rcnn import train_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+
+    class MixedLayer(_ToyLayer):
+        def forward(self):
+            out = _ToyLayer.forward(self)
+            if self.i % 2 == 0:                                   # every second frame: a smaller image
+                out["image_data"] = np.ascontiguousarray(out["image_data"][:, :5, :7])
+            return out
+
+    def toy_total_loss(layers, sigma=3.0):
+        loss = (layers["logits"] ** 2).mean()
+        z = loss.detach() * 0
+        return loss, (loss, z, z, z)
+
+    old = (train_mv.total_loss, train_mv.get_data_layer, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS)
+    try:
+        train_mv.total_loss = toy_total_loss
+        train_mv.get_data_layer = lambda roidb, nc: MixedLayer(roidb)
+        cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = 1, 100
+        assert len(train_mv.group_frames_by_shape([MixedLayer(_toy_roidb(2)).forward() for _ in range(1)])) == 1
+        net, ref = _ToyNet(3), _ToyNet(3)
+        sw = train_mv.SolverWrapper(None, None, net, _ToyImdb(), _toy_roidb(4), str(tmp_path / "snap"))
+        sw.log = lambda *_: None
+        hist = sw.train_model(None, 1, frames_per_step=2)
+        layer = MixedLayer(_toy_roidb(4))
+        frames = [layer.forward(), layer.forward()]
+        assert frames[0]["image_data"].shape != frames[1]["image_data"].shape
+        losses = [toy_total_loss(ref.forward(f))[0] for f in frames]
+        want = (losses[0] + losses[1]) / 2
+        opt = torch.optim.Adam(ref.parameters(), lr=sw.LEARNING_RATE)
+        want.backward()
+        opt.step()
+        assert abs(hist[0][0] - float(want)) < 1e-6 * abs(float(want))
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(a.detach(), b.detach(), atol=1e-7)
+    finally:
+        train_mv.total_loss, train_mv.get_data_layer, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = old

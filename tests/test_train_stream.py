@@ -166,3 +166,31 @@ def test_batch2_train_graph_uses_batched_entries_and_matches_oracle(gpu, oracle)
     finally:
         for name in counted:
             setattr(L_, name, orig[name])
+
+
+def test_dense_frame_grows_the_ground_truth_capacity(gpu, oracle):
+    """a frame with more than 64 ground-truth boxes must not abort training -- the graph rebuilds its path slots
+    with a larger capacity, and the path with 100 boxes equals the oracle."""
+    torch = gpu
+    from mv3d_tf_amd.networks import get_network
+    from mv3d_tf_amd.train_path import TrainPathStream
+    net = get_network("MV3D_train")
+    assert net._train_path(1, 76, 76, 3).max_gt == 64
+    assert net._train_path(1, 76, 76, 100).max_gt == 128
+    assert net._train_path(1, 76, 76, 5).max_gt == 128                # (capacities only grow: no rebuild per sparse frame)
+    dev = torch.device("cuda")
+    prob, pred, info, calib, _ = synth.rpn_head(4321, 76, 76, "peaky", return_gt=True)
+    gt = synth.gt_cars(np.random.RandomState(77), 100)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    path = TrainPathStream(1, 76, 76, dev, depth=1, max_gt=128)
+    with pytest.raises(ValueError):
+        TrainPathStream(1, 76, 76, dev, depth=1, max_gt=64).submit(t(prob), t(pred), t(info), t(calib[None]), [tuple(t(a) for a in gt)])
+    np.random.seed(4)
+    out = path.finish(path.submit(t(prob), t(pred), t(info), t(calib[None]), [tuple(t(a) for a in gt)]))
+    torch.cuda.synchronize()
+    np.random.seed(4)
+    w = _oracle_frame(oracle, (prob, pred, info, calib, gt), 0, dict(oracle.TRAIN))
+    assert np.array_equal(out["rpn_labels"][0].cpu().numpy(), w["labels"])
+    assert np.array_equal(out["rpn_targets"][0].cpu().numpy(), w["targets"])
+    assert np.array_equal(out["rois"]["bev"].cpu().numpy(), w["rois_bv"]) and np.array_equal(out["labels"].cpu().numpy(), w["rois_lab"])
+    assert np.array_equal(out["bbox_targets"].cpu().numpy(), w["rois_tg"])
