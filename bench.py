@@ -32,7 +32,8 @@ Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel of the step (larg
 with HIP events on the stream it is launched on; `roofline_kernels` lists the RoiPool forward and backward launches
 separately; `cpu_baseline` = the C oracle on the same workload on the host cores (bounded sample); `secondary` holds
 `fresh_inputs` (the same training path on NEW frames every batch: mv3d_tf_amd.train_path.TrainPathStream, host draws in the
-loop, pipelined), the TEST-cfg (configs[1]/[4]) line and `with_trunk`, the full training step with the torch VGG16 trunks and
+loop, pipelined), the TEST-cfg (configs[4]) line, `config1_latency` (configs[1]: one frame, BEV-only RPN + NMS with the trunk on the
+MFMA convolution) and `with_trunk`, the full training step with the torch VGG16 trunks and
 the bucketed gradient all-reduce (--no-trunk skips it).
 """
 import argparse
@@ -200,65 +201,66 @@ def roofline_entries(ring, workload, signature):
 
 
 def cpu_baseline(ring, workload, seconds):
-    """The C oracle on the same per-frame workload (frame 0 of batch 0), bounded sample: one thread first, then `cores`
-    threads that each process whole frames (ctypes releases the GIL inside the C calls)."""
-    import threading
+    """The C oracle on the same per-frame workload (frame 0 of batch 0), bounded sample, as SURVEY.md section 8(d) defines the
+    CPU baseline: one thread first, then ALL host cores -- one worker PROCESS per core (oracle/cpu_worker.py: its own numpy
+    global RNG for the subsampling draws, no lock, no shared GIL), every worker processing whole frames between a common
+    start and a common stop time."""
+    import tempfile
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_worker
     import oracle
     from mv3d_tf_amd import hot_path
+    oracle.build()
     prob, pred, info, calib, (gt_bv, gt_3d, gt_cnr) = ring.host_frames[0]
     slot = ring.slots[0]
-    maps = {v: m[0:1].cpu().numpy() for v, m in slot.maps.items()}
     key = "TRAIN" if workload == "train" else "TEST"
-    cfg = {key: hot_path.TRAIN_CFG if workload == "train" else hot_path.TEST_CFG}
-    score = np.zeros((1, 76, 76, 8), np.float32)
-    lock = threading.Lock()
-    YML_TRAIN = dict(oracle.TRAIN, BG_THRESH_LO=0.0, BG_THRESH_HI=0.5, FG_THRESH=0.7)      # faster_rcnn_end2end.yml:10-12
-
-    def frame(rng_guard):
-        bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, key, [8, ], cfg=cfg)
-        if workload == "train":
-            with rng_guard:                                    # the numpy global RNG is not thread-safe
-                oracle.anchor_target_layer(score, gt_bv, gt_3d, info, [8, ])
-                r_bv, r_img, _, _, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2, train=YML_TRAIN)
-            rois = {"bev": r_bv, "rgb": r_img, "fv": oracle.rois_3d_to_fv(r_3d)}
-        else:
-            rois = {"bev": bv, "rgb": img, "fv": oracle.rois_3d_to_fv(b3)}
-        for v in hot_path.VIEWS:
-            top, am = oracle.roi_pool(maps[v], rois[v], 7, 7, 0.125)
-            if workload == "train":
-                oracle.roi_pool_grad(maps[v], rois[v], am, top, 7, 7, 0.125)
-
+    cfgd = hot_path.TRAIN_CFG if workload == "train" else hot_path.TEST_CFG
+    arrays = dict(prob=prob, pred=pred, info=info, calib=calib, gt_bv=gt_bv, gt_3d=gt_3d, gt_cnr=gt_cnr)
+    arrays.update({"map_" + v: m[0:1].cpu().numpy() for v, m in slot.maps.items()})
+    arrays.update({"cfg_" + k: np.asarray(v) for k, v in cfgd.items()})
+    tmp = tempfile.mkdtemp(prefix="mv3d_cpu_")
+    path = os.path.join(tmp, "inputs.npz")
+    np.savez(path, **arrays)
+    # ---- one thread, in this process
+    frame = cpu_worker.make_frame(np.load(path), workload)
+    frame()
     n1, t0 = 0, time.perf_counter()
     while True:
-        frame(lock)
+        frame()
         n1 += 1
         dt1 = time.perf_counter() - t0
         if dt1 >= seconds / 3 or n1 >= 400:
             break
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    done = [0] * cores
-    stop_at = time.perf_counter() + 2 * seconds / 3
-
-    def worker(k):
-        while time.perf_counter() < stop_at:
-            frame(lock)
-            done[k] += 1
-
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dtm = time.perf_counter() - t0
-    nm = sum(done)
-    return {"value": round(nm / dtm, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    # ---- every host core: one process each
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    span = 2 * seconds / 3
+    start = time.time() + 4.0 + cores * 0.02              # (interpreter + numpy start-up of `cores` processes)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), path, workload, repr(start),
+                               repr(start + span), str(1000 + k)], stdout=subprocess.PIPE, env=env, text=True) for k in range(cores)]
+    done, late = [], 0
+    for p in procs:
+        out, _ = p.communicate(timeout=120 + 10 * seconds)
+        try:
+            n, t = out.split()
+            done.append((int(n), float(t)))
+        except ValueError:
+            late += 1
+    nm = sum(n for n, _ in done)
+    dtm = max([t for _, t in done] + [span])
+    try:
+        os.remove(path)
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    return {"value": round(nm / dtm, 3), "unit": "frames/s", "cores": len(done), "kind": "port",
             "one_thread_frames_per_s": round(n1 / dt1, 3),
-            "sample": "%d frames on %d threads in %.1f s (frame-parallel) after %d frames on 1 thread in %.1f s; the same "
-                      "per-frame workload (%s cfg path incl. target layers, 3-view RoiPool fwd%s, frame 0 of the ring); C "
-                      "restatement oracle/mv3d_oracle.c, gcc -O2; host has %d cores"
-                      % (nm, cores, dtm, n1, dt1, key, "+bwd" if workload == "train" else "", os.cpu_count())}
+            "sample": "%d frames by %d worker processes (one per host core, %d cores visible%s) in %.1f s after %d frames on 1 thread "
+                      "in %.1f s; the same per-frame workload (%s cfg path incl. target layers, 3-view RoiPool fwd%s, frame 0 of the "
+                      "ring); C restatement oracle/mv3d_oracle.c, gcc -O2 -ffp-contract=off.  Reference as shipped (its Python / "
+                      "Cython proposal_layer_3d alone, one thread, survey container, BASELINE.md section 2): 1.24 - 1.31 s per frame = "
+                      "0.8 frames/s" % (nm, len(done), os.cpu_count() or 0, (", %d workers failed" % late) if late else "", dtm, n1, dt1,
+                                        key, "+bwd" if workload == "train" else "")}
 
 
 def fresh_inputs_line(rank, variant, seconds=1.5):
@@ -447,6 +449,11 @@ def main():
         del r2
         torch.cuda.empty_cache()
         if not args.no_trunk:
+            if rank == 0:
+                # BASELINE configs[1]: one frame, BEV-only RPN + HIP NMS with the VGG16 trunk on the MFMA convolution, batch 1
+                from mv3d_tf_amd.fast_rcnn import test_mv as _tm
+                sec["config1_latency"] = _tm.bench_config1_latency()
+                torch.cuda.empty_cache()
             from mv3d_tf_amd.fast_rcnn import train_mv
             sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
             torch.cuda.empty_cache()

@@ -324,6 +324,36 @@ int mv3d_proposal_target_stage2_batch_devn(int batch, const float *const *rois_b
  * 8 = reflectance of the last point of the highest slice (numpy fancy-assignment order). */
 int mv3d_point_cloud_2_top(const float *points_dev, int num_points, float *top_dev, void *stream);
 
+/* ------------------------------------------------------------------ the target layers' random subsamplings (HOST code)
+ * The reference subsamples with `npr.choice(inds, size=k, replace=False)` on the numpy GLOBAL legacy RandomState
+ * (lib/rpn_msr/anchor_target_layer_tf.py:146-159,178-183; lib/rpn_msr/proposal_target_layer_tf.py:246-269) = 
+ * `inds[permutation(len(inds))[:k]]`; the stage-2 entries above take those permutations as index lists.  These two host
+ * functions draw them in C directly on the memory of numpy's generator (`mt19937_state` = the address numpy publishes as
+ * `np.random.mtrand._rand._bit_generator.ctypes.state_address`: {uint32 key[624]; int32 pos}), restating numpy's
+ * RandomState.permutation -> shuffle -> random_interval -> MT19937 genrand loop (numpy is a dependency of the reference that
+ * /root/reference does not vendor; pinned against numpy itself in tests/test_legacy_rng.py).  The caller holds the
+ * generator's lock (`bit_generator.lock`); no device work, no stream. */
+/* out[0 .. n) = RandomState.permutation(n) */
+int mv3d_legacy_permutation(void *mt19937_state, int32_t n, int32_t *out);
+typedef struct {
+    int32_t n_fg, n_bg, n_low;     /* anchor-target stage 1 counts: foreground / background / low-overlap candidates */
+    int32_t pt_n_fg, pt_n_bg;      /* proposal-target stage 1 counts */
+    int32_t reserved0;
+    const uint8_t *fg_alive;       /* (n_fg) host bytes: foreground candidate i still positive after the relabel (:176) */
+} mv3d_draw_frame;
+typedef struct {
+    int32_t rpn_batchsize;         /* cfg.TRAIN.RPN_BATCHSIZE */
+    int32_t rpn_num_fg;            /* int(cfg.TRAIN.RPN_FG_FRACTION * RPN_BATCHSIZE) */
+    int32_t rois_per_image;        /* cfg.TRAIN.BATCH_SIZE / images per batch (1) */
+    int32_t roi_fg_max;            /* np.round(cfg.TRAIN.FG_FRACTION * rois_per_image) */
+} mv3d_draw_params;
+/* All draws of a batch, frame by frame, anchor targets before proposal targets (the order the numpy-contract layers draw in):
+ * per frame five lists -- anchors to disable: surplus foreground, surplus background, surplus background after the relabel;
+ * ROIs to keep: foreground picks, background picks -- appended to `lists` (host, e.g. pinned), sizes[5 * b + k] = their
+ * lengths.  scratch: >= the largest candidate count, in int32 words.  MV3D_ERR_WORKSPACE if `lists` / `scratch` are too small. */
+int mv3d_draw_training_subsamples(void *mt19937_state, int batch, const mv3d_draw_frame *frames, const mv3d_draw_params *par,
+                                  int32_t *lists, size_t lists_cap, int32_t *sizes, int32_t *scratch, size_t scratch_cap);
+
 /* KITTI label rows -> ground-truth encodings (lib/datasets/kitti_mv3d.py:240-272 with computeCorners3D, camera_to_lidar_cnr,
  * lidar_cnr_to_3d, lidar_3d_to_bv of lib/utils/transform.py:441-465,502-524,172-187,113-142), one thread per labelled object:
  *   box_cam_dev (G,6) f32 [tx,ty,tz,l,w,h] (label columns 11-13, 10, 9, 8), cos_sin_dev (G,2) f64 = cos / sin of rotation_y,

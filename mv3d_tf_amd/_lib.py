@@ -50,6 +50,17 @@ class ProposalTargetParams(C.Structure):
                 ("bg_thresh_hi", C.c_double), ("bg_thresh_lo", C.c_double)]
 
 
+class DrawFrame(C.Structure):
+    """mv3d_draw_frame"""
+    _fields_ = [("n_fg", C.c_int32), ("n_bg", C.c_int32), ("n_low", C.c_int32), ("pt_n_fg", C.c_int32), ("pt_n_bg", C.c_int32),
+                ("reserved0", C.c_int32), ("fg_alive", C.c_void_p)]
+
+
+class DrawParams(C.Structure):
+    """mv3d_draw_params"""
+    _fields_ = [("rpn_batchsize", C.c_int32), ("rpn_num_fg", C.c_int32), ("rois_per_image", C.c_int32), ("roi_fg_max", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "mv3d_version": (C.c_int, []),
@@ -97,6 +108,9 @@ _SIGS = {
     "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
     "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),
+    "mv3d_legacy_permutation": (C.c_int, [_P, C.c_int32, _P]),
+    "mv3d_draw_training_subsamples": (C.c_int, [_P, C.c_int, C.POINTER(DrawFrame), C.POINTER(DrawParams), _P, C.c_size_t, _P, _P,
+                                                C.c_size_t]),
     "mv3d_gt_encode": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mv3d_conv3x3_f16": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

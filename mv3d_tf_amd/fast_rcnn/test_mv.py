@@ -161,3 +161,82 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
                    "fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
                    "(f32 accumulate), FC head autocast; both lower precision than the reference's fp32; the hot-path layers run in f32")
     return out
+
+
+def bench_config1_latency(reps=30, warmup=5, seed=11):
+    """BASELINE configs[1] for bench.py's `secondary.config1_latency`: ONE synthetic KITTI frame, BEV view only --
+    608 x 608 x 9 BEV -> VGG16 trunk (conv1_1 .. conv5_3, lib/networks/MV3D_test.py:34-58) and rpn_conv/3x3 on this library's
+    MFMA convolution -> the two 1 x 1 RPN heads + pairwise softmax (:82-93) -> mv3d_proposal_3d with the TEST cfg (23 104
+    anchors -> 6000 pre-NMS -> HIP NMS 0.7 -> 300 proposals, projection to the image included), on ONE stream, batch 1.
+    Per precision (f32 = the reference's, on the exact-f32 MFMA; f16 = f16 operands / f32 accumulation): the frame's latency
+    with eager launches (host enqueue + device time, synchronised after every frame) and as a captured hipGraph replayed and
+    synchronised per frame."""
+    import ctypes
+    import time
+    import torch.nn.functional as F
+    from .. import synth
+    from ..networks import get_network
+    from ..networks.mv3d import _VGG
+    from ..trunk import MfmaTrunks
+    dev = torch.device("cuda", torch.cuda.current_device())
+    net = get_network("MV3D_test")
+    rng = np.random.RandomState(seed)
+    bev = torch.as_tensor(((rng.random_sample((1, 608, 608, 9)) < 0.03) * rng.uniform(0, 2.4, (1, 608, 608, 9))).astype(np.float32)).to(dev)
+    info = torch.as_tensor(np.array([[608, 608, 1]], np.float32)).to(dev)
+    cal = torch.as_tensor(synth.KITTI_CALIB[None].astype(np.float32)).to(dev)
+    saved = (cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N)
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 6000, 300
+    params = ops.proposal_params(cfg.TEST, feat_stride=8)
+    out = {"workload": "BASELINE configs[1]: 1 frame, BEV only: 608x608x9 -> VGG16 trunk + rpn_conv/3x3 (14 MFMA convolutions, 3 pools) -> "
+                       "1x1 RPN heads + softmax -> mv3d_proposal_3d TEST cfg (23104 anchors -> 6000 -> NMS 0.7 -> 300); one stream, batch 1"}
+    try:
+        for name, dt in (("f32", torch.float32), ("f16", torch.float16)):
+            tr = MfmaTrunks(net, _VGG, dtype=dt)
+            heads = [(net.params[k][0].detach().reshape(net.params[k][0].shape[0], -1).to(dt).contiguous(),
+                      net.params[k][1].detach().to(dt).contiguous()) for k in ("rpn_cls_score", "rpn_bbox_pred")]
+            cap = ops.lib().mv3d_proposal_3d_capacity(76, 76, ctypes.byref(params))
+            outs = ops.proposal_3d_outputs(1, cap, dev)[1]
+
+            def frame():
+                with torch.no_grad():
+                    rpn = tr.rpn_conv(tr.trunk(bev, "", last_framed=True))                       # (1, 76, 76, 512)
+                    score = F.linear(rpn, *heads[0]).float()
+                    pred = F.linear(rpn, *heads[1]).float().contiguous()
+                    prob = F.softmax(score.reshape(-1, 2), dim=1).reshape(1, 76, 76, 8)          # reshape_layer(2) + softmax
+                    return ops.proposal_3d(prob, pred, info, cal, params, out=outs)
+
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    frame()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    frame()
+                    side.synchronize()
+                eager = (time.perf_counter() - t0) / reps
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for _ in range(reps):
+                    frame()
+                e1.record(side)
+                side.synchronize()
+                device_ms = e0.elapsed_time(e1) / reps
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                res = frame()
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    g.replay()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    g.replay()
+                    side.synchronize()
+                graph = (time.perf_counter() - t0) / reps
+            out[name] = {"ms_per_frame_eager": round(eager * 1e3, 4), "ms_per_frame_graph": round(graph * 1e3, 4),
+                         "ms_per_frame_device_back_to_back": round(device_ms, 4), "proposals": int(res[3][0].item())}
+            del g, tr
+    finally:
+        cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
+    return out

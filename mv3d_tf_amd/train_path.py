@@ -19,8 +19,10 @@ so a batch costs ONE host round trip, and it is taken off the device's critical 
 
 With `depth` slots a caller submits batch i + 1 before it finishes batch i: the device works on batch i's stage 2 / RoiPool
 (and, in the train graph, the dense layers) while the host draws.  What remains is the host's own work: the legacy
-`RandomState.permutation` shuffles every candidate (21 k background anchors per frame, twice) -- ~0.3 ms per frame on one
-core, which bounds a single process at ~3 k fresh frames / s whatever the device does."""
+`RandomState.permutation` shuffles every candidate (21 k background anchors per frame, twice).  Since round 4 that loop runs
+in C on numpy's own generator state (mv3d_draw_training_subsamples, csrc/legacy_rng.hip: one call per batch, lists written
+straight into pinned memory, ~2x numpy's own loop and none of its per-call Python); `draw_subsamples_host` /
+`draw_samples_host` below are the numpy statement of the same draws (tests compare the two, draw for draw)."""
 import ctypes as C
 import time
 
@@ -29,7 +31,7 @@ import numpy.random as npr
 import torch
 
 from . import ops
-from ._lib import AnchorTargetParams, ProposalTargetParams, check, lib
+from ._lib import AnchorTargetParams, DrawFrame, DrawParams, ProposalTargetParams, check, lib
 from .fast_rcnn.config import cfg
 
 _HEAD = 4096                       # bytes of (counts + foreground flags) per frame that travel with the first copy
@@ -137,6 +139,8 @@ class TrainPathStream:
         s.d_small = e((B, 6), torch.int32)
         s.list_cap = B * (3 * N + 2 * (self.cap + self.max_gt))                   # every index list at its largest
         s.h_lists = torch.empty((s.list_cap,), dtype=torch.int32).pin_memory()
+        s.h_scratch = torch.empty((max(N, self.cap + self.max_gt) + 64,), dtype=torch.int32)      # one permutation at its largest
+        s.frames_c, s.sizes_c = (DrawFrame * B)(), (C.c_int32 * (5 * B))()
         s.d_lists = e((s.list_cap,), torch.int32)
         s.event = torch.cuda.Event()
         # argument arrays that never change
@@ -202,6 +206,41 @@ class TrainPathStream:
             s.event.record()
         return s
 
+    # ------------------------------------------------------------------ the host's draws
+    def _draw(self, s, small):
+        """Every subsampling draw of the batch -- frame by frame, anchor targets before proposal targets, exactly the draws of
+        `draw_subsamples_host` / `draw_samples_host` -- by ONE C call (mv3d_draw_training_subsamples, csrc/legacy_rng.hip) that
+        shuffles on the memory of numpy's own global generator and writes the index lists straight into the slot's pinned
+        buffer; ctypes releases the GIL for its duration.  Returns (sizes[5 B], offsets[5 B], total)."""
+        B, N, T = self.B, self.N, cfg.TRAIN
+        head = s.h_report.numpy()
+        hsz = head.shape[1]
+        keep = []
+        for b in range(B):
+            n_inside, n_fg, n_bg, n_low = (int(v) for v in head[b, :16].view(np.int32))
+            if 32 + n_fg <= hsz:
+                flags = s.h_report.data_ptr() + b * hsz + 32
+            else:                                                     # (more positives than travel with the first copy: rare)
+                full = np.ascontiguousarray(s.report[b, 32:32 + n_fg].cpu().numpy())
+                keep.append(full)
+                flags = full.ctypes.data
+            s.frames_c[b] = DrawFrame(n_fg, n_bg, n_low, int(small[b, 1]), int(small[b, 2]), 0, flags)
+        rois_per_image = int(T.BATCH_SIZE) // 1
+        par = DrawParams(int(T.RPN_BATCHSIZE), int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE), rois_per_image,
+                         int(np.round(T.FG_FRACTION * rois_per_image)))
+        gen = npr.mtrand._rand._bit_generator                          # the numpy GLOBAL legacy RandomState's MT19937
+        with gen.lock:
+            rc = lib().mv3d_draw_training_subsamples(C.c_void_p(gen.ctypes.state_address), B, s.frames_c, C.byref(par),
+                                                     C.c_void_p(s.h_lists.data_ptr()), s.list_cap, s.sizes_c,
+                                                     C.c_void_p(s.h_scratch.data_ptr()), s.h_scratch.numel())
+        check(rc, "mv3d_draw_training_subsamples")
+        sizes = list(s.sizes_c)
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += n
+        return sizes, offs, o
+
     # ------------------------------------------------------------------ host draws + stage 2
     def finish(self, s):
         """Returns a dict of device tensors: rpn_labels (B,N), rpn_targets (B,N,6), anchors / anchors_3d / n_anchors,
@@ -216,24 +255,8 @@ class TrainPathStream:
         if int(small[:, 5].max()) & 1:
             s.busy = False
             raise ZeroDivisionError("float division")
-        head = s.h_report.numpy()
-        lists, sizes = [], []
-        for b in range(B):                                             # frame order; anchor targets before proposal targets
-            fetch = (lambda b=b: s.report[b, 32:].cpu().numpy())
-            dis = draw_subsamples_host(head[b], fetch, N)
-            fg_pick, bg_pick = draw_samples_host(small[b, :4])
-            for a in (*dis, fg_pick, bg_pick):
-                a = np.zeros(0, np.int32) if a is None else a
-                lists.append(a)
-                sizes.append(len(a))
-        total = sum(sizes)
+        sizes, offs, total = self._draw(s, small)
         self.t_draw += time.perf_counter() - t1
-        hl = s.h_lists.numpy()
-        o, offs = 0, []
-        for a, n in zip(lists, sizes):
-            hl[o:o + n] = a
-            offs.append(o)
-            o += n
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
         with ctx:
             if total:
