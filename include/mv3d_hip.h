@@ -431,6 +431,39 @@ int mv3d_maxpool2x2_bwd_bf16(const void *y_framed, const void *g_pooled_framed, 
                              int channels, void *stream);
 int mv3d_maxpool2x2_bwd_f32(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width,
                             int channels, void *stream);      /* the same on f32 maps (the fp32 training trunk) */
+/* Several views of ONE layer shape behind one launch (the BEV / image / front-view trunks of lib/networks/MV3D_train.py:44-81 at one
+ * VGG depth have the same channel counts and different map sizes): the grid is the concatenation of the views' tiles, so that
+ * the small maps of a training batch fill the chip together, on ONE stream.  Same arithmetic per view as the single-view
+ * entries above (which are these with num_views = 1).  gate_framed: optional (bf16 / f16, framed 16-bit output only; all views
+ * or none) = the ReLU gate of mv3d_conv3x3_gated_bf16. */
+#define MV3D_MAX_CONV_VIEWS 3
+typedef struct {
+    const void *x_framed;        /* (batch, height + 2, width + 2, c_in) */
+    const void *w_packed;        /* (c_out, 9 * c_in), this view's filter */
+    const float *bias;           /* (c_out) */
+    const void *gate_framed;     /* optional, (batch, height + 2, width + 2, c_out) */
+    void *y;                     /* framed (batch, height + 2, width + 2, c_out) or bare (batch, height, width, c_out) */
+    int32_t batch, height, width, reserved0;
+} mv3d_conv_view;
+int mv3d_conv3x3_views_f16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu,
+                           void *stream);
+int mv3d_conv3x3_views_bf16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu,
+                            void *stream);
+int mv3d_conv3x3_views_f32(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int relu, void *stream);
+/* The 2x2 pools of several views in one launch.  Forward: x_framed = the map, y_framed = the pooled map (g_pooled_framed unused).
+ * Backward (mv3d_maxpool2x2_bwd_*): x_framed = the pre-pool map y, g_pooled_framed = the gradient w.r.t. the pooled map,
+ * y_framed = the gradient w.r.t. y's pre-activation (written). */
+typedef struct {
+    const void *x_framed;
+    const void *g_pooled_framed;
+    void *y_framed;
+    int32_t batch, height, width, reserved0;      /* size of the UNPOOLED map */
+} mv3d_pool_view;
+int mv3d_maxpool2x2_views_f16(int num_views, const mv3d_pool_view *views, int channels, void *stream);
+int mv3d_maxpool2x2_views_bf16(int num_views, const mv3d_pool_view *views, int channels, void *stream);
+int mv3d_maxpool2x2_views_f32(int num_views, const mv3d_pool_view *views, int channels, void *stream);
+int mv3d_maxpool2x2_bwd_views_bf16(int num_views, const mv3d_pool_view *views, int channels, void *stream);
+int mv3d_maxpool2x2_bwd_views_f32(int num_views, const mv3d_pool_view *views, int channels, void *stream);
 /* Weight gradient of that convolution (csrc/conv3x3_wgrad.hip): dw (c_out, c_in_real, 3, 3) f32 [the OIHW filter layout; TF's
  * HWIO is its transpose(2, 3, 1, 0)], dw[co][ci][tap] = sum over the pixels of the batch of dy[pixel][co] * x[pixel + tap][ci],
  * for the first c_in_real <= c_in channels (the input layer's buffer is padded to 64 channels); db (c_out) f32 (may be NULL) =
@@ -445,10 +478,32 @@ int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *
 size_t mv3d_conv3x3_wgrad_f32_workspace_bytes(int batch, int height, int width, int c_in, int c_out);
 int mv3d_conv3x3_wgrad_f32(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
                            int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes, void *stream);
+/* The weight gradients of several views (one filter SHAPE, every view its own maps and its own dw / db: the three trunks at one VGG
+ * depth) behind one launch + one reduce launch.  db: NULL in every view or in none.  workspace: >=
+ * mv3d_conv3x3_wgrad_views_workspace_bytes(...) bytes (f32_maps: 0 for the bf16 entry, 1 for the f32 one), 16-byte aligned. */
+typedef struct {
+    const void *x_framed;        /* (batch, height + 2, width + 2, c_in) */
+    const void *dy_framed;       /* (batch, height + 2, width + 2, c_out), zero frame */
+    float *dw;                   /* (c_out, c_in_real, 3, 3) */
+    float *db;                   /* (c_out) or NULL */
+    int32_t batch, height, width, reserved0;
+} mv3d_wgrad_view;
+size_t mv3d_conv3x3_wgrad_views_workspace_bytes(int num_views, const mv3d_wgrad_view *views, int c_in, int c_out, int f32_maps);
+int mv3d_conv3x3_wgrad_views_bf16(int num_views, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+int mv3d_conv3x3_wgrad_views_f32(int num_views, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 /* fp32 OIHW filter (c_out, c_in, 3, 3) -> the packed bf16 forms of one training step in one launch: fwd_packed (c_out, 9 * c_in_pad)
  * [zero-initialised by the caller when c_in_pad > c_in] for mv3d_conv3x3_bf16, dgrad_packed (c_in, 9 * c_out) (may be NULL) for
  * the data-gradient convolution: the filter flipped by 180 degrees with its channel axes swapped. */
 int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, void *dgrad_packed, int c_out, int c_in, int c_in_pad, void *stream);
+/* the same for many filters in ONE launch (every 3x3 layer of the training graph at the top of a step) */
+typedef struct {
+    const float *w_oihw;
+    void *fwd_packed, *dgrad_packed;               /* dgrad_packed may be NULL */
+    int32_t c_out, c_in, c_in_pad, reserved0;
+} mv3d_pack_item;
+int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *items, void *stream);
 /* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */
 int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
 /* NHWC f32 (batch, height, width, channels) -> interior pixels, first `channels` channels of a framed f16 buffer

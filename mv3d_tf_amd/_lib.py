@@ -61,6 +61,30 @@ class DrawParams(C.Structure):
     _fields_ = [("rpn_batchsize", C.c_int32), ("rpn_num_fg", C.c_int32), ("rois_per_image", C.c_int32), ("roi_fg_max", C.c_int32)]
 
 
+class ConvView(C.Structure):
+    """mv3d_conv_view"""
+    _fields_ = [("x_framed", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("gate_framed", C.c_void_p), ("y", C.c_void_p),
+                ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class PoolView(C.Structure):
+    """mv3d_pool_view"""
+    _fields_ = [("x_framed", C.c_void_p), ("g_pooled_framed", C.c_void_p), ("y_framed", C.c_void_p),
+                ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class WgradView(C.Structure):
+    """mv3d_wgrad_view"""
+    _fields_ = [("x_framed", C.c_void_p), ("dy_framed", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class PackItem(C.Structure):
+    """mv3d_pack_item"""
+    _fields_ = [("w_oihw", C.c_void_p), ("fwd_packed", C.c_void_p), ("dgrad_packed", C.c_void_p),
+                ("c_out", C.c_int32), ("c_in", C.c_int32), ("c_in_pad", C.c_int32), ("reserved0", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "mv3d_version": (C.c_int, []),
@@ -127,6 +151,18 @@ _SIGS = {
     "mv3d_conv3x3_gated_bf16": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_maxpool2x2_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_maxpool2x2_bwd_bf16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_views_f16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_views_bf16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_views_f32": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_maxpool2x2_views_f16": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
+    "mv3d_maxpool2x2_views_bf16": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
+    "mv3d_maxpool2x2_views_f32": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
+    "mv3d_maxpool2x2_bwd_views_bf16": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
+    "mv3d_maxpool2x2_bwd_views_f32": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
+    "mv3d_conv3x3_wgrad_views_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(WgradView), C.c_int, C.c_int, C.c_int]),
+    "mv3d_conv3x3_wgrad_views_bf16": (C.c_int, [C.c_int, C.POINTER(WgradView), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_conv3x3_wgrad_views_f32": (C.c_int, [C.c_int, C.POINTER(WgradView), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_conv3x3_pack_many_bf16": (C.c_int, [C.c_int, C.POINTER(PackItem), _P]),
     "mv3d_maxpool2x2_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }

@@ -41,6 +41,14 @@ struct ConvArgs {
     int m_tiles, n_tiles;
 };
 
+// Several views (the BEV / image / front-view trunks at one VGG depth: same channel counts, different map sizes) behind ONE
+// launch: the grid is the concatenation of the views' tiles (each view's share a multiple of 8 workgroups, so the workgroup ->
+// XCD mapping of a view does not depend on its neighbours).  At a training batch of 2 a single view's launch does not fill the
+// chip (364 tiles of conv4_x on 512 workgroup slots); three trunks on three streams overlapped them, one grouped launch does it
+// on ONE stream -- which is what data parallelism and graph capture need.
+#define CONV_MAX_VIEWS 3
+struct ConvGroup { ConvArgs v[CONV_MAX_VIEWS]; int n; int first[CONV_MAX_VIEWS]; };
+
 #define BK_BYTES 128     // one K step = 128 bytes of channels of one tap: 64 f16 / bf16 values or 32 f32
 
 // FIRST: the layer fed by the network input (conv1_1: 9 / 3 channels zero-padded to 16 = 32 B per pixel): a K step is FOUR taps
@@ -50,9 +58,14 @@ struct ConvArgs {
 // float = the reference's precision on v_mfma_f32_32x32x2_f32 (exact f32 products and sums at the f32 matrix rate, 1/16 of f16's):
 // K steps of 32 channels, f32 maps in and out, MFMA-bound by a wide margin (8x the matrix time per staged byte).
 template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
-__global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArgs a)
+__global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGroup g)
 {
 #if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
+    int view = 0;
+#pragma unroll
+    for (int j = 1; j < CONV_MAX_VIEWS; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.first[j]) view = j;
+    const ConvArgs &a = g.v[view];
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int TP = BM / WP, TC = BN / WC, FP = TP / 32, FC = TC / 32;
     constexpr int STAGE = (BM + BN) * BK_BYTES;
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
     // whose taps re-read two of its three input rows -- run on the SAME XCD at about the same time and hit its L2), and the
     // n-tiles of one m-tile run back to back (they share the activation rows).  Round-robin m-tiles over the XCDs instead:
     // conv1_2 6-8 % slower, the rest equal.
-    const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int id = (int)blockIdx.x - g.first[view], xcd = id & 7, local = id >> 3;
     const int mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles, nt = local % a.n_tiles;
     if (mt >= a.m_tiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -240,14 +253,29 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvArg
 #endif
 }
 
+// the pools' views (one launch for the trunks of one depth, like ConvGroup): view k owns workgroups [first[k], first[k + 1])
+struct PoolView { const void *x, *g; void *y; int B, H, W, Ho, Wo; };
+struct PoolGroup { PoolView v[CONV_MAX_VIEWS]; int n, C8; int first[CONV_MAX_VIEWS + 1]; };
+__device__ __forceinline__ int pool_view_of(const PoolGroup &g)
+{
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < CONV_MAX_VIEWS; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.first[j]) k = j;
+    return k;
+}
+
 // 2x2 / stride 2 max pool, VALID (floor), framed NHWC -> framed NHWC; one thread = 8 channels of one output pixel
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2x2_kernel(const typename Vec<T>::v8 *__restrict__ x, typename Vec<T>::v8 *__restrict__ y, int B, int H,
-                                                          int W, int C8, int Ho, int Wo)
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const PoolGroup g)
 {
     typedef typename Vec<T>::v8 V;
-    const long total = (long)B * Ho * Wo * C8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = pool_view_of(g);
+    const V *__restrict__ x = (const V *)g.v[k].x;
+    V *__restrict__ y = (V *)g.v[k].y;
+    const int B = g.v[k].B, H = g.v[k].H, W = g.v[k].W, Ho = g.v[k].Ho, Wo = g.v[k].Wo, C8 = g.C8;
+    const long total = (long)B * Ho * Wo * C8, nblk = g.first[k + 1] - g.first[k];
+    for (long i = (long)(blockIdx.x - g.first[k]) * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
         const int c = (int)(i % C8);
         long r = i / C8;
         const int xo = (int)(r % Wo);
@@ -270,12 +298,16 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const typename Vec<T>::
 // the pooled gradient if it is > 0 (the ReLU mask), the other three positions 0.  Rows / columns the VALID pool drops are not
 // written (the owner zeroed the buffer once).  One thread = 8 channels of one pooled pixel.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const typename Vec<T>::v8 *__restrict__ y, const typename Vec<T>::v8 *__restrict__ g,
-                                                              typename Vec<T>::v8 *__restrict__ gy, int B, int H, int W, int C8, int Ho, int Wo)
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const PoolGroup pg)
 {
     typedef typename Vec<T>::v8 V;
-    const long total = (long)B * Ho * Wo * C8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = pool_view_of(pg);
+    const V *__restrict__ y = (const V *)pg.v[k].x;
+    const V *__restrict__ g = (const V *)pg.v[k].g;
+    V *__restrict__ gy = (V *)pg.v[k].y;
+    const int B = pg.v[k].B, H = pg.v[k].H, W = pg.v[k].W, Ho = pg.v[k].Ho, Wo = pg.v[k].Wo, C8 = pg.C8;
+    const long total = (long)B * Ho * Wo * C8, nblk = pg.first[k + 1] - pg.first[k];
+    for (long i = (long)(blockIdx.x - pg.first[k]) * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
         const int c = (int)(i % C8);
         long r = i / C8;
         const int xo = (int)(r % Wo);
@@ -314,91 +346,141 @@ __global__ __launch_bounds__(256) void frame_f32_kernel(const float *__restrict_
 }
 
 template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool FIRST>
-int launch_conv(const ConvArgs &a, int out_f32, hipStream_t s)
+int launch_conv(ConvGroup &g, int out_f32, hipStream_t s)
 {
-    ConvArgs b = a;
-    b.m_tiles = (a.M + BM - 1) / BM;
-    b.n_tiles = a.Cout / BN;
-    const int grid = (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
-    if (out_f32)
-        hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
-    else
-        hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, false, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, b);
+    int grid = 0;
+    for (int k = 0; k < g.n; ++k) {
+        ConvArgs &b = g.v[k];
+        b.m_tiles = (b.M + BM - 1) / BM;
+        b.n_tiles = b.Cout / BN;
+        g.first[k] = grid;
+        grid += (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
+    }
+    for (int k = g.n; k < CONV_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    if constexpr (sizeof(T) == 4) {                               // f32 operands: f32 maps only
+        hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, g);
+    } else {
+        if (out_f32)
+            hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, true, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, g);
+        else
+            hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, STAGES, false, FIRST>), dim3(grid), dim3(WP * WC * 64), 0, s, g);
+    }
     return mv3d_launch_status();
 }
 
 }  // namespace mv3d_conv
 using namespace mv3d_conv;
 
+// fills one view's arguments; false = invalid
+static bool conv_view_args(ConvArgs &a, const mv3d_conv_view &w, int c_in, int c_out, int out_framed, int out_f32, int relu, int es, bool first,
+                           bool gated)
+{
+    if (!w.x_framed || !w.w_packed || !w.bias || !w.y || w.batch <= 0 || w.height <= 0 || w.width <= 0) return false;
+    if ((((uintptr_t)w.x_framed | (uintptr_t)w.w_packed | (uintptr_t)w.bias | (uintptr_t)w.y | (uintptr_t)w.gate_framed) & 15) != 0) return false;   // 16-byte pieces
+    if (gated != (w.gate_framed != nullptr)) return false;
+    const size_t xb = (size_t)w.batch * (w.height + 2) * (w.width + 2) * c_in * es, wb = (size_t)c_out * (first ? 192 : 9 * c_in) * es;
+    const size_t yb = (size_t)w.batch * (w.height + 2 * (out_framed != 0)) * (w.width + 2 * (out_framed != 0)) * c_out * (out_f32 ? 4 : 2);
+    if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return false;                   // 32-bit buffer offsets
+    a.x = w.x_framed; a.w = w.w_packed; a.bias = w.bias; a.y = w.y; a.mask = w.gate_framed;
+    a.H = w.height; a.W = w.width; a.Cin = c_in; a.Cout = c_out; a.HW = w.height * w.width; a.M = w.batch * w.height * w.width; a.Bn = w.batch;
+    a.out_pad = out_framed != 0; a.relu = relu != 0;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    a.m_tiles = a.n_tiles = 0;
+    return true;
+}
+
+template <typename T>
+static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu, void *stream)
+{
+    if (num_views <= 0 || num_views > CONV_MAX_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
+    const bool first = c_in == 16;                                // the input layer's packing (see the header)
+    if (c_in <= 0 || (c_in % 64 && !first) || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    const bool gated = views[0].gate_framed != nullptr;
+    if (gated && (!out_framed || out_f32)) return MV3D_ERR_INVALID_ARG;
+    ConvGroup g;
+    g.n = num_views;
+    for (int k = 0; k < num_views; ++k)
+        if (!conv_view_args(g.v[k], views[k], c_in, c_out, out_framed, out_f32, relu, 2, first, gated)) return MV3D_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (first) return c_out % 128 == 0 ? launch_conv<T, 128, 128, 2, 2, 2, true>(g, out_f32, s) : launch_conv<T, 256, 64, 4, 1, 2, true>(g, out_f32, s);
+    // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
+    // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
+    if (c_out % 128 == 0) return launch_conv<T, 128, 128, 2, 2, 2, false>(g, out_f32, s);
+    return launch_conv<T, 256, 64, 4, 1, 2, false>(g, out_f32, s);
+}
+
 template <typename T>
 static int conv3x3_entry(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
                          int c_out, int out_framed, int out_f32, int relu, void *stream, const void *mask = nullptr)
 {
-    if (mask && (!out_framed || out_f32 || ((uintptr_t)mask & 15))) return MV3D_ERR_INVALID_ARG;
-    if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
-    if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;   // 16-byte pieces
-    const bool first = c_in == 16;                                // the input layer's packing (see the header)
-    if (c_in <= 0 || (c_in % 64 && !first) || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
-    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 2, wb = (size_t)c_out * (first ? 192 : 9 * c_in) * 2;
-    const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * (out_f32 ? 4 : 2);
-    if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
-    ConvArgs a;
-    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y; a.mask = mask;
-    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width; a.Bn = batch;
-    a.out_pad = out_framed != 0; a.relu = relu != 0;
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-    a.m_tiles = a.n_tiles = 0;
-    hipStream_t s = (hipStream_t)stream;
-    if (first) return c_out % 128 == 0 ? launch_conv<T, 128, 128, 2, 2, 2, true>(a, out_f32, s) : launch_conv<T, 256, 64, 4, 1, 2, true>(a, out_f32, s);
-    // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
-    // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
-    if (c_out % 128 == 0) return launch_conv<T, 128, 128, 2, 2, 2, false>(a, out_f32, s);
-    return launch_conv<T, 256, 64, 4, 1, 2, false>(a, out_f32, s);
+    mv3d_conv_view w;
+    w.x_framed = x_framed; w.w_packed = w_packed; w.bias = bias; w.gate_framed = mask; w.y = y;
+    w.batch = batch; w.height = height; w.width = width; w.reserved0 = 0;
+    return conv3x3_views_entry<T>(1, &w, c_in, c_out, out_framed, out_f32, relu, stream);
 }
 
 // exact-f32 variant: f32 framed activations (c_in a multiple of 32), f32 packed weights, f32 output
+static int conv3x3_f32_views_entry(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int relu, void *stream)
+{
+    if (num_views <= 0 || num_views > CONV_MAX_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
+    if (c_in <= 0 || c_in % 32 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    ConvGroup g;
+    g.n = num_views;
+    long tiles128 = 0;
+    for (int k = 0; k < num_views; ++k) {
+        if (!conv_view_args(g.v[k], views[k], c_in, c_out, out_framed, 1, relu, 4, false, false)) return MV3D_ERR_INVALID_ARG;
+        tiles128 += (long)((g.v[k].M + 127) / 128) * (c_out / 128);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // few tiles (a training batch): the f32 kernel is MFMA-bound even with one wave per SIMD, so a CU that holds two workgroups
+    // just takes twice as long -- half-size tiles balance the last round (fp32 training step on one stream 58.7 -> 56 ms)
+    if (c_out % 128 == 0 && tiles128 < 1024) return launch_conv<float, 64, 128, 2, 2, 2, false>(g, 1, s);
+    if (c_out % 128 == 0) return launch_conv<float, 128, 128, 2, 2, 2, false>(g, 1, s);
+    return launch_conv<float, 128, 64, 2, 2, 2, false>(g, 1, s);
+}
+
 static int conv3x3_f32_entry(const void *x_framed, const void *w_packed, const float *bias, void *y, int batch, int height, int width, int c_in,
                              int c_out, int out_framed, int relu, void *stream)
 {
-    if (!x_framed || !w_packed || !bias || !y || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
-    if ((((uintptr_t)x_framed | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    if (c_in <= 0 || c_in % 32 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
-    const size_t xb = (size_t)batch * (height + 2) * (width + 2) * c_in * 4, wb = (size_t)c_out * 9 * c_in * 4;
-    const size_t yb = (size_t)batch * (height + 2 * (out_framed != 0)) * (width + 2 * (out_framed != 0)) * c_out * 4;
-    if (xb >= 0x7fffffffu || wb >= 0x7fffffffu || yb >= 0xffffffffu) return MV3D_ERR_INVALID_ARG;   // 32-bit buffer offsets
-    ConvArgs a;
-    a.x = x_framed; a.w = w_packed; a.bias = bias; a.y = y; a.mask = nullptr;
-    a.H = height; a.W = width; a.Cin = c_in; a.Cout = c_out; a.HW = height * width; a.M = batch * height * width; a.Bn = batch;
-    a.out_pad = out_framed != 0; a.relu = relu != 0;
-    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-    hipStream_t s = (hipStream_t)stream;
-    if (c_out % 128 == 0 && ((a.M + 127) / 128) * (c_out / 128) < 1024) {
-        // few tiles (a training batch): the f32 kernel is MFMA-bound even with one wave per SIMD, so a CU that holds two workgroups
-        // just takes twice as long -- 364 tiles on 256 CUs cost two rounds.  Half-size tiles balance that (724 tiles: 1.5 rounds):
-        // the single-stream (data-parallel) fp32 training step 58.7 -> 56 ms; with the trunks on three streams it is a wash (46 ms).
-        a.m_tiles = (a.M + 63) / 64; a.n_tiles = c_out / 128;
-        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 64, 128, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
-    } else if (c_out % 128 == 0) {
-        a.m_tiles = (a.M + 127) / 128; a.n_tiles = c_out / 128;
-        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 128, 128, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
-    } else {
-        a.m_tiles = (a.M + 127) / 128; a.n_tiles = c_out / 64;
-        hipLaunchKernelGGL((conv3x3_f16_kernel<float, 128, 64, 2, 2, 2, true, false>), dim3((a.m_tiles + 7) / 8 * 8 * a.n_tiles), dim3(256), 0, s, a);
+    mv3d_conv_view w;
+    w.x_framed = x_framed; w.w_packed = w_packed; w.bias = bias; w.gate_framed = nullptr; w.y = y;
+    w.batch = batch; w.height = height; w.width = width; w.reserved0 = 0;
+    return conv3x3_f32_views_entry(1, &w, c_in, c_out, out_framed, relu, stream);
+}
+
+// x = the map to pool (forward) / the pre-pool map y (backward); g = gradient w.r.t. the pooled map (backward only)
+template <typename T, bool BWD>
+static int pool_views_entry(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    if (num_views <= 0 || num_views > CONV_MAX_VIEWS || !views || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
+    PoolGroup g;
+    g.n = num_views; g.C8 = channels / 8;
+    int grid = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_pool_view &w = views[k];
+        if (!w.x_framed || !w.y_framed || (BWD && !w.g_pooled_framed) || w.batch <= 0 || w.height < 2 || w.width < 2) return MV3D_ERR_INVALID_ARG;
+        if ((((uintptr_t)w.x_framed | (uintptr_t)w.y_framed | (uintptr_t)w.g_pooled_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
+        PoolView &v = g.v[k];
+        v.x = w.x_framed; v.g = w.g_pooled_framed; v.y = w.y_framed;
+        v.B = w.batch; v.H = w.height; v.W = w.width; v.Ho = w.height / 2; v.Wo = w.width / 2;
+        const long total = (long)v.B * v.Ho * v.Wo * g.C8;
+        g.first[k] = grid;
+        grid += (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     }
+    for (int k = num_views; k < CONV_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    g.first[num_views] = grid;
+    g.first[CONV_MAX_VIEWS] = grid;
+    if (BWD) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g);
     return mv3d_launch_status();
 }
 
 template <typename T>
 static int maxpool_entry(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream)
 {
-    if (!x_framed || !y_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
-    if ((((uintptr_t)x_framed | (uintptr_t)y_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    const int Ho = height / 2, Wo = width / 2;
-    const long total = (long)batch * Ho * Wo * (channels / 8);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const typename Vec<T>::v8 *)x_framed,
-                       (typename Vec<T>::v8 *)y_framed, batch, height, width, channels / 8, Ho, Wo);
-    return mv3d_launch_status();
+    mv3d_pool_view w;
+    w.x_framed = x_framed; w.g_pooled_framed = nullptr; w.y_framed = y_framed; w.batch = batch; w.height = height; w.width = width; w.reserved0 = 0;
+    return pool_views_entry<T, false>(1, &w, channels, stream);
 }
 
 template <typename T>
@@ -433,6 +515,20 @@ extern "C" int mv3d_conv3x3_f32(const void *x, const void *w, const float *bias,
 {
     return conv3x3_f32_entry(x, w, bias, y, batch, height, width, c_in, c_out, out_framed, relu, stream);
 }
+extern "C" int mv3d_conv3x3_views_f16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu,
+                                      void *stream)
+{
+    return conv3x3_views_entry<_Float16>(num_views, views, c_in, c_out, out_framed, out_f32, relu, stream);
+}
+extern "C" int mv3d_conv3x3_views_bf16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu,
+                                       void *stream)
+{
+    return conv3x3_views_entry<__bf16>(num_views, views, c_in, c_out, out_framed, out_f32, relu, stream);
+}
+extern "C" int mv3d_conv3x3_views_f32(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int relu, void *stream)
+{
+    return conv3x3_f32_views_entry(num_views, views, c_in, c_out, out_framed, relu, stream);
+}
 extern "C" int mv3d_maxpool2x2_f32(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
 {
     return maxpool_entry<float>(x, y, batch, height, width, channels, stream);
@@ -453,15 +549,30 @@ template <typename T>
 static int maxpool_bwd_entry(const void *y_framed, const void *g_pooled_framed, void *gy_framed, int batch, int height, int width, int channels,
                              void *stream)
 {
-    if (!y_framed || !g_pooled_framed || !gy_framed || batch <= 0 || height < 2 || width < 2 || channels <= 0 || channels % 8) return MV3D_ERR_INVALID_ARG;
-    if ((((uintptr_t)y_framed | (uintptr_t)g_pooled_framed | (uintptr_t)gy_framed) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    typedef typename Vec<T>::v8 V;
-    const int Ho = height / 2, Wo = width / 2;
-    const long total = (long)batch * Ho * Wo * (channels / 8);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const V *)y_framed, (const V *)g_pooled_framed,
-                       (V *)gy_framed, batch, height, width, channels / 8, Ho, Wo);
-    return mv3d_launch_status();
+    mv3d_pool_view w;
+    w.x_framed = y_framed; w.g_pooled_framed = g_pooled_framed; w.y_framed = gy_framed; w.batch = batch; w.height = height; w.width = width;
+    w.reserved0 = 0;
+    return pool_views_entry<T, true>(1, &w, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_views_f16(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    return pool_views_entry<_Float16, false>(num_views, views, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_views_bf16(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    return pool_views_entry<__bf16, false>(num_views, views, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_views_f32(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    return pool_views_entry<float, false>(num_views, views, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_bwd_views_bf16(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    return pool_views_entry<__bf16, true>(num_views, views, channels, stream);
+}
+extern "C" int mv3d_maxpool2x2_bwd_views_f32(int num_views, const mv3d_pool_view *views, int channels, void *stream)
+{
+    return pool_views_entry<float, true>(num_views, views, channels, stream);
 }
 extern "C" int mv3d_maxpool2x2_bwd_bf16(const void *y, const void *g, void *gy, int batch, int height, int width, int channels, void *stream)
 {

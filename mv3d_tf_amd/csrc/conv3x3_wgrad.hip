@@ -14,6 +14,7 @@
 // Workgroup = (co tile of 128 | 64) x (64 input channels) x (filter row dy: 3 taps = 192 GEMM columns) x (a range of K steps of
 // 64 pixels); 4 waves = 2 (co halves) x 2 (column halves: 3 fragments of 32 columns each).  Partial sums of the K ranges go to
 // part[split][co][tap][ci] (f32) and are folded in split order by conv3x3_wgrad_reduce_kernel: deterministic, no atomics.
+#include <stdlib.h>
 #include "common.h"
 
 namespace mv3d_wgrad {
@@ -32,14 +33,42 @@ struct WgradArgs {
     unsigned x_bytes, dy_bytes;
 };
 
+// Several views (the three trunks at one VGG depth) behind one launch, like ConvGroup of conv3x3_mfma.hip: view k owns the
+// workgroups [first[k], first[k + 1]); every view has its own maps, partial sums and number of K splits, the filter shape is shared.
+#define WG_MAX_VIEWS 3
+struct WgradView {
+    const void *x, *dy;
+    float *part, *bpart;          // split-K partial sums: filter [splits][Cout][9][Cin]; bias [splits][Cout] (or nullptr)
+    float *dw, *db;               // results (the reduce launch)
+    int Wp, steps, splits;
+    unsigned x_bytes, dy_bytes;
+};
+struct WgradGroup { WgradView v[WG_MAX_VIEWS]; int n, Cin, Cout, steps_per_split, ci_tiles, c_in_real; int first[WG_MAX_VIEWS]; };
+__device__ __forceinline__ WgradArgs wgrad_view_args(const WgradGroup &g, int &id)
+{
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < WG_MAX_VIEWS; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.first[j]) k = j;
+    const WgradView &v = g.v[k];
+    WgradArgs a;
+    a.x = v.x; a.dy = v.dy; a.part = v.part; a.bpart = v.bpart;
+    a.Wp = v.Wp; a.Cin = g.Cin; a.Cout = g.Cout; a.Q = 0; a.steps = v.steps; a.steps_per_split = g.steps_per_split; a.splits = v.splits;
+    a.ci_tiles = g.ci_tiles; a.x_bytes = v.x_bytes; a.dy_bytes = v.dy_bytes;
+    id = (int)blockIdx.x - g.first[k];
+    return a;
+}
+
 #define WG_PIX 64              // pixels per K step
 #define WG_XROWS 72            // staged X rows per step: 64 + 2 (dx = 0..2), padded to 9 pieces of 8 rows
 #define WG_OOB 0x7ffffff0      // a byte offset beyond every buffer: the load returns zeros
 
 template <int BMC>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp)
 {
 #if __HIP_DEVICE_COMPILE__
+    int id;
+    const WgradArgs a = wgrad_view_args(grp, id);
     constexpr int RB = BMC * 2;                                   // bytes of a dY tile row
     constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WG_PIX / RPP;   // lanes per row, rows per 1-KB piece, dY pieces
     constexpr int DY_BYTES = WG_PIX * RB, X_BYTES = WG_XROWS * 128, STAGE = DY_BYTES + X_BYTES;
@@ -51,7 +80,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;
     // workgroup -> (split, dy, ci tile, co tile)
-    int id = blockIdx.x;
     const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
     const int dyr = id % 3; id /= 3;
     const int split = id % a.splits;
@@ -195,9 +223,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a)
 #define WGF_PIX 32
 #define WGF_XROWS 40
 template <int BMC>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup grp)
 {
 #if __HIP_DEVICE_COMPILE__
+    int id;
+    const WgradArgs a = wgrad_view_args(grp, id);
     constexpr int RB = BMC * 4;                                   // bytes of a dY tile row (512 | 256)
     constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WGF_PIX / RPP;
     constexpr int XRB = 256, XRPP = 4, XPCS = WGF_XROWS / XRPP;   // activation rows: 64 channels x 4 B, 4 rows per 1-KB piece
@@ -209,7 +239,6 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;
-    int id = blockIdx.x;
     const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
     const int dyr = id % 3; id /= 3;
     const int split = id % a.splits;
@@ -315,25 +344,40 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradArgs 
 }
 
 // folds the split-K partial sums in split order and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3),
-// dropping the padding channels of the input layer (c_in_real <= c_in)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, long n, int splits, int c_in,
-                                                                    int c_in_real, const float *__restrict__ bpart, float *__restrict__ db, int c_out)
+// dropping the padding channels of the input layer (c_in_real <= c_in).  blockIdx.y = view.  A thread owns 4 consecutive input
+// channels of one (co, tap): 16-byte loads, four splits' loads in flight before they are added -- in split order: the sum is the
+// same sequence of f32 additions whatever the unrolling -- (the first version walked the splits one dependent 4-byte load at a
+// time: 43 us per launch for 75 MB of partials).
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradGroup g)
 {
-    const long total = n + (db ? c_out : 0);
+    const WgradView &v = g.v[blockIdx.y];
+    const float *__restrict__ part = v.part;
+    const int splits = v.splits, c_in = g.Cin, c_in_real = g.c_in_real, c_out = g.Cout;
+    const long n = (long)c_out * 9 * c_in, n4 = n / 4;
+    const long total = n4 + (v.db ? c_out : 0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        if (i >= n) {                                             // the bias gradient's partial sums
-            const int co = (int)(i - n);
-            float s = bpart[co];
-            for (int k = 1; k < splits; ++k) s += bpart[(long)k * c_out + co];
-            db[co] = s;
+        if (i >= n4) {                                            // the bias gradient's partial sums
+            const int co = (int)(i - n4);
+            float s = v.bpart[co];
+            for (int k = 1; k < splits; ++k) s += v.bpart[(long)k * c_out + co];
+            v.db[co] = s;
             continue;
         }
-        const int ci = (int)(i % c_in);
-        if (ci >= c_in_real) continue;
-        const long r = i / c_in;                                  // co * 9 + tap
-        float s = part[i];
-        for (int k = 1; k < splits; ++k) s += part[(long)k * n + i];
-        dw[((r / 9) * c_in_real + ci) * 9 + r % 9] = s;
+        const f32x4r *p = (const f32x4r *)part + i;
+        f32x4r s = p[0];
+        int k = 1;
+        for (; k + 4 <= splits; k += 4) {
+            const f32x4r a0 = p[(long)k * n4], a1 = p[(long)(k + 1) * n4], a2 = p[(long)(k + 2) * n4], a3 = p[(long)(k + 3) * n4];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; k < splits; ++k) s += p[(long)k * n4];
+        const int ci = (int)((i * 4) % c_in);
+        const long r = (i * 4) / c_in;                            // co * 9 + tap
+        float *o = v.dw + ((r / 9) * c_in_real + ci) * 9 + r % 9;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ci + e < c_in_real) o[e * 9] = s[e];
     }
 }
 
@@ -353,23 +397,76 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const float *__restri
     }
 }
 
+// the same for MANY filters in one launch (every 3x3 layer of the training graph at the top of a step: the packed copies only
+// change when the optimiser has stepped): item k owns the workgroups [first[k], first[k + 1])
+#define PACK_MAX 48
+struct PackItem { const float *w; __bf16 *fwd, *dgrad; int O, I, Ipad, first; };
+struct PackMany { PackItem it[PACK_MAX]; int n, blocks; };
+__global__ __launch_bounds__(256) void conv3x3_pack_many_kernel(const PackMany p)
+{
+    int k = 0;
+    for (int j = 1; j < p.n; ++j)
+        if ((int)blockIdx.x >= p.it[j].first) k = j;
+    const PackItem &t = p.it[k];
+    const int nblk = (k + 1 < p.n ? p.it[k + 1].first : p.blocks) - t.first;
+    const long n = (long)t.O * t.I * 9;
+    for (long i = (long)(blockIdx.x - t.first) * blockDim.x + threadIdx.x; i < n; i += (long)nblk * blockDim.x) {
+        const int tap = (int)(i % 9);
+        const long r = i / 9;
+        const int ci = (int)(r % t.I), o = (int)(r / t.I);
+        const __bf16 v = (__bf16)t.w[i];
+        t.fwd[((long)o * 9 + tap) * t.Ipad + ci] = v;
+        if (t.dgrad) t.dgrad[((long)ci * 9 + (8 - tap)) * t.O + o] = v;
+    }
+}
+
 }  // namespace mv3d_wgrad
 using namespace mv3d_wgrad;
 
-static int wgrad_splits(int tiles, int steps)
+// K steps per workgroup: the three workgroups per CU the LDS allows (~768 in all; 1024: 5-10 % slower and more partials), at
+// least 4 steps each
+static int wgrad_steps_per_split(int tiles, long total_steps)
 {
-    int ks = (768 + tiles - 1) / tiles;                           // ~768 workgroups = the three per CU the LDS allows (1024: 5-10 % slower, more partials)
-    if (ks > steps / 4) ks = steps / 4;                           // ... of at least 4 K steps each
-    return ks < 1 ? 1 : ks;
+#ifdef MV3D_TUNING
+    static const int target = getenv("MV3D_WGRAD_TARGET") ? atoi(getenv("MV3D_WGRAD_TARGET")) : 768;
+#else
+    const int target = 768;
+#endif
+    long s = (total_steps * tiles + target - 1) / target;
+    return (int)(s < 4 ? 4 : s);
+}
+
+struct WgradPlan { int steps[WG_MAX_VIEWS], splits[WG_MAX_VIEWS], steps_per_split, tiles, bmc; size_t q[WG_MAX_VIEWS], part_off[WG_MAX_VIEWS], bpart_off[WG_MAX_VIEWS], bytes; };
+
+static bool wgrad_plan(int n, const mv3d_wgrad_view *views, int c_in, int c_out, int pix, WgradPlan &P)
+{
+    if (n <= 0 || n > WG_MAX_VIEWS || !views || c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return false;
+    P.bmc = c_out % 128 == 0 ? 128 : 64;
+    P.tiles = (c_out / P.bmc) * (c_in / 64) * 3;
+    long total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (views[k].batch <= 0 || views[k].height <= 0 || views[k].width <= 0) return false;
+        P.q[k] = (size_t)views[k].batch * (views[k].height + 2) * (views[k].width + 2);
+        P.steps[k] = (int)((P.q[k] + pix - 1) / pix);
+        total += P.steps[k];
+    }
+    P.steps_per_split = wgrad_steps_per_split(P.tiles, total);
+    size_t o = 0;
+    for (int k = 0; k < n; ++k) {
+        P.splits[k] = (P.steps[k] + P.steps_per_split - 1) / P.steps_per_split;
+        P.part_off[k] = o; o += (size_t)P.splits[k] * c_out * 9 * c_in * 4;
+        P.bpart_off[k] = o; o += ((size_t)P.splits[k] * c_out * 4 + 15) / 16 * 16;
+    }
+    P.bytes = o;
+    return true;
 }
 
 static size_t wgrad_ws_bytes(int batch, int height, int width, int c_in, int c_out, int pix)
 {
-    if (batch <= 0 || height <= 0 || width <= 0 || c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return 0;
-    const int bmc = c_out % 128 == 0 ? 128 : 64;
-    const int steps = (batch * (height + 2) * (width + 2) + pix - 1) / pix;
-    const size_t ks = (size_t)wgrad_splits((c_out / bmc) * (c_in / 64) * 3, steps);
-    return ks * c_out * 9 * c_in * 4 + ks * c_out * 4;             // filter partials + bias partials
+    mv3d_wgrad_view w = {};
+    w.batch = batch; w.height = height; w.width = width;
+    WgradPlan P;
+    return wgrad_plan(1, &w, c_in, c_out, pix, P) ? P.bytes : 0;
 }
 
 extern "C" size_t mv3d_conv3x3_wgrad_workspace_bytes(int batch, int height, int width, int c_in, int c_out)
@@ -380,44 +477,58 @@ extern "C" size_t mv3d_conv3x3_wgrad_f32_workspace_bytes(int batch, int height, 
 {
     return wgrad_ws_bytes(batch, height, width, c_in, c_out, WGF_PIX);
 }
+extern "C" size_t mv3d_conv3x3_wgrad_views_workspace_bytes(int num_views, const mv3d_wgrad_view *views, int c_in, int c_out, int f32_maps)
+{
+    WgradPlan P;
+    return wgrad_plan(num_views, views, c_in, c_out, f32_maps ? WGF_PIX : WG_PIX, P) ? P.bytes : 0;
+}
+
+static int wgrad_views_entry(int n, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace, size_t workspace_bytes,
+                             void *stream, int es)
+{
+    if (c_in_real <= 0 || c_in_real > c_in || !workspace || ((uintptr_t)workspace & 15)) return MV3D_ERR_INVALID_ARG;
+    const int pix = es == 2 ? WG_PIX : WGF_PIX;
+    WgradPlan P;
+    if (!wgrad_plan(n, views, c_in, c_out, pix, P)) return MV3D_ERR_INVALID_ARG;
+    if (workspace_bytes < P.bytes) return MV3D_ERR_WORKSPACE;
+    WgradGroup g;
+    g.n = n; g.Cin = c_in; g.Cout = c_out; g.steps_per_split = P.steps_per_split; g.ci_tiles = c_in / 64; g.c_in_real = c_in_real;
+    int grid = 0;
+    const bool want_bias = views[0].db != nullptr;
+    for (int k = 0; k < n; ++k) {
+        const mv3d_wgrad_view &w = views[k];
+        if (!w.x_framed || !w.dy_framed || !w.dw || (want_bias != (w.db != nullptr))) return MV3D_ERR_INVALID_ARG;
+        if ((((uintptr_t)w.x_framed | (uintptr_t)w.dy_framed | (uintptr_t)w.dw) & 15) != 0) return MV3D_ERR_INVALID_ARG;
+        if (P.q[k] * c_in * es >= 0x7fffff00u || P.q[k] * c_out * es >= 0x7fffff00u) return MV3D_ERR_INVALID_ARG;    // 32-bit buffer offsets
+        WgradView &v = g.v[k];
+        v.x = w.x_framed; v.dy = w.dy_framed; v.dw = w.dw; v.db = w.db;
+        v.part = (float *)((char *)workspace + P.part_off[k]);
+        v.bpart = w.db ? (float *)((char *)workspace + P.bpart_off[k]) : nullptr;
+        v.Wp = w.width + 2; v.steps = P.steps[k]; v.splits = P.splits[k];
+        v.x_bytes = (unsigned)(P.q[k] * c_in * es); v.dy_bytes = (unsigned)(P.q[k] * c_out * es);
+        g.first[k] = grid;
+        grid += P.tiles * P.splits[k];
+    }
+    for (int k = n; k < WG_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    hipStream_t s = (hipStream_t)stream;
+    if (es == 2) {
+        if (P.bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, g);
+    } else {
+        if (P.bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<128>, dim3(grid), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<64>, dim3(grid), dim3(256), 0, s, g);
+    }
+    const long n4 = (long)c_out * 9 * c_in / 4 + c_out;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048), n), dim3(256), 0, s, g);
+    return mv3d_launch_status();
+}
 
 static int wgrad_entry(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width, int c_in, int c_in_real,
                        int c_out, void *workspace, size_t workspace_bytes, void *stream, int es)
 {
-    if (c_in_real <= 0 || c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
-    if (!x_framed || !dy_framed || !dw || !workspace || batch <= 0 || height <= 0 || width <= 0) return MV3D_ERR_INVALID_ARG;
-    if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
-    if ((((uintptr_t)x_framed | (uintptr_t)dy_framed | (uintptr_t)dw | (uintptr_t)workspace) & 15) != 0) return MV3D_ERR_INVALID_ARG;
-    const int pix = es == 2 ? WG_PIX : WGF_PIX;
-    const size_t need = wgrad_ws_bytes(batch, height, width, c_in, c_out, pix);
-    if (workspace_bytes < need) return MV3D_ERR_WORKSPACE;
-    const size_t q = (size_t)batch * (height + 2) * (width + 2);
-    if (q * c_in * es >= 0x7fffff00u || q * c_out * es >= 0x7fffff00u) return MV3D_ERR_INVALID_ARG;    // 32-bit buffer offsets
-    const int bmc = c_out % 128 == 0 ? 128 : 64;
-    WgradArgs a;
-    a.x = x_framed; a.dy = dy_framed; a.part = (float *)workspace;
-    a.bpart = nullptr;
-    a.Wp = width + 2; a.Cin = c_in; a.Cout = c_out; a.Q = (int)q;
-    a.steps = (int)((q + pix - 1) / pix);
-    a.ci_tiles = c_in / 64;
-    const int tiles = (c_out / bmc) * a.ci_tiles * 3;
-    a.splits = wgrad_splits(tiles, a.steps);
-    a.steps_per_split = (a.steps + a.splits - 1) / a.splits;
-    a.x_bytes = (unsigned)(q * c_in * es); a.dy_bytes = (unsigned)(q * c_out * es);
-    if (db) a.bpart = a.part + (size_t)a.splits * c_out * 9 * c_in;
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = tiles * a.splits;
-    if (es == 2) {
-        if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), 0, s, a);
-    } else {
-        if (bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<128>, dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<64>, dim3(grid), dim3(256), 0, s, a);
-    }
-    const long n = (long)c_out * 9 * c_in;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, a.part, dw, n,
-                       a.splits, c_in, c_in_real, a.bpart, db, c_out);
-    return mv3d_launch_status();
+    mv3d_wgrad_view w;
+    w.x_framed = x_framed; w.dy_framed = dy_framed; w.dw = dw; w.db = db; w.batch = batch; w.height = height; w.width = width; w.reserved0 = 0;
+    return wgrad_views_entry(1, &w, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, es);
 }
 
 extern "C" int mv3d_conv3x3_wgrad_bf16(const void *x_framed, const void *dy_framed, float *dw, float *db, int batch, int height, int width,
@@ -430,6 +541,16 @@ extern "C" int mv3d_conv3x3_wgrad_f32(const void *x_framed, const void *dy_frame
 {
     return wgrad_entry(x_framed, dy_framed, dw, db, batch, height, width, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, 4);
 }
+extern "C" int mv3d_conv3x3_wgrad_views_bf16(int num_views, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace,
+                                             size_t workspace_bytes, void *stream)
+{
+    return wgrad_views_entry(num_views, views, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, 2);
+}
+extern "C" int mv3d_conv3x3_wgrad_views_f32(int num_views, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace,
+                                            size_t workspace_bytes, void *stream)
+{
+    return wgrad_views_entry(num_views, views, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, 4);
+}
 
 extern "C" int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, void *dgrad_packed, int c_out, int c_in, int c_in_pad, void *stream)
 {
@@ -437,5 +558,28 @@ extern "C" int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, voi
     const long n = (long)c_out * c_in * 9;
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, w_oihw,
                        (__bf16 *)fwd_packed, (__bf16 *)dgrad_packed, c_out, c_in, c_in_pad);
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *items, void *stream)
+{
+    if (num_items <= 0 || !items) return MV3D_ERR_INVALID_ARG;
+    for (int i0 = 0; i0 < num_items; i0 += PACK_MAX) {
+        PackMany p;
+        p.n = num_items - i0 < PACK_MAX ? num_items - i0 : PACK_MAX;
+        int blocks = 0;
+        for (int k = 0; k < p.n; ++k) {
+            const mv3d_pack_item &w = items[i0 + k];
+            if (!w.w_oihw || !w.fwd_packed || w.c_out <= 0 || w.c_in <= 0 || w.c_in_pad < w.c_in) return MV3D_ERR_INVALID_ARG;
+            PackItem &t = p.it[k];
+            t.w = w.w_oihw; t.fwd = (__bf16 *)w.fwd_packed; t.dgrad = (__bf16 *)w.dgrad_packed; t.O = w.c_out; t.I = w.c_in; t.Ipad = w.c_in_pad;
+            t.first = blocks;
+            const long n = (long)w.c_out * w.c_in * 9;
+            blocks += (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+        }
+        for (int k = p.n; k < PACK_MAX; ++k) p.it[k] = p.it[0];
+        p.blocks = blocks;
+        hipLaunchKernelGGL(conv3x3_pack_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return mv3d_launch_status();
 }

@@ -40,20 +40,6 @@ _INPUTS = ("lidar_bv_data", "image_data", "lidar_fv_data", "im_info", "calib", "
            "gt_boxes_corners")
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_streams(device, n):
-    """the process's side streams of a device, made ONCE: every torch.cuda.Stream() takes the next slot of torch's stream pool, and
-    which hardware queue a slot lands on decides whether the trunks really overlap -- streams made per network gave a training
-    step that was 46.5 or 53 ms depending on how many networks had been built before"""
-    key = str(device)
-    have = _SIDE_STREAMS.setdefault(key, [])
-    while len(have) < n:
-        have.append(torch.cuda.Stream(device=device))
-    return have[:n]
-
-
 class MV3D:
     """One class for both graphs; `phase` is 'TEST' (MV3D_test) or 'TRAIN' (MV3D_train)."""
 
@@ -76,11 +62,7 @@ class MV3D:
         # with fp32 master weights (mv3d_tf_amd.trunk_train, next to amp_dtype = torch.bfloat16 for the other dense layers).
         self.mfma_trunk = False
         self._mfma = None
-        self._side = None
         self._train_pool = None
-        self._train_streams = []
-        self.trunk_streams = True          # training: the image / front-view trunks on side streams (single process only ...
-        self.trunk_streams_dp = False      # ... unless this is set: GradBucketer fences every bucket by its gradients' stream events)
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -164,23 +146,12 @@ class MV3D:
         if self._mfma is None or self._mfma.dtype != half:
             from ..trunk import MfmaTrunks
             self._mfma = MfmaTrunks(self, _VGG, dtype=half)
-        # the image (and front-view) trunk on a side stream: the trunks are independent chains of chip-filling launches, and
-        # the last, partly filled round of workgroups of a layer of one trunk overlaps the start of a layer of the other
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = _side_streams(self.device, 1)[0]
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            self._mfma.trunk(L["image_data"], "_2", last_framed=False)
-            if self.views == 3:
-                self._mfma.trunk(L["lidar_fv_data"], "_3", last_framed=False)
-        bev = self._mfma.trunk(L["lidar_bv_data"], "", last_framed=True)
+        # all trunks walked together: one launch per depth for the BEV / image / front-view maps (MfmaTrunks.trunks)
+        keys = [("", "lidar_bv_data"), ("_2", "image_data")] + ([("_3", "lidar_fv_data")] if self.views == 3 else [])
+        maps = self._mfma.trunks([L[k] for _, k in keys], [sfx for sfx, _ in keys], [sfx == "" for sfx, _ in keys])
+        bev = maps[0]
         L["conv5_3"] = bev[:, 1:-1, 1:-1].float().contiguous()       # the f32 NHWC map the RoiPool layer reads
         rpn = self._mfma.rpn_conv(bev)                               # (B, H, W, 512) f16
-        main.wait_stream(self._side)
-        for k in ("conv5_3_2", "conv5_3_3"):
-            if k in L:
-                L[k].record_stream(main)
         L["rpn_conv/3x3"] = rpn
         heads = []
         for name in ("rpn_cls_score", "rpn_bbox_pred"):               # 1x1 convolutions = a matmul over the channel axis
@@ -264,40 +235,19 @@ class MV3D:
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
         if self.mfma_trunk and self.phase == "TRAIN" and torch.is_grad_enabled():
             # mixed-precision training trunks: forward and backward convolutions on the bf16 MFMA kernel (mv3d_tf_amd.trunk_train)
-            from ..trunk_train import BufferPool, trunk as _trunk_fn
+            from ..trunk_train import BufferPool, trunks as _trunks_fn
             tdt = torch.bfloat16 if self.amp_dtype is not None else torch.float32     # amp_dtype None: the reference's fp32, exact-f32 MFMA
-            mfma_train_trunk = lambda *a_, **k_: _trunk_fn(*a_, dtype=tdt, **k_)
             if self._train_pool is None:
                 self._train_pool = BufferPool()         # (one forward / backward pair per network in flight)
-            # the image / front-view trunks on side streams: at a training batch of 2 their launches do not fill the chip, so the
-            # trunks' kernels overlap -- forward here, and backward too (autograd runs a Function's backward on its forward's stream)
-            # Single process only: under data parallelism the gradient buckets go on the wire from post-accumulate hooks, and a
-            # bucket whose gradients were produced on different streams would need cross-stream fences the bucketer does not have.
-            import torch.distributed as tdist
-            main = torch.cuda.current_stream()
-            side_in = [("_2", "image_data", "conv5_3_2")] + ([("_3", "lidar_fv_data", "conv5_3_3")] if self.views == 3 else [])
-            multi = self.trunk_streams and (self.trunk_streams_dp or
-                                            not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1))
-            if multi and not self._train_streams:
-                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)   # (torch >= 2.9)
-                if quiet is not None:
-                    quiet(False)                                                            # (the mismatch is the point)
-            if multi:
-                self._train_streams = _side_streams(self.device, len(side_in))
-            for k, (sfx, key, out) in enumerate(side_in):
-                if not multi:
-                    L[out] = mfma_train_trunk(_VGG, L[key], self.params, sfx, pool=self._train_pool)
-                    continue
-                st = self._train_streams[k]
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    L[out] = mfma_train_trunk(_VGG, L[key], self.params, sfx, pool=self._train_pool)
-            bev_nhwc = mfma_train_trunk(_VGG, L["lidar_bv_data"], self.params, "", pool=self._train_pool)
-            L["conv5_3"] = bev_nhwc
-            for k, (sfx, key, out) in enumerate(side_in):
-                if multi:
-                    main.wait_stream(self._train_streams[k])
-                    L[out].record_stream(main)
+            # the BEV / image / front-view trunks walk the same layer list: ONE launch per depth for all of them (grouped entries
+            # mv3d_conv3x3_views_*, mv3d_maxpool2x2*_views_*, mv3d_conv3x3_wgrad_views_*).  At a training batch of 2 one trunk's
+            # launches do not fill the chip, together they do -- on one stream, the same launches with and without data parallelism.
+            keys = [("", "lidar_bv_data", "conv5_3"), ("_2", "image_data", "conv5_3_2")] + \
+                ([("_3", "lidar_fv_data", "conv5_3_3")] if self.views == 3 else [])
+            maps = _trunks_fn(_VGG, [L[k] for _, k, _ in keys], self.params, [sfx for sfx, _, _ in keys], pool=self._train_pool, dtype=tdt)
+            for (_, _, out), m in zip(keys, maps):
+                L[out] = m
+            bev_nhwc = L["conv5_3"]
             from ..trunk_train import conv_relu
             rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"], dtype=tdt)   # (B, H, W, 512) f32, same kernels
             L["rpn_conv/3x3"] = rpn_nhwc

@@ -519,6 +519,118 @@ def conv3x3_gated_bf16(x_framed, w_packed, bias, gate_framed, out):
     return out
 
 
+# ------------------------------------------------------------------ several views of one layer shape behind one launch
+# (the BEV / image / front-view trunks at one VGG depth: lib/networks/MV3D_train.py:44-81 -- same channel counts, different map
+# sizes; at a training batch one view's tiles do not fill the chip, together they do, on one stream)
+_OFF32 = 2 ** 31 - 1
+
+
+def conv3x3_views(views, out_framed=True, out_f32=False, relu=True):
+    """views: list of (x_framed, w_packed, bias, gate_framed | None, out); the same (c_in, c_out) and type in every view.
+    One launch (mv3d_conv3x3_views_*); `out` is written (framed of the operand type, or bare in that type / f32)."""
+    x0, w0 = views[0][0], views[0][1]
+    cin, cout, dt = x0.shape[3], w0.shape[0], x0.dtype
+    f32 = dt == torch.float32
+    big = False
+    for x, w, b, g, out in views:
+        if x.dtype != dt or w.dtype != dt or x.shape[3] != cin or w.shape[0] != cout:
+            raise TypeError("views of one layer shape and type expected")
+        big = big or x.numel() * x.element_size() > _OFF32 or out.numel() * out.element_size() > _OFF32
+    if big or len(views) > 3:                                     # beyond the kernel's 32-bit offsets: per view, in batch chunks
+        for x, w, b, g, out in views:
+            if g is not None:
+                conv3x3_gated_bf16(x, w, b, g, out)
+            else:
+                conv3x3_f16(x, w, b, out=out, out_framed=out_framed, out_f32=out_f32, relu=relu)
+        return [v[4] for v in views]
+    arr = (_lib.ConvView * len(views))()
+    for k, (x, w, b, g, out) in enumerate(views):
+        B, Hp, Wp, _ = x.shape
+        arr[k] = _lib.ConvView(x.data_ptr(), w.data_ptr(), b.data_ptr(), g.data_ptr() if g is not None else None, out.data_ptr(),
+                               B, Hp - 2, Wp - 2, 0)
+    fn, name = _half_entry("mv3d_conv3x3_views", dt)
+    if f32:
+        check(fn(len(views), arr, cin, cout, int(out_framed), int(relu), _stream()), name)
+    else:
+        check(fn(len(views), arr, cin, cout, int(out_framed), int(out_f32), int(relu), _stream()), name)
+    return [v[4] for v in views]
+
+
+def maxpool2x2_views(views):
+    """views: list of (x_framed, out_framed): the 2x2 pools of several maps of one channel count in one launch"""
+    arr = (_lib.PoolView * len(views))()
+    for k, (x, out) in enumerate(views):
+        B, Hp, Wp, _ = x.shape
+        arr[k] = _lib.PoolView(x.data_ptr(), None, out.data_ptr(), B, Hp - 2, Wp - 2, 0)
+    fn, name = _half_entry("mv3d_maxpool2x2_views", views[0][0].dtype)
+    check(fn(len(views), arr, views[0][0].shape[3], _stream()), name)
+    return [v[1] for v in views]
+
+
+def maxpool2x2_bwd_views(views):
+    """views: list of (y_framed, g_pooled_framed, out): gradient of ReLU + 2x2 max pool of several maps in one launch"""
+    dt = views[0][0].dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise TypeError("bfloat16 or float32 maps expected")
+    arr = (_lib.PoolView * len(views))()
+    for k, (y, g, out) in enumerate(views):
+        B, Hp, Wp, _ = y.shape
+        arr[k] = _lib.PoolView(y.data_ptr(), g.data_ptr(), out.data_ptr(), B, Hp - 2, Wp - 2, 0)
+    fn, name = _half_entry("mv3d_maxpool2x2_bwd_views", dt)
+    check(fn(len(views), arr, views[0][0].shape[3], _stream()), name)
+    return [v[2] for v in views]
+
+
+def conv3x3_wgrad_views(views, c_in_real=None, want_bias=False):
+    """views: list of (x_framed, dy_framed) of one layer shape -> [(dw (Cout, c_in_real, 3, 3) f32, db (Cout) f32 | None), ...]:
+    one weight-gradient launch + one reduce launch for all of them."""
+    x0, dy0 = views[0]
+    cin, cout, dt = x0.shape[3], dy0.shape[3], x0.dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise TypeError("bfloat16 or float32 maps expected")
+    creal = cin if c_in_real is None else int(c_in_real)
+    if len(views) > 3 or any(x.numel() * x.element_size() > _OFF32 - 256 or dy.numel() * dy.element_size() > _OFF32 - 256 for x, dy in views):
+        return [conv3x3_wgrad_bf16(x, dy, creal, want_bias=True) if want_bias else (conv3x3_wgrad_bf16(x, dy, creal), None) for x, dy in views]
+    dev = x0.device
+    arr = (_lib.WgradView * len(views))()
+    res = []
+    for k, (x, dy) in enumerate(views):
+        if x.dtype != dt or dy.dtype != dt or x.shape[3] != cin or dy.shape[3] != cout:
+            raise TypeError("views of one layer shape and type expected")
+        B, Hp, Wp, _ = x.shape
+        dw = torch.empty((cout, creal, 3, 3), dtype=torch.float32, device=dev)
+        db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
+        arr[k] = _lib.WgradView(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Hp - 2, Wp - 2, 0)
+        res.append((dw, db))
+    f32 = dt == torch.float32
+    need = lib().mv3d_conv3x3_wgrad_views_workspace_bytes(len(views), arr, cin, cout, int(f32))
+    if need == 0:
+        raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, "mv3d_conv3x3_wgrad_views_workspace_bytes")
+    ws = _workspace(need, dev, "wgrad")
+    fn, name = (lib().mv3d_conv3x3_wgrad_views_f32, "mv3d_conv3x3_wgrad_views_f32") if f32 else \
+        (lib().mv3d_conv3x3_wgrad_views_bf16, "mv3d_conv3x3_wgrad_views_bf16")
+    check(fn(len(views), arr, cin, creal, cout, _ptr(ws), ws.numel(), _stream()), name)
+    return res
+
+
+def pack_conv3x3_train_many_bf16(items):
+    """items: list of (w_oihw f32 (O, I, 3, 3), c_in_pad | None, want_dgrad) -> [(fwd (O, 9 I') bf16, dgrad (I, 9 O) bf16 | None)]:
+    every filter of a training step packed by ONE launch."""
+    arr = (_lib.PackItem * len(items))()
+    res, keep = [], []
+    for k, (w_oihw, c_in_pad, want_dgrad) in enumerate(items):
+        O, I = w_oihw.shape[:2]
+        Ip = c_in_pad or I
+        w = w_oihw.detach().contiguous()
+        fwd = (torch.zeros if Ip > I else torch.empty)((O, 9 * Ip), dtype=torch.bfloat16, device=w.device)
+        dg = torch.empty((I, 9 * O), dtype=torch.bfloat16, device=w.device) if want_dgrad else None
+        arr[k] = _lib.PackItem(w.data_ptr(), fwd.data_ptr(), dg.data_ptr() if dg is not None else None, O, I, Ip, 0)
+        keep.append(w)
+        res.append((fwd, dg))
+    check(lib().mv3d_conv3x3_pack_many_bf16(len(items), arr, _stream()), "mv3d_conv3x3_pack_many_bf16")
+    return res
+
+
 # type-neutral names (the `_f16` / `_bf16` suffixes above are historical: each function picks the C entry by its tensors' dtype)
 frame_nhwc = frame_nhwc_f16
 conv3x3 = conv3x3_f16

@@ -88,7 +88,7 @@ class _Slot:
 
 
 class TrainPathStream:
-    def __init__(self, B, H, W, device, num_classes=2, depth=2, max_gt=64, want_fv=True, stream=None):
+    def __init__(self, B, H, W, device, num_classes=2, depth=2, max_gt=64, want_fv=True, stream=None, async_draws=True):
         self.B, self.H, self.W, self.dev, self.nc = int(B), int(H), int(W), torch.device(device), int(num_classes)
         self.N = self.H * self.W * 4
         self.want_fv = bool(want_fv)
@@ -107,6 +107,11 @@ class TrainPathStream:
         self.slots = [self._make_slot() for _ in range(int(depth))]
         self._next = 0
         self.t_wait = self.t_draw = 0.0                  # host seconds spent waiting for stage 1 / drawing (diagnostics)
+        # The host stage of a batch (wait for its reports, draw) runs on ONE helper thread, in submission order: the event wait and
+        # the C draws release the GIL, so the submitting thread keeps enqueueing launches meanwhile.  Between submit() and finish()
+        # of a slot the numpy global RNG belongs to the path (any other draw in that window would interleave with the batch's).
+        self._helper = None
+        self.async_draws = bool(async_draws)
 
     # ------------------------------------------------------------------ buffers of one batch in flight
     def _make_slot(self):
@@ -204,7 +209,26 @@ class TrainPathStream:
             s.h_report.copy_(s.report[:, :s.h_report.shape[1]], non_blocking=True)
             s.h_small.copy_(s.d_small, non_blocking=True)
             s.event.record()
+        s.future = None
+        if self.async_draws:
+            if self._helper is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mv3d-draws")
+            s.future = self._helper.submit(self._host_stage, s)
         return s
+
+    def _host_stage(self, s):
+        """wait for the batch's reports, then draw (helper thread, or finish() itself with async_draws = False)"""
+        t0 = time.perf_counter()
+        s.event.synchronize()                                          # the batch's reports are on the host
+        t1 = time.perf_counter()
+        small = s.h_small.numpy()
+        if int(small[:, 5].max()) & 1:
+            raise ZeroDivisionError("float division")
+        res = self._draw(s, small)
+        self.t_wait += t1 - t0
+        self.t_draw += time.perf_counter() - t1
+        return res
 
     # ------------------------------------------------------------------ the host's draws
     def _draw(self, s, small):
@@ -247,16 +271,12 @@ class TrainPathStream:
         rois {bev, rgb, fv} (S,5) with the frame index in column 0, rois_3d (S,7), labels (S,1) i32, bbox_targets (S,24 nc),
         S (list of the frames' row counts), num_proposals (list)."""
         B, H, W, N, L = self.B, self.H, self.W, self.N, lib()
-        t0 = time.perf_counter()
-        s.event.synchronize()                                          # the batch's reports are on the host
-        t1 = time.perf_counter()
-        self.t_wait += t1 - t0
-        small = s.h_small.numpy()
-        if int(small[:, 5].max()) & 1:
+        try:
+            sizes, offs, total = s.future.result() if s.future is not None else self._host_stage(s)
+        except Exception:
             s.busy = False
-            raise ZeroDivisionError("float division")
-        sizes, offs, total = self._draw(s, small)
-        self.t_draw += time.perf_counter() - t1
+            raise
+        small = s.h_small.numpy()
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
         with ctx:
             if total:

@@ -72,6 +72,50 @@ class MfmaTrunks:
             x = y
         return x
 
+    def trunks(self, xs_nhwc, suffixes, last_framed):
+        """Several trunks walked together: every depth is ONE launch for all views (mv3d_conv3x3_views_*, mv3d_maxpool2x2_views_*:
+        the views' tiles share the grid, so a view's partly filled last round of workgroups is filled by the others' -- what the
+        side stream of round 3 did, from one stream, graph-capturable).  xs_nhwc[v] (B, H, W, 9 | 3) f32; last_framed[v]: conv5_3 of
+        view v as a framed map of the trunk's type (rpn_conv/3x3 reads it) instead of the bare f32 NHWC map.  Returns the list."""
+        nv, n = len(xs_nhwc), len(self.vgg)
+        dev = xs_nhwc[0].device
+        L = self.net.layers
+        cpad = 32 if self.dtype == torch.float32 else 16
+        cur, hw = [], []
+        for x, sfx in zip(xs_nhwc, suffixes):
+            B, H, W, _ = x.shape
+            cur.append(ops.frame_nhwc_f16(x.contiguous(), self._framed("in" + sfx, B, H, W, cpad, dev)))
+            hw.append((H, W))
+        outs = [None] * nv
+        for i, (stem, cout, pool) in enumerate(self.vgg):
+            wb = [self._packed(stem + sfx, input_layer=(i == 0)) for sfx in suffixes]
+            if i == n - 1:
+                for framed in (True, False):                      # (the two output forms are two launches)
+                    vs = [v for v in range(nv) if bool(last_framed[v]) == framed]
+                    if not vs:
+                        continue
+                    if framed:
+                        ys = [self._framed(stem + suffixes[v], cur[v].shape[0], hw[v][0], hw[v][1], cout, dev) for v in vs]
+                    else:
+                        ys = [torch.empty((cur[v].shape[0], hw[v][0], hw[v][1], cout), dtype=torch.float32, device=dev) for v in vs]
+                    ops.conv3x3_views([(cur[v], wb[v][0], wb[v][1], None, y) for v, y in zip(vs, ys)], out_framed=framed, out_f32=not framed)
+                    for v, y in zip(vs, ys):
+                        outs[v] = y
+                        L[stem + suffixes[v]] = y[:, 1:-1, 1:-1] if framed else y
+                return outs
+            ys = [self._framed(stem + suffixes[v], cur[v].shape[0], hw[v][0], hw[v][1], cout, dev) for v in range(nv)]
+            ops.conv3x3_views([(cur[v], wb[v][0], wb[v][1], None, ys[v]) for v in range(nv)])
+            for v in range(nv):
+                L[stem + suffixes[v]] = ys[v][:, 1:-1, 1:-1]
+            if pool:
+                hw = [(h // 2, w // 2) for h, w in hw]
+                ps = [self._framed(stem + suffixes[v] + "/pool", ys[v].shape[0], hw[v][0], hw[v][1], cout, dev) for v in range(nv)]
+                ops.maxpool2x2_views([(ys[v], ps[v]) for v in range(nv)])
+                cur = ps
+            else:
+                cur = ys
+        return outs
+
     def rpn_conv(self, conv5_3_framed):
         """rpn_conv/3x3 (MV3D_test.py:82-84) on the framed BEV conv5_3 -> (B, H, W, 512) NHWC of the trunk's type"""
         wp, bias = self._packed("rpn_conv/3x3")

@@ -97,76 +97,108 @@ def _pack_pair(w, c_in_pad, want_dgrad, dtype):
     return fwd, (ops.pack_conv3x3_weights(w.detach().flip(2, 3).transpose(0, 1), dtype=dtype) if want_dgrad else None)
 
 
-class TrunkFunction(torch.autograd.Function):
-    """apply(layers, wgrad, pool, x_nhwc_f32, w_0, b_0, ..., w_12, b_12) -> conv5_3 (B, H', W', 512) f32;
-    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> ((O, c_in, 3, 3) f32, (O,) f32),
-    pool = (BufferPool | None, tag, dtype)"""
+class TrunksFunction(torch.autograd.Function):
+    """apply(layers, wgrad, pool, nv, x_0 .. x_{nv-1}, (w, b) x 13 of view 0, ... of view nv - 1) -> nv x conv5_3 (B, H', W', 512) f32;
+    layers = [(name, c_out, pool_after)], wgrad = callable(x_framed, dy_framed, c_in) -> ((O, c_in, 3, 3) f32, (O,) f32) or None = the
+    library's grouped kernel, pool = (BufferPool | None, [tag per view], dtype).
+
+    The nv trunks (BEV / image / front view of lib/networks/MV3D_train.py:44-81) walk the SAME layer list, so every depth is ONE
+    launch for all of them -- forward convolution, pool, data gradient (+ ReLU gate), pool gradient, weight gradient + reduce -- and
+    all filters of the step are packed by one launch.  At a training batch of 2 a single trunk's launches leave the chip partly idle
+    (364 tiles of conv4_x on 512 workgroup slots); the grouped launches fill it from ONE stream, which is also what data parallelism
+    and graph capture want (the side streams of round 3 are gone)."""
 
     @staticmethod
-    def forward(ctx, layers, wgrad, pool_tag, x_nhwc, *wb):
-        B, H, W, c0 = x_nhwc.shape
-        dev = x_nhwc.device
-        bufs, tag, dt = (pool_tag[0] or _NoPool), pool_tag[1], pool_tag[2]
+    def forward(ctx, layers, wgrad, pool_tag, nv, *args):
+        xs, wb = args[:nv], args[nv:]
+        n = len(layers)
+        dev = xs[0].device
+        bufs, tags, dt = (pool_tag[0] or _NoPool), pool_tag[1], pool_tag[2]
         # (the input layer's channels zero-padded to 64: the same kernels as every other layer, forward and both gradients)
         cpad0 = 64
-        ctx.gen = bufs.begin(tag)
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), bufs.get(tag + "/in", B, H, W, cpad0, dev, dt))
-        saved = []                                     # per layer: (framed input, framed output | None for the last, H, W)
-        packed_dgrad = []
-        n = len(layers)
-        out = None
+        ctx.gens = [bufs.begin(t) for t in tags]
+        W = lambda v, i: wb[(v * n + i) * 2]
+        Bs = lambda v, i: wb[(v * n + i) * 2 + 1]
+        if dt == BF:                                   # every filter of the step, both packings, in one launch
+            packed = ops.pack_conv3x3_train_many_bf16([(W(v, i), cpad0 if i == 0 else None, i > 0) for v in range(nv) for i in range(n)])
+        else:
+            packed = [_pack_pair(W(v, i), cpad0 if i == 0 else None, i > 0, dt) for v in range(nv) for i in range(n)]
+        wp = lambda v, i: packed[v * n + i][0]
+        shapes = [tuple(x.shape) for x in xs]
+        cur = [ops.frame_nhwc_f16(x.contiguous(), bufs.get(tags[v] + "/in", x.shape[0], x.shape[1], x.shape[2], cpad0, dev, dt))
+               for v, x in enumerate(xs)]
+        hw = [(s[1], s[2]) for s in shapes]
+        saved = [[] for _ in range(nv)]                # per view and layer: (framed input, framed output | None for the last, H, W)
+        outs = None
         for i, (_, cout, pool) in enumerate(layers):
-            w, b = wb[2 * i], wb[2 * i + 1]
-            wp, wd = _pack_pair(w, cpad0 if i == 0 else None, i > 0, dt)              # (bf16: both packings in one launch)
-            packed_dgrad.append(wd)
-            bias = b.detach().float().contiguous()
+            biases = [Bs(v, i).detach().float().contiguous() for v in range(nv)]
             if i == n - 1:
-                out = ops.conv3x3_f16(x, wp, bias, out_framed=False, out_f32=True)
-                saved.append((x, None, H, W))
+                outs = [torch.empty((shapes[v][0], hw[v][0], hw[v][1], cout), dtype=torch.float32, device=dev) for v in range(nv)]
+                ops.conv3x3_views([(cur[v], wp(v, i), biases[v], None, outs[v]) for v in range(nv)], out_framed=False, out_f32=True)
+                for v in range(nv):
+                    saved[v].append((cur[v], None, hw[v][0], hw[v][1]))
                 break
-            y = ops.conv3x3_f16(x, wp, bias, out=bufs.get("%s/y%d" % (tag, i), B, H, W, cout, dev, dt))
-            saved.append((x, y, H, W))
+            ys = [bufs.get("%s/y%d" % (tags[v], i), shapes[v][0], hw[v][0], hw[v][1], cout, dev, dt) for v in range(nv)]
+            ops.conv3x3_views([(cur[v], wp(v, i), biases[v], None, ys[v]) for v in range(nv)])
+            for v in range(nv):
+                saved[v].append((cur[v], ys[v], hw[v][0], hw[v][1]))
             if pool:
-                H, W = H // 2, W // 2
-                x = ops.maxpool2x2_f16(y, out=bufs.get("%s/p%d" % (tag, i), B, H, W, cout, dev, dt))
+                hw = [(h // 2, w // 2) for h, w in hw]
+                ps = [bufs.get("%s/p%d" % (tags[v], i), shapes[v][0], hw[v][0], hw[v][1], cout, dev, dt) for v in range(nv)]
+                ops.maxpool2x2_views([(ys[v], ps[v]) for v in range(nv)])
+                cur = ps
             else:
-                x = y
-        ctx.layers, ctx.wgrad, ctx.saved, ctx.c0, ctx.bufs, ctx.tag, ctx.dt = layers, wgrad, saved, c0, bufs, tag, dt
-        ctx.packed_dgrad = packed_dgrad
-        ctx.save_for_backward(out)
-        return out
+                cur = ys
+        ctx.layers, ctx.wgrad, ctx.saved, ctx.bufs, ctx.tags, ctx.dt, ctx.nv = layers, wgrad, saved, bufs, tags, dt, nv
+        ctx.c0 = [s[3] for s in shapes]
+        ctx.packed_dgrad = [[packed[v * n + i][1] for i in range(n)] for v in range(nv)]
+        ctx.save_for_backward(*outs)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g):
-        (out,) = ctx.saved_tensors
-        layers, saved = ctx.layers, ctx.saved
+    def backward(ctx, *gs):
+        outs = ctx.saved_tensors
+        layers, saved, nv, bufs, tags, dt = ctx.layers, ctx.saved, ctx.nv, ctx.bufs, ctx.tags, ctx.dt
         n = len(layers)
-        B = g.shape[0]
-        dev = g.device
-        grads = [None] * (2 * n)
-        # gradient w.r.t. conv5_3's pre-activation, framed
-        bufs, tag, dt = ctx.bufs, ctx.tag, ctx.dt
-        bufs.check(tag, ctx.gen)
-        x_last, _, H, W = saved[n - 1]
-        dy = ops.frame_nhwc_f16((g * (out > 0)).contiguous(), bufs.get(tag + "/g%d" % (n - 1), B, H, W, layers[n - 1][1], dev, dt))
+        dev = outs[0].device
+        for t, gen in zip(tags, ctx.gens):
+            bufs.check(t, gen)
+        grads = [None] * (2 * n * nv)
+        # gradient w.r.t. conv5_3's pre-activation, framed (a view nobody used downstream has a zero gradient)
+        dys = []
+        for v in range(nv):
+            _, _, H, W = saved[v][n - 1]
+            g = gs[v] if gs[v] is not None else torch.zeros_like(outs[v])
+            dys.append(ops.frame_nhwc_f16((g * (outs[v] > 0)).contiguous(),
+                                          bufs.get(tags[v] + "/g%d" % (n - 1), g.shape[0], H, W, layers[n - 1][1], dev, dt)))
         zero_bias = torch.zeros(max(c for _, c, _ in layers), dtype=torch.float32, device=dev)      # (the data-gradient convolutions add no bias)
         for i in range(n - 1, -1, -1):
-            x_in, _, H, W = saved[i]
-            c_in = ctx.c0 if i == 0 else layers[i - 1][1]
-            grads[2 * i], grads[2 * i + 1] = ctx.wgrad(x_in, dy, c_in)
+            c_ins = [ctx.c0[v] if i == 0 else layers[i - 1][1] for v in range(nv)]
+            if ctx.wgrad is None and len(set(c_ins)) == 1:                                        # one launch + one reduce for the views
+                res = ops.conv3x3_wgrad_views([(saved[v][i][0], dys[v]) for v in range(nv)], c_ins[0], want_bias=True)
+            else:                                      # (the input layers: 9 / 3 real channels -> different gradient shapes; or a yardstick wgrad)
+                fn = ctx.wgrad or wgrad_mfma
+                res = [fn(saved[v][i][0], dys[v], c_ins[v]) for v in range(nv)]
+            for v in range(nv):
+                grads[(v * n + i) * 2], grads[(v * n + i) * 2 + 1] = res[v]
             if i == 0:
                 break
+            c_in = c_ins[0]
             # two gradient buffers per resolution alternate (dy of layer i is read while dx = dy of layer i - 1 is written)
-            _, y_prev, Hp, Wp_ = saved[i - 1]
-            out_buf = bufs.get("%s/dx%d" % (tag, i), B, H, W, c_in, dev, dt)
+            obufs = [bufs.get("%s/dx%d" % (tags[v], i), dys[v].shape[0], saved[v][i][2], saved[v][i][3], c_in, dev, dt) for v in range(nv)]
+            y_prev = [saved[v][i - 1][1] for v in range(nv)]
+            wd = [ctx.packed_dgrad[v][i] for v in range(nv)]
             if layers[i - 1][2]:                       # a pool sits between layer i - 1 and layer i: route through it (mask fused)
-                dx = ops.conv3x3_f16(dy, ctx.packed_dgrad[i], zero_bias, relu=False, out=out_buf)
-                dy = ops.maxpool2x2_bwd_bf16(y_prev, dx, bufs.get("%s/g%d" % (tag, i - 1), B, Hp, Wp_, c_in, dev, dt))
+                ops.conv3x3_views([(dys[v], wd[v], zero_bias, None, obufs[v]) for v in range(nv)], relu=False)
+                gbufs = [bufs.get("%s/g%d" % (tags[v], i - 1), dys[v].shape[0], saved[v][i - 1][2], saved[v][i - 1][3], c_in, dev, dt)
+                         for v in range(nv)]
+                dys = ops.maxpool2x2_bwd_views([(y_prev[v], obufs[v], gbufs[v]) for v in range(nv)])
             elif dt == BF:                             # data gradient and the ReLU mask of layer i - 1's output in one launch
-                dy = ops.conv3x3_gated_bf16(dy, ctx.packed_dgrad[i], zero_bias, y_prev, out_buf)
+                dys = ops.conv3x3_views([(dys[v], wd[v], zero_bias, y_prev[v], obufs[v]) for v in range(nv)], relu=False)
             else:
-                dy = ops.conv3x3_f16(dy, ctx.packed_dgrad[i], zero_bias, relu=False, out=out_buf).mul_(y_prev > 0)
-        return (None, None, None, None) + tuple(grads)
+                ops.conv3x3_views([(dys[v], wd[v], zero_bias, None, obufs[v]) for v in range(nv)], relu=False)
+                dys = [obufs[v].mul_(y_prev[v] > 0) for v in range(nv)]
+        return (None, None, None, None) + (None,) * nv + tuple(grads)
 
 
 class ConvReluFunction(torch.autograd.Function):
@@ -196,23 +228,28 @@ class ConvReluFunction(torch.autograd.Function):
         return None, dx, gw, gb
 
 
-def _default_wgrad(dtype):
-    return wgrad_mfma                         # (bf16: transposing LDS reads; f32: one ds_read_b32 per operand -- csrc/conv3x3_wgrad.hip)
-
-
 def conv_relu(x_nhwc, w, b, wgrad=None, dtype=BF):
-    return ConvReluFunction.apply((wgrad or _default_wgrad(dtype), dtype), x_nhwc, w, b)
+    return ConvReluFunction.apply((wgrad or wgrad_mfma, dtype), x_nhwc, w, b)     # (wgrad_mfma: csrc/conv3x3_wgrad.hip, bf16 or f32 by dtype)
+
+
+def trunks(layers, xs_nhwc, params, suffixes, wgrad=None, pool=None, dtype=BF):
+    """conv1_1<suffix> .. conv5_3<suffix> of the TRAIN graph's trunks, ALL of them walked together (one launch per depth and kind):
+    xs_nhwc = [x (B, H, W, c) f32 per view], suffixes = ["", "_2", "_3"]; params = {name: [w, b]} (fp32, OIHW); pool: a BufferPool
+    that keeps the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call.  dtype =
+    bfloat16: mixed precision; float32: the reference's precision on the exact-f32 MFMA kernels -- forward, data gradient and
+    weight gradient alike.  wgrad: None = the library's kernel (grouped); a callable = per view (tests' yardsticks).
+    Returns the list of conv5_3 maps (B, H', W', 512) f32."""
+    wb = []
+    for suffix in suffixes:
+        for stem, _, _ in layers:
+            wb += list(params[stem + suffix])
+    tags = ["trunk" + sfx for sfx in suffixes]
+    return list(TrunksFunction.apply(layers, wgrad, (pool, tags, dtype), len(xs_nhwc), *xs_nhwc, *wb))
 
 
 def trunk(layers, x_nhwc, params, suffix, wgrad=None, pool=None, dtype=BF):
-    """conv1_1<suffix> .. conv5_3<suffix> of a TRAIN graph: params = {name: [w, b]} (fp32, OIHW); pool: a BufferPool that keeps
-    the framed buffers across steps (one forward / backward pair in flight), None = fresh buffers every call.  dtype = bfloat16:
-    mixed precision; float32: the reference's precision on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32) -- forward, data
-    gradient and weight gradient alike."""
-    wb = []
-    for stem, _, _ in layers:
-        wb += list(params[stem + suffix])
-    return TrunkFunction.apply(layers, wgrad or _default_wgrad(dtype), (pool, "trunk" + suffix, dtype), x_nhwc, *wb)
+    """one trunk (see trunks())"""
+    return trunks(layers, [x_nhwc], params, [suffix], wgrad=wgrad, pool=pool, dtype=dtype)[0]
 
 
 def bench_wgrad_layers(vgg, batch=2, reps=3, dtype=BF):

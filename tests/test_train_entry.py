@@ -305,14 +305,14 @@ def test_stack_blobs_batches_frames():
 
 
 @pytest.mark.gpu
-def test_side_streams_under_data_parallelism_give_the_same_gradients():
-    """two gloo ranks sharing the GPU: the mixed-precision training graph with its trunks on side streams (`trunk_streams_dp`, the
-    GradBucketer fencing every bucket by its gradients' stream events) all-reduces the same bits as with the trunks on one stream"""
+def test_data_parallel_mixed_precision_step_is_deterministic_and_agrees_across_ranks():
+    """two gloo ranks sharing the GPU: the mixed-precision training graph (grouped trunk launches on one stream, the GradBucketer's
+    all-reduce overlapping backward) ends with the same averaged gradient bits on both ranks, and the same bits when run again"""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29633", os.path.join(ROOT, "tools", "dp_streams_probe.py"), "--no-timing"],
+                          "--master-port", "29633", os.path.join(ROOT, "tools", "dp_grad_probe.py"), "--no-timing"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "averaged gradients bit-identical: True" in out.stdout, out.stdout[-1000:]

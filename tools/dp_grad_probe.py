@@ -1,6 +1,6 @@
-"""Two gloo ranks sharing ONE GPU: the mixed-precision training step with the trunks on one stream vs on side streams (GradBucketer
-fencing each bucket by its gradients' stream events): step time, and are the averaged gradients the same bits?
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 tools/dp_streams_probe.py"""
+"""Two gloo ranks sharing ONE GPU run the mixed-precision training step (grouped trunk launches on one stream, bucketed gradient
+all-reduce overlapping backward): are the averaged gradients the same bits on both ranks, and the same bits when the step is run again?
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 tools/dp_grad_probe.py"""
 import os
 import sys
 
@@ -18,10 +18,10 @@ rank, world = dist.get_rank(), dist.get_world_size()
 torch.cuda.set_device(0)
 
 
-def grads(streams_dp):
+def grads():
     torch.manual_seed(0)
     net = get_network("MV3D_train")
-    net.mfma_trunk, net.amp_dtype, net.trunk_streams_dp = True, torch.bfloat16, streams_dp
+    net.mfma_trunk, net.amp_dtype = True, torch.bfloat16
     params = net.parameters()
     b = sharding.GradBucketer(params, dist)
     rng = np.random.RandomState(10 + rank)
@@ -43,15 +43,19 @@ def grads(streams_dp):
     return out
 
 
-a = grads(False)
-c = grads(True)
+a = grads()
+c = grads()
 same = all(torch.equal(x, y) for x, y in zip(a, c))
 worst = max(float((x - y).abs().max()) for x, y in zip(a, c))
-for mode in (() if "--no-timing" in sys.argv else (True, "dp", True, "dp")):
-    r = bench_train_step(rank, world, dist, steps=4, warmup=2, amp=torch.bfloat16, mfma=True, trunk_streams=mode)
+flat = torch.cat([x.reshape(-1).double().cpu() for x in a])
+both = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+across = all(torch.equal(both[0], t) for t in both[1:])
+if "--no-timing" not in sys.argv:
+    r = bench_train_step(rank, world, dist, steps=4, warmup=2, amp=torch.bfloat16, mfma=True)
     if rank == 0:
-        print("streams under DP" if mode == "dp" else "one stream      ", r["ms_per_step"], flush=True)
+        print("ms per step (2 gloo ranks on one GPU):", r["ms_per_step"], flush=True)
 if rank == 0:
-    print("averaged gradients bit-identical:", same, "max abs diff", worst, flush=True)
+    print("averaged gradients bit-identical:", same and across, "(run to run:", same, "max abs diff", worst, "; across ranks:", across, ")", flush=True)
 dist.barrier()
 dist.destroy_process_group()
