@@ -435,7 +435,7 @@ int mv3d_maxpool2x2_bwd_f32(const void *y_framed, const void *g_pooled_framed, v
  * VGG depth have the same channel counts and different map sizes): the grid is the concatenation of the views' tiles, so that
  * the small maps of a training batch fill the chip together, on ONE stream.  Same arithmetic per view as the single-view
  * entries above (which are these with num_views = 1).  gate_framed: optional (bf16 / f16, framed 16-bit output only; all views
- * or none) = the ReLU gate of mv3d_conv3x3_gated_bf16. */
+ * or none) = the ReLU gate of mv3d_conv3x3_gated_bf16; the f32 entry takes an f32 gate (framed f32 output). */
 #define MV3D_MAX_CONV_VIEWS 3
 typedef struct {
     const void *x_framed;        /* (batch, height + 2, width + 2, c_in) */
@@ -504,6 +504,7 @@ typedef struct {
     int32_t c_out, c_in, c_in_pad, reserved0;
 } mv3d_pack_item;
 int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *items, void *stream);
+int mv3d_conv3x3_pack_many_f32(int num_items, const mv3d_pack_item *items, void *stream);    /* f32 packings (c_out % 64 == 0 in both) */
 /* framed f16 (batch, height + 2, width + 2, channels) -> framed (batch, height / 2 + 2, width / 2 + 2, channels); channels % 8 == 0 */
 int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int height, int width, int channels, void *stream);
 /* NHWC f32 (batch, height, width, channels) -> interior pixels, first `channels` channels of a framed f16 buffer

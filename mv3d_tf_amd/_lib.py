@@ -163,6 +163,7 @@ _SIGS = {
     "mv3d_conv3x3_wgrad_views_bf16": (C.c_int, [C.c_int, C.POINTER(WgradView), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_conv3x3_wgrad_views_f32": (C.c_int, [C.c_int, C.POINTER(WgradView), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_conv3x3_pack_many_bf16": (C.c_int, [C.c_int, C.POINTER(PackItem), _P]),
+    "mv3d_conv3x3_pack_many_f32": (C.c_int, [C.c_int, C.POINTER(PackItem), _P]),
     "mv3d_maxpool2x2_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }

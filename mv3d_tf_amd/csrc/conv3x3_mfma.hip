@@ -248,6 +248,13 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
             for (int e = 0; e < 8; ++e) o[e] = (float)m[e] > 0.f ? o[e] : (T)0.f;
             v = __builtin_bit_cast(u32x4, o);
         }
+        if constexpr (OUT_F32 && ES == 4) if (a.mask) {           // f32 maps: the same gate on the piece's 4 values
+            const f32x4 m = *(const f32x4 *)((const char *)a.mask + (size_t)n0 * ESZ + off + s * 16);
+            f32x4 o = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+            v = __builtin_bit_cast(u32x4, o);
+        }
         *(u32x4 *)(yb + off + s * 16) = v;
     }
 #endif
@@ -424,11 +431,13 @@ static int conv3x3_f32_views_entry(int num_views, const mv3d_conv_view *views, i
 {
     if (num_views <= 0 || num_views > CONV_MAX_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
     if (c_in <= 0 || c_in % 32 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    const bool gated = views[0].gate_framed != nullptr;          // (an f32 gate map, framed like the output)
+    if (gated && !out_framed) return MV3D_ERR_INVALID_ARG;
     ConvGroup g;
     g.n = num_views;
     long tiles128 = 0;
     for (int k = 0; k < num_views; ++k) {
-        if (!conv_view_args(g.v[k], views[k], c_in, c_out, out_framed, 1, relu, 4, false, false)) return MV3D_ERR_INVALID_ARG;
+        if (!conv_view_args(g.v[k], views[k], c_in, c_out, out_framed, 1, relu, 4, false, gated)) return MV3D_ERR_INVALID_ARG;
         tiles128 += (long)((g.v[k].M + 127) / 128) * (c_out / 128);
     }
     hipStream_t s = (hipStream_t)stream;

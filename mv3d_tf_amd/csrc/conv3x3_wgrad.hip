@@ -398,42 +398,57 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const float *__restri
 }
 
 // the same for MANY filters in one launch (every 3x3 layer of the training graph at the top of a step: the packed copies only
-// change when the optimiser has stepped): item k owns the workgroups [first[k], first[k + 1])
+// change when the optimiser has stepped), in the trunk's type T (bf16, or f32 for the reference-precision trunk).  A workgroup
+// owns a tile of 64 output x 32 input channels x 9 taps: read as it lies in the OIHW filter (runs of 32 x 9 contiguous floats),
+// turned in LDS, written as 32-channel runs of the forward packing and 64-filter runs of the data-gradient packing -- the first
+// version stored both packings element by element at the strides of the OTHER layout (0.53 ms per step for 44 M weights).
 #define PACK_MAX 48
-struct PackItem { const float *w; __bf16 *fwd, *dgrad; int O, I, Ipad, first; };
+struct PackItem { const float *w; void *fwd, *dgrad; int O, I, Ipad, first; };
 struct PackMany { PackItem it[PACK_MAX]; int n, blocks; };
+template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_pack_many_kernel(const PackMany p)
 {
+    __shared__ T tile[64][32 * 9 + 2];
     int k = 0;
     for (int j = 1; j < p.n; ++j)
         if ((int)blockIdx.x >= p.it[j].first) k = j;
     const PackItem &t = p.it[k];
-    const int nblk = (k + 1 < p.n ? p.it[k + 1].first : p.blocks) - t.first;
-    const long n = (long)t.O * t.I * 9;
-    for (long i = (long)(blockIdx.x - t.first) * blockDim.x + threadIdx.x; i < n; i += (long)nblk * blockDim.x) {
-        const int tap = (int)(i % 9);
-        const long r = i / 9;
-        const int ci = (int)(r % t.I), o = (int)(r / t.I);
-        const __bf16 v = (__bf16)t.w[i];
-        t.fwd[((long)o * 9 + tap) * t.Ipad + ci] = v;
-        if (t.dgrad) t.dgrad[((long)ci * 9 + (8 - tap)) * t.O + o] = v;
+    const int O = t.O, I = t.I, Ipad = t.Ipad;
+    const int ci_tiles = (I + 31) / 32, b = (int)blockIdx.x - t.first;
+    const int o0 = (b / ci_tiles) * 64, c0 = (b % ci_tiles) * 32, nc = min(32, I - c0), run = nc * 9;
+    const float *__restrict__ w = t.w;
+    for (int idx = threadIdx.x; idx < 64 * run; idx += 256) {
+        const int o = idx / run, r = idx - o * run;
+        tile[o][r] = (T)w[((long)(o0 + o) * I + c0) * 9 + r];
+    }
+    __syncthreads();
+    T *__restrict__ fwd = (T *)t.fwd;
+    for (int idx = threadIdx.x; idx < 64 * run; idx += 256) {                  // (o, tap, ci): ci fastest
+        const int ci = idx % nc, t2 = idx / nc, tap = t2 % 9, o = t2 / 9;
+        fwd[((long)(o0 + o) * 9 + tap) * Ipad + c0 + ci] = tile[o][ci * 9 + tap];
+    }
+    T *__restrict__ dgrad = (T *)t.dgrad;
+    if (dgrad) {
+        for (int idx = threadIdx.x; idx < 64 * run; idx += 256) {              // (ci, tap, o): o fastest
+            const int o = idx & 63, t2 = idx >> 6, tap = t2 % 9, ci = t2 / 9;
+            dgrad[((long)(c0 + ci) * 9 + (8 - tap)) * O + o0 + o] = tile[o][ci * 9 + tap];
+        }
     }
 }
 
 }  // namespace mv3d_wgrad
 using namespace mv3d_wgrad;
 
-// K steps per workgroup: the three workgroups per CU the LDS allows (~768 in all; 1024: 5-10 % slower and more partials), at
-// least 4 steps each
-static int wgrad_steps_per_split(int tiles, long total_steps)
+// the workgroups the chip holds at once: three per CU (LDS).  More than that is a second, mostly empty round of an MFMA-bound
+// kernel (1024 measured 5-10 % slower, and more partial sums to fold)
+static int wgrad_target()
 {
 #ifdef MV3D_TUNING
     static const int target = getenv("MV3D_WGRAD_TARGET") ? atoi(getenv("MV3D_WGRAD_TARGET")) : 768;
+    return target;
 #else
-    const int target = 768;
+    return 768;
 #endif
-    long s = (total_steps * tiles + target - 1) / target;
-    return (int)(s < 4 ? 4 : s);
 }
 
 struct WgradPlan { int steps[WG_MAX_VIEWS], splits[WG_MAX_VIEWS], steps_per_split, tiles, bmc; size_t q[WG_MAX_VIEWS], part_off[WG_MAX_VIEWS], bpart_off[WG_MAX_VIEWS], bytes; };
@@ -450,7 +465,17 @@ static bool wgrad_plan(int n, const mv3d_wgrad_view *views, int c_in, int c_out,
         P.steps[k] = (int)((P.q[k] + pix - 1) / pix);
         total += P.steps[k];
     }
-    P.steps_per_split = wgrad_steps_per_split(P.tiles, total);
+    // K steps per workgroup: the smallest number (>= 4) with which ALL views' workgroups fit the chip at once -- every view rounds
+    // its last split up, so the sum is checked, not estimated: 10 x 96 workgroups instead of 8 x 96 would be a second round
+    const int target = wgrad_target();
+    long sps = (total * P.tiles + target - 1) / target;
+    if (sps < 4) sps = 4;
+    for (;; ++sps) {
+        long wgs = 0;
+        for (int k = 0; k < n; ++k) wgs += (P.steps[k] + sps - 1) / sps;
+        if (wgs * P.tiles <= target || wgs <= n) break;
+    }
+    P.steps_per_split = (int)sps;
     size_t o = 0;
     for (int k = 0; k < n; ++k) {
         P.splits[k] = (P.steps[k] + P.steps_per_split - 1) / P.steps_per_split;
@@ -561,7 +586,8 @@ extern "C" int mv3d_conv3x3_pack_bf16(const float *w_oihw, void *fwd_packed, voi
     return mv3d_launch_status();
 }
 
-extern "C" int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *items, void *stream)
+template <typename T>
+static int pack_many_entry(int num_items, const mv3d_pack_item *items, void *stream)
 {
     if (num_items <= 0 || !items) return MV3D_ERR_INVALID_ARG;
     for (int i0 = 0; i0 < num_items; i0 += PACK_MAX) {
@@ -570,16 +596,23 @@ extern "C" int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *
         int blocks = 0;
         for (int k = 0; k < p.n; ++k) {
             const mv3d_pack_item &w = items[i0 + k];
-            if (!w.w_oihw || !w.fwd_packed || w.c_out <= 0 || w.c_in <= 0 || w.c_in_pad < w.c_in) return MV3D_ERR_INVALID_ARG;
+            if (!w.w_oihw || !w.fwd_packed || w.c_out <= 0 || w.c_out % 64 || w.c_in <= 0 || w.c_in_pad < w.c_in) return MV3D_ERR_INVALID_ARG;
             PackItem &t = p.it[k];
-            t.w = w.w_oihw; t.fwd = (__bf16 *)w.fwd_packed; t.dgrad = (__bf16 *)w.dgrad_packed; t.O = w.c_out; t.I = w.c_in; t.Ipad = w.c_in_pad;
+            t.w = w.w_oihw; t.fwd = w.fwd_packed; t.dgrad = w.dgrad_packed; t.O = w.c_out; t.I = w.c_in; t.Ipad = w.c_in_pad;
             t.first = blocks;
-            const long n = (long)w.c_out * w.c_in * 9;
-            blocks += (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+            blocks += (w.c_out / 64) * ((w.c_in + 31) / 32);
         }
         for (int k = p.n; k < PACK_MAX; ++k) p.it[k] = p.it[0];
         p.blocks = blocks;
-        hipLaunchKernelGGL(conv3x3_pack_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(conv3x3_pack_many_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     }
     return mv3d_launch_status();
+}
+extern "C" int mv3d_conv3x3_pack_many_bf16(int num_items, const mv3d_pack_item *items, void *stream)
+{
+    return pack_many_entry<__bf16>(num_items, items, stream);
+}
+extern "C" int mv3d_conv3x3_pack_many_f32(int num_items, const mv3d_pack_item *items, void *stream)
+{
+    return pack_many_entry<float>(num_items, items, stream);
 }

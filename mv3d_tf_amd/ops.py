@@ -613,22 +613,26 @@ def conv3x3_wgrad_views(views, c_in_real=None, want_bias=False):
     return res
 
 
-def pack_conv3x3_train_many_bf16(items):
-    """items: list of (w_oihw f32 (O, I, 3, 3), c_in_pad | None, want_dgrad) -> [(fwd (O, 9 I') bf16, dgrad (I, 9 O) bf16 | None)]:
-    every filter of a training step packed by ONE launch."""
+def pack_conv3x3_train_many(items, dtype=torch.bfloat16):
+    """items: list of (w_oihw f32 (O, I, 3, 3), c_in_pad | None, want_dgrad) -> [(fwd (O, 9 I') of `dtype` (bf16 | f32), dgrad (I, 9 O)
+    | None)]: every filter of a training step packed by ONE launch."""
     arr = (_lib.PackItem * len(items))()
     res, keep = [], []
     for k, (w_oihw, c_in_pad, want_dgrad) in enumerate(items):
         O, I = w_oihw.shape[:2]
         Ip = c_in_pad or I
         w = w_oihw.detach().contiguous()
-        fwd = (torch.zeros if Ip > I else torch.empty)((O, 9 * Ip), dtype=torch.bfloat16, device=w.device)
-        dg = torch.empty((I, 9 * O), dtype=torch.bfloat16, device=w.device) if want_dgrad else None
+        fwd = (torch.zeros if Ip > I else torch.empty)((O, 9 * Ip), dtype=dtype, device=w.device)
+        dg = torch.empty((I, 9 * O), dtype=dtype, device=w.device) if want_dgrad else None
         arr[k] = _lib.PackItem(w.data_ptr(), fwd.data_ptr(), dg.data_ptr() if dg is not None else None, O, I, Ip, 0)
         keep.append(w)
         res.append((fwd, dg))
-    check(lib().mv3d_conv3x3_pack_many_bf16(len(items), arr, _stream()), "mv3d_conv3x3_pack_many_bf16")
+    fn, name = _half_entry("mv3d_conv3x3_pack_many", dtype)
+    check(fn(len(items), arr, _stream()), name)
     return res
+
+
+pack_conv3x3_train_many_bf16 = pack_conv3x3_train_many
 
 
 # type-neutral names (the `_f16` / `_bf16` suffixes above are historical: each function picks the C entry by its tensors' dtype)

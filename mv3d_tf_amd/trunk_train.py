@@ -90,11 +90,8 @@ class _NoPool:
 
 
 def _pack_pair(w, c_in_pad, want_dgrad, dtype):
-    """(forward packing, data-gradient packing | None) of an fp32 OIHW filter in the trunk's type"""
-    if dtype == BF:
-        return ops.pack_conv3x3_train_bf16(w, c_in_pad, want_dgrad=want_dgrad)
-    fwd = ops.pack_conv3x3_weights(w, c_in_pad, dtype=dtype)
-    return fwd, (ops.pack_conv3x3_weights(w.detach().flip(2, 3).transpose(0, 1), dtype=dtype) if want_dgrad else None)
+    """(forward packing, data-gradient packing | None) of an fp32 OIHW filter in the trunk's type (one launch)"""
+    return ops.pack_conv3x3_train_many([(w, c_in_pad, want_dgrad)], dtype=dtype)[0]
 
 
 class TrunksFunction(torch.autograd.Function):
@@ -119,10 +116,8 @@ class TrunksFunction(torch.autograd.Function):
         ctx.gens = [bufs.begin(t) for t in tags]
         W = lambda v, i: wb[(v * n + i) * 2]
         Bs = lambda v, i: wb[(v * n + i) * 2 + 1]
-        if dt == BF:                                   # every filter of the step, both packings, in one launch
-            packed = ops.pack_conv3x3_train_many_bf16([(W(v, i), cpad0 if i == 0 else None, i > 0) for v in range(nv) for i in range(n)])
-        else:
-            packed = [_pack_pair(W(v, i), cpad0 if i == 0 else None, i > 0, dt) for v in range(nv) for i in range(n)]
+        # every filter of the step, both packings, in one launch
+        packed = ops.pack_conv3x3_train_many([(W(v, i), cpad0 if i == 0 else None, i > 0) for v in range(nv) for i in range(n)], dtype=dt)
         wp = lambda v, i: packed[v * n + i][0]
         shapes = [tuple(x.shape) for x in xs]
         cur = [ops.frame_nhwc_f16(x.contiguous(), bufs.get(tags[v] + "/in", x.shape[0], x.shape[1], x.shape[2], cpad0, dev, dt))
@@ -193,11 +188,8 @@ class TrunksFunction(torch.autograd.Function):
                 gbufs = [bufs.get("%s/g%d" % (tags[v], i - 1), dys[v].shape[0], saved[v][i - 1][2], saved[v][i - 1][3], c_in, dev, dt)
                          for v in range(nv)]
                 dys = ops.maxpool2x2_bwd_views([(y_prev[v], obufs[v], gbufs[v]) for v in range(nv)])
-            elif dt == BF:                             # data gradient and the ReLU mask of layer i - 1's output in one launch
+            else:                                      # data gradient and the ReLU mask of layer i - 1's output in one launch
                 dys = ops.conv3x3_views([(dys[v], wd[v], zero_bias, y_prev[v], obufs[v]) for v in range(nv)], relu=False)
-            else:
-                ops.conv3x3_views([(dys[v], wd[v], zero_bias, None, obufs[v]) for v in range(nv)], relu=False)
-                dys = [obufs[v].mul_(y_prev[v] > 0) for v in range(nv)]
         return (None, None, None, None) + (None,) * nv + tuple(grads)
 
 

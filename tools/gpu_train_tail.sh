@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU box: steady-state kernel totals of one training-step configuration (rocprofv3 kernel trace of tools/train_probe.py, the last
+# 40 % of the trace = the timed steps).   tools/gpu_train_tail.sh <tag> <fp32|bf16|bf16_mfma|fp32_mfma> [steps]
+set -u
+TAG=$1; CFG=$2; STEPS=${3:-8}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace -d $OUT/tr -o r -- python $GRAFT_REPO_ROOT/tools/train_probe.py $CFG $STEPS > $OUT/$CFG.log 2>&1
+tail -1 $OUT/$CFG.log
+python - $OUT/tr/r_results.db $STEPS > $OUT/${CFG}_tail.txt <<'PY'
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1]); steps = float(sys.argv[2])
+rows = c.execute("select name, start, end from kernels order by start").fetchall()
+# the timed steps = the last `steps` of steps + 2 warm-up: cut at the Adam launch (multi_tensor_apply) that ends warm-up step 2
+adam = [r[1] for r in rows if "multi_tensor_apply" in r[0]]
+per = len(adam) / (steps + 2)
+cut = adam[int(round(2 * per)) - 1] if adam else rows[0][1]
+agg = {}
+for n, s, e in rows:
+    if s > cut:
+        a = agg.setdefault(n, [0, 0]); a[0] += 1; a[1] += e - s
+tot = sum(v[1] for v in agg.values()); span = rows[-1][2] - cut
+print("timed window %.1f ms, kernel time %.1f ms; per step: kernel %.2f ms of %.2f ms wall" % (span / 1e6, tot / 1e6, tot / 1e6 / steps, span / 1e6 / steps))
+for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+    print("%-100s n/step %6.1f  ms/step %7.3f  %5.1f%%" % (n[:100], v[0] / steps, v[1] / 1e6 / steps, 100.0 * v[1] / tot))
+PY
+rm -rf $OUT/tr
+head -24 $OUT/${CFG}_tail.txt | cut -c1-170

@@ -1,4 +1,4 @@
-"""One training-step configuration of bench_train_step on its own (for rocprofv3):  python tools/train_probe.py [fp32|bf16|bf16_mfma] [steps]"""
+"""One training-step configuration of bench_train_step on its own (for rocprofv3):  python tools/train_probe.py [fp32|bf16|bf16_mfma|fp32_mfma] [steps]"""
 import json
 import os
 import sys
@@ -10,5 +10,5 @@ from mv3d_tf_amd.fast_rcnn.train_mv import bench_train_step  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bf16_mfma"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-r = bench_train_step(0, 1, None, steps=steps, warmup=2, amp=None if name == "fp32" else torch.bfloat16, mfma=name == "bf16_mfma")
+r = bench_train_step(0, 1, None, steps=steps, warmup=2, amp=None if name.startswith("fp32") else torch.bfloat16, mfma=name.endswith("_mfma"))
 print(json.dumps({"config": name, "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"]}))
