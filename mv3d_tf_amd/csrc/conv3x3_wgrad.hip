@@ -146,17 +146,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // bias gradient (sum over the pixels of dY): the workgroups of input-channel tile 0 / filter row 0 multiply their dY
-    // fragments by an all-ones operand as well -- every column of that product is the column sum
+    // bias gradient (sum over the pixels of dY): the waves of input-channel tile 0 / filter row 0 / column half 0 add up their dY
+    // operand fragments on the vector ALU -- a lane holds 8 pixels of ONE output channel (row lane & 31, k-group lane >> 5).
+    // (Round 3 multiplied the fragments by an all-ones operand as well: 33 % more matrix work for those workgroups -- the launch
+    // is one round of workgroups, so its time was THEIR time -- and 32 more accumulator registers for everybody: 2 instead of 3
+    // workgroups per CU.)
     const bool do_bias = a.bpart != nullptr && ci_t == 0 && dyr == 0 && wb == 0;       // (wave-uniform)
-    f32x16 accb[FA];
+    float bsum[FA];
 #pragma unroll
-    for (int i = 0; i < FA; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int i = 0; i < FA; ++i) bsum[i] = 0.f;
 
     if (s0 < s1) issue(s0, 0);
     for (int s = s0; s < s1; ++s) {
@@ -187,17 +185,19 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < FA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += (float)fa[i][e];
             }
         }
     }
 
-    if (do_bias && (lane & 31) == 0) {                            // column 0 of the ones-product: rows (co) 8 q + 4 (lane >> 5) + {0..3}
+    if (do_bias) {                                                // the two k-groups of a channel sit in lanes l and l + 32
 #pragma unroll
-        for (int i = 0; i < FA; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = accb[i][r];
+        for (int i = 0; i < FA; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            if (lane < 32) a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + lane] = tot;
+        }
     }
     // partial sums: D layout = lane holds column (GEMM column n) lane & 31, rows (co) 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2
     float *const out = a.part + (size_t)split * a.Cout * 9 * a.Cin;
@@ -285,11 +285,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup
         boff[j] = DY_BYTES + phys(h + n0 / 64, (n0 % 64 + c) * 4, XRB);          // (2 u rows further per substep: the parity stays)
     }
 
-    f32x16 acc[FA][3], accb[FA];
+    f32x16 acc[FA][3];
+    float bsum[FA];                                               // bias gradient on the vector ALU (see the bf16 kernel)
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+        bsum[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -316,17 +316,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < FA; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], 1.0f, accb[i], 0, 0, 0);
+                for (int i = 0; i < FA; ++i) bsum[i] += fa[i];
             }
         }
     }
 
-    if (do_bias && (lane & 31) == 0) {
+    if (do_bias) {                                                // a lane holds channel lane & 31 of the pixel rows of parity lane >> 5
 #pragma unroll
-        for (int i = 0; i < FA; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)] = accb[i][r];
+        for (int i = 0; i < FA; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            if (lane < 32) a.bpart[(size_t)split * a.Cout + co0 + wa * (BMC / 2) + 32 * i + lane] = tot;
+        }
     }
     float *const out = a.part + (size_t)split * a.Cout * 9 * a.Cin;
 #pragma unroll
@@ -439,16 +439,31 @@ __global__ __launch_bounds__(256) void conv3x3_pack_many_kernel(const PackMany p
 }  // namespace mv3d_wgrad
 using namespace mv3d_wgrad;
 
-// the workgroups the chip holds at once: three per CU (LDS).  More than that is a second, mostly empty round of an MFMA-bound
-// kernel (1024 measured 5-10 % slower, and more partial sums to fold)
-static int wgrad_target()
+// the workgroups the chip holds at once, for the kernel the plan is made for (registers and LDS decide: asked from the runtime
+// once per kernel).  The launch should be ONE round of resident workgroups: an MFMA-bound kernel gains nothing from more, and a
+// partly filled second round leaves some CUs with twice the work of others (measured: CUs busy 69 % of the launch).
+template <typename K>
+static int resident_workgroups(K kernel)
+{
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0)
+        return 512;
+    return per_cu * prop.multiProcessorCount;
+}
+static int wgrad_target(int bmc, int es)
 {
 #ifdef MV3D_TUNING
-    static const int target = getenv("MV3D_WGRAD_TARGET") ? atoi(getenv("MV3D_WGRAD_TARGET")) : 768;
-    return target;
-#else
-    return 768;
+    if (getenv("MV3D_WGRAD_TARGET")) return atoi(getenv("MV3D_WGRAD_TARGET"));
 #endif
+    static int cache[2][2] = {{0, 0}, {0, 0}};
+    int &t = cache[es == 4][bmc == 128];
+    if (!t) {
+        if (es == 4) t = bmc == 128 ? resident_workgroups(conv3x3_wgrad_f32_kernel<128>) : resident_workgroups(conv3x3_wgrad_f32_kernel<64>);
+        else t = bmc == 128 ? resident_workgroups(conv3x3_wgrad_kernel<128>) : resident_workgroups(conv3x3_wgrad_kernel<64>);
+    }
+    return t;
 }
 
 struct WgradPlan { int steps[WG_MAX_VIEWS], splits[WG_MAX_VIEWS], steps_per_split, tiles, bmc; size_t q[WG_MAX_VIEWS], part_off[WG_MAX_VIEWS], bpart_off[WG_MAX_VIEWS], bytes; };
@@ -467,7 +482,7 @@ static bool wgrad_plan(int n, const mv3d_wgrad_view *views, int c_in, int c_out,
     }
     // K steps per workgroup: the smallest number (>= 4) with which ALL views' workgroups fit the chip at once -- every view rounds
     // its last split up, so the sum is checked, not estimated: 10 x 96 workgroups instead of 8 x 96 would be a second round
-    const int target = wgrad_target();
+    const int target = wgrad_target(P.bmc, pix == WG_PIX ? 2 : 4);
     long sps = (total * P.tiles + target - 1) / target;
     if (sps < 4) sps = 4;
     for (;; ++sps) {
