@@ -486,7 +486,8 @@ typedef struct {
     const void *dy_framed;       /* (batch, height + 2, width + 2, c_out), zero frame */
     float *dw;                   /* (c_out, c_in_real, 3, 3) */
     float *db;                   /* (c_out) or NULL */
-    int32_t batch, height, width, reserved0;
+    int32_t batch, height, width;
+    int32_t c_in_real;           /* this view's real input channels (the input layers: 9 BEV, 3 image / front view); 0 = the call's */
 } mv3d_wgrad_view;
 size_t mv3d_conv3x3_wgrad_views_workspace_bytes(int num_views, const mv3d_wgrad_view *views, int c_in, int c_out, int f32_maps);
 int mv3d_conv3x3_wgrad_views_bf16(int num_views, const mv3d_wgrad_view *views, int c_in, int c_in_real, int c_out, void *workspace,

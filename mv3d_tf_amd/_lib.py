@@ -76,7 +76,7 @@ class PoolView(C.Structure):
 class WgradView(C.Structure):
     """mv3d_wgrad_view"""
     _fields_ = [("x_framed", C.c_void_p), ("dy_framed", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p),
-                ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("reserved0", C.c_int32)]
+                ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("c_in_real", C.c_int32)]
 
 
 class PackItem(C.Structure):

@@ -40,7 +40,7 @@ struct WgradView {
     const void *x, *dy;
     float *part, *bpart;          // split-K partial sums: filter [splits][Cout][9][Cin]; bias [splits][Cout] (or nullptr)
     float *dw, *db;               // results (the reduce launch)
-    int Wp, steps, splits;
+    int Wp, steps, splits, c_in_real;
     unsigned x_bytes, dy_bytes;
 };
 struct WgradGroup { WgradView v[WG_MAX_VIEWS]; int n, Cin, Cout, steps_per_split, ci_tiles, c_in_real; int first[WG_MAX_VIEWS]; };
@@ -343,42 +343,56 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup
 #endif
 }
 
-// folds the split-K partial sums in split order and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3),
-// dropping the padding channels of the input layer (c_in_real <= c_in).  blockIdx.y = view.  A thread owns 4 consecutive input
-// channels of one (co, tap): 16-byte loads, four splits' loads in flight before they are added -- in split order: the sum is the
-// same sequence of f32 additions whatever the unrolling -- (the first version walked the splits one dependent 4-byte load at a
-// time: 43 us per launch for 75 MB of partials).
+// folds the split-K partial sums and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3), dropping the
+// padding channels of the input layer (c_in_real <= c_in).  blockIdx.y = view; a workgroup owns one output channel x 64 input
+// channels x 9 taps = 144 16-byte pieces of every split: RED_G thread groups each add a contiguous range of the splits in split
+// order (four loads in flight), the groups' sums are added in group order -- a fixed order, the same bits every run --, the
+// 64 x 9 results are turned in LDS and leave as ONE contiguous run of dw (the first version stored every float on its own at a
+// stride of 36 bytes and walked the splits one dependent 4-byte load at a time: 43 us per launch).
+#define RED_G 4
 typedef float f32x4r __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradGroup g)
+__global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const WgradGroup g)
 {
+    __shared__ f32x4r s_sum[RED_G][144];
+    __shared__ float s_out[64 * 9];
     const WgradView &v = g.v[blockIdx.y];
-    const float *__restrict__ part = v.part;
-    const int splits = v.splits, c_in = g.Cin, c_in_real = g.c_in_real, c_out = g.Cout;
-    const long n = (long)c_out * 9 * c_in, n4 = n / 4;
-    const long total = n4 + (v.db ? c_out : 0);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        if (i >= n4) {                                            // the bias gradient's partial sums
-            const int co = (int)(i - n4);
+    const int splits = v.splits, c_in = g.Cin, c_in_real = v.c_in_real, c_out = g.Cout, c4 = c_in / 4, chunks = c_in / 64;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= c_out * chunks) {                      // the bias gradient's partial sums
+        const int co = ((int)blockIdx.x - c_out * chunks) * (144 * RED_G) + tid;
+        if (v.db && co < c_out) {
             float s = v.bpart[co];
             for (int k = 1; k < splits; ++k) s += v.bpart[(long)k * c_out + co];
             v.db[co] = s;
-            continue;
         }
-        const f32x4r *p = (const f32x4r *)part + i;
-        f32x4r s = p[0];
-        int k = 1;
-        for (; k + 4 <= splits; k += 4) {
-            const f32x4r a0 = p[(long)k * n4], a1 = p[(long)(k + 1) * n4], a2 = p[(long)(k + 2) * n4], a3 = p[(long)(k + 3) * n4];
-            s += a0; s += a1; s += a2; s += a3;
-        }
-        for (; k < splits; ++k) s += p[(long)k * n4];
-        const int ci = (int)((i * 4) % c_in);
-        const long r = (i * 4) / c_in;                            // co * 9 + tap
-        float *o = v.dw + ((r / 9) * c_in_real + ci) * 9 + r % 9;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (ci + e < c_in_real) o[e * 9] = s[e];
+        return;
     }
+    const int co = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x % chunks;
+    const int nreal = min(64, c_in_real - chunk * 64);            // real input channels of this chunk
+    if (nreal <= 0) return;
+    const int item = tid % 144, grp = tid / 144, tap = item / 16, q = item % 16;
+    const long n4 = (long)c_out * 9 * c4;                         // float4 per split
+    const f32x4r *p = (const f32x4r *)v.part + ((long)co * 9 + tap) * c4 + chunk * 16 + q;
+    const int per = (splits + RED_G - 1) / RED_G, k0 = grp * per, k1 = min(splits, k0 + per);
+    f32x4r s = {0.f, 0.f, 0.f, 0.f};
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const f32x4r a0 = p[(long)k * n4], a1 = p[(long)(k + 1) * n4], a2 = p[(long)(k + 2) * n4], a3 = p[(long)(k + 3) * n4];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < k1; ++k) s += p[(long)k * n4];
+    s_sum[grp][item] = s;
+    __syncthreads();
+    if (grp == 0) {
+        f32x4r t = s_sum[0][item];
+#pragma unroll
+        for (int j = 1; j < RED_G; ++j) t += s_sum[j][item];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_out[(q * 4 + e) * 9 + tap] = t[e];
+    }
+    __syncthreads();
+    float *o = v.dw + ((long)co * c_in_real + chunk * 64) * 9;
+    for (int j = tid; j < nreal * 9; j += 144 * RED_G) o[j] = s_out[j];
 }
 
 // fp32 OIHW filter -> the two packed bf16 forms the trunk's step needs, in one launch: fwd (O, 9 * Ipad), k = tap * Ipad + i (the
@@ -545,6 +559,8 @@ static int wgrad_views_entry(int n, const mv3d_wgrad_view *views, int c_in, int 
         v.part = (float *)((char *)workspace + P.part_off[k]);
         v.bpart = w.db ? (float *)((char *)workspace + P.bpart_off[k]) : nullptr;
         v.Wp = w.width + 2; v.steps = P.steps[k]; v.splits = P.splits[k];
+        v.c_in_real = w.c_in_real > 0 ? w.c_in_real : c_in_real;
+        if (v.c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
         v.x_bytes = (unsigned)(P.q[k] * c_in * es); v.dy_bytes = (unsigned)(P.q[k] * c_out * es);
         g.first[k] = grid;
         grid += P.tiles * P.splits[k];
@@ -558,8 +574,8 @@ static int wgrad_views_entry(int n, const mv3d_wgrad_view *views, int c_in, int 
         if (P.bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<128>, dim3(grid), dim3(256), 0, s, g);
         else hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<64>, dim3(grid), dim3(256), 0, s, g);
     }
-    const long n4 = (long)c_out * 9 * c_in / 4 + c_out;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048), n), dim3(256), 0, s, g);
+    const unsigned rblocks = (unsigned)(c_out * (c_in / 64) + (want_bias ? (c_out + 144 * RED_G - 1) / (144 * RED_G) : 0));
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(rblocks, n), dim3(144 * RED_G), 0, s, g);
     return mv3d_launch_status();
 }
 
@@ -567,7 +583,7 @@ static int wgrad_entry(const void *x_framed, const void *dy_framed, float *dw, f
                        int c_out, void *workspace, size_t workspace_bytes, void *stream, int es)
 {
     mv3d_wgrad_view w;
-    w.x_framed = x_framed; w.dy_framed = dy_framed; w.dw = dw; w.db = db; w.batch = batch; w.height = height; w.width = width; w.reserved0 = 0;
+    w.x_framed = x_framed; w.dy_framed = dy_framed; w.dw = dw; w.db = db; w.batch = batch; w.height = height; w.width = width; w.c_in_real = 0;
     return wgrad_views_entry(1, &w, c_in, c_in_real, c_out, workspace, workspace_bytes, stream, es);
 }
 

@@ -583,14 +583,16 @@ def maxpool2x2_bwd_views(views):
 
 def conv3x3_wgrad_views(views, c_in_real=None, want_bias=False):
     """views: list of (x_framed, dy_framed) of one layer shape -> [(dw (Cout, c_in_real, 3, 3) f32, db (Cout) f32 | None), ...]:
-    one weight-gradient launch + one reduce launch for all of them."""
+    one weight-gradient launch + one reduce launch for all of them.  c_in_real: one number, or one per view (the input layers' 9 / 3
+    real channels inside their 64-channel buffers)."""
     x0, dy0 = views[0]
     cin, cout, dt = x0.shape[3], dy0.shape[3], x0.dtype
     if dt not in (torch.bfloat16, torch.float32):
         raise TypeError("bfloat16 or float32 maps expected")
-    creal = cin if c_in_real is None else int(c_in_real)
+    reals = list(c_in_real) if isinstance(c_in_real, (list, tuple)) else [cin if c_in_real is None else int(c_in_real)] * len(views)
+    creal = reals[0]
     if len(views) > 3 or any(x.numel() * x.element_size() > _OFF32 - 256 or dy.numel() * dy.element_size() > _OFF32 - 256 for x, dy in views):
-        return [conv3x3_wgrad_bf16(x, dy, creal, want_bias=True) if want_bias else (conv3x3_wgrad_bf16(x, dy, creal), None) for x, dy in views]
+        return [conv3x3_wgrad_bf16(x, dy, r, want_bias=True) if want_bias else (conv3x3_wgrad_bf16(x, dy, r), None) for (x, dy), r in zip(views, reals)]
     dev = x0.device
     arr = (_lib.WgradView * len(views))()
     res = []
@@ -598,9 +600,9 @@ def conv3x3_wgrad_views(views, c_in_real=None, want_bias=False):
         if x.dtype != dt or dy.dtype != dt or x.shape[3] != cin or dy.shape[3] != cout:
             raise TypeError("views of one layer shape and type expected")
         B, Hp, Wp, _ = x.shape
-        dw = torch.empty((cout, creal, 3, 3), dtype=torch.float32, device=dev)
+        dw = torch.empty((cout, reals[k], 3, 3), dtype=torch.float32, device=dev)
         db = torch.empty((cout,), dtype=torch.float32, device=dev) if want_bias else None
-        arr[k] = _lib.WgradView(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Hp - 2, Wp - 2, 0)
+        arr[k] = _lib.WgradView(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Hp - 2, Wp - 2, reals[k])
         res.append((dw, db))
     f32 = dt == torch.float32
     need = lib().mv3d_conv3x3_wgrad_views_workspace_bytes(len(views), arr, cin, cout, int(f32))

@@ -169,9 +169,9 @@ class TrunksFunction(torch.autograd.Function):
         zero_bias = torch.zeros(max(c for _, c, _ in layers), dtype=torch.float32, device=dev)      # (the data-gradient convolutions add no bias)
         for i in range(n - 1, -1, -1):
             c_ins = [ctx.c0[v] if i == 0 else layers[i - 1][1] for v in range(nv)]
-            if ctx.wgrad is None and len(set(c_ins)) == 1:                                        # one launch + one reduce for the views
-                res = ops.conv3x3_wgrad_views([(saved[v][i][0], dys[v]) for v in range(nv)], c_ins[0], want_bias=True)
-            else:                                      # (the input layers: 9 / 3 real channels -> different gradient shapes; or a yardstick wgrad)
+            if ctx.wgrad is None:                      # one launch + one reduce for the views (the input layers: 9 / 3 real channels each)
+                res = ops.conv3x3_wgrad_views([(saved[v][i][0], dys[v]) for v in range(nv)], c_ins, want_bias=True)
+            else:                                      # (a yardstick wgrad of the tests)
                 fn = ctx.wgrad or wgrad_mfma
                 res = [fn(saved[v][i][0], dys[v], c_ins[v]) for v in range(nv)]
             for v in range(nv):
@@ -245,42 +245,52 @@ def trunk(layers, x_nhwc, params, suffix, wgrad=None, pool=None, dtype=BF):
 
 
 def bench_wgrad_layers(vgg, batch=2, reps=3, dtype=BF):
-    """Roofline entry of the weight-gradient kernel for bench.py: every trunk layer of the 3-view TRAIN graph it serves (conv1_2 ..
-    conv5_3 of the three trunks; the 64-channel-padded input layers are left out of the flop count) at the training batch, each
-    timed with HIP events on the launch stream over `reps` launches (kernel + its split-K reduce) after one warm-up.
-    achieved = 2 * B*H*W * c_out * 9 * c_in / time; peak = the dense MFMA peak of MI355X_MICROARCH.md for the operand type (bf16:
-    2.5 PFLOP/s; f32: 157.3 TFLOP/s)."""
-    from .trunk import serving_layers
+    """Roofline entry of the weight-gradient kernel for bench.py, AS THE TRAINING STEP LAUNCHES IT: per VGG depth one grouped launch
+    (+ one reduce launch) for the BEV / image / front-view trunks of the 3-view TRAIN graph at the training batch (conv1_2 .. conv5_3;
+    the 64-channel-padded input layers are left out of the flop count), each timed with HIP events on the launch stream over `reps`
+    launches after one warm-up.  achieved = sum over the views of 2 * B*H*W * c_out * 9 * c_in / time; peak = the dense MFMA peak of
+    MI355X_MICROARCH.md for the operand type (bf16: 2.5 PFLOP/s; f32: 157.3 TFLOP/s)."""
     dev = torch.device("cuda")
+    inputs = (("", 608, 608), ("_2", 375, 1242), ("_3", 64, 512))
+    hw = [(h, w) for _, h, w in inputs]
     tot_fl, tot_ms, n = 0.0, 0.0, 0
     best = (None, 0.0, 0.0)
-    for name, H, W, cin, cout in serving_layers(vgg):
-        if cin < 64 or name.startswith("rpn_conv"):
-            continue
-        x = ops.framed_buffer(batch, H, W, cin, dev, dtype)
-        x[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cin), device=dev, dtype=dtype)
-        dy = ops.framed_buffer(batch, H, W, cout, dev, dtype)
-        dy[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cout), device=dev, dtype=dtype)
-        ops.conv3x3_wgrad_bf16(x, dy)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.conv3x3_wgrad_bf16(x, dy)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        fl = 2.0 * batch * H * W * cout * 9 * cin
-        tot_fl += fl
-        tot_ms += ms
-        n += 1
-        if fl / ms / 1e9 > best[1]:
-            best = (name, fl / ms / 1e9, ms)
+    cin = None
+    for stem, cout, pool in vgg:
+        if cin is not None:
+            views = []
+            fl = 0.0
+            for H, W in hw:
+                x = ops.framed_buffer(batch, H, W, cin, dev, dtype)
+                x[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cin), device=dev, dtype=dtype)
+                dy = ops.framed_buffer(batch, H, W, cout, dev, dtype)
+                dy[:, 1:-1, 1:-1] = torch.randn((batch, H, W, cout), device=dev, dtype=dtype)
+                views.append((x, dy))
+                fl += 2.0 * batch * H * W * cout * 9 * cin
+            ops.conv3x3_wgrad_views(views, want_bias=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.conv3x3_wgrad_views(views, want_bias=True)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            tot_fl += fl
+            tot_ms += ms
+            n += 1
+            if fl / ms / 1e9 > best[1]:
+                best = (stem, fl / ms / 1e9, ms)
+            del views
+        cin = cout
+        if pool:
+            hw = [(h // 2, w // 2) for h, w in hw]
     ach = tot_fl / tot_ms / 1e9
     f32 = dtype == torch.float32
     peak = 157.3 if f32 else 2500.0
     how = "conv3x3_wgrad_f32_kernel + reduce (v_mfma_f32_32x32x2_f32, exact f32" if f32 else \
         "conv3x3_wgrad_kernel + reduce (v_mfma_f32_32x32x16_bf16 fed by ds_read_b64_tr_b16"
-    return {"kernel": "%s; the %d weight gradients of the 3-view training trunks, batch %d)" % (how, n, batch),
+    return {"kernel": "%s; the weight gradients of the 3-view training trunks as the step launches them: %d grouped launches "
+                      "(BEV + image + front view per VGG depth), batch %d)" % (how, n, batch),
             "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": n * reps,
             "best_layer": {"name": best[0], "tflops": round(best[1], 1), "ms": round(best[2], 4)}, "traffic": None}
