@@ -200,6 +200,30 @@ def roofline_entries(ring, workload, signature):
     return out
 
 
+def usable_cores():
+    """host cores this process may really use: the affinity mask, cut by the container's CPU quota (cgroup v2 cpu.max / v1
+    cfs_quota_us): 256 worker processes on a 16-CPU quota just time-slice (measured: half the rate of 64 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = ""
+    try:
+        quota = period = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota, period = (None if q == "max" else float(q)), float(p)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if quota <= 0 else quota
+        if quota is not None and period:
+            lim = max(1, int(quota / period + 0.5))
+            if lim < n:
+                note = ", CPU quota of the container: %d of them" % lim
+                n = lim
+    except (OSError, ValueError):
+        pass
+    return max(1, n), note
+
+
 def cpu_baseline(ring, workload, seconds):
     """The C oracle on the same per-frame workload (frame 0 of batch 0), bounded sample, as SURVEY.md section 8(d) defines the
     CPU baseline: one thread first, then ALL host cores -- one worker PROCESS per core (oracle/cpu_worker.py: its own numpy
@@ -232,9 +256,9 @@ def cpu_baseline(ring, workload, seconds):
         if dt1 >= seconds / 3 or n1 >= 400:
             break
     # ---- every host core: one process each
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores, quota_note = usable_cores()
     span = 2 * seconds / 3
-    start = time.time() + 4.0 + cores * 0.02              # (interpreter + numpy start-up of `cores` processes)
+    start = time.time() + 3.0 + cores * 0.05              # (interpreter + numpy start-up of `cores` processes)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), path, workload, repr(start),
                                repr(start + span), str(1000 + k)], stdout=subprocess.PIPE, env=env, text=True) for k in range(cores)]
@@ -255,11 +279,11 @@ def cpu_baseline(ring, workload, seconds):
         pass
     return {"value": round(nm / dtm, 3), "unit": "frames/s", "cores": len(done), "kind": "port",
             "one_thread_frames_per_s": round(n1 / dt1, 3),
-            "sample": "%d frames by %d worker processes (one per host core, %d cores visible%s) in %.1f s after %d frames on 1 thread "
+            "sample": "%d frames by %d worker processes (one per usable host core; %d hardware threads visible%s%s) in %.1f s after %d frames on 1 thread "
                       "in %.1f s; the same per-frame workload (%s cfg path incl. target layers, 3-view RoiPool fwd%s, frame 0 of the "
                       "ring); C restatement oracle/mv3d_oracle.c, gcc -O2 -ffp-contract=off.  Reference as shipped (its Python / "
                       "Cython proposal_layer_3d alone, one thread, survey container, BASELINE.md section 2): 1.24 - 1.31 s per frame = "
-                      "0.8 frames/s" % (nm, len(done), os.cpu_count() or 0, (", %d workers failed" % late) if late else "", dtm, n1, dt1,
+                      "0.8 frames/s" % (nm, len(done), os.cpu_count() or 0, quota_note, (", %d workers failed" % late) if late else "", dtm, n1, dt1,
                                         key, "+bwd" if workload == "train" else "")}
 
 

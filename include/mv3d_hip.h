@@ -450,6 +450,12 @@ int mv3d_conv3x3_views_f16(int num_views, const mv3d_conv_view *views, int c_in,
 int mv3d_conv3x3_views_bf16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int out_f32, int relu,
                             void *stream);
 int mv3d_conv3x3_views_f32(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int relu, void *stream);
+/* Convolution + bias + ReLU + the 2x2 / stride 2 VALID max pool that follows it (lib/networks/network.py:182-189) in ONE launch, for
+ * layers whose full-size output only the pool reads (the serving graph's conv1_2 / conv2_2 / conv3_3): y = the POOLED framed map
+ * (batch, height / 2 + 2, width / 2 + 2, c_out); the full-size map is never written.  Same values as the convolution entry followed
+ * by mv3d_maxpool2x2_*. */
+int mv3d_conv3x3_pool_views_f16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, void *stream);
+int mv3d_conv3x3_pool_views_bf16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, void *stream);
 /* The 2x2 pools of several views in one launch.  Forward: x_framed = the map, y_framed = the pooled map (g_pooled_framed unused).
  * Backward (mv3d_maxpool2x2_bwd_*): x_framed = the pre-pool map y, g_pooled_framed = the gradient w.r.t. the pooled map,
  * y_framed = the gradient w.r.t. y's pre-activation (written). */

@@ -154,6 +154,8 @@ _SIGS = {
     "mv3d_conv3x3_views_f16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_views_bf16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_views_f32": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_pool_views_f16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, _P]),
+    "mv3d_conv3x3_pool_views_bf16": (C.c_int, [C.c_int, C.POINTER(ConvView), C.c_int, C.c_int, _P]),
     "mv3d_maxpool2x2_views_f16": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
     "mv3d_maxpool2x2_views_bf16": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),
     "mv3d_maxpool2x2_views_f32": (C.c_int, [C.c_int, C.POINTER(PoolView), C.c_int, _P]),

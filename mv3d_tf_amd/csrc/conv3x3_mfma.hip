@@ -39,6 +39,7 @@ struct ConvArgs {
     int out_pad, relu;
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
+    int Ho, Wo, xtiles;           // POOL mode: pooled size (H / 2, W / 2) and 2-row tiles per pair of rows
 };
 
 // Several views (the BEV / image / front-view trunks at one VGG depth: same channel counts, different map sizes) behind ONE
@@ -57,7 +58,11 @@ struct ConvGroup { ConvArgs v[CONV_MAX_VIEWS]; int n; int first[CONV_MAX_VIEWS];
 // T: the operand / activation type: _Float16 (serving), __bf16 (the training trunk: f16's 5-bit exponent would need loss scaling), or
 // float = the reference's precision on v_mfma_f32_32x32x2_f32 (exact f32 products and sums at the f32 matrix rate, 1/16 of f16's):
 // K steps of 32 channels, f32 maps in and out, MFMA-bound by a wide margin (8x the matrix time per staged byte).
-template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST>
+// POOL: the layer's 2x2 / stride 2 max pool (Network.max_pool(2, 2, 2, 2, 'VALID'), network.py:182-189) in the epilogue -- for the
+// serving graph's conv1_2 / conv2_2, whose full-size outputs nothing but the pool reads: an M tile is then TWO map rows x BM / 2
+// columns (complete pooling windows), the epilogue takes the maximum of every window out of the LDS tile and writes only the
+// pooled framed map (a quarter of the bytes; the separate pool launch, its read of the full map and the full map's write are gone).
+template <typename T, int BM, int BN, int WP, int WC, int STAGES, bool OUT_F32, bool FIRST, bool POOL = false>
 __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGroup g)
 {
 #if __HIP_DEVICE_COMPILE__      // (the LDS address-space casts below do not parse in the host pass, which only needs the stub)
@@ -72,6 +77,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
     constexpr int XCH = BM / 8 / NW, WCH = BN / 8 / NW;          // 8-row DMA pieces per wave and stage
     constexpr int ES = sizeof(T), CPS = BK_BYTES / ES;            // element size, channels per K step
     static_assert(ES == 2 || (OUT_F32 && !FIRST), "f32 operands: f32 maps, no input-layer packing");
+    static_assert(!POOL || (!OUT_F32 && !FIRST), "pooled epilogue: 16-bit framed output of an ordinary layer");
+    constexpr int TW = BM / 2;                                    // POOL: columns of the two-row tile
     constexpr int ESZ = OUT_F32 ? 4 : 2;
     constexpr int OUT_BYTES = BM * BN * ESZ;
     constexpr int LDS_BYTES = STAGES * STAGE > OUT_BYTES + BM * 4 ? STAGES * STAGE : OUT_BYTES + BM * 4;
@@ -87,6 +94,8 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
     const int mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles, nt = local % a.n_tiles;
     if (mt >= a.m_tiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
+    int pb = 0, pyo = 0, pxt = 0;                                 // POOL: frame, pooled row, column tile of this workgroup
+    if constexpr (POOL) { pxt = mt % a.xtiles; const int t = mt / a.xtiles; pyo = t % a.Ho; pb = t / a.Ho; }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K2 = FIRST ? 3 * BK_BYTES : 9 * a.Cin * ES;         // bytes of one weight row
@@ -97,7 +106,14 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
     // (one pair of integer divisions per lane, the other pieces' pixels by walking NW * 8 pixels on: sixteen runtime divisions
     // per lane were a visible part of a short-K workgroup's life)
     int xoff[XCH];
-    {
+    if constexpr (POOL) {                                         // pixel p of the tile = (row p / TW, column p % TW) of the row pair
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int p = (j * NW + wave) * 8 + (lane >> 3);
+            const int xx = min(pxt * TW + (p % TW), a.W - 1), yy = 2 * pyo + p / TW;       // (columns past the map: computed, never stored)
+            xoff[j] = ((pb * (a.H + 2) + yy) * Wp + xx) * a.Cin * ES + gsel * 16;
+        }
+    } else {
         int m = m0 + wave * 8 + (lane >> 3);
         int b = m / a.HW, r = m - b * a.HW, yy = r / a.W, xx = r - yy * a.W;
         const int last = ((a.Bn * (a.H + 2) - 3) * Wp + a.W - 1) * a.Cin * ES;     // pixel M - 1: rows past the end read it (never stored)
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
         }
     }
     __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
-    {   // output address of every pixel of the tile: the tile's first pixel by division (wave-uniform), the others by walking
+    if constexpr (!POOL) {   // output address of every pixel of the tile: the tile's first pixel by division (wave-uniform), the others by walking
         const int b0 = m0 / a.HW, r0 = m0 - b0 * a.HW, y0 = r0 / a.W, x0 = r0 - y0 * a.W;
         const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
         for (int p = tid; p < BM; p += NT) {
@@ -234,6 +250,27 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
     }
     __syncthreads();
     char *const yb = (char *)a.y + (size_t)n0 * ESZ;
+    if constexpr (POOL) {                                         // the maximum of every 2x2 window, written to the pooled framed map
+        typedef typename Vec<T>::v8 V8;
+        const size_t row0 = ((size_t)(pb * (a.Ho + 2) + pyo + 1) * (a.Wo + 2) + 1) * (size_t)(a.Cout * ESZ);
+        for (int u = tid; u < (TW / 2) * SLOTS; u += NT) {
+            const int xo = u / SLOTS, sl = u % SLOTS, xg = pxt * (TW / 2) + xo;
+            if (xg >= a.Wo) continue;
+            V8 m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int P = (q >> 1) * TW + 2 * xo + (q & 1);
+                const V8 v = *(const V8 *)(lds + P * ROWB + ((sl ^ (P & (SLOTS - 1))) << 4));
+                if (q == 0) m = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = (float)v[e] > (float)m[e] ? v[e] : m[e];
+                }
+            }
+            *(V8 *)(yb + row0 + (size_t)xg * (a.Cout * ESZ) + sl * 16) = m;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int u = tid; u < BM * SLOTS; u += NT) {
         const int P = u / SLOTS, s = u % SLOTS;
@@ -375,6 +412,24 @@ int launch_conv(ConvGroup &g, int out_f32, hipStream_t s)
     return mv3d_launch_status();
 }
 
+template <typename T, int BM, int BN, int WP, int WC>
+int launch_conv_pool(ConvGroup &g, hipStream_t s)
+{
+    int grid = 0;
+    for (int k = 0; k < g.n; ++k) {
+        ConvArgs &b = g.v[k];
+        b.Ho = b.H / 2; b.Wo = b.W / 2;
+        b.xtiles = (2 * b.Wo + BM / 2 - 1) / (BM / 2);
+        b.m_tiles = b.Bn * b.Ho * b.xtiles;
+        b.n_tiles = b.Cout / BN;
+        g.first[k] = grid;
+        grid += (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
+    }
+    for (int k = g.n; k < CONV_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, 2, false, false, true>), dim3(grid), dim3(WP * WC * 64), 0, s, g);
+    return mv3d_launch_status();
+}
+
 }  // namespace mv3d_conv
 using namespace mv3d_conv;
 
@@ -414,6 +469,23 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
     // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
     if (c_out % 128 == 0) return launch_conv<T, 128, 128, 2, 2, 2, false>(g, out_f32, s);
     return launch_conv<T, 256, 64, 4, 1, 2, false>(g, out_f32, s);
+}
+
+// convolution + bias + ReLU + 2x2 max pool: y = the POOLED framed map (batch, height / 2 + 2, width / 2 + 2, c_out)
+template <typename T>
+static int conv3x3_pool_views_entry(int num_views, const mv3d_conv_view *views, int c_in, int c_out, void *stream)
+{
+    if (num_views <= 0 || num_views > CONV_MAX_VIEWS || !views) return MV3D_ERR_INVALID_ARG;
+    if (c_in <= 0 || c_in % 64 || c_out <= 0 || c_out % 64) return MV3D_ERR_INVALID_ARG;
+    ConvGroup g;
+    g.n = num_views;
+    for (int k = 0; k < num_views; ++k) {
+        if (views[k].height < 2 || views[k].width < 2 || views[k].gate_framed) return MV3D_ERR_INVALID_ARG;
+        if (!conv_view_args(g.v[k], views[k], c_in, c_out, 1, 0, 1, 2, false, false)) return MV3D_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (c_out % 128 == 0) return launch_conv_pool<T, 128, 128, 2, 2>(g, s);
+    return launch_conv_pool<T, 256, 64, 4, 1>(g, s);
 }
 
 template <typename T>
@@ -537,6 +609,14 @@ extern "C" int mv3d_conv3x3_views_bf16(int num_views, const mv3d_conv_view *view
 extern "C" int mv3d_conv3x3_views_f32(int num_views, const mv3d_conv_view *views, int c_in, int c_out, int out_framed, int relu, void *stream)
 {
     return conv3x3_f32_views_entry(num_views, views, c_in, c_out, out_framed, relu, stream);
+}
+extern "C" int mv3d_conv3x3_pool_views_f16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, void *stream)
+{
+    return conv3x3_pool_views_entry<_Float16>(num_views, views, c_in, c_out, stream);
+}
+extern "C" int mv3d_conv3x3_pool_views_bf16(int num_views, const mv3d_conv_view *views, int c_in, int c_out, void *stream)
+{
+    return conv3x3_pool_views_entry<__bf16>(num_views, views, c_in, c_out, stream);
 }
 extern "C" int mv3d_maxpool2x2_f32(const void *x, void *y, int batch, int height, int width, int channels, void *stream)
 {

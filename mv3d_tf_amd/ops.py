@@ -556,6 +556,24 @@ def conv3x3_views(views, out_framed=True, out_f32=False, relu=True):
     return [v[4] for v in views]
 
 
+def conv3x3_pool_views(views):
+    """views: list of (x_framed, w_packed, bias, out_pooled_framed): convolution + bias + ReLU + the 2x2 max pool behind it in one
+    launch (mv3d_conv3x3_pool_views_*); `out` (B, H / 2 + 2, W / 2 + 2, Cout) is the POOLED framed map."""
+    x0, w0 = views[0][0], views[0][1]
+    cin, cout, dt = x0.shape[3], w0.shape[0], x0.dtype
+    arr = (_lib.ConvView * len(views))()
+    for k, (x, w, b, out) in enumerate(views):
+        B, Hp, Wp, _ = x.shape
+        if x.dtype != dt or w.dtype != dt or x.shape[3] != cin or w.shape[0] != cout or tuple(out.shape) != (B, (Hp - 2) // 2 + 2, (Wp - 2) // 2 + 2, cout):
+            raise TypeError("views of one layer shape and type, pooled framed outputs expected")
+        if x.numel() * x.element_size() > _OFF32:
+            raise ValueError("map beyond the kernel's 32-bit offsets: pool separately")
+        arr[k] = _lib.ConvView(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), B, Hp - 2, Wp - 2, 0)
+    fn, name = _half_entry("mv3d_conv3x3_pool_views", dt)
+    check(fn(len(views), arr, cin, cout, _stream()), name)
+    return [v[3] for v in views]
+
+
 def maxpool2x2_views(views):
     """views: list of (x_framed, out_framed): the 2x2 pools of several maps of one channel count in one launch"""
     arr = (_lib.PoolView * len(views))()

@@ -23,6 +23,7 @@ class MfmaTrunks:
                                              # float32 = the reference's precision on the f32 MFMA
         self._w = {}                         # name -> (version, packed f16 weights, f32 bias)
         self._buf = {}                       # (tag, B, H, W, C) -> framed f16 buffer (frame stays zero: only interiors are written)
+        self.fuse_pools = True               # trunks(): conv1_2 / conv2_2 with their pools in one launch (16-bit trunks)
 
     def _packed(self, name, input_layer=False):
         w, b = self.net.params[name]
@@ -103,6 +104,16 @@ class MfmaTrunks:
                         outs[v] = y
                         L[stem + suffixes[v]] = y[:, 1:-1, 1:-1] if framed else y
                 return outs
+            if pool and self.fuse_pools and i > 0 and self.dtype != torch.float32 and self._pool_waste(hw, cout) < 0.08 and \
+                    all(c.numel() * c.element_size() < 2 ** 31 - 1 for c in cur):
+                # the pool in the convolution's epilogue (mv3d_conv3x3_pool_views_*): the full-size map is never written (and is
+                # not in net.layers: only the pooled one exists).  Skipped where the two-row tiles would hang too far over the
+                # maps' right edge (conv3_3 of the 152-wide BEV map: 21 % of the tiles' columns)
+                hw = [(h // 2, w // 2) for h, w in hw]
+                ps = [self._framed(stem + suffixes[v] + "/pool", cur[v].shape[0], hw[v][0], hw[v][1], cout, dev) for v in range(nv)]
+                ops.conv3x3_pool_views([(cur[v], wb[v][0], wb[v][1], ps[v]) for v in range(nv)])
+                cur = ps
+                continue
             ys = [self._framed(stem + suffixes[v], cur[v].shape[0], hw[v][0], hw[v][1], cout, dev) for v in range(nv)]
             ops.conv3x3_views([(cur[v], wb[v][0], wb[v][1], None, ys[v]) for v in range(nv)])
             for v in range(nv):
@@ -115,6 +126,14 @@ class MfmaTrunks:
             else:
                 cur = ys
         return outs
+
+    @staticmethod
+    def _pool_waste(hw, cout):
+        """share of the pooled-epilogue tiles' columns that hang over the maps' right edge (tile = 2 rows x 64 | 128 columns)"""
+        tw = 128 if cout % 128 else 64
+        used = sum((h // 2) * 2 * (w // 2) for h, w in hw)
+        tiled = sum((h // 2) * ((2 * (w // 2) + tw - 1) // tw) * tw for h, w in hw)
+        return 1.0 - used / max(tiled, 1)
 
     def rpn_conv(self, conv5_3_framed):
         """rpn_conv/3x3 (MV3D_test.py:82-84) on the framed BEV conv5_3 -> (B, H, W, 512) NHWC of the trunk's type"""

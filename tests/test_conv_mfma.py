@@ -532,3 +532,94 @@ def test_fp32_training_trunk_matches_torch_autograd(gpu):
         for k in (0, 1):
             assert cos(got[name][k], g32[name][k]) >= 0.99999, (name, k, cos(got[name][k], g32[name][k]))
             assert float((got[name][k] - g32[name][k]).abs().max()) <= 1e-3 * float(g32[name][k].abs().max()), (name, k)
+
+
+# ---------------------------------------------------------------------------------------------------- grouped launches (round 4)
+_VIEW_SIZES = [(2, 19, 23), (1, 37, 50), (2, 8, 64)]            # three "trunks" of one layer shape, different maps
+
+
+@pytest.mark.parametrize("dt,cin,cout", [("f16", 64, 64), ("bf16", 128, 256), ("f32", 64, 128), ("bf16", 512, 512)])
+def test_grouped_views_equal_the_single_view_entries(gpu, dt, cin, cout):
+    """mv3d_conv3x3_views_* / maxpool2x2[_bwd]_views_* / conv3x3_wgrad_views_*: one launch for several maps of one layer shape gives,
+    per view, the bits of the single-view entry (same kernels, same tiles -- a view's workgroups only start at another block index)"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    T = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dt]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xs, ws, bs = [], [], []
+    for B, H, W in _VIEW_SIZES:
+        xs.append(ops.frame_nhwc_f16(torch.randn((B, H, W, cin), device="cuda", generator=g), ops.framed_buffer(B, H, W, cin, "cuda", T)))
+        ws.append(ops.pack_conv3x3_weights(torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * 0.05, dtype=T))
+        bs.append(torch.randn(cout, device="cuda", generator=g))
+    single = [ops.conv3x3_f16(x, w, b) for x, w, b in zip(xs, ws, bs)]
+    outs = [torch.zeros_like(y) for y in single]
+    ops.conv3x3_views([(x, w, b, None, o) for x, w, b, o in zip(xs, ws, bs, outs)])
+    for a, b in zip(single, outs):
+        assert torch.equal(a, b)
+    # gate (the data-gradient form): grouped == conv followed by the mask
+    if dt != "f16":
+        gates = [torch.randn(y.shape, device="cuda", generator=g).to(T) * (y != 0) for y in single]
+        outs2 = [torch.zeros_like(y) for y in single]
+        ops.conv3x3_views([(x, w, b, gt, o) for x, w, b, gt, o in zip(xs, ws, bs, gates, outs2)], relu=False)
+        for x, w, b, gt, o in zip(xs, ws, bs, gates, outs2):
+            want = ops.conv3x3_f16(x, w, b, relu=False) * (gt > 0)
+            assert torch.equal(o, want)
+    # pools
+    pooled = [ops.maxpool2x2_f16(y) for y in single]
+    pouts = [torch.zeros_like(p) for p in pooled]
+    ops.maxpool2x2_views([(y, o) for y, o in zip(single, pouts)])
+    for a, b in zip(pooled, pouts):
+        assert torch.equal(a, b)
+    if dt != "f16":
+        gs = [torch.randn(p.shape, device="cuda", generator=g).to(T) for p in pooled]
+        for gq in gs:
+            gq[:, 0] = 0; gq[:, -1] = 0; gq[:, :, 0] = 0; gq[:, :, -1] = 0
+        want = [ops.maxpool2x2_bwd_bf16(y, gq, torch.zeros_like(y)) for y, gq in zip(single, gs)]
+        got = ops.maxpool2x2_bwd_views([(y, gq, torch.zeros_like(y)) for y, gq in zip(single, gs)])
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        # weight gradients: grouped plans split K differently from single launches -> same values up to the f32 summation order
+        dys = [torch.randn(y.shape, device="cuda", generator=g).to(T) * (y != 0) for y in single]
+        want = [ops.conv3x3_wgrad_bf16(x, dy, want_bias=True) for x, dy in zip(xs, dys)]
+        got = ops.conv3x3_wgrad_views(list(zip(xs, dys)), want_bias=True)
+        for (dw, db), (gw, gb) in zip(want, got):
+            assert float((dw - gw).abs().max()) <= 2e-4 * float(dw.abs().max()) and float((db - gb).abs().max()) <= 2e-4 * float(db.abs().max())
+        again = ops.conv3x3_wgrad_views(list(zip(xs, dys)), want_bias=True)
+        for (gw, gb), (hw, hb) in zip(got, again):
+            assert torch.equal(gw, hw) and torch.equal(gb, hb)                  # deterministic: a fixed fold order
+
+
+@pytest.mark.parametrize("dt,cin,cout", [("f16", 64, 64), ("f16", 128, 128), ("bf16", 64, 256)])
+def test_convolution_with_the_pool_in_its_epilogue(gpu, dt, cin, cout):
+    """mv3d_conv3x3_pool_views_*: convolution + ReLU + 2x2 VALID max pool in one launch == the convolution entry followed by the pool
+    entry, bit for bit (odd heights / widths drop their last row / column; maps narrower than a tile; tiles over the right edge)"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    T = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    views, want = [], []
+    for B, H, W in [(2, 19, 23), (1, 37, 150), (2, 8, 64), ][:3]:
+        x = ops.frame_nhwc_f16(torch.randn((B, H, W, cin), device="cuda", generator=g), ops.framed_buffer(B, H, W, cin, "cuda", T))
+        w = ops.pack_conv3x3_weights(torch.randn((cout, cin, 3, 3), device="cuda", generator=g) * 0.05, dtype=T)
+        b = torch.randn(cout, device="cuda", generator=g)
+        want.append(ops.maxpool2x2_f16(ops.conv3x3_f16(x, w, b)))
+        views.append((x, w, b, ops.framed_buffer(B, H // 2, W // 2, cout, "cuda", T)))
+    got = ops.conv3x3_pool_views(views)
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
+def test_one_launch_packing_of_many_filters(gpu):
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ws = [torch.randn(s, device="cuda", generator=g) for s in [(64, 9, 3, 3), (64, 64, 3, 3), (128, 64, 3, 3), (512, 256, 3, 3), (64, 3, 3, 3)]]
+    for T in (torch.bfloat16, torch.float32):
+        got = ops.pack_conv3x3_train_many([(w, 64 if w.shape[1] < 64 else None, w.shape[1] >= 64) for w in ws], dtype=T)
+        for w, (fwd, dg) in zip(ws, got):
+            assert torch.equal(fwd, ops.pack_conv3x3_weights(w, 64 if w.shape[1] < 64 else None, dtype=T))
+            if w.shape[1] >= 64:
+                assert torch.equal(dg, ops.pack_conv3x3_weights(w.flip(2, 3).transpose(0, 1), dtype=T))
+            else:
+                assert dg is None
