@@ -154,10 +154,16 @@ def events_ms(stream, fns, rounds):
 
 
 def pmc_traffic(kernel, signature):
-    """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r03_pmc_traffic.json: one table per
+    """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r0N_pmc_traffic.json: one table per
     signature it was collected with); None otherwise -- never a stale number."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["signatures"].get(signature)
+        table = None
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):           # the newest pass that holds this configuration
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                table = json.load(open(path))["signatures"].get(signature)
+            if table:
+                break
         if not table:
             return None
         keys = [k for k in table["kernels"] if kernel in k]          # RoiPoolGrad = three kernels behind one call: summed

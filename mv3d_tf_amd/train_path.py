@@ -118,7 +118,8 @@ class TrainPathStream:
         B, H, W, N, dev, nc, L = self.B, self.H, self.W, self.N, self.dev, self.nc, lib()
         s = _Slot()
         e = lambda shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
-        _, s.prop = ops.proposal_3d_outputs(B, self.cap, dev)
+        s.pack, s.prop = ops.proposal_3d_outputs(B, self.cap, dev)
+        s.tail = s.pack[s.pack.numel() - 2 * B:].view(torch.int32)             # [proposal counts (B) | status words (B)], contiguous
         s.pws = e((max(L.mv3d_proposal_3d_workspace_bytes(B, H, W, C.byref(self.pparams)), 256),), torch.uint8)
         s.rpn_labels, s.rpn_targets = e((B, N)), e((B, N, 6))
         s.anchors, s.anchors_3d = e((B, self.anchor_cap, 5)), e((B, self.anchor_cap, 7))
@@ -127,7 +128,7 @@ class TrainPathStream:
         # bytes of every row with one strided copy
         s.row = (32 + N + 255) // 256 * 256
         s.report = e((B, s.row), torch.uint8)
-        s.pt_counts = e((B, 4), torch.int32)
+        s.pt_counts = e((B, 4), torch.int32)                                  # (written in place by stage 1, fetched as it lies)
         awsz = max(L.mv3d_anchor_target_workspace_bytes(H, W, self.max_gt), 256)
         s.aws = [e((awsz,), torch.uint8) for _ in range(B)]
         s.awsz = awsz
@@ -140,8 +141,8 @@ class TrainPathStream:
         # pinned host staging: reports in, index lists out
         head = min(_HEAD, s.row)
         s.h_report = torch.empty((B, head), dtype=torch.uint8).pin_memory()
-        s.h_small = torch.empty((B, 4 + 2), dtype=torch.int32).pin_memory()       # pt counts | proposal count, status
-        s.d_small = e((B, 6), torch.int32)
+        s.h_small = torch.empty((B, 4), dtype=torch.int32).pin_memory()           # proposal-target counts
+        s.h_tail = torch.empty((2 * B,), dtype=torch.int32).pin_memory()          # proposal counts | status words
         s.list_cap = B * (3 * N + 2 * (self.cap + self.max_gt))                   # every index list at its largest
         s.h_lists = torch.empty((s.list_cap,), dtype=torch.int32).pin_memory()
         s.h_scratch = torch.empty((max(N, self.cap + self.max_gt) + 64,), dtype=torch.int32)      # one permutation at its largest
@@ -203,11 +204,9 @@ class TrainPathStream:
                                                        s.p_ws, s.p_wsz, st), "mv3d_proposal_target_stage1_batch_devn")
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
         with ctx:
-            s.d_small[:, :4] = s.pt_counts
-            s.d_small[:, 4] = num
-            s.d_small[:, 5] = status
-            s.h_report.copy_(s.report[:, :s.h_report.shape[1]], non_blocking=True)
-            s.h_small.copy_(s.d_small, non_blocking=True)
+            s.h_report.copy_(s.report[:, :s.h_report.shape[1]], non_blocking=True)      # three device-to-host copies, no kernel
+            s.h_small.copy_(s.pt_counts, non_blocking=True)
+            s.h_tail.copy_(s.tail, non_blocking=True)
             s.event.record()
         s.future = None
         if self.async_draws:
@@ -223,7 +222,7 @@ class TrainPathStream:
         s.event.synchronize()                                          # the batch's reports are on the host
         t1 = time.perf_counter()
         small = s.h_small.numpy()
-        if int(small[:, 5].max()) & 1:
+        if int(s.h_tail.numpy()[self.B:].max()) & 1:
             raise ZeroDivisionError("float division")
         res = self._draw(s, small)
         self.t_wait += t1 - t0
@@ -276,14 +275,16 @@ class TrainPathStream:
         except Exception:
             s.busy = False
             raise
-        small = s.h_small.numpy()
         ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
         with ctx:
             if total:
                 s.d_lists[:total].copy_(s.h_lists[:total], non_blocking=True)
         st = self._sid()
-        dl = lambda k: (s.d_lists[offs[k]:offs[k] + sizes[k]] if sizes[k] else None)
-        a_d = [_ptrs([dl(5 * b + k) for b in range(B)]) for k in range(3)]
+        # argument arrays by pointer arithmetic (a torch slice per pointer cost more host time than the launches they feed)
+        lists0 = s.d_lists.data_ptr()
+        lp = lambda k: (lists0 + 4 * offs[k]) if sizes[k] else 0
+        vp = lambda ps: (C.c_void_p * len(ps))(*ps)
+        a_d = [vp([lp(5 * b + k) for b in range(B)]) for k in range(3)]
         a_n = [_ints([sizes[5 * b + k] for b in range(B)]) for k in range(3)]
         check(L.mv3d_anchor_target_stage2_batch(B, H, W, C.byref(self.aparams), a_d[0], a_n[0], a_d[1], a_n[1], a_d[2], a_n[2],
                                                 _P(s.rpn_labels), _P(s.anchors), _P(s.anchors_3d), _P(s.n_anchors), self.anchor_cap,
@@ -291,13 +292,15 @@ class TrainPathStream:
         n_fg = [sizes[5 * b + 3] for b in range(B)]
         n_bg = [sizes[5 * b + 4] for b in range(B)]
         S = [n_fg[b] + n_bg[b] for b in range(B)]
-        off = np.concatenate([[0], np.cumsum(S)]).astype(int)
-        sl = lambda t: _ptrs([t[off[b]:off[b + 1]] if S[b] else None for b in range(B)])
+        off = [0]
+        for v in S:
+            off.append(off[-1] + v)
+        rows = lambda t: vp([(t.data_ptr() + off[b] * t.stride(0) * t.element_size()) if S[b] else 0 for b in range(B)])
         prob, pred, im_info, calib, gt = s.inputs
-        p_cal = _ptrs([calib[b] for b in range(B)])
-        p_fg, p_bg = _ptrs([dl(5 * b + 3) for b in range(B)]), _ptrs([dl(5 * b + 4) for b in range(B)])
-        outs = [sl(s.rois["bev"]), sl(s.rois["rgb"]), sl(s.labels), sl(s.bbox_targets), sl(s.rois_3d)]
-        p_fv = sl(s.rois["fv"]) if self.want_fv else None
+        p_cal = vp([calib.data_ptr() + b * calib.stride(0) * calib.element_size() for b in range(B)])
+        p_fg, p_bg = vp([lp(5 * b + 3) for b in range(B)]), vp([lp(5 * b + 4) for b in range(B)])
+        outs = [rows(s.rois["bev"]), rows(s.rois["rgb"]), rows(s.labels), rows(s.bbox_targets), rows(s.rois_3d)]
+        p_fv = rows(s.rois["fv"]) if self.want_fv else None
         check(L.mv3d_proposal_target_stage2_batch_devn(B, s.p_bv, s.p_b3, s.p_cap, s.p_num, s.a_gtbv, s.a_gt3d, s.a_gtc, s.a_G, p_cal,
                                                        s.tpar, p_fg, _ints(n_fg), p_bg, _ints(n_bg), outs[0], outs[1], outs[2], outs[3],
                                                        outs[4], p_fv, s.p_ws, s.p_wsz, st), "mv3d_proposal_target_stage2_batch_devn")
@@ -307,7 +310,7 @@ class TrainPathStream:
         return {"rpn_labels": s.rpn_labels, "rpn_targets": s.rpn_targets, "anchors": s.anchors, "anchors_3d": s.anchors_3d,
                 "n_anchors": s.n_anchors, "rois": {k: v[:St] for k, v in s.rois.items()}, "rois_3d": s.rois_3d[:St],
                 "labels": s.labels[:St], "bbox_targets": s.bbox_targets[:St], "S": S,
-                "num_proposals": [int(v) for v in small[:, 4]], "proposals": s.prop}
+                "num_proposals": [int(v) for v in s.h_tail.numpy()[:B]], "proposals": s.prop}
 
 
 class _Null:

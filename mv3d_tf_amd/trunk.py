@@ -156,45 +156,70 @@ def serving_layers(vgg, inputs=(("", 608, 608, 9), ("_2", 375, 1242, 3), ("_3", 
 
 
 def bench_conv_layers(vgg, batch=16, reps=3, dtype=torch.float16):
-    """Roofline entry of the convolution kernel for bench.py: every 3x3 layer of the 3-view serving graph (40 launches: BEV
-    trunk, rpn_conv/3x3, RGB trunk, front-view trunk) at `batch` frames, each timed with HIP events on the launch stream over `reps` launches after one
-    warm-up.  achieved = ALGORITHMIC flops (2 * B*H*W * c_out * 9 * c_in with the true c_in, i.e. conv1_1's zero padding is not
-    counted) / time; peak = the dense MFMA peak of MI355X_MICROARCH.md for the operand type (f16 / bf16: 2.5 PFLOP/s; f32 on
+    """Roofline entry of the convolution kernel for bench.py, AS THE SERVING STEP LAUNCHES IT: per VGG depth one grouped launch for the
+    BEV / image / front-view trunks of the 3-view serving graph (conv1_2 / conv2_2 of the 16-bit trunks with their 2x2 pools in the
+    epilogue), conv5_3 in its two output forms, rpn_conv/3x3 on the BEV map -- 15 launches for the 40 convolutions at `batch` frames,
+    each timed with HIP events on the launch stream over `reps` launches after one warm-up.  achieved = ALGORITHMIC flops (2 * B*H*W *
+    c_out * 9 * c_in with the true c_in, i.e. conv1_1's zero padding is not counted; the pools' comparisons are not counted either)
+    / time; peak = the dense MFMA peak of MI355X_MICROARCH.md for the operand type (f16 / bf16: 2.5 PFLOP/s; f32 on
     v_mfma_f32_32x32x2_f32: 157.3 TFLOP/s)."""
     dev = torch.device("cuda")
     f32 = dtype == torch.float32
     peak = 157.3 if f32 else 2500.0
-    tot_fl, tot_ms, per = 0.0, 0.0, {}
-    for name, H, W, cin, cout in serving_layers(vgg):
-        first = cin < 16
+    inputs = (("", 608, 608, 9), ("_2", 375, 1242, 3), ("_3", 64, 512, 3))
+    hw = [(h, w) for _, h, w, _ in inputs]
+    cins = [c for _, _, _, c in inputs]
+    tot_fl, tot_ms, per, nconv = 0.0, 0.0, {}, 0
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def operands(H, W, cin, cout, first):
         cpad = (32 if f32 else 16) if first else cin
         x = ops.framed_buffer(batch, H, W, cpad, dev, dtype)
         x[:, 1:-1, 1:-1, :cin] = torch.randn((batch, H, W, cin), device=dev, dtype=dtype)
         w = torch.randn((cout, cin, 3, 3), device=dev) * (2.0 / (9 * cin)) ** 0.5
-        if first and not f32:
-            wp = ops.pack_conv3x3_weights_input_layer(w, dtype=dtype)
+        wp = ops.pack_conv3x3_weights_input_layer(w, dtype=dtype) if (first and not f32) else ops.pack_conv3x3_weights(w, cpad, dtype=dtype)
+        return x, wp, torch.zeros(cout, device=dev)
+
+    for i, (stem, cout, pool) in enumerate(vgg):
+        ops_v = [operands(hw[v][0], hw[v][1], cins[v], cout, i == 0) for v in range(3)]
+        fl = sum(2.0 * batch * hw[v][0] * hw[v][1] * cout * 9 * cins[v] for v in range(3))
+        fused = pool and i > 0 and not f32 and MfmaTrunks._pool_waste(hw, cout) < 0.08
+        if fused:
+            outs = [ops.framed_buffer(batch, h // 2, w // 2, cout, dev, dtype) for h, w in hw]
+            ms = timed(lambda: ops.conv3x3_pool_views([(ops_v[v][0], ops_v[v][1], ops_v[v][2], outs[v]) for v in range(3)]))
         else:
-            wp = ops.pack_conv3x3_weights(w, cpad, dtype=dtype)
-        b = torch.zeros(cout, device=dev)
-        out = ops.framed_buffer(batch, H, W, cout, dev, dtype)
-        ops.conv3x3_f16(x, wp, b, out=out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.conv3x3_f16(x, wp, b, out=out)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        fl = 2.0 * batch * H * W * cout * 9 * cin
+            outs = [ops.framed_buffer(batch, h, w, cout, dev, dtype) for h, w in hw]
+            ms = timed(lambda: ops.conv3x3_views([(ops_v[v][0], ops_v[v][1], ops_v[v][2], None, outs[v]) for v in range(3)]))
+        per[stem + (" (+ pool)" if fused else "")] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
         tot_fl += fl
         tot_ms += ms
-        per[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
-        del x, out
+        nconv += 3
+        cins = [cout] * 3
+        if pool:
+            hw = [(h // 2, w // 2) for h, w in hw]
+        del ops_v, outs
+    x, wp, b = operands(hw[0][0], hw[0][1], 512, 512, False)                     # rpn_conv/3x3 on the BEV conv5_3
+    out = torch.empty((batch, hw[0][0], hw[0][1], 512), dtype=dtype, device=dev)
+    ms = timed(lambda: ops.conv3x3_f16(x, wp, b, out=out, out_framed=False, out_f32=f32))
+    fl = 2.0 * batch * hw[0][0] * hw[0][1] * 512 * 9 * 512
+    per["rpn_conv/3x3"] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1)}
+    tot_fl += fl
+    tot_ms += ms
+    nconv += 1
     ach = tot_fl / tot_ms / 1e9
     best = max(per.items(), key=lambda kv: kv[1]["tflops"])
     mfma = "v_mfma_f32_32x32x2_f32 (exact f32)" if f32 else "v_mfma_f32_32x32x16_%s" % ("f16" if dtype == torch.float16 else "bf16")
-    return {"kernel": "conv3x3_f16_kernel<%s> (%s; the %d 3x3 convolutions of the 3-view serving graph, batch %d)"
-                      % (str(dtype).split(".")[-1], mfma, len(per), batch),
+    return {"kernel": "conv3x3_f16_kernel<%s> (%s; the %d 3x3 convolutions of the 3-view serving graph as the step launches them: %d "
+                      "grouped launches, batch %d)" % (str(dtype).split(".")[-1], mfma, nconv, len(per), batch),
             "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": len(per) * reps,
-            "best_layer": {"name": best[0], **best[1]}, "traffic": None}
+            "best_layer": {"name": best[0], **best[1]}, "per_depth": per, "traffic": None}
