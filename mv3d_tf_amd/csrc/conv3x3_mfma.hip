@@ -467,7 +467,14 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
     if (first) return c_out % 128 == 0 ? launch_conv<T, 128, 128, 2, 2, 2, true>(g, out_f32, s) : launch_conv<T, 256, 64, 4, 1, 2, true>(g, out_f32, s);
     // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
     // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)
-    if (c_out % 128 == 0) return launch_conv<T, 128, 128, 2, 2, 2, false>(g, out_f32, s);
+    if (c_out % 128 == 0) {
+        // few tiles (one frame: 184 tiles of conv4_x / conv5_x on 512 workgroup slots): half-height tiles put twice as many CUs to
+        // work -- the latency of a batch-1 frame (BASELINE configs[1]) is these layers' tile time, not their throughput
+        long tiles128 = 0;
+        for (int k = 0; k < num_views; ++k) tiles128 += (long)((g.v[k].M + 127) / 128) * (c_out / 128);
+        if (tiles128 < 512) return launch_conv<T, 64, 128, 2, 2, 2, false>(g, out_f32, s);
+        return launch_conv<T, 128, 128, 2, 2, 2, false>(g, out_f32, s);
+    }
     return launch_conv<T, 256, 64, 4, 1, 2, false>(g, out_f32, s);
 }
 
