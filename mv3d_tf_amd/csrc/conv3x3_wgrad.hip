@@ -13,7 +13,9 @@
 //
 // Workgroup = (co tile of 128 | 64) x (64 input channels) x (filter row dy: 3 taps = 192 GEMM columns) x (a range of K steps of
 // 64 pixels); 4 waves = 2 (co halves) x 2 (column halves: 3 fragments of 32 columns each).  Partial sums of the K ranges go to
-// part[split][co][tap][ci] (f32) and are folded in split order by conv3x3_wgrad_reduce_kernel: deterministic, no atomics.
+// part[split][tap][ci][co] (f32: a lane's four accumulator rows are four consecutive co = one 16-byte store; with one 4-byte
+// store per value the 98 KB of a workgroup's partial sums cost about as long as its K loop at a training batch) and are folded in a
+// fixed order by conv3x3_wgrad_reduce_kernel: deterministic, no atomics.
 #include <stdlib.h>
 #include "common.h"
 
@@ -23,12 +25,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4p __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
 struct WgradArgs {
     const void *x, *dy;
-    float *part, *bpart;          // split-K partial sums: filter [splits][Cout][9][Cin]; bias [splits][Cout] (or nullptr)
+    float *part, *bpart;          // split-K partial sums: filter [splits][9][Cin][Cout]; bias [splits][Cout] (or nullptr)
     int Wp, Cin, Cout, Q, steps, steps_per_split, splits, ci_tiles;
     unsigned x_bytes, dy_bytes;
 };
@@ -38,7 +41,7 @@ struct WgradArgs {
 #define WG_MAX_VIEWS 3
 struct WgradView {
     const void *x, *dy;
-    float *part, *bpart;          // split-K partial sums: filter [splits][Cout][9][Cin]; bias [splits][Cout] (or nullptr)
+    float *part, *bpart;          // split-K partial sums: filter [splits][9][Cin][Cout]; bias [splits][Cout] (or nullptr)
     float *dw, *db;               // results (the reduce launch)
     int Wp, steps, splits, c_in_real;
     unsigned x_bytes, dy_bytes;
@@ -207,9 +210,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp
         for (int j = 0; j < 3; ++j) {
             const int n0 = 96 * wb + 32 * j, tap = 3 * dyr + n0 / 64, ci = ci0 + n0 % 64 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                out[((size_t)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+            for (int q = 0; q < 4; ++q) {                         // a register quad = 4 consecutive output channels: one 16-byte store
+                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * q + 4 * (lane >> 5);
+                const f32x4p v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *(f32x4p *)(out + ((size_t)tap * a.Cin + ci) * a.Cout + co) = v;
             }
         }
 #endif
@@ -335,31 +339,32 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup
         for (int j = 0; j < 3; ++j) {
             const int n0 = 96 * wb + 32 * j, tap = 3 * dyr + n0 / 64, ci = ci0 + n0 % 64 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                out[((size_t)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+            for (int q = 0; q < 4; ++q) {                         // a register quad = 4 consecutive output channels: one 16-byte store
+                const int co = co0 + wa * (BMC / 2) + 32 * i + 8 * q + 4 * (lane >> 5);
+                const f32x4p v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *(f32x4p *)(out + ((size_t)tap * a.Cin + ci) * a.Cout + co) = v;
             }
         }
 #endif
 }
 
-// folds the split-K partial sums and writes the gradient in the framework's filter layout (c_out, c_in_real, 3, 3), dropping the
-// padding channels of the input layer (c_in_real <= c_in).  blockIdx.y = view; a workgroup owns one output channel x 64 input
-// channels x 9 taps = 144 16-byte pieces of every split: RED_G thread groups each add a contiguous range of the splits in split
-// order (four loads in flight), the groups' sums are added in group order -- a fixed order, the same bits every run --, the
-// 64 x 9 results are turned in LDS and leave as ONE contiguous run of dw (the first version stored every float on its own at a
-// stride of 36 bytes and walked the splits one dependent 4-byte load at a time: 43 us per launch).
+// folds the split-K partial sums (part[split][tap][ci][co]) and writes the gradient in the framework's filter layout (c_out,
+// c_in_real, 3, 3), dropping the padding channels of the input layer (c_in_real <= c_in).  blockIdx.y = view; a workgroup owns 16
+// output channels x 4 input channels x 9 taps = 144 16-byte pieces of every split: RED_G thread groups each add a contiguous range of
+// the splits in split order (four loads in flight), the groups' sums are added in group order -- a fixed order, the same bits every
+// run --, the 16 x 36 results are turned in LDS and leave as 16 contiguous runs of dw (the first version stored every float on its
+// own at a stride of 36 bytes and walked the splits one dependent 4-byte load at a time: 43 us per launch).
 #define RED_G 4
 typedef float f32x4r __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const WgradGroup g)
 {
     __shared__ f32x4r s_sum[RED_G][144];
-    __shared__ float s_out[64 * 9];
+    __shared__ float s_out[16 * 36];
     const WgradView &v = g.v[blockIdx.y];
-    const int splits = v.splits, c_in = g.Cin, c_in_real = v.c_in_real, c_out = g.Cout, c4 = c_in / 4, chunks = c_in / 64;
+    const int splits = v.splits, c_in = g.Cin, c_in_real = v.c_in_real, c_out = g.Cout, ciq = c_in / 4, cob = c_out / 16;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= c_out * chunks) {                      // the bias gradient's partial sums
-        const int co = ((int)blockIdx.x - c_out * chunks) * (144 * RED_G) + tid;
+    if ((int)blockIdx.x >= cob * ciq) {                           // the bias gradient's partial sums
+        const int co = ((int)blockIdx.x - cob * ciq) * (144 * RED_G) + tid;
         if (v.db && co < c_out) {
             float s = v.bpart[co];
             for (int k = 1; k < splits; ++k) s += v.bpart[(long)k * c_out + co];
@@ -367,12 +372,12 @@ __global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const
         }
         return;
     }
-    const int co = (int)blockIdx.x / chunks, chunk = (int)blockIdx.x % chunks;
-    const int nreal = min(64, c_in_real - chunk * 64);            // real input channels of this chunk
+    const int co0 = ((int)blockIdx.x / ciq) * 16, ci0 = ((int)blockIdx.x % ciq) * 4;
+    const int nreal = min(4, c_in_real - ci0);                    // real input channels of this block
     if (nreal <= 0) return;
-    const int item = tid % 144, grp = tid / 144, tap = item / 16, q = item % 16;
-    const long n4 = (long)c_out * 9 * c4;                         // float4 per split
-    const f32x4r *p = (const f32x4r *)v.part + ((long)co * 9 + tap) * c4 + chunk * 16 + q;
+    const int item = tid % 144, grp = tid / 144, tap = item / 16, ci_l = (item >> 2) & 3, c4 = item & 3;
+    const long n4 = (long)c_out * 9 * c_in / 4;                   // float4 per split
+    const f32x4r *p = (const f32x4r *)v.part + (((long)tap * c_in + ci0 + ci_l) * c_out + co0) / 4 + c4;
     const int per = (splits + RED_G - 1) / RED_G, k0 = grp * per, k1 = min(splits, k0 + per);
     f32x4r s = {0.f, 0.f, 0.f, 0.f};
     int k = k0;
@@ -388,11 +393,13 @@ __global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const
 #pragma unroll
         for (int j = 1; j < RED_G; ++j) t += s_sum[j][item];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s_out[(q * 4 + e) * 9 + tap] = t[e];
+        for (int e = 0; e < 4; ++e) s_out[((c4 * 4 + e) * 4 + ci_l) * 9 + tap] = t[e];
     }
     __syncthreads();
-    float *o = v.dw + ((long)co * c_in_real + chunk * 64) * 9;
-    for (int j = tid; j < nreal * 9; j += 144 * RED_G) o[j] = s_out[j];
+    for (int j = tid; j < 16 * 36; j += 144 * RED_G) {
+        const int co_l = j / 36, r = j % 36;
+        if (r < nreal * 9) v.dw[((long)(co0 + co_l) * c_in_real + ci0) * 9 + r] = s_out[j];
+    }
 }
 
 // fp32 OIHW filter -> the two packed bf16 forms the trunk's step needs, in one launch: fwd (O, 9 * Ipad), k = tap * Ipad + i (the
@@ -574,7 +581,7 @@ static int wgrad_views_entry(int n, const mv3d_wgrad_view *views, int c_in, int 
         if (P.bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<128>, dim3(grid), dim3(256), 0, s, g);
         else hipLaunchKernelGGL(conv3x3_wgrad_f32_kernel<64>, dim3(grid), dim3(256), 0, s, g);
     }
-    const unsigned rblocks = (unsigned)(c_out * (c_in / 64) + (want_bias ? (c_out + 144 * RED_G - 1) / (144 * RED_G) : 0));
+    const unsigned rblocks = (unsigned)((c_out / 16) * (c_in / 4) + (want_bias ? (c_out + 144 * RED_G - 1) / (144 * RED_G) : 0));
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(rblocks, n), dim3(144 * RED_G), 0, s, g);
     return mv3d_launch_status();
 }
