@@ -51,27 +51,9 @@ class MfmaTrunks:
         return buf
 
     def trunk(self, x_nhwc, suffix, last_framed):
-        """x_nhwc (B, H, W, 9 | 3) f32 -> the trunk's conv5_3: framed f16 if `last_framed` (rpn_conv/3x3 reads it) else the bare
-        f32 NHWC map.  Intermediate maps are left in net.layers as f16 NHWC views of their framed buffers."""
-        B, H, W, c = x_nhwc.shape
-        dev = x_nhwc.device
-        L = self.net.layers
-        x = ops.frame_nhwc_f16(x_nhwc.contiguous(), self._framed("in" + suffix, B, H, W, 32 if self.dtype == torch.float32 else 16, dev))
-        n = len(self.vgg)
-        for i, (stem, cout, pool) in enumerate(self.vgg):
-            name = stem + suffix
-            wp, bias = self._packed(name, input_layer=(i == 0))
-            if i == n - 1 and not last_framed:
-                y = ops.conv3x3_f16(x, wp, bias, out_framed=False, out_f32=True)
-                L[name] = y
-                return y
-            y = ops.conv3x3_f16(x, wp, bias, out=self._framed(name, B, H, W, cout, dev))
-            L[name] = y[:, 1:-1, 1:-1]
-            if pool:
-                H, W = H // 2, W // 2
-                y = ops.maxpool2x2_f16(y, out=self._framed(name + "/pool", B, H, W, cout, dev))
-            x = y
-        return x
+        """one trunk (see trunks()): x_nhwc (B, H, W, 9 | 3) f32 -> its conv5_3, framed in the trunk's type if `last_framed` (rpn_conv/3x3
+        reads it) else the bare f32 NHWC map"""
+        return self.trunks([x_nhwc], [suffix], [last_framed])[0]
 
     def trunks(self, xs_nhwc, suffixes, last_framed):
         """Several trunks walked together: every depth is ONE launch for all views (mv3d_conv3x3_views_*, mv3d_maxpool2x2_views_*:

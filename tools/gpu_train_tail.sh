@@ -23,6 +23,19 @@ tot = sum(v[1] for v in agg.values()); span = rows[-1][2] - cut
 print("timed window %.1f ms, kernel time %.1f ms; per step: kernel %.2f ms of %.2f ms wall" % (span / 1e6, tot / 1e6, tot / 1e6 / steps, span / 1e6 / steps))
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
     print("%-100s n/step %6.1f  ms/step %7.3f  %5.1f%%" % (n[:100], v[0] / steps, v[1] / 1e6 / steps, 100.0 * v[1] / tot))
+# where the device idles: gaps between consecutive kernels of the timed window (one stream: the end of one to the start of the next)
+tw = [(s, e, n) for n, s, e in rows if s > cut]
+gaps = {}
+end = tw[0][1]
+for (s, e, n), (ps, pe, pn) in zip(tw[1:], tw[:-1]):
+    g = s - end
+    end = max(end, e)
+    if g > 0:
+        k = (pn[:60], n[:60])
+        a = gaps.setdefault(k, [0, 0]); a[0] += 1; a[1] += g
+print("idle between kernels: %.2f ms per step; largest contributors (previous kernel -> next kernel):" % (sum(v[1] for v in gaps.values()) / 1e6 / steps))
+for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+    print("  %6.1f us x %5.1f / step   %s  ->  %s" % (v[1] / v[0] / 1e3, v[0] / steps, k[0], k[1]))
 PY
 rm -rf $OUT/tr
-head -24 $OUT/${CFG}_tail.txt | cut -c1-170
+head -24 $OUT/${CFG}_tail.txt | cut -c1-170; grep -A15 '^idle between' $OUT/${CFG}_tail.txt | cut -c1-200
