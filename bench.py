@@ -309,6 +309,8 @@ def fresh_inputs_line(rank, variant, seconds=1.5):
         pool.append(((t(np.concatenate([f[0] for f in frames])), t(np.concatenate([f[1] for f in frames])),
                       t(np.concatenate([f[2] for f in frames])), t(np.stack([f[3] for f in frames])),
                       [tuple(t(a) for a in f[4]) for f in frames]), hot_path.synth_maps(B, 900 + k, dev)))
+    # (one stream: per-slot streams -- TrainPathStream(streams=...) -- were measured and change nothing here: 5.9 - 6.1 k frames/s
+    # either way, the submitting thread's own ~0.3 ms of Python per batch is the limit, not the device and not the draws)
     path = TrainPathStream(B, 76, 76, dev, depth=2)
     cap = B * path.roi_cap
     g = torch.Generator(device=dev).manual_seed(5)
@@ -349,7 +351,7 @@ def fresh_inputs_line(rank, variant, seconds=1.5):
         for k in range(NV):
             fwd[k].num_rois = St
             bwd[k].num_rois = St
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = C.c_void_p((out["stream"] or torch.cuda.current_stream()).cuda_stream)
         check(L.mv3d_roi_pool_forward_views(NV, fwd, 7, 7, st), "mv3d_roi_pool_forward_views")
         check(L.mv3d_roi_pool_backward_views(NV, bwd, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "mv3d_roi_pool_backward_views")
 

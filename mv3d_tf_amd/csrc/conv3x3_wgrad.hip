@@ -46,19 +46,30 @@ struct WgradView {
     int Wp, steps, splits, c_in_real;
     unsigned x_bytes, dy_bytes;
 };
-struct WgradGroup { WgradView v[WG_MAX_VIEWS]; int n, Cin, Cout, steps_per_split, ci_tiles, c_in_real; int first[WG_MAX_VIEWS]; };
-__device__ __forceinline__ WgradArgs wgrad_view_args(const WgradGroup &g, int &id)
+// first[k] = view k's first GLOBAL split index (the views' K splits are numbered through), tiles = (co tiles) x (ci tiles) x 3,
+// gsplits = all views' splits.  Workgroup -> (global split, tile): the global split is what the XCD index (blockIdx & 7) walks, so
+// that ALL tiles of one K range run on ONE XCD: they read the same dY / X pixel windows (a dY window is shared by the 3 x ci-tiles
+// workgroups of its co tile, an X window by the co tiles), which then sit in that XCD's L2 once instead of being pulled over the
+// fabric into eight L2s by workgroups that the round-robin placement had spread over all XCDs.
+struct WgradGroup { WgradView v[WG_MAX_VIEWS]; int n, Cin, Cout, steps_per_split, ci_tiles, c_in_real, tiles, gsplits; int first[WG_MAX_VIEWS]; };
+__device__ __forceinline__ WgradArgs wgrad_view_args(const WgradGroup &g, int &id, int &split)
 {
+    const int row = 8 * g.tiles, b = (int)blockIdx.x;
+    int gs = (b / row) * 8 + (b & 7);                             // global split of this workgroup; its XCD = gs % 8
+    id = (b % row) >> 3;                                          // tile
+    // (3 tiles -- the 64 -> 64 layers: one co tile, one ci tile, the three filter rows -- measured 8 - 15 % SLOWER that way; they keep
+    // the plain order, tile fastest)
+    if (g.tiles <= 3) { gs = b / g.tiles; id = b % g.tiles; }
     int k = 0;
 #pragma unroll
     for (int j = 1; j < WG_MAX_VIEWS; ++j)
-        if (j < g.n && (int)blockIdx.x >= g.first[j]) k = j;
+        if (j < g.n && gs >= g.first[j]) k = j;
+    split = gs < g.gsplits ? gs - g.first[k] : -1;                // (the grid is padded to a multiple of 8 splits: -1 = nothing to do)
     const WgradView &v = g.v[k];
     WgradArgs a;
     a.x = v.x; a.dy = v.dy; a.part = v.part; a.bpart = v.bpart;
     a.Wp = v.Wp; a.Cin = g.Cin; a.Cout = g.Cout; a.Q = 0; a.steps = v.steps; a.steps_per_split = g.steps_per_split; a.splits = v.splits;
     a.ci_tiles = g.ci_tiles; a.x_bytes = v.x_bytes; a.dy_bytes = v.dy_bytes;
-    id = (int)blockIdx.x - g.first[k];
     return a;
 }
 
@@ -70,8 +81,9 @@ template <int BMC>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp)
 {
 #if __HIP_DEVICE_COMPILE__
-    int id;
-    const WgradArgs a = wgrad_view_args(grp, id);
+    int id, split;
+    const WgradArgs a = wgrad_view_args(grp, id, split);
+    if (split < 0) return;
     constexpr int RB = BMC * 2;                                   // bytes of a dY tile row
     constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WG_PIX / RPP;   // lanes per row, rows per 1-KB piece, dY pieces
     constexpr int DY_BYTES = WG_PIX * RB, X_BYTES = WG_XROWS * 128, STAGE = DY_BYTES + X_BYTES;
@@ -84,9 +96,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradGroup grp
     const int wa = wave & 1, wb = wave >> 1;
     // workgroup -> (split, dy, ci tile, co tile)
     const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
-    const int dyr = id % 3; id /= 3;
-    const int split = id % a.splits;
-    const int co_t = id / a.splits;
+    const int dyr = id % 3;
+    const int co_t = id / 3;
     const int co0 = co_t * BMC, ci0 = ci_t * 64;
     const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
 
@@ -230,8 +241,9 @@ template <int BMC>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup grp)
 {
 #if __HIP_DEVICE_COMPILE__
-    int id;
-    const WgradArgs a = wgrad_view_args(grp, id);
+    int id, split;
+    const WgradArgs a = wgrad_view_args(grp, id, split);
+    if (split < 0) return;
     constexpr int RB = BMC * 4;                                   // bytes of a dY tile row (512 | 256)
     constexpr int LPR = RB / 16, RPP = 64 / LPR, DYP = WGF_PIX / RPP;
     constexpr int XRB = 256, XRPP = 4, XPCS = WGF_XROWS / XRPP;   // activation rows: 64 channels x 4 B, 4 rows per 1-KB piece
@@ -244,9 +256,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f32_kernel(const WgradGroup
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave & 1, wb = wave >> 1;
     const int ci_t = id % a.ci_tiles; id /= a.ci_tiles;
-    const int dyr = id % 3; id /= 3;
-    const int split = id % a.splits;
-    const int co_t = id / a.splits;
+    const int dyr = id % 3;
+    const int co_t = id / 3;
     const int co0 = co_t * BMC, ci0 = ci_t * 64;
     const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
 
@@ -569,10 +580,12 @@ static int wgrad_views_entry(int n, const mv3d_wgrad_view *views, int c_in, int 
         v.c_in_real = w.c_in_real > 0 ? w.c_in_real : c_in_real;
         if (v.c_in_real > c_in) return MV3D_ERR_INVALID_ARG;
         v.x_bytes = (unsigned)(P.q[k] * c_in * es); v.dy_bytes = (unsigned)(P.q[k] * c_out * es);
-        g.first[k] = grid;
-        grid += P.tiles * P.splits[k];
+        g.first[k] = grid;                                        // (counts global splits here)
+        grid += P.splits[k];
     }
     for (int k = n; k < WG_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    g.tiles = P.tiles; g.gsplits = grid;
+    grid = (grid + 7) / 8 * 8 * P.tiles;                          // workgroups: (global splits padded to a multiple of 8) x tiles
     hipStream_t s = (hipStream_t)stream;
     if (es == 2) {
         if (P.bmc == 128) hipLaunchKernelGGL(conv3x3_wgrad_kernel<128>, dim3(grid), dim3(256), 0, s, g);

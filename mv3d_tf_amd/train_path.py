@@ -88,11 +88,16 @@ class _Slot:
 
 
 class TrainPathStream:
-    def __init__(self, B, H, W, device, num_classes=2, depth=2, max_gt=64, want_fv=True, stream=None, async_draws=True):
+    def __init__(self, B, H, W, device, num_classes=2, depth=2, max_gt=64, want_fv=True, stream=None, async_draws=True, streams=None):
         self.B, self.H, self.W, self.dev, self.nc = int(B), int(H), int(W), torch.device(device), int(num_classes)
         self.N = self.H * self.W * 4
         self.want_fv = bool(want_fv)
         self.stream = stream
+        # streams: one HIP stream per slot (slot k's launches and copies go to streams[k % len]): the batches in flight then overlap on
+        # the device as well -- stage 1 of a batch is a chain of small, latency-bound launches that leaves the chip mostly idle, which
+        # on ONE stream sits in front of the previous batch's RoiPool launches.  submit() orders the slot's stream behind the caller's
+        # current stream (the inputs); the caller consumes a batch's outputs on out["stream"].
+        self.streams = list(streams) if streams else None
         self.max_gt = int(max_gt)
         T = cfg.TRAIN
         self.pparams = ops.proposal_params(T)
@@ -105,6 +110,8 @@ class TrainPathStream:
         if self.cap < 0:
             check(1, "mv3d_proposal_3d_capacity")
         self.slots = [self._make_slot() for _ in range(int(depth))]
+        for k, sl_ in enumerate(self.slots):
+            sl_.stream = self.streams[k % len(self.streams)] if self.streams else self.stream
         self._next = 0
         self.t_wait = self.t_draw = 0.0                  # host seconds spent waiting for stage 1 / drawing (diagnostics)
         # The host stage of a batch (wait for its reports, draw) runs on ONE helper thread, in submission order: the event wait and
@@ -165,8 +172,8 @@ class TrainPathStream:
         s.busy = False
         return s
 
-    def _sid(self):
-        return C.c_void_p((self.stream or torch.cuda.current_stream()).cuda_stream)
+    def _sid(self, s):
+        return C.c_void_p((s.stream or torch.cuda.current_stream()).cuda_stream)
 
     # ------------------------------------------------------------------ stage 1
     def submit(self, prob, pred, im_info, calib, gt):
@@ -178,7 +185,9 @@ class TrainPathStream:
         if s.busy:
             raise RuntimeError("TrainPathStream: every slot is in flight (finish() one first, or raise `depth`)")
         s.busy = True
-        st = self._sid()
+        if s.stream is not None:
+            s.stream.wait_stream(torch.cuda.current_stream())            # the inputs were produced on the caller's stream
+        st = self._sid(s)
         G = [int(g[0].shape[0]) for g in gt]
         if max(G) > self.max_gt or min(G) <= 0:
             # (no box at all: the reference's anchor_target_layer takes argmax over an empty axis and raises as well --
@@ -202,7 +211,7 @@ class TrainPathStream:
               "mv3d_anchor_target_stage1_batch")
         check(L.mv3d_proposal_target_stage1_batch_devn(B, s.p_bv, s.p_b3, s.p_cap, s.p_num, s.a_gtbv, s.a_gt3d, s.a_G, s.tpar, s.p_cnt,
                                                        s.p_ws, s.p_wsz, st), "mv3d_proposal_target_stage1_batch_devn")
-        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        ctx = torch.cuda.stream(s.stream) if s.stream is not None else _Null()
         with ctx:
             s.h_report.copy_(s.report[:, :s.h_report.shape[1]], non_blocking=True)      # three device-to-host copies, no kernel
             s.h_small.copy_(s.pt_counts, non_blocking=True)
@@ -275,11 +284,11 @@ class TrainPathStream:
         except Exception:
             s.busy = False
             raise
-        ctx = torch.cuda.stream(self.stream) if self.stream is not None else _Null()
+        ctx = torch.cuda.stream(s.stream) if s.stream is not None else _Null()
         with ctx:
             if total:
                 s.d_lists[:total].copy_(s.h_lists[:total], non_blocking=True)
-        st = self._sid()
+        st = self._sid(s)
         # argument arrays by pointer arithmetic (a torch slice per pointer cost more host time than the launches they feed)
         lists0 = s.d_lists.data_ptr()
         lp = lambda k: (lists0 + 4 * offs[k]) if sizes[k] else 0
@@ -310,7 +319,7 @@ class TrainPathStream:
         return {"rpn_labels": s.rpn_labels, "rpn_targets": s.rpn_targets, "anchors": s.anchors, "anchors_3d": s.anchors_3d,
                 "n_anchors": s.n_anchors, "rois": {k: v[:St] for k, v in s.rois.items()}, "rois_3d": s.rois_3d[:St],
                 "labels": s.labels[:St], "bbox_targets": s.bbox_targets[:St], "S": S,
-                "num_proposals": [int(v) for v in s.h_tail.numpy()[:B]], "proposals": s.prop}
+                "num_proposals": [int(v) for v in s.h_tail.numpy()[:B]], "proposals": s.prop, "stream": s.stream}
 
 
 class _Null:

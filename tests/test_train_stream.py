@@ -47,7 +47,8 @@ def test_fresh_batches_pipelined_vs_oracle(gpu, oracle, yml):
     try:
         B, NB = 2, 4
         dev = torch.device("cuda")
-        path = TrainPathStream(B, 76, 76, dev, depth=2)
+        # (yml case: every slot on its own stream -- the batches in flight overlap on the device as well)
+        path = TrainPathStream(B, 76, 76, dev, depth=2, streams=[torch.cuda.Stream(), torch.cuda.Stream()] if yml else None)
         batches = [[synth.rpn_head(4100 + 10 * i + b, 76, 76, "peaky", return_gt=True) for b in range(B)] for i in range(NB)]
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
 
