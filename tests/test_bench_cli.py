@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -130,3 +131,37 @@ def test_conv_roofline_accounting():
     assert by["conv5_3_2"][1:] == (46, 155, 512, 512) and by["conv4_1_3"][1:] == (8, 64, 256, 512) and by["conv1_2_3"][1:] == (64, 512, 64, 64)
     flop = sum(2.0 * 16 * H * W * cout * 9 * cin for _, H, W, cin, cout in rows)
     assert abs(flop - 11.2e12) < 0.05e12
+
+
+def test_cpu_baseline_worker_and_usable_cores(tmp_path):
+    """bench.py's all-core CPU baseline: one worker PROCESS per usable core runs the C oracle on whole frames between a
+    common start and stop time (oracle/cpu_worker.py; its own numpy global RNG, no lock); `usable_cores` = affinity cut by the
+    container's CPU quota.  Small frame here (24 x 24 head, small maps): the worker reports frames done and its elapsed time."""
+    import importlib.util
+    import time
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd import hot_path, synth
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    n, note = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and isinstance(note, str)
+    prob, pred, info, calib, (gt_bv, gt_3d, gt_cnr) = synth.rpn_head(5, 24, 24, "peaky", return_gt=True)
+    rng = np.random.RandomState(0)
+    arrays = dict(prob=prob, pred=pred, info=info, calib=calib, gt_bv=gt_bv, gt_3d=gt_3d, gt_cnr=gt_cnr)
+    for v, (H, W, Cc) in zip(("bev", "rgb", "fv"), ((24, 24, 64), (12, 40, 64), (8, 16, 64))):
+        arrays["map_" + v] = rng.rand(1, H, W, Cc).astype(np.float32)
+    arrays.update({"cfg_" + k: np.asarray(v) for k, v in hot_path.TRAIN_CFG.items()})
+    path = str(tmp_path / "in.npz")
+    np.savez(path, **arrays)
+    start = time.time() + 1.5
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), path, "train", repr(start), repr(start + 0.5), str(k)],
+                              stdout=subprocess.PIPE, text=True) for k in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        frames, secs = out.split()
+        assert int(frames) >= 1 and 0.0 < float(secs) < 30.0
