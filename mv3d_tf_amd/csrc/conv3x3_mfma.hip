@@ -15,6 +15,7 @@
 // their 16-byte k-groups XOR-swizzled by (row >> 1) & 7 (applied on the SOURCE address: the DMA image is lane-linear), which
 // makes the ds_read_b128 of the MFMA operands (32 consecutive rows, one k-group) bank-conflict-free per 16 lanes.
 // Accumulators go back through LDS so that every global store is a full 16-byte piece of a pixel's channel row.
+#include <stdlib.h>
 #include "common.h"
 
 namespace mv3d_conv {
@@ -412,6 +413,23 @@ int launch_conv(ConvGroup &g, int out_f32, hipStream_t s)
     return mv3d_launch_status();
 }
 
+// 16-bit output only (tiles whose f32 output image would not fit the LDS)
+template <typename T, int BM, int BN, int WP, int WC>
+int launch_conv16(ConvGroup &g, hipStream_t s)
+{
+    int grid = 0;
+    for (int k = 0; k < g.n; ++k) {
+        ConvArgs &b = g.v[k];
+        b.m_tiles = (b.M + BM - 1) / BM;
+        b.n_tiles = b.Cout / BN;
+        g.first[k] = grid;
+        grid += (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
+    }
+    for (int k = g.n; k < CONV_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    hipLaunchKernelGGL((conv3x3_f16_kernel<T, BM, BN, WP, WC, 2, false, false>), dim3(grid), dim3(WP * WC * 64), 0, s, g);
+    return mv3d_launch_status();
+}
+
 template <typename T, int BM, int BN, int WP, int WC>
 int launch_conv_pool(ConvGroup &g, hipStream_t s)
 {
@@ -473,6 +491,26 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
         long tiles128 = 0;
         for (int k = 0; k < num_views; ++k) tiles128 += (long)((g.v[k].M + 127) / 128) * (c_out / 128);
         if (tiles128 < 512) return launch_conv<T, 64, 128, 2, 2, 2, false>(g, out_f32, s);
+        // many tiles and 16-bit maps out: 256 x 256 workgroups of 8 waves, each wave a 128-pixel x 64-cout tile -- per matrix
+        // instruction half the DMA pieces and 3/4 of the LDS operand reads of the 128 x 128 / 64 x 64 form (one workgroup per CU:
+        // 128 KB of LDS).  Batch-16 serving layers: conv4_2 954 -> 1063 TFLOP/s, conv3_2 848 -> 911, image conv4_2 988 -> 1020;
+        // needs enough tiles for several rounds of 256 workgroups (a training batch keeps the 128 x 128 form).
+        long tiles256 = 0;
+        for (int k = 0; k < num_views; ++k) tiles256 += (long)((g.v[k].M + 255) / 256) * (c_out / 256);
+#ifdef MV3D_TUNING
+        static const int big_min = getenv("MV3D_CONV_BIG_MIN") ? atoi(getenv("MV3D_CONV_BIG_MIN")) : 640;
+        static const int big_wp = getenv("MV3D_CONV_BIG_WP") ? atoi(getenv("MV3D_CONV_BIG_WP")) : 2;
+#else
+        const int big_min = 640, big_wp = 2;
+#endif
+        if (!out_f32 && c_out % 256 == 0 && tiles256 >= big_min)
+            return big_wp == 2 ? launch_conv16<T, 256, 256, 2, 4>(g, s) : launch_conv16<T, 256, 256, 4, 2>(g, s);
+#ifdef MV3D_TUNING                                                // experiment builds: the 256 x 256 workgroup, 8 waves of 128 x 64
+        static const int big = getenv("MV3D_CONV_TILE") ? atoi(getenv("MV3D_CONV_TILE")) : 0;
+        if (big == 256 && c_out % 256 == 0 && !out_f32) return launch_conv16<T, 256, 256, 2, 4>(g, s);
+        if (big == 2561 && c_out % 128 == 0 && !out_f32) return launch_conv16<T, 256, 128, 2, 2>(g, s);
+        if (big == 2562 && c_out % 128 == 0 && !out_f32) return launch_conv16<T, 256, 128, 4, 2>(g, s);
+#endif
         return launch_conv<T, 128, 128, 2, 2, 2, false>(g, out_f32, s);
     }
     return launch_conv<T, 256, 64, 4, 1, 2, false>(g, out_f32, s);
