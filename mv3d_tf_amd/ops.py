@@ -477,6 +477,9 @@ def maxpool2x2_bwd_bf16(y_framed, g_pooled_framed, out):
     return out
 
 
+_WGRAD_CHUNK_BYTES = 2 ** 31 - 512          # what one weight-gradient launch may address per map
+
+
 def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None, want_bias=False):
     """x_framed (B, H + 2, W + 2, Cin), dy_framed (B, H + 2, W + 2, Cout) with a zero frame, both bf16 or both f32 -> the filter
     gradient (Cout, c_in_real, 3, 3) f32 (c_in_real <= Cin: the input layer's padding channels are dropped) [, the bias gradient
@@ -489,6 +492,18 @@ def conv3x3_wgrad_bf16(x_framed, dy_framed, c_in_real=None, want_bias=False):
     ws_fn = lib().mv3d_conv3x3_wgrad_f32_workspace_bytes if f32 else lib().mv3d_conv3x3_wgrad_workspace_bytes
     fn, name = (lib().mv3d_conv3x3_wgrad_f32, "mv3d_conv3x3_wgrad_f32") if f32 else (lib().mv3d_conv3x3_wgrad_bf16, "mv3d_conv3x3_wgrad_bf16")
     creal = cin if c_in_real is None else int(c_in_real)
+    # the kernel addresses each map with 32-bit offsets: the gradient is a sum over the frames, so a larger batch goes in chunks
+    per_frame = Hp * Wp * max(cin, cout) * x_framed.element_size()
+    step = max(1, _WGRAD_CHUNK_BYTES // per_frame)
+    if B > step:
+        dw = db = None
+        for b0 in range(0, B, step):
+            r = conv3x3_wgrad_bf16(x_framed[b0:b0 + step], dy_framed[b0:b0 + step], creal, want_bias=want_bias)
+            w_, b_ = r if want_bias else (r, None)
+            dw = w_ if dw is None else dw.add_(w_)
+            if want_bias:
+                db = b_ if db is None else db.add_(b_)
+        return (dw, db) if want_bias else dw
     need = ws_fn(B, Hp - 2, Wp - 2, cin, cout)
     if need == 0:
         raise _lib.Mv3dError(_lib.ERR_INVALID_ARG, name + "_workspace_bytes")

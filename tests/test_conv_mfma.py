@@ -149,6 +149,22 @@ def test_large_batches_are_split_into_chunks(gpu, monkeypatch):
     assert calls == [1, 1, 1, 1, 1] and torch.equal(got, want)
 
 
+def test_weight_gradient_of_a_large_batch_is_summed_over_chunks(gpu, monkeypatch):
+    """maps beyond the kernel's 32-bit offsets were refused; the wrapper now sums the gradient over batch chunks (here
+    forced by a tiny limit) -- same values up to the f32 summation order"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, H, W = 5, 12, 20
+    x = ops.frame_nhwc_f16(torch.randn((B, H, W, 64), device="cuda", generator=g), ops.framed_buffer(B, H, W, 64, "cuda", torch.bfloat16))
+    dy = ops.frame_nhwc_f16(torch.randn((B, H, W, 128), device="cuda", generator=g), ops.framed_buffer(B, H, W, 128, "cuda", torch.bfloat16))
+    want_w, want_b = ops.conv3x3_wgrad_bf16(x, dy, want_bias=True)
+    monkeypatch.setattr(ops, "_WGRAD_CHUNK_BYTES", 2 * (H + 2) * (W + 2) * 128 * 2)          # two frames per launch
+    got_w, got_b = ops.conv3x3_wgrad_bf16(x, dy, want_bias=True)
+    assert float((got_w - want_w).abs().max()) <= 1e-4 * float(want_w.abs().max())
+    assert float((got_b - want_b).abs().max()) <= 1e-4 * float(want_b.abs().max())
+
+
 def test_bad_arguments_are_refused(gpu):
     torch = gpu
     from mv3d_tf_amd import _lib, ops
