@@ -490,7 +490,12 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
         // work -- the latency of a batch-1 frame (BASELINE configs[1]) is these layers' tile time, not their throughput
         long tiles128 = 0;
         for (int k = 0; k < num_views; ++k) tiles128 += (long)((g.v[k].M + 127) / 128) * (c_out / 128);
-        if (tiles128 < 512) return launch_conv<T, 64, 128, 2, 2, 2, false>(g, out_f32, s);
+#ifdef MV3D_TUNING
+        static const int small_max = getenv("MV3D_CONV_SMALL_MAX") ? atoi(getenv("MV3D_CONV_SMALL_MAX")) : 512;
+#else
+        const int small_max = 512;
+#endif
+        if (tiles128 < small_max) return launch_conv<T, 64, 128, 2, 2, 2, false>(g, out_f32, s);
         // many tiles and 16-bit maps out: 256 x 256 workgroups of 8 waves, each wave a 128-pixel x 64-cout tile -- per matrix
         // instruction half the DMA pieces and 3/4 of the LDS operand reads of the 128 x 128 / 64 x 64 form (one workgroup per CU:
         // 128 KB of LDS).  Batch-16 serving layers: conv4_2 954 -> 1063 TFLOP/s, conv3_2 848 -> 911, image conv4_2 988 -> 1020;

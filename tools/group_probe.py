@@ -6,9 +6,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mv3d_tf_amd import build, ops  # noqa: E402
+from mv3d_tf_amd import _lib, build, ops  # noqa: E402
 
-build.build()
+if "--lib" in sys.argv:                      # an experiment build of the library (tools only)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+else:
+    build.build()
 DT = torch.float32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else torch.bfloat16
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 VIEWS = [("bev", 608, 608), ("rgb", 375, 1242), ("fv", 64, 512)]
