@@ -63,7 +63,6 @@ class MV3D:
         self.mfma_trunk = False
         self._mfma = None
         self._train_pool = None
-        self._fc_cast = {}
         self._wcache = {}
         self.params = {}
         g = torch.Generator().manual_seed(seed)
@@ -187,7 +186,7 @@ class MV3D:
             return F.relu(y) if relu else y
         if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)
             x = x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
-        w, b = self._fc_cast.get(name) or self.params[name]         # (16-bit copies made while the host drew, see forward())
+        w, b = self.params[name]
         with self._amp():
             y = F.linear(x, w, b)
             return F.relu(y) if relu else y
@@ -291,15 +290,7 @@ class MV3D:
             # behind one launch per kernel; the subsampling draws come from the numpy global RNG, frame by frame
             gt = [tuple(t.reshape(-1, c).contiguous() for t, c in zip(g, (5, 7, 25))) for g in self._gt_frames(L, B)]
             path = self._train_path(B, h, w, max(int(g[0].shape[0]) for g in gt))
-            slot = path.submit(prob, pred, info, cal, gt)
-            # the device would idle while the host waits for stage 1's counts and draws (~0.2 - 0.3 ms): give it the 16-bit casts of
-            # the FC head's weights (214 M parameters' worth of autocast copies, 0.3 ms) that the towers need anyway
-            self._fc_cast = {}
-            if self.amp_dtype is not None and torch.is_grad_enabled():
-                for name in [n for n in self.params if n.startswith(("fc6", "fc7", "cls_score", "bbox_pred"))]:
-                    wq, bq = self.params[name]
-                    self._fc_cast[name] = (wq.to(self.amp_dtype), bq.to(self.amp_dtype))
-            out = path.finish(slot)                                                   # (views of the slot's buffers: valid for two steps)
+            out = path.finish(path.submit(prob, pred, info, cal, gt))                 # (views of the slot's buffers: valid for two steps)
             L["roi_rows"] = out["S"]
             bvb, imgb, b3b = out["proposals"][:3]
             cnt = out["num_proposals"]
@@ -350,5 +341,4 @@ class MV3D:
         L["cls_score"] = self._fc(fused, "cls_score", relu=False).float()
         L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
         L["bbox_pred"] = self._fc(fused, "bbox_pred", relu=False).float()
-        self._fc_cast = {}
         return L
