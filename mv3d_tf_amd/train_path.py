@@ -225,6 +225,18 @@ class TrainPathStream:
             s.future = self._helper.submit(self._host_stage, s)
         return s
 
+    def close(self):
+        """stop the helper thread (idempotent; the stream object stays usable with async_draws falling back to finish())"""
+        h, self._helper = self._helper, None
+        if h is not None:
+            h.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _host_stage(self, s):
         """wait for the batch's reports, then draw (helper thread, or finish() itself with async_draws = False)"""
         t0 = time.perf_counter()
