@@ -293,7 +293,7 @@ def cpu_baseline(ring, workload, seconds):
                                         key, "+bwd" if workload == "train" else "")}
 
 
-def fresh_inputs_line(rank, variant, seconds=1.5):
+def fresh_inputs_line(rank, variant, seconds=1.5, depth=3, nstreams=3):
     """The training path on FRESH inputs: every batch brings new RPN heads / ground truth / feature maps (a pool of 8 resident
     input batches, each processed as new: stage 1 -> counts to the host -> numpy-global-RNG draws -> index lists back -> stage
     2 -> RoiPool forward + backward on its ROIs), batch i + 1 submitted before batch i is finished so that the device never
@@ -309,13 +309,15 @@ def fresh_inputs_line(rank, variant, seconds=1.5):
         pool.append(((t(np.concatenate([f[0] for f in frames])), t(np.concatenate([f[1] for f in frames])),
                       t(np.concatenate([f[2] for f in frames])), t(np.stack([f[3] for f in frames])),
                       [tuple(t(a) for a in f[4]) for f in frames]), hot_path.synth_maps(B, 900 + k, dev)))
-    # (one stream: per-slot streams -- TrainPathStream(streams=...) -- were measured and change nothing here: 5.9 - 6.1 k frames/s
-    # either way, the submitting thread's own ~0.3 ms of Python per batch is the limit, not the device and not the draws)
-    path = TrainPathStream(B, 76, 76, dev, depth=2)
+    # `depth` batches in flight, slot k on stream k % nstreams: a batch is one submit / finish pair of the C object mv3d_train_path
+    # (csrc/train_stream.hip) plus the two RoiPool calls, so the host no longer limits the path and the batches in flight overlap on
+    # the device the way the resident replay's three streams do
+    streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams else None
+    path = TrainPathStream(B, 76, 76, dev, depth=depth, streams=streams)
     cap = B * path.roi_cap
     g = torch.Generator(device=dev).manual_seed(5)
     bufs = []
-    for _ in range(2):
+    for _ in range(depth):
         d = {}
         for v in hot_path.VIEWS:
             H, W, Cc = hot_path.VIEW_MAPS[v]
@@ -356,12 +358,12 @@ def fresh_inputs_line(rank, variant, seconds=1.5):
         check(L.mv3d_roi_pool_backward_views(NV, bwd, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "mv3d_roi_pool_backward_views")
 
     def run(nb):
-        slot = path.submit(*pool[0][0])
+        flight = [path.submit(*pool[j % POOL][0]) for j in range(min(depth - 1, nb))]
         for i in range(nb):
-            nxt = path.submit(*pool[(i + 1) % POOL][0]) if i + 1 < nb else None
-            out = path.finish(slot)
-            roi(out, pool[i % POOL][1], bufs[i % 2], (i % POOL, i % 2))
-            slot = nxt
+            if i + depth - 1 < nb:
+                flight.append(path.submit(*pool[(i + depth - 1) % POOL][0]))
+            out = path.finish(flight.pop(0))
+            roi(out, pool[i % POOL][1], bufs[i % depth], (i % POOL, i % depth))
 
     np.random.seed(7 + rank)
     run(8)
@@ -371,18 +373,20 @@ def fresh_inputs_line(rank, variant, seconds=1.5):
     torch.cuda.synchronize()
     per = (time.perf_counter() - t0) / 40
     nb = max(40, int(seconds / per))
-    path.t_draw = path.t_wait = 0.0
+    path.host_seconds
     t0 = time.perf_counter()
     run(nb)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    t_wait, t_draw = path.host_seconds
+    path.close()
     return {"workload": "the default line's training path on FRESH inputs (mv3d_tf_amd.train_path.TrainPathStream): new heads / "
                         "ground truth / maps every batch of 2 frames, one host round trip per batch for the numpy-global-RNG "
-                        "subsampling draws (exactly the reference's, draw for draw), batch i + 1 submitted before batch i is "
-                        "finished; RoiPool fwd + bwd of the 3 views on the batch's ROIs; 1 stream, eager launches",
+                        "subsampling draws (exactly the reference's, draw for draw) on the library's helper thread, %d batches "
+                        "in flight on %d stream(s); RoiPool fwd + bwd of the 3 views on the batch's ROIs; eager launches" % (depth, max(nstreams, 1)),
             "frames_per_s": round(nb * B / dt, 2), "batches_timed": nb,
-            "host_draw_ms_per_frame": round(path.t_draw / (nb * B) * 1e3, 4),
-            "host_wait_for_device_ms_per_frame": round(path.t_wait / (nb * B) * 1e3, 4),
+            "host_draw_ms_per_frame": round(t_draw / (nb * B) * 1e3, 4),
+            "host_wait_for_device_ms_per_frame": round(t_wait / (nb * B) * 1e3, 4),
             "bound": "host: the legacy RandomState.permutation of every candidate list (~21 k background anchors per frame, twice) "
                      "is the reference's subsampling contract; one process draws for one GPU"}
 

@@ -354,6 +354,74 @@ typedef struct {
 int mv3d_draw_training_subsamples(void *mt19937_state, int batch, const mv3d_draw_frame *frames, const mv3d_draw_params *par,
                                   int32_t *lists, size_t lists_cap, int32_t *sizes, int32_t *scratch, size_t scratch_cap);
 
+/* ------------------------------------------------------------------ the training path on fresh frames, driven from C
+ * One object runs what lib/networks/MV3D_train.py:83-112 wires behind the RPN heads for every training batch --
+ *   proposal_layer_3d (TRAIN cfg)      lib/rpn_msr/proposal_layer_tf.py:25-202       = mv3d_proposal_3d
+ *   anchor_target_layer                lib/rpn_msr/anchor_target_layer_tf.py:21-250  = mv3d_anchor_target_stage1/2_batch
+ *   proposal_target_layer_3d           lib/rpn_msr/proposal_target_layer_tf.py:19-94 = mv3d_proposal_target_stage1/2_batch_devn
+ * -- with the reference's host-side subsampling draws (mv3d_draw_training_subsamples on numpy's global generator) in between:
+ *   submit()  enqueues every launch up to the candidate lists on `stream`, the copies of the counts to the slot's pinned host
+ *             buffers and an event; returns at once.
+ *   a helper thread owned by the object (created with helper_thread = 1) waits for that event, draws -- slots strictly in
+ *             submission order, so the generator's stream is the reference's: frame by frame, anchor targets before proposal
+ *             targets -- uploads the index lists and enqueues stage 2 on the same stream.
+ *   finish()  waits until the slot's stage 2 is ENQUEUED (not executed) and reports the frames' row counts; the outputs are in the
+ *             slot's buffers, ordered on the stream given to submit().  With helper_thread = 0 finish() does the helper's work itself.
+ * A caller keeps up to `depth` batches in flight (submit batch i + 1 before finish of batch i): the host's draws of one batch then run
+ * while the device works on its neighbours, and a batch costs its caller two calls.  Between submit() and finish() of a slot the
+ * generator behind `mt19937_state` belongs to the object.  All buffers are the caller's (layouts: see the per-entry comments above;
+ * B = batch <= 16, N = 4 H W anchors, cap = mv3d_proposal_3d_capacity): the object allocates only events and its thread. */
+typedef struct {
+    int32_t batch, H, W, num_classes;
+    int32_t proposal_cap;          /* mv3d_proposal_3d_capacity(H, W, &proposal): rows per frame of the proposal blobs */
+    int32_t anchor_cap;            /* rows per frame of anchors / anchors_3d */
+    int32_t roi_cap;               /* rows per frame of the sampled-ROI outputs (cfg.TRAIN.BATCH_SIZE) */
+    int32_t max_gt;                /* ground-truth boxes per frame the workspaces were sized for */
+    mv3d_proposal_params proposal;
+    mv3d_anchor_target_params anchor;
+    mv3d_proposal_target_params target;      /* thresholds (frame_index is set per frame by the object) */
+    mv3d_draw_params draw;
+} mv3d_train_path_config;
+typedef struct {
+    /* device */
+    float *blob_bv, *blob_img, *blob_3d;     /* proposals (B,cap,5) (B,cap,5) (B,cap,7) */
+    int32_t *num_proposals;                  /* (2 B): the frames' proposal counts, then mv3d_proposal_3d's status words */
+    void *proposal_ws; size_t proposal_ws_bytes;
+    float *rpn_labels, *rpn_targets;         /* (B,N) (B,N,6) */
+    float *anchors, *anchors_3d;             /* (B,anchor_cap,5) (B,anchor_cap,7) */
+    int32_t *n_anchors;                      /* (B) */
+    uint8_t *report; size_t report_row;      /* (B,report_row): per frame [counts 32 B | foreground flags N B], report_row % 256 == 0 */
+    int32_t *pt_counts;                      /* (B,4) */
+    void *anchor_ws; size_t anchor_ws_bytes; /* B workspaces back to back, each anchor_ws_bytes (a multiple of 256) */
+    void *target_ws; size_t target_ws_bytes; /* the same for the proposal-target workspaces */
+    float *rois_bev, *rois_rgb, *rois_fv;    /* (B roi_cap,5) each, frame b's rows behind frame b - 1's; rois_fv may be NULL */
+    float *rois_3d; int32_t *labels; float *bbox_targets;    /* (B roi_cap,7) (B roi_cap) (B roi_cap, 24 num_classes) */
+    int32_t *lists; size_t lists_cap;        /* the index lists of a batch, int32 words: >= B (3 N + 2 (cap + max_gt)) */
+    /* host (pinned, except h_scratch) */
+    uint8_t *h_report; size_t h_report_row;  /* (B,h_report_row): the first h_report_row <= report_row bytes of every report row */
+    int32_t *h_pt_counts;                    /* (B,4) */
+    int32_t *h_num_proposals;                /* (2 B) */
+    int32_t *h_lists;                        /* lists_cap words */
+    int32_t *h_scratch; size_t scratch_cap;  /* >= max(N, cap + max_gt) words: one permutation at its largest */
+} mv3d_train_path_slot;
+typedef struct mv3d_train_path mv3d_train_path;
+int mv3d_train_path_create(const mv3d_train_path_config *config, int depth, const mv3d_train_path_slot *slots, int helper_thread,
+                           mv3d_train_path **out);
+/* replace the parameter structs (thresholds, NMS settings, draw sizes; the geometry must be unchanged); no slot may be in flight */
+int mv3d_train_path_configure(mv3d_train_path *path, const mv3d_train_path_config *config);
+/* prob (B,H,W,8), pred (B,H,W,24), im_info (B,3), calib (B,4,12): device f32; gt_*: host arrays of B device pointers -- gt_bv (G,5),
+ * gt_3d (G,7), gt_corners (G,25) -- and G (B) with 1 <= G[b] <= max_gt.  The inputs must stay valid until finish() has returned. */
+int mv3d_train_path_submit(mv3d_train_path *path, int slot, const float *prob_dev, const float *pred_dev, const float *im_info_dev,
+                           const float *calib_dev, const float *const *gt_bv_dev, const float *const *gt_3d_dev,
+                           const float *const *gt_corners_dev, const int *G, void *mt19937_state, void *stream);
+/* rows_out (B): sampled ROIs per frame (frame b's rows start at the sum of the frames before it); num_proposals_out (B); sizes_out
+ * (5 B, may be NULL): the lengths of the drawn lists as mv3d_draw_training_subsamples reports them.  Returns the first error of the
+ * slot's host stage (MV3D_ERR_ZERO_DIVISION where the reference's NMS raises); the slot is free again either way. */
+int mv3d_train_path_finish(mv3d_train_path *path, int slot, int32_t *rows_out, int32_t *num_proposals_out, int32_t *sizes_out);
+/* host seconds the helper spent waiting for stage 1 / drawing since the last call (diagnostics); either pointer may be NULL */
+int mv3d_train_path_host_seconds(mv3d_train_path *path, double *wait_s, double *draw_s);
+void mv3d_train_path_destroy(mv3d_train_path *path);     /* waits for the slots in flight, joins the thread */
+
 /* KITTI label rows -> ground-truth encodings (lib/datasets/kitti_mv3d.py:240-272 with computeCorners3D, camera_to_lidar_cnr,
  * lidar_cnr_to_3d, lidar_3d_to_bv of lib/utils/transform.py:441-465,502-524,172-187,113-142), one thread per labelled object:
  *   box_cam_dev (G,6) f32 [tx,ty,tz,l,w,h] (label columns 11-13, 10, 9, 8), cos_sin_dev (G,2) f64 = cos / sin of rotation_y,

@@ -61,6 +61,26 @@ class DrawParams(C.Structure):
     _fields_ = [("rpn_batchsize", C.c_int32), ("rpn_num_fg", C.c_int32), ("rois_per_image", C.c_int32), ("roi_fg_max", C.c_int32)]
 
 
+class TrainPathConfig(C.Structure):
+    """mv3d_train_path_config"""
+    _fields_ = [("batch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("num_classes", C.c_int32), ("proposal_cap", C.c_int32),
+                ("anchor_cap", C.c_int32), ("roi_cap", C.c_int32), ("max_gt", C.c_int32), ("proposal", ProposalParams),
+                ("anchor", AnchorTargetParams), ("target", ProposalTargetParams), ("draw", DrawParams)]
+
+
+class TrainPathSlot(C.Structure):
+    """mv3d_train_path_slot"""
+    _fields_ = [("blob_bv", C.c_void_p), ("blob_img", C.c_void_p), ("blob_3d", C.c_void_p), ("num_proposals", C.c_void_p),
+                ("proposal_ws", C.c_void_p), ("proposal_ws_bytes", C.c_size_t), ("rpn_labels", C.c_void_p), ("rpn_targets", C.c_void_p),
+                ("anchors", C.c_void_p), ("anchors_3d", C.c_void_p), ("n_anchors", C.c_void_p), ("report", C.c_void_p),
+                ("report_row", C.c_size_t), ("pt_counts", C.c_void_p), ("anchor_ws", C.c_void_p), ("anchor_ws_bytes", C.c_size_t),
+                ("target_ws", C.c_void_p), ("target_ws_bytes", C.c_size_t), ("rois_bev", C.c_void_p), ("rois_rgb", C.c_void_p),
+                ("rois_fv", C.c_void_p), ("rois_3d", C.c_void_p), ("labels", C.c_void_p), ("bbox_targets", C.c_void_p),
+                ("lists", C.c_void_p), ("lists_cap", C.c_size_t), ("h_report", C.c_void_p), ("h_report_row", C.c_size_t),
+                ("h_pt_counts", C.c_void_p), ("h_num_proposals", C.c_void_p), ("h_lists", C.c_void_p), ("h_scratch", C.c_void_p),
+                ("scratch_cap", C.c_size_t)]
+
+
 class ConvView(C.Structure):
     """mv3d_conv_view"""
     _fields_ = [("x_framed", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("gate_framed", C.c_void_p), ("y", C.c_void_p),
@@ -135,6 +155,12 @@ _SIGS = {
     "mv3d_legacy_permutation": (C.c_int, [_P, C.c_int32, _P]),
     "mv3d_draw_training_subsamples": (C.c_int, [_P, C.c_int, C.POINTER(DrawFrame), C.POINTER(DrawParams), _P, C.c_size_t, _P, _P,
                                                 C.c_size_t]),
+    "mv3d_train_path_create": (C.c_int, [C.POINTER(TrainPathConfig), C.c_int, C.POINTER(TrainPathSlot), C.c_int, C.POINTER(C.c_void_p)]),
+    "mv3d_train_path_configure": (C.c_int, [_P, C.POINTER(TrainPathConfig)]),
+    "mv3d_train_path_submit": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mv3d_train_path_finish": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "mv3d_train_path_host_seconds": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mv3d_train_path_destroy": (None, [_P]),
     "mv3d_gt_encode": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mv3d_conv3x3_f16": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_conv3x3_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -14,39 +14,29 @@ so a batch costs ONE host round trip, and it is taken off the device's critical 
     submit(...)   stage 1 of a batch: every launch up to the candidate lists, then the counts (and the foreground flags the
                   third anchor draw needs) travel to PINNED host memory behind an event; the proposals' number never leaves
                   the device (`*_devn` entries).  Returns at once.
-    finish(slot)  waits for that event only, draws, uploads the index lists (one pinned buffer, one copy), launches stage 2
+    host stage    waits for that event only, draws, uploads the index lists (one pinned buffer, one copy), launches stage 2
                   into fixed-capacity ROI buffers (frame b's rows behind frame b - 1's, S <= B * cfg.TRAIN.BATCH_SIZE).
+    finish(slot)  waits until the host stage has ENQUEUED stage 2 and returns the batch's tensors.
 
 With `depth` slots a caller submits batch i + 1 before it finishes batch i: the device works on batch i's stage 2 / RoiPool
-(and, in the train graph, the dense layers) while the host draws.  What remains is the host's own work: the legacy
-`RandomState.permutation` shuffles every candidate (21 k background anchors per frame, twice).  Since round 4 that loop runs
-in C on numpy's own generator state (mv3d_draw_training_subsamples, csrc/legacy_rng.hip: one call per batch, lists written
-straight into pinned memory, ~2x numpy's own loop and none of its per-call Python); `draw_subsamples_host` /
-`draw_samples_host` below are the numpy statement of the same draws (tests compare the two, draw for draw)."""
+(and, in the train graph, the dense layers) while the host draws.  Since round 4 the whole sequence is C
+(`mv3d_train_path_*`, csrc/train_stream.hip): submit() and finish() are ONE library call each, the host stage runs on a helper
+thread the library owns, and the legacy `RandomState.permutation` shuffles (21 k background anchors per frame, twice) run in C
+on numpy's own generator state (`mv3d_draw_training_subsamples`, csrc/legacy_rng.hip).  Between submit() and finish() of a slot
+the numpy global RNG belongs to the path (any other draw in that window would interleave with the batch's).
+`draw_subsamples_host` / `draw_samples_host` below are the numpy statement of the same draws (tests compare the two, draw for
+draw)."""
 import ctypes as C
-import time
 
 import numpy as np
 import numpy.random as npr
 import torch
 
 from . import ops
-from ._lib import AnchorTargetParams, DrawFrame, DrawParams, ProposalTargetParams, check, lib
+from ._lib import AnchorTargetParams, DrawParams, ProposalTargetParams, TrainPathConfig, TrainPathSlot, check, lib
 from .fast_rcnn.config import cfg
 
 _HEAD = 4096                       # bytes of (counts + foreground flags) per frame that travel with the first copy
-
-
-def _P(t):
-    return C.c_void_p(0 if t is None else t.data_ptr())
-
-
-def _ptrs(ts):
-    return (C.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
-
-
-def _ints(vs):
-    return (C.c_int * len(vs))(*[int(v) for v in vs])
 
 
 def draw_subsamples_host(head, n_fg_flags_fetch, N):
@@ -88,6 +78,11 @@ class _Slot:
 
 
 class TrainPathStream:
+    """Python face of the C object `mv3d_train_path` (include/mv3d_hip.h, csrc/train_stream.hip): this class allocates the slots'
+    buffers (torch tensors: device memory and pinned host memory), hands their addresses over once, and then costs its caller
+    ONE C call per submit() and one per finish(); the launches, the copies, the event, the draws and the helper thread live in
+    the library.  `async_draws=False` builds the object without its helper thread (finish() then does the host stage itself)."""
+
     def __init__(self, B, H, W, device, num_classes=2, depth=2, max_gt=64, want_fv=True, stream=None, async_draws=True, streams=None):
         self.B, self.H, self.W, self.dev, self.nc = int(B), int(H), int(W), torch.device(device), int(num_classes)
         self.N = self.H * self.W * 4
@@ -100,30 +95,47 @@ class TrainPathStream:
         self.streams = list(streams) if streams else None
         self.max_gt = int(max_gt)
         T = cfg.TRAIN
-        self.pparams = ops.proposal_params(T)
-        self.aparams = AnchorTargetParams(8, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP),
-                                          float(T.RPN_POSITIVE_OVERLAP))
         self.anchor_cap = max(int(T.RPN_BATCHSIZE), 1) * 2
         self.roi_cap = int(T.BATCH_SIZE)
         L = lib()
+        self.pparams = ops.proposal_params(T)
         self.cap = L.mv3d_proposal_3d_capacity(self.H, self.W, C.byref(self.pparams))
         if self.cap < 0:
             check(1, "mv3d_proposal_3d_capacity")
-        self.slots = [self._make_slot() for _ in range(int(depth))]
+        self._cfg_key, self._config = self._make_config()
+        self.slots = [self._make_slot(k) for k in range(int(depth))]
         for k, sl_ in enumerate(self.slots):
             sl_.stream = self.streams[k % len(self.streams)] if self.streams else self.stream
-        self._next = 0
-        self.t_wait = self.t_draw = 0.0                  # host seconds spent waiting for stage 1 / drawing (diagnostics)
-        # The host stage of a batch (wait for its reports, draw) runs on ONE helper thread, in submission order: the event wait and
-        # the C draws release the GIL, so the submitting thread keeps enqueueing launches meanwhile.  Between submit() and finish()
-        # of a slot the numpy global RNG belongs to the path (any other draw in that window would interleave with the batch's).
-        self._helper = None
+        self._slots_c = (TrainPathSlot * len(self.slots))(*[sl_.c for sl_ in self.slots])
+        self._h = C.c_void_p()
         self.async_draws = bool(async_draws)
+        with torch.cuda.device(self.dev):
+            check(L.mv3d_train_path_create(C.byref(self._config), len(self.slots), self._slots_c, 1 if self.async_draws else 0,
+                                           C.byref(self._h)), "mv3d_train_path_create")
+        self._next = 0
+        self._mt = None
+
+    # ------------------------------------------------------------------ parameters (cfg may change between batches: cfg_from_file)
+    def _make_config(self):
+        T = cfg.TRAIN
+        rois_per_image = int(T.BATCH_SIZE) // 1
+        key = (float(T.FG_THRESH), float(T.BG_THRESH_HI), float(T.BG_THRESH_LO), int(T.RPN_BATCHSIZE), float(T.RPN_FG_FRACTION),
+               float(T.FG_FRACTION), rois_per_image, bool(T.RPN_CLOBBER_POSITIVES), float(T.RPN_NEGATIVE_OVERLAP), float(T.RPN_POSITIVE_OVERLAP))
+        c = TrainPathConfig()
+        c.batch, c.H, c.W, c.num_classes = self.B, self.H, self.W, self.nc
+        c.proposal_cap, c.anchor_cap, c.roi_cap, c.max_gt = self.cap, self.anchor_cap, self.roi_cap, self.max_gt
+        c.proposal = self.pparams
+        c.anchor = AnchorTargetParams(8, 1 if T.RPN_CLOBBER_POSITIVES else 0, float(T.RPN_NEGATIVE_OVERLAP), float(T.RPN_POSITIVE_OVERLAP))
+        c.target = ProposalTargetParams(self.nc, 0, float(T.FG_THRESH), float(T.BG_THRESH_HI), float(T.BG_THRESH_LO))
+        c.draw = DrawParams(int(T.RPN_BATCHSIZE), int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE), rois_per_image,
+                            int(np.round(T.FG_FRACTION * rois_per_image)))
+        return key, c
 
     # ------------------------------------------------------------------ buffers of one batch in flight
-    def _make_slot(self):
+    def _make_slot(self, index):
         B, H, W, N, dev, nc, L = self.B, self.H, self.W, self.N, self.dev, self.nc, lib()
         s = _Slot()
+        s.index = index
         e = lambda shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
         s.pack, s.prop = ops.proposal_3d_outputs(B, self.cap, dev)
         s.tail = s.pack[s.pack.numel() - 2 * B:].view(torch.int32)             # [proposal counts (B) | status words (B)], contiguous
@@ -136,12 +148,10 @@ class TrainPathStream:
         s.row = (32 + N + 255) // 256 * 256
         s.report = e((B, s.row), torch.uint8)
         s.pt_counts = e((B, 4), torch.int32)                                  # (written in place by stage 1, fetched as it lies)
-        awsz = max(L.mv3d_anchor_target_workspace_bytes(H, W, self.max_gt), 256)
-        s.aws = [e((awsz,), torch.uint8) for _ in range(B)]
-        s.awsz = awsz
-        twsz = max(L.mv3d_proposal_target_workspace_bytes(self.cap, self.max_gt), 256)
-        s.tws = [e((twsz,), torch.uint8) for _ in range(B)]
-        s.twsz = twsz
+        s.awsz = (max(L.mv3d_anchor_target_workspace_bytes(H, W, self.max_gt), 256) + 255) // 256 * 256
+        s.aws = e((B, s.awsz), torch.uint8)
+        s.twsz = (max(L.mv3d_proposal_target_workspace_bytes(self.cap, self.max_gt), 256) + 255) // 256 * 256
+        s.tws = e((B, s.twsz), torch.uint8)
         S = B * self.roi_cap
         s.rois = {"bev": e((S, 5)), "rgb": e((S, 5)), "fv": e((S, 5))}
         s.rois_3d, s.labels, s.bbox_targets = e((S, 7)), e((S, 1), torch.int32), e((S, 24 * nc))
@@ -153,83 +163,65 @@ class TrainPathStream:
         s.list_cap = B * (3 * N + 2 * (self.cap + self.max_gt))                   # every index list at its largest
         s.h_lists = torch.empty((s.list_cap,), dtype=torch.int32).pin_memory()
         s.h_scratch = torch.empty((max(N, self.cap + self.max_gt) + 64,), dtype=torch.int32)      # one permutation at its largest
-        s.frames_c, s.sizes_c = (DrawFrame * B)(), (C.c_int32 * (5 * B))()
         s.d_lists = e((s.list_cap,), torch.int32)
-        s.event = torch.cuda.Event()
-        # argument arrays that never change
-        s.a_cnt = _ptrs([s.report[b, :32] for b in range(B)])
-        s.a_fgh = _ptrs([s.report[b, 32:] for b in range(B)])
-        s.a_ws = _ptrs(s.aws)
-        s.p_bv = _ptrs([s.prop[0][b] for b in range(B)])
-        s.p_b3 = _ptrs([s.prop[2][b] for b in range(B)])
-        s.p_cap = _ints([self.cap] * B)
-        s.p_num = _ptrs([s.prop[3][b:b + 1] for b in range(B)])
-        s.p_cnt = _ptrs([s.pt_counts[b] for b in range(B)])
-        s.p_ws = _ptrs(s.tws)
-        s.p_wsz = (C.c_size_t * B)(*[twsz] * B)
-        s.tpar = (ProposalTargetParams * B)(*[ProposalTargetParams(nc, b, float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
-                                                                   float(cfg.TRAIN.BG_THRESH_LO)) for b in range(B)])
+        bv, img, b3, num, status = s.prop
+        assert s.tail.data_ptr() == num.data_ptr() and status.data_ptr() == num.data_ptr() + 4 * B
+        c = s.c = TrainPathSlot()
+        c.blob_bv, c.blob_img, c.blob_3d, c.num_proposals = bv.data_ptr(), img.data_ptr(), b3.data_ptr(), s.tail.data_ptr()
+        c.proposal_ws, c.proposal_ws_bytes = s.pws.data_ptr(), s.pws.numel()
+        c.rpn_labels, c.rpn_targets, c.anchors, c.anchors_3d = (t.data_ptr() for t in (s.rpn_labels, s.rpn_targets, s.anchors, s.anchors_3d))
+        c.n_anchors, c.report, c.report_row, c.pt_counts = s.n_anchors.data_ptr(), s.report.data_ptr(), s.row, s.pt_counts.data_ptr()
+        c.anchor_ws, c.anchor_ws_bytes, c.target_ws, c.target_ws_bytes = s.aws.data_ptr(), s.awsz, s.tws.data_ptr(), s.twsz
+        c.rois_bev, c.rois_rgb = s.rois["bev"].data_ptr(), s.rois["rgb"].data_ptr()
+        c.rois_fv = s.rois["fv"].data_ptr() if self.want_fv else None
+        c.rois_3d, c.labels, c.bbox_targets = s.rois_3d.data_ptr(), s.labels.data_ptr(), s.bbox_targets.data_ptr()
+        c.lists, c.lists_cap = s.d_lists.data_ptr(), s.list_cap
+        c.h_report, c.h_report_row, c.h_pt_counts, c.h_num_proposals = s.h_report.data_ptr(), head, s.h_small.data_ptr(), s.h_tail.data_ptr()
+        c.h_lists, c.h_scratch, c.scratch_cap = s.h_lists.data_ptr(), s.h_scratch.data_ptr(), s.h_scratch.numel()
+        s.rows_c, s.nprop_c, s.sizes_c = (C.c_int32 * B)(), (C.c_int32 * B)(), (C.c_int32 * (5 * B))()
         s.busy = False
         return s
-
-    def _sid(self, s):
-        return C.c_void_p((s.stream or torch.cuda.current_stream()).cuda_stream)
 
     # ------------------------------------------------------------------ stage 1
     def submit(self, prob, pred, im_info, calib, gt):
         """prob (B,H,W,8), pred (B,H,W,24), im_info (B,3), calib (B,4,12): device f32 tensors; gt: list (len B) of (gt_bv
         (G,5), gt_3d (G,7), gt_corners (G,25)) device tensors.  Returns the slot handle for finish()."""
-        B, H, W, L = self.B, self.H, self.W, lib()
+        B, L = self.B, lib()
         s = self.slots[self._next]
-        self._next = (self._next + 1) % len(self.slots)
         if s.busy:
             raise RuntimeError("TrainPathStream: every slot is in flight (finish() one first, or raise `depth`)")
-        s.busy = True
-        if s.stream is not None:
-            s.stream.wait_stream(torch.cuda.current_stream())            # the inputs were produced on the caller's stream
-        st = self._sid(s)
         G = [int(g[0].shape[0]) for g in gt]
-        if max(G) > self.max_gt or min(G) <= 0:
+        if len(G) != B or max(G) > self.max_gt or min(G) <= 0:
             # (no box at all: the reference's anchor_target_layer takes argmax over an empty axis and raises as well --
             # filter_roidb keeps such frames out of training; more than max_gt: build the stream with a larger `max_gt`, as
             # networks/mv3d.py does on demand)
-            s.busy = False
-            raise ValueError("TrainPathStream: 1 .. max_gt = %d ground-truth boxes per frame, got %s" % (self.max_gt, G))
-        # torch's cfg thresholds may have changed since the slot was built (cfg_from_file): refresh the parameter structs
-        for b in range(B):
-            s.tpar[b].fg_thresh, s.tpar[b].bg_thresh_hi, s.tpar[b].bg_thresh_lo = (float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI),
-                                                                                  float(cfg.TRAIN.BG_THRESH_LO))
+            raise ValueError("TrainPathStream: %d frames with 1 .. max_gt = %d ground-truth boxes each, got %s" % (B, self.max_gt, G))
+        key, conf = self._make_config()                                  # cfg's thresholds may have changed since the last batch
+        if key != self._cfg_key:
+            if any(sl_.busy for sl_ in self.slots):
+                raise RuntimeError("TrainPathStream: cfg.TRAIN changed while a batch is in flight")
+            check(L.mv3d_train_path_configure(self._h, C.byref(conf)), "mv3d_train_path_configure")
+            self._cfg_key, self._config = key, conf
+        self._next = (self._next + 1) % len(self.slots)
+        if s.stream is not None:
+            s.stream.wait_stream(torch.cuda.current_stream())            # the inputs were produced on the caller's stream
+        st = (s.stream or torch.cuda.current_stream()).cuda_stream
         s.inputs = (prob, pred, im_info, calib, gt)                              # (kept alive until finish())
         s.G = G
-        bv, img, b3, num, status = s.prop
-        check(L.mv3d_proposal_3d(_P(prob), _P(pred), B, H, W, _P(im_info), _P(calib), C.byref(self.pparams), _P(bv), _P(img), _P(b3),
-                                 _P(num), _P(status), _P(s.pws), C.c_size_t(s.pws.numel()), st), "mv3d_proposal_3d")
-        s.a_gtbv, s.a_gt3d, s.a_gtc = _ptrs([g[0] for g in gt]), _ptrs([g[1] for g in gt]), _ptrs([g[2] for g in gt])
-        s.a_G = _ints(G)
-        check(L.mv3d_anchor_target_stage1_batch(B, H, W, _P(im_info), s.a_gtbv, s.a_gt3d, s.a_G, C.byref(self.aparams), _P(s.rpn_labels),
-                                                _P(s.rpn_targets), s.a_cnt, s.a_fgh, s.a_ws, C.c_size_t(s.awsz), st),
-              "mv3d_anchor_target_stage1_batch")
-        check(L.mv3d_proposal_target_stage1_batch_devn(B, s.p_bv, s.p_b3, s.p_cap, s.p_num, s.a_gtbv, s.a_gt3d, s.a_G, s.tpar, s.p_cnt,
-                                                       s.p_ws, s.p_wsz, st), "mv3d_proposal_target_stage1_batch_devn")
-        ctx = torch.cuda.stream(s.stream) if s.stream is not None else _Null()
-        with ctx:
-            s.h_report.copy_(s.report[:, :s.h_report.shape[1]], non_blocking=True)      # three device-to-host copies, no kernel
-            s.h_small.copy_(s.pt_counts, non_blocking=True)
-            s.h_tail.copy_(s.tail, non_blocking=True)
-            s.event.record()
-        s.future = None
-        if self.async_draws:
-            if self._helper is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._helper = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mv3d-draws")
-            s.future = self._helper.submit(self._host_stage, s)
+        if self._mt is None:
+            self._mt = npr.mtrand._rand._bit_generator.ctypes.state_address     # the numpy GLOBAL legacy RandomState's MT19937
+        PP = C.c_void_p * B
+        check(L.mv3d_train_path_submit(self._h, s.index, prob.data_ptr(), pred.data_ptr(), im_info.data_ptr(), calib.data_ptr(),
+                                       PP(*[g[0].data_ptr() for g in gt]), PP(*[g[1].data_ptr() for g in gt]),
+                                       PP(*[g[2].data_ptr() for g in gt]), (C.c_int * B)(*G), self._mt, st), "mv3d_train_path_submit")
+        s.busy = True
         return s
 
     def close(self):
-        """stop the helper thread (idempotent; the stream object stays usable with async_draws falling back to finish())"""
-        h, self._helper = self._helper, None
-        if h is not None:
-            h.shutdown(wait=True)
+        """destroy the C object: waits for the batches in flight, joins the helper thread (idempotent)"""
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().mv3d_train_path_destroy(h)
 
     def __del__(self):
         try:
@@ -237,106 +229,23 @@ class TrainPathStream:
         except Exception:
             pass
 
-    def _host_stage(self, s):
-        """wait for the batch's reports, then draw (helper thread, or finish() itself with async_draws = False)"""
-        t0 = time.perf_counter()
-        s.event.synchronize()                                          # the batch's reports are on the host
-        t1 = time.perf_counter()
-        small = s.h_small.numpy()
-        if int(s.h_tail.numpy()[self.B:].max()) & 1:
-            raise ZeroDivisionError("float division")
-        res = self._draw(s, small)
-        self.t_wait += t1 - t0
-        self.t_draw += time.perf_counter() - t1
-        return res
-
-    # ------------------------------------------------------------------ the host's draws
-    def _draw(self, s, small):
-        """Every subsampling draw of the batch -- frame by frame, anchor targets before proposal targets, exactly the draws of
-        `draw_subsamples_host` / `draw_samples_host` -- by ONE C call (mv3d_draw_training_subsamples, csrc/legacy_rng.hip) that
-        shuffles on the memory of numpy's own global generator and writes the index lists straight into the slot's pinned
-        buffer; ctypes releases the GIL for its duration.  Returns (sizes[5 B], offsets[5 B], total)."""
-        B, N, T = self.B, self.N, cfg.TRAIN
-        head = s.h_report.numpy()
-        hsz = head.shape[1]
-        keep = []
-        for b in range(B):
-            n_inside, n_fg, n_bg, n_low = (int(v) for v in head[b, :16].view(np.int32))
-            if 32 + n_fg <= hsz:
-                flags = s.h_report.data_ptr() + b * hsz + 32
-            else:                                                     # (more positives than travel with the first copy: rare)
-                full = np.ascontiguousarray(s.report[b, 32:32 + n_fg].cpu().numpy())
-                keep.append(full)
-                flags = full.ctypes.data
-            s.frames_c[b] = DrawFrame(n_fg, n_bg, n_low, int(small[b, 1]), int(small[b, 2]), 0, flags)
-        rois_per_image = int(T.BATCH_SIZE) // 1
-        par = DrawParams(int(T.RPN_BATCHSIZE), int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE), rois_per_image,
-                         int(np.round(T.FG_FRACTION * rois_per_image)))
-        gen = npr.mtrand._rand._bit_generator                          # the numpy GLOBAL legacy RandomState's MT19937
-        with gen.lock:
-            rc = lib().mv3d_draw_training_subsamples(C.c_void_p(gen.ctypes.state_address), B, s.frames_c, C.byref(par),
-                                                     C.c_void_p(s.h_lists.data_ptr()), s.list_cap, s.sizes_c,
-                                                     C.c_void_p(s.h_scratch.data_ptr()), s.h_scratch.numel())
-        check(rc, "mv3d_draw_training_subsamples")
-        sizes = list(s.sizes_c)
-        offs, o = [], 0
-        for n in sizes:
-            offs.append(o)
-            o += n
-        return sizes, offs, o
+    @property
+    def host_seconds(self):
+        """(seconds the host stage waited for stage 1, seconds it drew) since the last read"""
+        w, d = C.c_double(), C.c_double()
+        check(lib().mv3d_train_path_host_seconds(self._h, C.byref(w), C.byref(d)), "mv3d_train_path_host_seconds")
+        return w.value, d.value
 
     # ------------------------------------------------------------------ host draws + stage 2
     def finish(self, s):
         """Returns a dict of device tensors: rpn_labels (B,N), rpn_targets (B,N,6), anchors / anchors_3d / n_anchors,
         rois {bev, rgb, fv} (S,5) with the frame index in column 0, rois_3d (S,7), labels (S,1) i32, bbox_targets (S,24 nc),
         S (list of the frames' row counts), num_proposals (list)."""
-        B, H, W, N, L = self.B, self.H, self.W, self.N, lib()
-        try:
-            sizes, offs, total = s.future.result() if s.future is not None else self._host_stage(s)
-        except Exception:
-            s.busy = False
-            raise
-        ctx = torch.cuda.stream(s.stream) if s.stream is not None else _Null()
-        with ctx:
-            if total:
-                s.d_lists[:total].copy_(s.h_lists[:total], non_blocking=True)
-        st = self._sid(s)
-        # argument arrays by pointer arithmetic (a torch slice per pointer cost more host time than the launches they feed)
-        lists0 = s.d_lists.data_ptr()
-        lp = lambda k: (lists0 + 4 * offs[k]) if sizes[k] else 0
-        vp = lambda ps: (C.c_void_p * len(ps))(*ps)
-        a_d = [vp([lp(5 * b + k) for b in range(B)]) for k in range(3)]
-        a_n = [_ints([sizes[5 * b + k] for b in range(B)]) for k in range(3)]
-        check(L.mv3d_anchor_target_stage2_batch(B, H, W, C.byref(self.aparams), a_d[0], a_n[0], a_d[1], a_n[1], a_d[2], a_n[2],
-                                                _P(s.rpn_labels), _P(s.anchors), _P(s.anchors_3d), _P(s.n_anchors), self.anchor_cap,
-                                                s.a_ws, C.c_size_t(s.awsz), st), "mv3d_anchor_target_stage2_batch")
-        n_fg = [sizes[5 * b + 3] for b in range(B)]
-        n_bg = [sizes[5 * b + 4] for b in range(B)]
-        S = [n_fg[b] + n_bg[b] for b in range(B)]
-        off = [0]
-        for v in S:
-            off.append(off[-1] + v)
-        rows = lambda t: vp([(t.data_ptr() + off[b] * t.stride(0) * t.element_size()) if S[b] else 0 for b in range(B)])
-        prob, pred, im_info, calib, gt = s.inputs
-        p_cal = vp([calib.data_ptr() + b * calib.stride(0) * calib.element_size() for b in range(B)])
-        p_fg, p_bg = vp([lp(5 * b + 3) for b in range(B)]), vp([lp(5 * b + 4) for b in range(B)])
-        outs = [rows(s.rois["bev"]), rows(s.rois["rgb"]), rows(s.labels), rows(s.bbox_targets), rows(s.rois_3d)]
-        p_fv = rows(s.rois["fv"]) if self.want_fv else None
-        check(L.mv3d_proposal_target_stage2_batch_devn(B, s.p_bv, s.p_b3, s.p_cap, s.p_num, s.a_gtbv, s.a_gt3d, s.a_gtc, s.a_G, p_cal,
-                                                       s.tpar, p_fg, _ints(n_fg), p_bg, _ints(n_bg), outs[0], outs[1], outs[2], outs[3],
-                                                       outs[4], p_fv, s.p_ws, s.p_wsz, st), "mv3d_proposal_target_stage2_batch_devn")
-        St = int(off[-1])
-        s.keep = (a_d, a_n, p_cal, p_fg, p_bg, outs, p_fv)                       # (argument arrays outlive the launches)
         s.busy = False
+        check(lib().mv3d_train_path_finish(self._h, s.index, s.rows_c, s.nprop_c, s.sizes_c), "mv3d_train_path_finish")
+        S = list(s.rows_c)
+        St = sum(S)
         return {"rpn_labels": s.rpn_labels, "rpn_targets": s.rpn_targets, "anchors": s.anchors, "anchors_3d": s.anchors_3d,
                 "n_anchors": s.n_anchors, "rois": {k: v[:St] for k, v in s.rois.items()}, "rois_3d": s.rois_3d[:St],
                 "labels": s.labels[:St], "bbox_targets": s.bbox_targets[:St], "S": S,
-                "num_proposals": [int(v) for v in s.h_tail.numpy()[:B]], "proposals": s.prop, "stream": s.stream}
-
-
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
+                "num_proposals": list(s.nprop_c), "proposals": s.prop, "stream": s.stream, "draw_sizes": list(s.sizes_c)}

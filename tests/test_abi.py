@@ -71,6 +71,26 @@ def test_workspace_queries_and_argument_validation(hiplib):
     assert L.mv3d_frame_nhwc_f16(A, A, 1, 8, 8, 9, 8, None) == hiplib.ERR_INVALID_ARG
 
 
+def test_train_path_object_rejects_bad_arguments_before_any_device_call(hiplib):
+    """mv3d_train_path_*: configuration and slot tables are checked on the host (no GPU needed to be refused)"""
+    import ctypes as C
+    L = hiplib.lib()
+    conf, slot, h = hiplib.TrainPathConfig(), hiplib.TrainPathSlot(), C.c_void_p()
+    assert L.mv3d_train_path_create(C.byref(conf), 1, C.byref(slot), 1, C.byref(h)) == hiplib.ERR_INVALID_ARG       # batch 0
+    conf.batch, conf.H, conf.W, conf.num_classes, conf.proposal_cap, conf.anchor_cap, conf.roi_cap, conf.max_gt = 2, 76, 76, 2, 2000, 512, 128, 64
+    conf.draw = hiplib.DrawParams(256, 128, 128, 32)
+    assert L.mv3d_train_path_create(C.byref(conf), 1, C.byref(slot), 1, C.byref(h)) == hiplib.ERR_INVALID_ARG       # NULL buffers
+    conf.draw = hiplib.DrawParams(256, 128, 256, 32)                                                                 # more rows than roi_cap
+    assert L.mv3d_train_path_create(C.byref(conf), 1, C.byref(slot), 1, C.byref(h)) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_train_path_create(C.byref(conf), 0, C.byref(slot), 1, C.byref(h)) == hiplib.ERR_INVALID_ARG
+    assert not h.value
+    assert L.mv3d_train_path_finish(None, 0, None, None, None) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_train_path_submit(None, 0, *([None] * 10)) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_train_path_configure(None, C.byref(conf)) == hiplib.ERR_INVALID_ARG
+    assert L.mv3d_train_path_host_seconds(None, None, None) == hiplib.ERR_INVALID_ARG
+    L.mv3d_train_path_destroy(None)
+
+
 def test_missing_library_fails_loudly(hiplib, monkeypatch, tmp_path):
     monkeypatch.setattr(hiplib, "_lib", None)
     monkeypatch.setattr(hiplib, "LIB_PATH", str(tmp_path / "libmv3d_hip.so"))

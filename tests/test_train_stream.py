@@ -92,16 +92,61 @@ def test_fresh_batches_pipelined_vs_oracle(gpu, oracle, yml):
             cfg.TRAIN[k] = v
 
 
+@pytest.mark.parametrize("helper", [True, False])
+def test_host_stage_without_helper_thread_and_with_spilled_flags(gpu, oracle, helper, monkeypatch):
+    """The C object's host stage (a) run by finish() itself (helper_thread = 0) and (b) with a report head too small for a frame's
+    foreground flags (the flags are then fetched from the device before the third anchor draw): same outputs, draw for draw."""
+    torch = gpu
+    from mv3d_tf_amd import train_path
+    monkeypatch.setattr(train_path, "_HEAD", 32 + 8)                    # 8 flags travel with the counts; the frames have more positives
+    dev = torch.device("cuda")
+    B = 2
+    path = train_path.TrainPathStream(B, 76, 76, dev, depth=2, async_draws=helper)
+    frames = [synth.rpn_head(5200 + b, 76, 76, "peaky", return_gt=True) for b in range(B)]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+    args = (t(np.concatenate([f[0] for f in frames])), t(np.concatenate([f[1] for f in frames])), t(np.concatenate([f[2] for f in frames])),
+            t(np.stack([f[3] for f in frames])), [tuple(t(a) for a in f[4]) for f in frames])
+    np.random.seed(33)
+    out = path.finish(path.submit(*args))
+    torch.cuda.synchronize()
+    state_after = np.random.get_state()[1].copy()
+    np.random.seed(33)
+    off = 0
+    for b in range(B):
+        w = _oracle_frame(oracle, frames[b], b, dict(oracle.TRAIN))
+        assert np.array_equal(out["rpn_labels"][b].cpu().numpy(), w["labels"])
+        m = int(out["n_anchors"][b])
+        assert m == w["anchors"].shape[0] and np.array_equal(out["anchors"][b, :m].cpu().numpy(), w["anchors"])
+        S = w["rois_bv"].shape[0]
+        assert out["S"][b] == S and np.array_equal(out["rois"]["bev"][off:off + S].cpu().numpy(), w["rois_bv"])
+        assert np.array_equal(out["bbox_targets"][off:off + S].cpu().numpy(), w["rois_tg"])
+        off += S
+    assert np.array_equal(np.random.get_state()[1], state_after)         # the generator ends where the reference's draws leave it
+    # a slot can be submitted only once before it is finished; finish() of an idle slot is refused by the library
+    s0 = path.submit(*args)
+    s1 = path.submit(*args)
+    with pytest.raises(RuntimeError):
+        path.submit(*args)
+    path.finish(s0), path.finish(s1)
+    from mv3d_tf_amd._lib import Mv3dError
+    with pytest.raises(Mv3dError):
+        path.finish(s0)
+    path.close()
+    path.close()
+
+
 def test_batch2_train_graph_uses_batched_entries_and_matches_oracle(gpu, oracle):
     torch = gpu
     from mv3d_tf_amd import _lib
     from mv3d_tf_amd.fast_rcnn.train_mv import total_loss
     from mv3d_tf_amd.networks import get_network
     L_ = _lib.lib()
-    counted = ("mv3d_proposal_3d", "mv3d_anchor_target_stage1_batch", "mv3d_anchor_target_stage2_batch",
-               "mv3d_proposal_target_stage1_batch_devn", "mv3d_proposal_target_stage2_batch_devn", "mv3d_roi_pool_forward_views",
-               "mv3d_roi_pool_backward_views", "mv3d_roi_pool_forward", "mv3d_roi_pool_backward", "mv3d_anchor_target_stage1",
-               "mv3d_proposal_target_stage1")
+    # (the target layers + proposal layer of a batch are ONE submit / finish pair of the C object mv3d_train_path, which issues the
+    # batched entries itself; none of the per-frame or per-stage entries is called from Python any more)
+    counted = ("mv3d_train_path_submit", "mv3d_train_path_finish", "mv3d_roi_pool_forward_views", "mv3d_roi_pool_backward_views",
+               "mv3d_proposal_3d", "mv3d_anchor_target_stage1_batch", "mv3d_anchor_target_stage2_batch",
+               "mv3d_proposal_target_stage1_batch_devn", "mv3d_proposal_target_stage2_batch_devn",
+               "mv3d_roi_pool_forward", "mv3d_roi_pool_backward", "mv3d_anchor_target_stage1", "mv3d_proposal_target_stage1")
     calls, orig = {k: [] for k in counted}, {}
     for name in counted:
         orig[name] = getattr(L_, name)
@@ -130,11 +175,11 @@ def test_batch2_train_graph_uses_batched_entries_and_matches_oracle(gpu, oracle)
         loss.backward()
         torch.cuda.synchronize()
         # ---- every hot-path layer of the step ran ONCE, through the batched / multi-view entries
-        for name in counted[:7]:
+        for name in counted[:4]:
             assert len(calls[name]) == 1, (name, len(calls[name]))
-        for name in counted[7:]:
+        for name in counted[4:]:
             assert len(calls[name]) == 0, (name, len(calls[name]))
-        assert calls["mv3d_proposal_3d"][0][2] == B and calls["mv3d_anchor_target_stage1_batch"][0][0] == B
+        assert len(L["roi_rows"]) == B
         assert calls["mv3d_roi_pool_forward_views"][0][0] == 2
         bw = calls["mv3d_roi_pool_backward_views"][0]
         assert bw[0] == 2 and bw[4].value not in (None, 0) and bw[5] > 0        # the workspace (indexed gather) path
