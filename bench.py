@@ -63,11 +63,12 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="frames per batch per GPU (default: 2 for train, 16 for test)")
     ap.add_argument("--ring", type=int, default=0, help="distinct resident batches per GPU (default: 16 train, 4 test)")
     ap.add_argument("--batches-per-step", type=int, default=0, help="batches per step (default: 1664 train, 208 test)")
-    ap.add_argument("--streams", type=int, default=3)
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="graph: every ring batch is captured once into a hipGraph on its stream and replayed (one host call "
-                         "per batch; eager enqueueing of a batch's ~28 launches costs the host more than the GPU needs to run "
-                         "them once three batches are in flight); eager: plain in-order launches")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams = batches in flight (default: 8 for --launch path, 3 otherwise)")
+    ap.add_argument("--launch", default="path", choices=["path", "graph", "eager"],
+                    help="path (train workload's default): the product's own driver, mv3d_train_path + RoiPool, on the ring's inputs -- "
+                         "nothing of a batch precomputed, the subsampling draws inside the timed region; graph: every ring batch "
+                         "(index lists drawn during set-up) is captured once into a hipGraph on its stream and replayed; eager: the "
+                         "same frozen batches as plain in-order launches from Python")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
@@ -114,27 +115,118 @@ class Ring:
                 self.host_frames = frames
         self.cursor = 0
         self.play = [s.run for s in self.slots]
+        self.driver = None
+        if args.launch == "path" and workload == "train":
+            # the PRODUCT's own driver (mv3d_train_path, csrc/train_stream.hip) on the ring's inputs and maps: nothing of a batch is
+            # precomputed -- stage 1, the counts' trip to the host, the numpy-global-RNG draws, stage 2, RoiPool forward + backward
+            self.driver = PathDriver([(s.prob, s.pred, s.info, s.calib, s.gt) for s in self.slots], [s.maps for s in self.slots],
+                                     depth=max(1, args.streams))
         if args.launch == "graph":
-            self.graphs = []
-            for s in self.slots:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s.stream):           # the bound launches target s.stream = the capture stream
-                    s.run()
-                self.graphs.append(g)
-            torch.cuda.synchronize()
+            self.make_graphs()
 
-            def player(g, st):
-                def play():
-                    with torch.cuda.stream(st):                       # CUDAGraph.replay() launches on the current stream
-                        g.replay()
-                return play
-            self.play = [player(g, s.stream) for g, s in zip(self.graphs, self.slots)]
+    def make_graphs(self):
+        """every ring batch captured once into a hipGraph on its stream; run() then replays (the resident-replay figure)"""
+        self.graphs = []
+        for s in self.slots:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s.stream):               # the bound launches target s.stream = the capture stream
+                s.run()
+            self.graphs.append(g)
+        torch.cuda.synchronize()
+
+        def player(g, st):
+            def play():
+                with torch.cuda.stream(st):                           # CUDAGraph.replay() launches on the current stream
+                    g.replay()
+            return play
+        self.play = [player(g, s.stream) for g, s in zip(self.graphs, self.slots)]
+        self.driver = None
 
     def run(self, nbatches):
+        if self.driver is not None:
+            return self.driver.run(nbatches)
         n = len(self.slots)
         for _ in range(nbatches):
             self.play[self.cursor % n]()
             self.cursor += 1
+
+
+class PathDriver:
+    """The training path as a caller drives it: `depth` batches in flight through mv3d_tf_amd.train_path.TrainPathStream (one
+    submit / finish pair of the C object mv3d_train_path per batch; the library's helper thread draws on numpy's global generator,
+    draw for draw the reference's), slot k on its own HIP stream, RoiPool forward + backward of the three views on the batch's
+    sampled ROIs behind it on the same stream.  Inputs and maps are the caller's resident tensors (a ring of distinct batches)."""
+
+    def __init__(self, inputs, maps, depth, cold=True, seed=5):
+        import ctypes as C
+        from mv3d_tf_amd import hot_path
+        from mv3d_tf_amd._lib import RoiGradView, RoiView, check, lib
+        from mv3d_tf_amd.train_path import TrainPathStream
+        self.inputs, self.maps, self.depth = inputs, maps, int(depth)
+        dev = inputs[0][0].device
+        B = int(inputs[0][0].shape[0])
+        self.B = B
+        self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
+        self.path = TrainPathStream(B, int(inputs[0][0].shape[1]), int(inputs[0][0].shape[2]), dev, depth=self.depth, streams=self.streams)
+        cap = self.cap = B * self.path.roi_cap
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.bufs = []
+        for _ in range(self.depth):
+            d = {}
+            for v in hot_path.VIEWS:
+                H, W, Cc = hot_path.VIEW_MAPS[v]
+                d[v] = (torch.empty((cap, 7, 7, Cc), device=dev), torch.empty((cap, 7, 7, Cc), dtype=torch.int32, device=dev),
+                        torch.rand((cap, 7, 7, Cc), generator=g, device=dev) * 2.0 - 1.0, torch.empty((B, H, W, Cc), device=dev))
+            self.bufs.append(d)
+        self.C, self.L, self.check, self.views = C, lib(), check, hot_path.VIEWS
+        self.fwd_fn = self.L.mv3d_roi_pool_forward_views_cold if cold else self.L.mv3d_roi_pool_forward_views
+        self.fwd_name = "mv3d_roi_pool_forward_views_cold" if cold else "mv3d_roi_pool_forward_views"
+        self.RoiView, self.RoiGradView = RoiView, RoiGradView
+        self.structs = {}
+        self.cursor = 0
+        self.rows = 0
+
+    def roi(self, out, k):
+        """RoiPool forward + backward on the batch's ROIs: the argument structs of a (maps, slot) combination are built once (every
+        buffer has the slots' fixed capacity), a batch only sets its row count -- a caller's steady state, no per-batch slicing"""
+        C, L, NV = self.C, self.L, len(self.views)
+        St = out["rois"]["bev"].shape[0]
+        j = k % self.depth                                       # the slot (and its buffers / stream) this batch went through
+        key = (k % len(self.inputs), j)
+        hit = self.structs.get(key)
+        if hit is None:
+            maps, d = self.maps[key[0]], self.bufs[j]
+            fwd, bwd = (self.RoiView * NV)(), (self.RoiGradView * NV)()
+            for i, v in enumerate(self.views):
+                Bm, H, W, Cc = maps[v].shape
+                r = out["rois"][v].data_ptr()
+                fwd[i] = self.RoiView(maps[v].data_ptr(), r, d[v][0].data_ptr(), d[v][1].data_ptr(), 0.125, Bm, self.cap, H, W, Cc)
+                bwd[i] = self.RoiGradView(d[v][3].data_ptr(), r, d[v][2].data_ptr(), d[v][1].data_ptr(), 0.125, Bm, self.cap, H, W, Cc)
+            ws = self.bufs[j].get("ws")
+            if ws is None:
+                wsz = L.mv3d_roi_pool_backward_workspace_bytes(NV, bwd, 7, 7)
+                ws = self.bufs[j]["ws"] = torch.zeros(max(wsz, 256), dtype=torch.uint8, device=maps[self.views[0]].device)
+            hit = self.structs[key] = (fwd, bwd, ws)
+        fwd, bwd, ws = hit
+        for i in range(NV):
+            fwd[i].num_rois = St
+            bwd[i].num_rois = St
+        st = C.c_void_p(out["stream"].cuda_stream)
+        self.check(self.fwd_fn(NV, fwd, 7, 7, st), self.fwd_name)
+        self.check(L.mv3d_roi_pool_backward_views(NV, bwd, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "mv3d_roi_pool_backward_views")
+        self.rows += St
+
+    def run(self, nb):
+        path, n, k0 = self.path, len(self.inputs), self.cursor
+        flight = [path.submit(*self.inputs[(k0 + j) % n]) for j in range(min(self.depth - 1, nb))]
+        for i in range(nb):
+            if i + self.depth - 1 < nb:
+                flight.append(path.submit(*self.inputs[(k0 + i + self.depth - 1) % n]))
+            self.roi(path.finish(flight.pop(0)), k0 + i)
+        self.cursor = k0 + nb
+
+    def close(self):
+        self.path.close()
 
 
 def events_ms(stream, fns, rounds):
@@ -445,7 +537,13 @@ def main():
     batch = args.batch or (2 if wl == "train" else 16)
     nb = args.batches_per_step or (1664 if wl == "train" else 208)
     ring_n = args.ring or (16 if wl == "train" else 4)
-    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    if wl != "train" and args.launch == "path":
+        args.launch = "graph"                          # (the TEST-cfg path has no host stage: the frozen batch IS the path)
+    if args.streams <= 0:
+        # (8: the runtime multiplexes streams onto 4 hardware queues -- 4 / 6 / 10 streams measured 12.2 - 12.7 k frames/s, 8 / 12 / 16
+        # 13.6 - 13.75 k; GPU_MAX_HW_QUEUES=8 is slower)
+        args.streams = 8 if args.launch == "path" else 3
+    streams = [torch.cuda.Stream() for _ in range(max(1, min(args.streams, 3) if args.launch == "path" else args.streams))]
     ring = Ring(args, rank, wl, batch, ring_n, streams)
     dt, t_enq = timed(ring, nb, args.steps, args.warmup, barrier)
     dt = sharding.max_over_ranks(dt, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
@@ -456,8 +554,11 @@ def main():
         if wl == "train":
             desc = ("BASELINE configs[2] path-only: batch %d, 3 views; proposal_layer_3d TRAIN cfg (23104 BEV anchors, "
                     "pre/post-NMS 12000/2000, NMS 0.7) + anchor_target + proposal_target (%d sampled ROIs in batch 0) + FV ROIs "
-                    "+ RoiPool 7x7 fwd+bwd on BEV 76x76x512 / RGB 46x155x512 / FV 8x64x512; %s scores"
-                    % (batch, s0.num_rois, args.variant))
+                    "+ RoiPool 7x7 fwd+bwd on BEV 76x76x512 / RGB 46x155x512 / FV 8x64x512; %s scores; %s"
+                    % (batch, s0.num_rois, args.variant,
+                       "driven by the library's own mv3d_train_path (submit -> counts to the host -> numpy-global-RNG draws on the helper "
+                       "thread -> stage 2) + RoiPool on the sampled ROIs, %d batches in flight, one HIP stream each" % args.streams
+                       if args.launch == "path" else "frozen batches (index lists drawn during set-up), %s launches" % args.launch))
         else:
             desc = ("BASELINE configs[4] per-GPU path: batch %d, TEST cfg (pre/post-NMS 6000/300, NMS 0.7) proposal_layer_3d + FV "
                     "ROIs + RoiPool 7x7 fwd on 3 views, R=%d rows; %s scores" % (batch, s0.num_rois, args.variant))
@@ -467,7 +568,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": batch, "batches_per_step": nb, "frames_per_step_per_gpu": nb * batch,
-                       "ring_batches": ring_n, "streams": len(streams), "hipgraph": args.launch == "graph", "timed_region_s": round(dt, 3),
+                       "ring_batches": ring_n, "streams": args.streams, "launch": args.launch, "hipgraph": args.launch == "graph",
+                       "host_draws_in_timed_region": args.launch == "path", "timed_region_s": round(dt, 3),
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
         }
         # one batch alone on one stream: the latency of the path
@@ -488,23 +590,45 @@ def main():
             res["cpu_baseline"] = cpu_baseline(ring, wl, args.cpu_seconds)
     if not args.no_secondary and wl == "train":
         sec = {}
-        del ring
-        torch.cuda.empty_cache()
-        if not args.no_fresh:
+        if not args.no_fresh and args.launch == "path":
+            # the figure rounds 1-4 headlined: the same ring with every batch's index lists drawn during set-up, each batch one
+            # hipGraph replayed on three streams (no host stage inside the timed region)
+            host = ring.driver.path.host_seconds
+            ring.driver.close()
+            ring.make_graphs()
+            dt_r, _ = timed(ring, nb, 3, 1, barrier)
+            rep = sharding.sum_over_ranks(3 * nb * batch / dt_r, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            if rank == 0:
+                sec["resident_replay"] = {"frames_per_s": round(rep, 2), "launch": "hipGraph replay of frozen batches, 3 streams",
+                                          "note": "rounds 1-4 reported this as `value`: index lists of the two target layers drawn during "
+                                                  "set-up and resident, so no host stage in the timed region"}
+                nfr = (args.steps + args.warmup) * nb * batch
+                sec["fresh_inputs"] = {"frames_per_s": res["value"], "fraction_of_resident_replay": round(res["value"] / rep, 4),
+                                       "host_draw_ms_per_frame": round(host[1] / nfr * 1e3, 4),
+                                       "host_wait_for_device_ms_per_frame": round(host[0] / nfr * 1e3, 4),
+                                       "note": "= the headline since round 4 (the path on new inputs, draws in the loop); host_* = the "
+                                               "library's helper thread on rank 0: drawing / waiting for a batch's stage 1"}
+        elif not args.no_fresh:
             fr = fresh_inputs_line(rank, args.variant)
             fr["frames_per_s"] = round(sharding.sum_over_ranks(fr["frames_per_s"], dist, device="cuda" if args.dist_backend == "nccl" else "cpu"), 2)
             if rank == 0:
                 fr["fraction_of_resident_replay"] = round(fr["frames_per_s"] / res["value"], 4)
                 sec["fresh_inputs"] = fr
             torch.cuda.empty_cache()
+        if ring.driver is not None:
+            ring.driver.close()
+        del ring
+        torch.cuda.empty_cache()
         args2 = argparse.Namespace(**vars(args))
+        if args2.launch == "path":
+            args2.launch = "graph"
         r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
         nb2, st2 = 48, max(2, args.steps // 2)
         dt2, _ = timed(r2, nb2, st2, 1, barrier)
         dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
         if rank == 0:
             sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
-                                           "views, ring of 3 batches on the step's streams (%s launches)" % args.launch,
+                                           "views, ring of 3 batches on the step's streams (%s launches)" % args2.launch,
                                "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
                                "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
         del r2

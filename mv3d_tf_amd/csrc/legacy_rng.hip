@@ -55,31 +55,42 @@ inline uint32_t mt_next(MtState *s)
 // RandomState.permutation(n) into x[0 .. n).  The reference loop per element is "draw until (draw & mask) <= i, swap": its
 // rejection branch (taken ~1 in 4 draws) is unpredictable, so the loop is written per DRAW instead and branch-free: a rejected
 // draw swaps x[i] with itself and does not advance i.  Same draws, same swaps, same generator state afterwards.
+// Two more things keep the loop-carried chain short (it is what bounds the path on fresh frames: ~45 k shuffled elements per
+// frame on ONE generator): the mask only changes when i crosses a power of two, so the loop runs segment by segment with the
+// mask loop-invariant (the chain through i is then compare + subtract), and the tempering of a block of generator words is
+// done ahead of the shuffle in a loop of its own that the compiler vectorises.
 void permutation(MtState *s, int32_t n, int32_t *x)
 {
     for (int32_t i = 0; i < n; ++i) x[i] = i;
     int32_t i = n - 1;
     int pos = s->pos;
+    uint32_t t[MT_N];
+    int t_lo = MT_N;                                                 // t[t_lo .. MT_N) = tempered key[t_lo .. MT_N) of the current block
     while (i >= 1) {
-        if (pos == MT_N) { mt_gen(s); pos = 0; }
-        int room = MT_N - pos;                                   // draws left in this block of generator words
-        const uint32_t *k = s->key + pos;
-        int used = 0;
-        while (used < room && i >= 1) {
-            uint32_t y = k[used++];
-            y ^= (y >> 11);
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= (y >> 18);
-            const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);      // smallest all-ones mask >= i (i >= 1)
-            const uint32_t j = y & mask;
-            const bool ok = j <= (uint32_t)i;
-            const uint32_t jj = ok ? j : (uint32_t)i;
-            const int32_t a = x[i], b = x[jj];
-            x[i] = b; x[jj] = a;
-            i -= ok ? 1 : 0;
+        const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);          // smallest all-ones mask >= i (i >= 1)
+        const int32_t lo = (int32_t)(mask >> 1);                     // the mask serves i in (lo, mask]
+        while (i > lo) {
+            if (pos == MT_N) { mt_gen(s); pos = 0; t_lo = MT_N; }
+            if (t_lo > pos) {
+                for (int k = pos; k < MT_N; ++k) {
+                    uint32_t y = s->key[k];
+                    y ^= (y >> 11);
+                    y ^= (y << 7) & 0x9d2c5680u;
+                    y ^= (y << 15) & 0xefc60000u;
+                    y ^= (y >> 18);
+                    t[k] = y;
+                }
+                t_lo = pos;
+            }
+            while (pos < MT_N && i > lo) {
+                const uint32_t j = t[pos++] & mask;
+                const bool ok = j <= (uint32_t)i;
+                const uint32_t jj = ok ? j : (uint32_t)i;
+                const int32_t a = x[i], b = x[jj];
+                x[i] = b; x[jj] = a;
+                i -= ok ? 1 : 0;
+            }
         }
-        pos += used;
     }
     s->pos = pos;
 }

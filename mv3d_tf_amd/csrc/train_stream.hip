@@ -233,7 +233,9 @@ extern "C" int mv3d_train_path_create(const mv3d_train_path_config *config, int 
         Slot &s = tp->slots[k];
         s.buf = slots[k];
         slot_tables(tp->cfg, s);
-        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) {
+        // (blocking sync: the helper sleeps while it waits for a batch's reports instead of spinning on a core -- one process per GPU
+        // on a node shares the host's cores with seven others; with several batches in flight the wake-up latency is hidden)
+        if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) {
             for (int j = 0; j < k; ++j) (void)hipEventDestroy(tp->slots[j].ev);
             delete tp;
             return MV3D_ERR_HIP;

@@ -21,7 +21,7 @@ def bench(monkeypatch):
 
 def test_defaults_match_the_driver_contract(bench, monkeypatch):
     a = bench.parse()
-    assert (a.gpus, a.workload, a.launch, a.streams) == (1, "train", "graph", 3) and a.steps > 0 and a.warmup >= 0
+    assert (a.gpus, a.workload, a.launch, a.streams) == (1, "train", "path", 0) and a.steps > 0 and a.warmup >= 0
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
