@@ -113,7 +113,6 @@ class TrainPathStream:
             check(L.mv3d_train_path_create(C.byref(self._config), len(self.slots), self._slots_c, 1 if self.async_draws else 0,
                                            C.byref(self._h)), "mv3d_train_path_create")
         self._next = 0
-        self._mt = None
 
     # ------------------------------------------------------------------ parameters (cfg may change between batches: cfg_from_file)
     def _make_config(self):
@@ -208,12 +207,11 @@ class TrainPathStream:
         st = (s.stream or torch.cuda.current_stream()).cuda_stream
         s.inputs = (prob, pred, im_info, calib, gt)                              # (kept alive until finish())
         s.G = G
-        if self._mt is None:
-            self._mt = npr.mtrand._rand._bit_generator.ctypes.state_address     # the numpy GLOBAL legacy RandomState's MT19937
+        mt = npr.mtrand._rand._bit_generator.ctypes.state_address               # the numpy GLOBAL legacy RandomState's MT19937
         PP = C.c_void_p * B
         check(L.mv3d_train_path_submit(self._h, s.index, prob.data_ptr(), pred.data_ptr(), im_info.data_ptr(), calib.data_ptr(),
                                        PP(*[g[0].data_ptr() for g in gt]), PP(*[g[1].data_ptr() for g in gt]),
-                                       PP(*[g[2].data_ptr() for g in gt]), (C.c_int * B)(*G), self._mt, st), "mv3d_train_path_submit")
+                                       PP(*[g[2].data_ptr() for g in gt]), (C.c_int * B)(*G), mt, st), "mv3d_train_path_submit")
         s.busy = True
         return s
 
