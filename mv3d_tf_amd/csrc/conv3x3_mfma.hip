@@ -137,7 +137,10 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
     int sx = 0, sw = 0, tapv = 0;                                 // source offsets of the step being fetched (next())
     char *dst = lds;
     auto next = [&](const int kt) __attribute__((always_inline)) {
-        sx = FIRST ? 0 : ((ty * Wp + tx) * a.Cin + cc * CPS) * ES;
+        // (readfirstlane: the compiler keeps the loop-carried tap / slice counters in vector registers and, without it, wraps EVERY
+        // X-side `buffer_load ... lds` of a K step in a waterfall loop -- readfirstlane, compare, saveexec, load, branch -- to
+        // legalise the scalar offset: four such loops per step sat between the barrier and the step's first MFMA)
+        sx = FIRST ? 0 : __builtin_amdgcn_readfirstlane(((ty * Wp + tx) * a.Cin + cc * CPS) * ES);
         sw = wrow0 + kt * BK_BYTES;
         dst = lds + (kt % STAGES) * STAGE;
         if (FIRST) {                                              // this lane's tap of the step (per lane, not per step)

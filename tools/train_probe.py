@@ -6,6 +6,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:                      # an experiment build of the library (tools only)
+    from mv3d_tf_amd import _lib
+    _i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[_i + 1])
+    del sys.argv[_i:_i + 2]
 from mv3d_tf_amd.fast_rcnn.train_mv import bench_train_step  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bf16_mfma"
