@@ -199,9 +199,18 @@ def bench_conv_layers(vgg, batch=16, reps=3, dtype=torch.float16):
     nconv += 1
     ach = tot_fl / tot_ms / 1e9
     best = max(per.items(), key=lambda kv: kv[1]["tflops"])
+    # what a plain library GEMM reaches on THIS box right now (torch.matmul = hipBLASLt, 8192 x 4608 x 8192, randn operands): the
+    # matrix cores do not hold the clock the datasheet peak assumes, so `frac` against 2.5 PFLOP/s understates how close a kernel is
+    # to what the part sustains (profiles/r04_gemm_ceiling.txt: 1.2 - 1.36 PFLOP/s); reported next to `peak`, never instead of it
+    lib = None
+    if not f32:
+        a_, b_ = torch.randn(8192, 4608, device=dev, dtype=dtype), torch.randn(4608, 8192, device=dev, dtype=dtype)
+        lib = round(2.0 * 8192 * 4608 * 8192 / timed(lambda: torch.matmul(a_, b_)) / 1e9, 1)
+        del a_, b_
     mfma = "v_mfma_f32_32x32x2_f32 (exact f32)" if f32 else "v_mfma_f32_32x32x16_%s" % ("f16" if dtype == torch.float16 else "bf16")
     return {"kernel": "conv3x3_f16_kernel<%s> (%s; the %d 3x3 convolutions of the 3-view serving graph as the step launches them: %d "
                       "grouped launches, batch %d)" % (str(dtype).split(".")[-1], mfma, nconv, len(per), batch),
             "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "alg_flop_per_step": tot_fl, "ms_per_step": round(tot_ms, 3), "launches_timed": len(per) * reps,
-            "best_layer": {"name": best[0], **best[1]}, "per_depth": per, "traffic": None}
+            "best_layer": {"name": best[0], **best[1]}, "per_depth": per, "traffic": None,
+            "library_gemm_tflops_same_box": lib}
