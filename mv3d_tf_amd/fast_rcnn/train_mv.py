@@ -313,7 +313,7 @@ def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters
     return history
 
 
-def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False):
+def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False, step_hook=None):
     """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
     VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
     frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
@@ -365,8 +365,12 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if step_hook is not None:                                # (diagnostics: tools/train_gap_probe.py brackets steps with a profiler)
+            step_hook(i, 0)
         step()
+        if step_hook is not None:
+            step_hook(i, 1)
     barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cuda")
     nparam = sum(p.numel() for p in params)
