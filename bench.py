@@ -15,11 +15,19 @@ A "step" = one pass over `--batches-per-step` such batches (default 1664 batches
 ~5 s timed region, not a burst), cycling through a ring of `--ring` (default 16) DISTINCT batches per GPU -- distinct frames
 and distinct feature maps (1.1 GB of maps + 3.3 GB of outputs per ring), so that nothing is served from the 256 MB Infinity
 Cache by re-reading the previous step's frame.
-Batches are enqueued round-robin on `--streams` HIP streams (a batch is a dependent chain of ~20 small launches +
-two HBM-bound RoiPool launches; independent batches overlap).  Inputs are resident in HBM before the timed region,
-including the random-subsample index lists of the two target layers, which are arguments of the C-ABI (drawn from the
-numpy RNG exactly as the reference draws them, during set-up; see mv3d_tf_amd/hot_path.py).  No host synchronisation
-happens inside the timed region.  The VGG16 trunks / FC head are not part of the path.
+
+How a batch is driven (`--launch`):
+  path (default)  the way a caller drives it: the library's own training-path object (`mv3d_train_path_*`, csrc/train_stream.hip,
+      through mv3d_tf_amd.train_path.TrainPathStream) on the ring's inputs -- ONE submit and ONE finish call per batch; the counts of
+      the candidate lists travel to the host, the library's helper thread draws the subsamples on numpy's global generator exactly as
+      the reference draws them (INSIDE the timed region), uploads the lists and enqueues stage 2 -- then RoiPool forward + backward of
+      the three views on the batch's sampled ROIs.  `--streams` (default 8) batches in flight, one HIP stream per slot.  Inputs (RPN
+      heads, ground truth, feature maps) are resident in HBM before the timed region; nothing else of a batch is precomputed.
+  graph / eager   the frozen-batch replay rounds 1 - 3 headlined (mv3d_tf_amd/hot_path.py): the index lists of the two target layers are
+      drawn during set-up (from the numpy RNG, exactly as the reference draws them) and resident, every batch is one hipGraph (or its
+      eager launches) on one of `--streams` (default 3) streams, no host stage in the timed region.  With `--launch path` this figure
+      is still taken, for three steps, and reported as `secondary.resident_replay`.
+The VGG16 trunks / FC head are not part of the path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|test] [--ring R] [--batches-per-step M]
 

@@ -192,6 +192,16 @@ int host_stage(mv3d_train_path *tp, Slot &s)
                                                   s.p_wsz, s.stream);
 }
 
+// (the C-ABI promises "no exceptions": an allocation failure of the spill buffer becomes a status)
+int host_stage_noexcept(mv3d_train_path *tp, Slot &s)
+{
+    try {
+        return host_stage(tp, s);
+    } catch (...) {
+        return MV3D_ERR_WORKSPACE;
+    }
+}
+
 void helper_main(mv3d_train_path *tp)
 {
     (void)hipSetDevice(tp->device);
@@ -205,7 +215,7 @@ void helper_main(mv3d_train_path *tp)
             tp->queue.pop_front();
         }
         Slot &s = tp->slots[k];
-        const int rc = host_stage(tp, s);
+        const int rc = host_stage_noexcept(tp, s);
         {
             std::lock_guard<std::mutex> g(tp->m);
             s.rc = rc;
@@ -228,7 +238,12 @@ extern "C" int mv3d_train_path_create(const mv3d_train_path_config *config, int 
     set_params(tp, *config);
     tp->depth = depth;
     if (hipGetDevice(&tp->device) != hipSuccess) { delete tp; return MV3D_ERR_HIP; }
-    tp->slots.resize((size_t)depth);
+    try {
+        tp->slots.resize((size_t)depth);
+    } catch (...) {
+        delete tp;
+        return MV3D_ERR_HIP;
+    }
     for (int k = 0; k < depth; ++k) {
         Slot &s = tp->slots[k];
         s.buf = slots[k];
@@ -242,7 +257,15 @@ extern "C" int mv3d_train_path_create(const mv3d_train_path_config *config, int 
         }
     }
     tp->threaded = helper_thread != 0;
-    if (tp->threaded) tp->helper = std::thread(helper_main, tp);
+    if (tp->threaded) {
+        try {
+            tp->helper = std::thread(helper_main, tp);
+        } catch (...) {                                               // (no thread to be had: refuse rather than run without the helper)
+            for (Slot &s : tp->slots) (void)hipEventDestroy(s.ev);
+            delete tp;
+            return MV3D_ERR_HIP;
+        }
+    }
     *out = tp;
     return MV3D_OK;
 }
@@ -300,7 +323,14 @@ extern "C" int mv3d_train_path_submit(mv3d_train_path *tp, int slot, const float
         std::lock_guard<std::mutex> g(tp->m);
         s.state = TP_SUBMITTED;
         s.rc = MV3D_OK;
-        if (tp->threaded) tp->queue.push_back(slot);
+        if (tp->threaded) {
+            try {
+                tp->queue.push_back(slot);
+            } catch (...) {
+                s.state = TP_IDLE;
+                return MV3D_ERR_HIP;
+            }
+        }
     }
     if (tp->threaded) tp->cv_work.notify_one();
     return MV3D_OK;
@@ -321,7 +351,7 @@ extern "C" int mv3d_train_path_finish(mv3d_train_path *tp, int slot, int32_t *ro
             std::lock_guard<std::mutex> g(tp->m);
             if (s.state != TP_SUBMITTED) return MV3D_ERR_INVALID_ARG;
         }
-        rc = host_stage(tp, s);
+        rc = host_stage_noexcept(tp, s);
     }
     const int B = tp->cfg.batch;
     if (rc == MV3D_OK) {
