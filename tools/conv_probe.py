@@ -24,7 +24,11 @@ SHAPES = [("bev conv1_1", 608, 608, 9, 64), ("rgb conv1_1", 375, 1242, 3, 64), (
           ("rgb conv4_2", 46, 155, 512, 512),
           # fixed cost per workgroup: the same tiles with 2x / 4x the K steps (time(2K) - time(K) = K steps of pure loop)
           ("fix c1_2 k18", 608, 608, 128, 64), ("fix c1_2 k36", 608, 608, 256, 64), ("fix c2_2 k36", 304, 304, 256, 128),
-          ("fix c4_2 k36", 76, 76, 256, 512)]
+          ("fix c4_2 k36", 76, 76, 256, 512),
+          # address-stride probes: the same layer with pixel strides that are not a power of two (1152 / 896 B instead of 1024)
+          ("stride c4 cin576", 76, 76, 576, 512), ("stride c4 cin448", 76, 76, 448, 512), ("stride c3 cin320", 152, 152, 320, 256),
+          ("stride c3 cin256", 152, 152, 256, 256)]
+
 
 
 def timed(fn, n=10):
