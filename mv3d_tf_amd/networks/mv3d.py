@@ -90,6 +90,8 @@ class MV3D:
 
     # ---- lib/networks/network.py plumbing
     def get_output(self, layer):
+        """The hot-path tensors of a TRAIN step (`rpn_rois`, `rpn_data`, `roi_data_3d`, ...) are VIEWS of the path's slot
+        buffers: valid until the second-next forward() of the same batch shape; clone what has to live longer."""
         try:
             return self.layers[layer]
         except KeyError:
@@ -106,17 +108,23 @@ class MV3D:
                 if not ignore_missing:
                     raise ValueError("no variable scope %s" % key)
                 continue
-            w = torch.as_tensor(np.asarray(sub["weights"], np.float32))
-            w = w.permute(3, 2, 0, 1) if w.ndim == 4 else w.t()
-            b = torch.as_tensor(np.asarray(sub["biases"], np.float32))
-            want_w, want_b = self.params[key]
-            if tuple(w.shape) != tuple(want_w.shape) or tuple(b.shape) != tuple(want_b.shape):
-                # (the reference's tf.assign refuses a mismatching shape as well; a silent reshape would scramble a filter)
-                raise ValueError("%s: checkpoint weights %s / biases %s do not fit the variables %s / %s"
-                                 % (key, tuple(w.shape), tuple(b.shape), tuple(want_w.shape), tuple(want_b.shape)))
-            with torch.no_grad():
-                want_w.copy_(w)
-                want_b.copy_(b)
+            # per subkey, as network.py:55-64: a tensor that does not fit its variable (tf.assign's ValueError) is skipped under
+            # ignore_missing -- VGG_imagenet.npy's conv1_1 filter is (3,3,3,64), the BEV variable (3,3,9,64): the reference
+            # prints "ignore conv1_1", still assigns the biases and trains -- and raises otherwise.  Never reshaped.
+            for subkey, want in zip(("weights", "biases"), self.params[key]):
+                if subkey not in sub:
+                    continue
+                t = torch.as_tensor(np.asarray(sub[subkey], np.float32))
+                if subkey == "weights":
+                    t = t.permute(3, 2, 0, 1) if t.ndim == 4 else (t.t() if t.ndim == 2 else t)
+                if tuple(t.shape) != tuple(want.shape):
+                    print("ignore " + key)
+                    if not ignore_missing:
+                        raise ValueError("%s/%s: checkpoint tensor %s does not fit the variable %s"
+                                         % (key, subkey, tuple(t.shape), tuple(want.shape)))
+                    continue
+                with torch.no_grad():
+                    want.copy_(t)
 
     # ---- dense layers (torch; NHWC kept as channels_last NCHW views)
     def _amp(self):
@@ -192,20 +200,30 @@ class MV3D:
             return F.relu(y) if relu else y
 
     # ---- hot-path plumbing
+    _TP_CACHE = 4                 # TrainPathStream objects kept alive (KITTI has four image sizes -> four sub-batch shapes)
+
     def _train_path(self, B, H, W, max_gt=1):
         """The batched target-layer path for B frames of an H x W head.  Two slots alternate, so the tensors a step's layers
-        dict holds stay valid until the step after the next one starts (no per-step copies); the slots are rebuilt when the
-        batch / grid changes or a frame brings more ground-truth boxes than they were sized for (a dense frame
-        must not abort training) -- capacities grow in powers of two from 64."""
+        dict holds stay valid until the step after the next one OF THE SAME SHAPE starts (no per-step copies).  One C object
+        (helper thread, pinned staging, device slots) per (B, H, W, capacity), kept in a small LRU: a step whose frames come in
+        several image sizes runs one sub-batch per size (train_mv.group_frames_by_shape), each on its own object, so mixed-size
+        steps neither rebuild the path nor overwrite each other's layer tensors.  A frame with more ground-truth
+        boxes than the slots were sized for gets a larger object (a dense frame must not abort training) --
+        capacities grow in powers of two from 64."""
         from ..train_path import TrainPathStream
         cap = getattr(self, "_tp_max_gt", 64)
         while cap < max_gt:
             cap *= 2
+        self._tp_max_gt = cap
         key = (B, H, W, cap)
-        if getattr(self, "_tp_key", None) != key:
-            self._tp = TrainPathStream(B, H, W, self.device, num_classes=n_classes, depth=2, max_gt=cap, want_fv=(self.views == 3))
-            self._tp_key, self._tp_max_gt = key, cap
-        return self._tp
+        cache = self.__dict__.setdefault("_tp_cache", {})
+        tp = cache.pop(key, None)
+        if tp is None:
+            tp = TrainPathStream(B, H, W, self.device, num_classes=n_classes, depth=2, max_gt=cap, want_fv=(self.views == 3))
+            while len(cache) >= self._TP_CACHE:                   # least recently used first (dicts keep insertion order)
+                cache.pop(next(iter(cache))).close()
+        cache[key] = tp                                           # (re-inserted: most recently used last)
+        return tp
 
     @staticmethod
     def _gt_frames(L, B):

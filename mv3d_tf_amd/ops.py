@@ -551,12 +551,17 @@ def conv3x3_views(views, out_framed=True, out_f32=False, relu=True):
         if x.dtype != dt or w.dtype != dt or x.shape[3] != cin or w.shape[0] != cout:
             raise TypeError("views of one layer shape and type expected")
         big = big or x.numel() * x.element_size() > _OFF32 or out.numel() * out.element_size() > _OFF32
-    if big or len(views) > 3:                                     # beyond the kernel's 32-bit offsets: per view, in batch chunks
+    if big or len(views) > 3:
+        # beyond the kernel's 32-bit offsets (or its three view slots): view by view, each in batch chunks that fit, through the
+        # one-view form of this same entry -- so the gated (data-gradient) views keep their own type (bf16 or f32: ADVICE r04)
         for x, w, b, g, out in views:
-            if g is not None:
-                conv3x3_gated_bf16(x, w, b, g, out)
-            else:
-                conv3x3_f16(x, w, b, out=out, out_framed=out_framed, out_f32=out_f32, relu=relu)
+            per_frame = max(x[0].numel() * x.element_size(), out[0].numel() * out.element_size())
+            step = _OFF32 // per_frame
+            if step < 1:
+                raise ValueError("one frame of %d bytes is beyond the convolution kernel's 32-bit offsets" % per_frame)
+            for b0 in range(0, x.shape[0], step):
+                conv3x3_views([(x[b0:b0 + step], w, b, None if g is None else g[b0:b0 + step], out[b0:b0 + step])],
+                              out_framed=out_framed, out_f32=out_f32, relu=relu)
         return [v[4] for v in views]
     arr = (_lib.ConvView * len(views))()
     for k, (x, w, b, g, out) in enumerate(views):

@@ -73,6 +73,18 @@ def draw_samples_host(counts):
     return fg_pick, bg_pick
 
 
+def _global_mt19937_address():
+    """Address of the {uint32 key[624]; int pos} state of the numpy GLOBAL legacy RandomState, which the library draws on in C
+    (csrc/legacy_rng.hip).  Refused unless that generator IS an MT19937 (`np.random.set_bit_generator` can replace it by a PCG64
+    or anything else, whose state the C code would scribble over: ADVICE r04).  Threading contract: the helper thread draws
+    without numpy's generator lock (a threading.Lock it cannot take from C) -- between submit() and finish() of a slot no other
+    thread of the process may draw from the global RNG; the path is for one submitting thread per process."""
+    bg = npr.mtrand._rand._bit_generator
+    if not isinstance(bg, npr.MT19937):
+        raise TypeError("TrainPathStream draws on numpy's global legacy MT19937; the global bit generator is a %s" % type(bg).__name__)
+    return bg.ctypes.state_address
+
+
 class _Slot:
     pass
 
@@ -207,7 +219,7 @@ class TrainPathStream:
         st = (s.stream or torch.cuda.current_stream()).cuda_stream
         s.inputs = (prob, pred, im_info, calib, gt)                              # (kept alive until finish())
         s.G = G
-        mt = npr.mtrand._rand._bit_generator.ctypes.state_address               # the numpy GLOBAL legacy RandomState's MT19937
+        mt = _global_mt19937_address()                                           # the numpy GLOBAL legacy RandomState's MT19937
         PP = C.c_void_p * B
         check(L.mv3d_train_path_submit(self._h, s.index, prob.data_ptr(), pred.data_ptr(), im_info.data_ptr(), calib.data_ptr(),
                                        PP(*[g[0].data_ptr() for g in gt]), PP(*[g[1].data_ptr() for g in gt]),

@@ -89,3 +89,20 @@ def test_batch_draws_equal_the_numpy_statement(L):
                                                scratch.ctypes.data_as(C.c_void_p), scratch.size) == 2
         assert L.mv3d_draw_training_subsamples(_state_addr(), B, frames, C.byref(par), lists.ctypes.data_as(C.c_void_p), lists.size, sizes,
                                                scratch.ctypes.data_as(C.c_void_p), 100) == 2
+
+
+def test_a_replaced_global_bit_generator_is_refused():
+    """the C draws write {uint32 key[624]; int pos} at the global generator's state address -- only an MT19937 has
+    that layout; any other global bit generator must raise instead of being scribbled over."""
+    from mv3d_tf_amd.train_path import _global_mt19937_address
+    assert _global_mt19937_address() == npr.mtrand._rand._bit_generator.ctypes.state_address
+    if not hasattr(npr, "set_bit_generator"):
+        pytest.skip("numpy without set_bit_generator")
+    saved = npr.get_bit_generator()
+    try:
+        npr.set_bit_generator(npr.PCG64(1))
+        with pytest.raises(TypeError):
+            _global_mt19937_address()
+    finally:
+        npr.set_bit_generator(saved)
+    assert _global_mt19937_address() == saved.ctypes.state_address

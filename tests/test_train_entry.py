@@ -361,3 +361,29 @@ def test_train_model_with_mixed_image_sizes_in_one_step(tmp_path):
             assert torch.allclose(a.detach(), b.detach(), atol=1e-7)
     finally:
         train_mv.total_loss, train_mv.get_data_layer, cfg.TRAIN.DISPLAY, cfg.TRAIN.SNAPSHOT_ITERS = old
+
+
+# ---------------------------------------------------------------------------------------------------- network.load (CPU)
+def test_load_skips_a_misfitting_tensor_like_the_reference_does(tmp_path, capsys):
+    """network.py:52-64: the ValueError of a tensor that does not fit its variable is caught PER SUBKEY and swallowed under
+    ignore_missing (VGG_imagenet.npy's conv1_1 filter is (3,3,3,64), the BEV variable (3,3,9,64)): the biases still load."""
+    import types
+    from mv3d_tf_amd.networks.mv3d import MV3D
+    net = types.SimpleNamespace(params={"conv1_1": [torch.zeros(64, 9, 3, 3), torch.zeros(64)],
+                                        "conv1_2": [torch.zeros(64, 64, 3, 3), torch.zeros(64)],
+                                        "fc6_1": [torch.zeros(8, 6), torch.zeros(8)]})
+    rng = np.random.RandomState(0)
+    vgg = {"conv1_1": {"weights": rng.randn(3, 3, 3, 64).astype(np.float32), "biases": rng.randn(64).astype(np.float32)},
+           "conv1_2": {"weights": rng.randn(3, 3, 64, 64).astype(np.float32), "biases": rng.randn(64).astype(np.float32)},
+           "fc6_1": {"weights": rng.randn(6, 8).astype(np.float32), "biases": rng.randn(8).astype(np.float32)},
+           "fc8": {"weights": rng.randn(4, 4).astype(np.float32), "biases": rng.randn(4).astype(np.float32)}}
+    path = str(tmp_path / "VGG_imagenet.npy")
+    np.save(path, vgg, allow_pickle=True)
+    MV3D.load(net, path, ignore_missing=True)
+    assert "ignore conv1_1" in capsys.readouterr().out
+    assert torch.count_nonzero(net.params["conv1_1"][0]) == 0                          # the misfitting filter is left alone
+    assert torch.equal(net.params["conv1_1"][1], torch.as_tensor(vgg["conv1_1"]["biases"]))       # ... its biases load
+    assert torch.equal(net.params["conv1_2"][0], torch.as_tensor(vgg["conv1_2"]["weights"]).permute(3, 2, 0, 1))
+    assert torch.equal(net.params["fc6_1"][0], torch.as_tensor(vgg["fc6_1"]["weights"]).t())
+    with pytest.raises(ValueError):                                                     # without ignore_missing: raise
+        MV3D.load(net, path, ignore_missing=False)
