@@ -107,6 +107,7 @@ class Ring:
     def __init__(self, args, rank, workload, batch, n, streams):
         from mv3d_tf_amd import hot_path, synth
         self.slots = []
+        self.host_frames_all = []
         dev = torch.device("cuda", torch.cuda.current_device())
         np.random.seed(3 + rank)                                   # cfg.RNG_SEED (tools/train_net.py:78-80), per rank
         for k in range(n):
@@ -119,6 +120,7 @@ class Ring:
             else:
                 slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st, cold_maps=True)
             self.slots.append(slot.setup())
+            self.host_frames_all.append(frames)
             if k == 0:
                 self.host_frames = frames
         self.cursor = 0
@@ -187,16 +189,17 @@ class PathDriver:
                         torch.rand((cap, 7, 7, Cc), generator=g, device=dev) * 2.0 - 1.0, torch.empty((B, H, W, Cc), device=dev))
             self.bufs.append(d)
         self.C, self.L, self.check, self.views = C, lib(), check, hot_path.VIEWS
-        self.fwd_fn = self.L.mv3d_roi_pool_forward_views_cold if cold else self.L.mv3d_roi_pool_forward_views
-        self.fwd_name = "mv3d_roi_pool_forward_views_cold" if cold else "mv3d_roi_pool_forward_views"
+        self.cold = 1 if cold else 0
         self.RoiView, self.RoiGradView = RoiView, RoiGradView
         self.structs = {}
         self.cursor = 0
         self.rows = 0
 
-    def roi(self, out, k):
-        """RoiPool forward + backward on the batch's ROIs: the argument structs of a (maps, slot) combination are built once (every
-        buffer has the slots' fixed capacity), a batch only sets its row count -- a caller's steady state, no per-batch slicing"""
+    def roi(self, out, k, marks=None):
+        """RoiPool forward (+ the gradient's candidate index, same launch) and backward (one launch) on the batch's ROIs: the
+        argument structs of a (maps, slot) combination are built once (every buffer has the slots' fixed capacity), a batch only
+        sets its row count -- a caller's steady state, no per-batch slicing.  marks: {"fwd": [], "bwd": []} gets a HIP event pair
+        per call, recorded on the batch's own stream (the calls' durations with the other batches in flight)."""
         C, L, NV = self.C, self.L, len(self.views)
         St = out["rois"]["bev"].shape[0]
         j = k % self.depth                                       # the slot (and its buffers / stream) this batch went through
@@ -212,26 +215,103 @@ class PathDriver:
                 bwd[i] = self.RoiGradView(d[v][3].data_ptr(), r, d[v][2].data_ptr(), d[v][1].data_ptr(), 0.125, Bm, self.cap, H, W, Cc)
             ws = self.bufs[j].get("ws")
             if ws is None:
-                wsz = L.mv3d_roi_pool_backward_workspace_bytes(NV, bwd, 7, 7)
+                wsz = L.mv3d_roi_pool_index_workspace_bytes(NV, fwd, 7, 7)          # (at the slots' capacity)
                 ws = self.bufs[j]["ws"] = torch.zeros(max(wsz, 256), dtype=torch.uint8, device=maps[self.views[0]].device)
             hit = self.structs[key] = (fwd, bwd, ws)
         fwd, bwd, ws = hit
         for i in range(NV):
             fwd[i].num_rois = St
             bwd[i].num_rois = St
-        st = C.c_void_p(out["stream"].cuda_stream)
-        self.check(self.fwd_fn(NV, fwd, 7, 7, st), self.fwd_name)
-        self.check(L.mv3d_roi_pool_backward_views(NV, bwd, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "mv3d_roi_pool_backward_views")
+        stream = out["stream"]
+        st = C.c_void_p(stream.cuda_stream)
+        wp, wn = C.c_void_p(ws.data_ptr()), ws.numel()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
+        if ev:
+            ev[0].record(stream)
+        self.check(L.mv3d_roi_pool_forward_views_indexed(NV, fwd, 7, 7, self.cold, wp, wn, st), "mv3d_roi_pool_forward_views_indexed")
+        if ev:
+            ev[1].record(stream)
+        self.check(L.mv3d_roi_pool_backward_views_indexed(NV, bwd, 7, 7, wp, wn, st), "mv3d_roi_pool_backward_views_indexed")
+        if ev:
+            ev[2].record(stream)
+            marks["fwd"].append((ev[0], ev[1]))
+            marks["bwd"].append((ev[1], ev[2]))
         self.rows += St
 
-    def run(self, nb):
+    def run(self, nb, capture=None, marks=None):
         path, n, k0 = self.path, len(self.inputs), self.cursor
         flight = [path.submit(*self.inputs[(k0 + j) % n]) for j in range(min(self.depth - 1, nb))]
         for i in range(nb):
             if i + self.depth - 1 < nb:
                 flight.append(path.submit(*self.inputs[(k0 + i + self.depth - 1) % n]))
-            self.roi(path.finish(flight.pop(0)), k0 + i)
+            out = path.finish(flight.pop(0))
+            self.roi(out, k0 + i, marks)
+            if capture is not None:
+                capture.append((k0 + i, out))
         self.cursor = k0 + nb
+
+    def in_flight_us(self, nb=64):
+        """average duration of the RoiPool forward / backward calls as the timed loop runs them: `depth` batches in flight, HIP
+        event pairs on each batch's own stream around the two calls"""
+        marks = {"fwd": [], "bwd": []}
+        self.run(2 * self.depth)
+        torch.cuda.synchronize()
+        self.run(nb, marks=marks)
+        torch.cuda.synchronize()
+        skip = self.depth                                          # (the pipeline's ramp)
+        avg = lambda prs: sum(a.elapsed_time(b) for a, b in prs[skip:]) / max(1, len(prs) - skip) * 1e3
+        return {"forward_us": round(avg(marks["fwd"]), 2), "backward_us": round(avg(marks["bwd"]), 2), "batches_in_flight": self.depth,
+                "calls_timed": len(marks["fwd"]) - skip}
+
+    def verify(self, host_frames, nbatches=2, seed=1234):
+        """What the timed loop computes, checked AFTER it: `nbatches` more batches through this very driver (same slots, buffers,
+        argument structs, streams) under a known numpy seed; their ROIs, top / argmax planes and bottom_diff are read back and
+        compared, bit for bit, with the oracle run on the same inputs with the same seed (frame by frame, anchor draws before
+        proposal draws: the reference's order).  Returns the `verified` object of the bench line."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        from mv3d_tf_amd import hot_path
+        oracle.build()
+        torch.cuda.synchronize()
+        nbatches = min(nbatches, self.depth)                      # (every checked batch in its own slot: nothing is overwritten)
+        np.random.seed(seed)
+        cap = []
+        self.run(nbatches, capture=cap)
+        torch.cuda.synchronize()
+        from mv3d_tf_amd.fast_rcnn.config import cfg
+        o_train = dict(oracle.TRAIN, BG_THRESH_LO=float(cfg.TRAIN.BG_THRESH_LO), BG_THRESH_HI=float(cfg.TRAIN.BG_THRESH_HI),
+                       FG_THRESH=float(cfg.TRAIN.FG_THRESH))
+        np.random.seed(seed)
+        bad, rows = [], 0
+        for k, out in cap:
+            frames = host_frames[k % len(self.inputs)]
+            j = k % self.depth
+            want = {"bev": [], "rgb": [], "fv": []}
+            for b, (prob, pred, info, calib, (gt_bv, gt_3d, gt_cnr)) in enumerate(frames):
+                oracle.anchor_target_layer(np.zeros((1, prob.shape[1], prob.shape[2], 8), np.float32), gt_bv, gt_3d, info, [8, ])
+                bv, img, b3 = oracle.proposal_layer_3d(prob, pred, info, calib, "TRAIN", [8, ], cfg={"TRAIN": hot_path.TRAIN_CFG})
+                r_bv, r_img, _, _, r_3d = oracle.proposal_target_layer_3d(bv, b3, gt_bv, gt_3d, gt_cnr, calib, 2, train=o_train)
+                for a in (r_bv, r_img, r_3d):
+                    a[:, 0] = b
+                want["bev"].append(r_bv); want["rgb"].append(r_img); want["fv"].append(oracle.rois_3d_to_fv(r_3d))
+            St = out["rois"]["bev"].shape[0]
+            rows += St
+            for v in self.views:
+                rois = np.concatenate(want[v])
+                if rois.shape[0] != St or not np.array_equal(out["rois"][v].cpu().numpy(), rois):
+                    bad.append("batch %d rois_%s" % (k, v))
+                    continue
+                m = self.maps[k % len(self.inputs)][v].cpu().numpy()
+                top, am, td, bd = (t.cpu().numpy() for t in self.bufs[j][v])
+                o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
+                o_bd = oracle.roi_pool_grad(m, rois, o_am, td[:St], 7, 7, 0.125)
+                for name, a, b_ in (("top", top[:St], o_top), ("argmax", am[:St], o_am), ("bottom_diff", bd, o_bd)):
+                    if not np.array_equal(a, b_):
+                        bad.append("batch %d %s_%s" % (k, name, v))
+        return {"batches": len(cap), "rows": rows, "bit_exact": not bad, "mismatches": bad[:8],
+                "what": "after the timed region: %d more batches through the SAME PathDriver (depth %d, its slots / buffers / argument "
+                        "structs), numpy seed %d; rois of the 3 views, RoiPool top + argmax, RoiPoolGrad bottom_diff read back and compared "
+                        "with oracle/ on the same inputs, seed and draw order" % (len(cap), self.depth, seed)}
 
     def close(self):
         self.path.close()
@@ -258,7 +338,7 @@ def pmc_traffic(kernel, signature):
     signature it was collected with); None otherwise -- never a stale number."""
     try:
         table = None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):           # the newest pass that holds this configuration
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):     # the newest pass that holds this configuration
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 table = json.load(open(path))["signatures"].get(signature)
@@ -280,10 +360,13 @@ def roofline_entries(ring, workload, signature):
     a cache-warm loop."""
     s0 = ring.slots[0].stream
     mine = [s for s in ring.slots if s.stream is s0]
-    legs = [("roi_pool_fwd_xcd_multi%s_kernel" % ("_cold" if getattr(mine[0], "cold_maps", False) else ""),
-             mine[0].fwd_fn.__name__, "roi_forward_bytes")]
     if workload == "train":
-        legs.append(("roi_bwd_index_kernel<false> + <true> + roi_bwd_gather_kernel", "mv3d_roi_pool_backward_views", "roi_backward_bytes"))
+        # RoiPool + the gradient's candidate index in one launch, RoiPoolGrad (zero fill + gather) in one launch
+        legs = [("roi_pool_fwd_indexed_kernel", "mv3d_roi_pool_forward_views_indexed", "roi_forward_bytes"),
+                ("roi_bwd_fill_gather_kernel", "mv3d_roi_pool_backward_views_indexed", "roi_backward_bytes")]
+    else:
+        legs = [("roi_pool_fwd_xcd_multi%s_kernel" % ("_cold" if getattr(mine[0], "cold_maps", False) else ""),
+                 mine[0].fwd_fn.__name__, "roi_forward_bytes")]
     marks = {fn: [] for _, fn, _ in legs}
     torch.cuda.synchronize()
     with torch.cuda.stream(s0):
@@ -301,7 +384,7 @@ def roofline_entries(ring, workload, signature):
         out.append({"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512 views, R=%d rows each, batch %d)"
                               % (kname, mine[0].num_rois, mine[0].B),
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("roi_bwd_" if "bwd" in kname else kname, signature),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, signature),
                     "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(marks[fn])})
     return out
 
@@ -492,15 +575,39 @@ def fresh_inputs_line(rank, variant, seconds=1.5, depth=3, nstreams=3):
 
 
 def timed(ring, nbatches, steps, warmup, barrier):
+    """-> (wall seconds of the timed region, seconds the host spent enqueueing it, CPU seconds of this PROCESS inside it:
+    time.process_time() = user + system time of every thread, the submitting thread and the library's helper thread alike)"""
     for _ in range(warmup):
         ring.run(nbatches)
     barrier()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(steps):
         ring.run(nbatches)
     t_enq = time.perf_counter() - t0
     barrier()
-    return time.perf_counter() - t0, t_enq
+    return time.perf_counter() - t0, t_enq, time.process_time() - c0
+
+
+def plan_host_threads(world, local_rank, usable, affinity):
+    """Where a rank's two host threads (the submitting thread and the library's helper thread, which draws the subsamples) run when
+    N ranks share a node, and whether the host can carry `--launch path` at all:
+
+        usable >= 2 * world   every rank gets its own PAIR of cores out of the affinity mask (rank r: cores 2r, 2r + 1 of the sorted
+                              mask) -- the ranks' threads then never time-slice one another;
+        usable <  2 * world   not enough cores for a submitting + a drawing thread per rank: fall back to `--launch graph` (frozen
+                              batches, no host stage in the timed region) and say so in the line.
+
+    world == 1 pins nothing.  Pure function of its arguments (CPU test); returns {"launch", "cores", "note"}."""
+    cores = sorted(affinity)
+    if world <= 1:
+        return {"launch": "path", "cores": None, "note": "1 rank: no pinning (%d usable cores)" % usable}
+    if usable < 2 * world or len(cores) < 2 * world:
+        return {"launch": "graph", "cores": None,
+                "note": "%d usable host cores for %d ranks (< 2 per rank: a submitting and a drawing thread each): --launch graph "
+                        "(frozen batches, no host stage in the timed region) instead of --launch path" % (usable, world)}
+    pair = [cores[2 * local_rank], cores[2 * local_rank + 1]]
+    return {"launch": "path", "cores": pair, "note": "rank-local core pair %s of %d usable cores" % (pair, usable)}
 
 
 def main():
@@ -547,14 +654,25 @@ def main():
     ring_n = args.ring or (16 if wl == "train" else 4)
     if wl != "train" and args.launch == "path":
         args.launch = "graph"                          # (the TEST-cfg path has no host stage: the frozen batch IS the path)
+    ncores, quota_note = usable_cores()
+    host_plan = plan_host_threads(world, local, ncores, os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else range(os.cpu_count() or 1))
+    if wl == "train" and args.launch == "path":
+        if host_plan["launch"] != "path":
+            args.launch = host_plan["launch"]
+        elif host_plan["cores"] and hasattr(os, "sched_setaffinity"):
+            # this thread and the threads it creates from here on (the library's helper thread inherits the mask)
+            os.sched_setaffinity(0, host_plan["cores"])
     if args.streams <= 0:
         # (8: the runtime multiplexes streams onto 4 hardware queues -- 4 / 6 / 10 streams measured 12.2 - 12.7 k frames/s, 8 / 12 / 16
         # 13.6 - 13.75 k; GPU_MAX_HW_QUEUES=8 is slower)
         args.streams = 8 if args.launch == "path" else 3
     streams = [torch.cuda.Stream() for _ in range(max(1, min(args.streams, 3) if args.launch == "path" else args.streams))]
     ring = Ring(args, rank, wl, batch, ring_n, streams)
-    dt, t_enq = timed(ring, nb, args.steps, args.warmup, barrier)
-    dt = sharding.max_over_ranks(dt, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    dt, t_enq, cpu_s = timed(ring, nb, args.steps, args.warmup, barrier)
+    host_draws = ring.driver.path.host_seconds if ring.driver is not None else (0.0, 0.0)      # (helper thread: waited, drew) since set-up
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+    dt = sharding.max_over_ranks(dt, dist, device=red_dev)
+    cpu_all = sharding.gather_over_ranks(cpu_s / args.steps, dist, device=red_dev)          # host CPU seconds per step, every rank
 
     if rank == 0:
         frames = args.steps * nb * batch * world
@@ -578,7 +696,12 @@ def main():
             "config": {"workload": desc, "batch_per_gpu": batch, "batches_per_step": nb, "frames_per_step_per_gpu": nb * batch,
                        "ring_batches": ring_n, "streams": args.streams, "launch": args.launch, "hipgraph": args.launch == "graph",
                        "host_draws_in_timed_region": args.launch == "path", "timed_region_s": round(dt, 3),
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world},
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "parallelism": "frames/%d" % world,
+                       # CPU seconds (user + system, all threads: submitting thread + the library's helper) a rank's process spent
+                       # per step of the timed region; next to ms_per_step it tells host-bound from device-bound at any N
+                       "host_cpu_s_per_step": round(cpu_all[0], 5), "host_cpu_s_per_step_per_rank": [round(c, 5) for c in cpu_all],
+                       "host_cores": {"usable": ncores, "note": ("%d hardware threads visible%s" % (os.cpu_count() or 0, quota_note)),
+                                      "pinned": host_plan["cores"], "plan": host_plan["note"]}},
         }
         # one batch alone on one stream: the latency of the path
         torch.cuda.synchronize()
@@ -594,6 +717,16 @@ def main():
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "
                                          "configuration or null")
         res["roofline_kernels"] = entries
+        if ring.driver is not None:
+            # the same two calls as the TIMED loop runs them (8 batches in flight), next to the isolated figures above
+            fl = ring.driver.in_flight_us()
+            res["roofline"]["in_flight"] = dict(fl, note="HIP event pairs on each batch's own stream around the RoiPool calls while the "
+                                                         "path driver keeps its batches in flight (the mode `value` is measured in)")
+            for e in entries:
+                us = fl["backward_us"] if "bwd" in e["kernel"] else fl["forward_us"]
+                e["in_flight_us"] = us
+                e["in_flight_frac"] = round(e["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            res["verified"] = ring.driver.verify(ring.host_frames_all)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ring, wl, args.cpu_seconds)
     if not args.no_secondary and wl == "train":
@@ -601,10 +734,10 @@ def main():
         if not args.no_fresh and args.launch == "path":
             # the figure rounds 1-4 headlined: the same ring with every batch's index lists drawn during set-up, each batch one
             # hipGraph replayed on three streams (no host stage inside the timed region)
-            host = ring.driver.path.host_seconds
+            host = host_draws
             ring.driver.close()
             ring.make_graphs()
-            dt_r, _ = timed(ring, nb, 3, 1, barrier)
+            dt_r, _, _ = timed(ring, nb, 3, 1, barrier)
             rep = sharding.sum_over_ranks(3 * nb * batch / dt_r, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
             if rank == 0:
                 sec["resident_replay"] = {"frames_per_s": round(rep, 2), "launch": "hipGraph replay of frozen batches, 3 streams",
@@ -632,7 +765,7 @@ def main():
             args2.launch = "graph"
         r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
         nb2, st2 = 48, max(2, args.steps // 2)
-        dt2, _ = timed(r2, nb2, st2, 1, barrier)
+        dt2, _, _ = timed(r2, nb2, st2, 1, barrier)
         dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
         if rank == 0:
             sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
@@ -685,6 +818,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and "verified" in res and not res["verified"]["bit_exact"]:
+        raise SystemExit("bench.py: the path driver's outputs differ from the oracle: %s" % res["verified"]["mismatches"])
 
 
 if __name__ == "__main__":

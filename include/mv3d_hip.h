@@ -173,11 +173,46 @@ size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad
                                               int pooled_width);
 /* workspace (optional, 256-B aligned): with at least mv3d_roi_pool_backward_workspace_bytes() bytes the call runs as three
  * launches -- per-pixel candidate index (sizes, then lists), then a gather that reads every (roi, bin) record slice on one
- * XCD -- which is the fast path (same C for all views, C in {64, 128, 256 k}, pooled sizes <= 15, 16-byte aligned buffers).
+ * XCD -- which is the fast path for ANY argmax plane (same C for all views, C in {64, 128, 256, 512}, pooled sizes <= 15,
+ * 16-byte aligned buffers).
  * The workspace needs no initialisation (every word is written before it is read).  With workspace == NULL the call needs
  * no scratch memory and is slower (one launch, XCD-sliced, geometry recomputed per slice). */
 int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* RoiPool and the candidate index of its gradient in ONE launch, RoiPoolGrad in ONE launch (the fast training path).
+ * The per-pixel candidate lists RoiPoolGrad gathers over (roi_pooling_op.cc:392-431: which (roi, ph, pw) bins may name a pixel)
+ * are a function of the ROIs alone, so mv3d_roi_pool_forward_views_indexed builds them while it pools -- index workgroups spread
+ * between the pooling workgroups of the same launch: the pooling is bound by its output writes, the index is LDS / ALU work -- into
+ * `index_ws`, and mv3d_roi_pool_backward_views_indexed is then one launch: fill workgroups zero the pixels without candidates,
+ * the gather writes the others.  Results are bit-identical to mv3d_roi_pool_forward_views / mv3d_roi_pool_backward_views.
+ *   index_ws        caller-owned, 256-B aligned, >= mv3d_roi_pool_index_workspace_bytes(); its FIRST 256 + 24 * segments bytes
+ *                   (simply: the whole buffer) must be ZERO before the first call that uses it -- the library leaves them zero
+ *                   again after every call (the look-back words of the in-launch index are cleared by the launch itself);
+ *                   one forward -> backward pair at a time per buffer, both on streams ordered after each other.
+ *   backward        the views must be the forward's (same order, shapes, spatial_scale and the SAME bottom_rois pointers); an
+ *                   index that is not theirs is refused loudly: bottom_diff is filled with NaN.  `argmax_data` must be the plane
+ *                   the forward wrote (for a foreign argmax use mv3d_roi_pool_backward_views, which builds its index on demand).
+ *   cold_maps       != 0: as mv3d_roi_pool_forward_views_cold.
+ * Shapes outside the fused kernels (C not in {256, 512, 1024} / not the same for all views, pooled sizes > 15, an empty view) take
+ * the plain forward and the index-on-demand backward behind the same two entries. */
+size_t mv3d_roi_pool_index_workspace_bytes(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width);
+int mv3d_roi_pool_forward_views_indexed(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                        int cold_maps, void *index_ws, size_t index_ws_bytes, void *stream);
+int mv3d_roi_pool_backward_views_indexed(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                         void *index_ws, size_t index_ws_bytes, void *stream);
+
+/* Call-compatible aliases of the reference's two launchers (roi_pooling_op_gpu.h:18-27): EXACTLY their argument order -- the
+ * forward WITHOUT a batch size (out-of-range batch indices are then the caller's problem, as in the reference) -- with `void *stream`
+ * where the reference passes `const Eigen::GpuDevice &d` (a maintainer's call site passes `d.stream()`), returning `bool`-like
+ * 1 on success and 0 on failure where the reference returns d.ok().  For a port of roi_pooling_op.cc:250-287 / :505-554 that
+ * keeps its call sites untouched. */
+int mv3d_ROIPoolForwardLaucher(const float *bottom_data, float spatial_scale, int num_rois, int height, int width, int channels,
+                               int pooled_height, int pooled_width, const float *bottom_rois, float *top_data,
+                               int32_t *argmax_data, void *stream);
+int mv3d_ROIPoolBackwardLaucher(const float *top_diff, float spatial_scale, int batch_size, int num_rois, int height, int width,
+                                int channels, int pooled_height, int pooled_width, const float *bottom_rois,
+                                float *bottom_diff, const int32_t *argmax_data, void *stream);
 
 /* ------------------------------------------------------------------ third (front-view) ROI
  * rois_3d_dev (R,7) [b,x,y,z,l,w,h] -> rois_fv_dev (R,5) [b,x1,y1,x2,y2] on the 64 x 512 cylindrical front-view map

@@ -301,6 +301,260 @@ __global__ __launch_bounds__(WP * WC * 64) void conv3x3_f16_kernel(const ConvGro
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 256 x 256 workgroup with a WAVE-SPECIALISED K loop: no barrier at which all eight waves stand behind one fetch.
+//
+// The two-stage loop above runs the deep layers at ~1.05 PFLOP/s with its waves parked ~49 % of their cycles at the one
+// `vmcnt(0)` + barrier of a K step: ONE workgroup per CU, eight waves that fetch together, wait together and multiply together.
+// Here the eight waves are two GROUPS of four (one wave of each group on every SIMD) that run the same program ONE BARRIER
+// INTERVAL APART: while a SIMD's group-0 wave is in a matrix segment (8 MFMAs, 256 cycles of the SIMD's matrix pipe), its
+// group-1 wave is in a load segment (LDS operand reads of its next segment + its two DMA pieces + its counted wait), and the
+// other way round in the next interval -- the matrix pipe of a SIMD always has a wave that is multiplying.
+//
+//   * K tile = 64 channels of one tap (as above), cut into FOUR half-tiles of 16 KB that are staged and consumed separately:
+//     X0 / X1 = the first / second 64 pixels of every wave's 128, W0 / W1 = the first / second 32 couts of every wave's 64.
+//     A K tile is four PHASES, each a load segment and a matrix segment over one quadrant (64 pixels x 32 couts) of the wave's
+//     128 x 64 output tile:   P1 reads X0 + W0 (12 ds_read_b128) and multiplies (X0, W0);  P2 reads W1 (4), (X0, W1);
+//     P3 reads X1 (8), (X1, W1);  P4 reads nothing, (X1, W0) -- W0's fragments stay in registers from P1.  24 operand reads per
+//     K tile and wave, 32 MFMAs.
+//   * the DMA stream is ONE half-tile per phase, six half-tiles ahead of the phase that reads it, into two K-tile buffers
+//     (2 x 64 KB): phase P1 of tile t issues W1[t + 1], P2 X1[t + 1], P3 X0[t + 2], P4 W0[t + 2].  A slot is rewritten at the
+//     earliest three barrier intervals after the lagging group's last read of it (whose `lgkmcnt(0)` has retired by then).
+//   * waits are COUNTED and never zero in the steady state: a wave waits `vmcnt(8)` (its own two pieces of the four youngest
+//     half-tiles stay in flight) in P4 / P1 / P2 -- before the phase's first barrier, for the half-tile that the NEXT phase
+//     reads -- so every piece has four phases (~2 k cycles) to land, and the barrier behind the wait publishes it to the readers
+//     of both groups (the lagging group's wait precedes the barrier the leading group passes before it reads).
+//   * barriers: two per phase (load | matrix), raw `s_barrier`; group 1 takes one extra at the start, group 0 one at the end.
+// Same LDS image (rows of 128 B, 16-byte k-groups XOR-swizzled by (row >> 1) & 7 on the DMA's source side), same fragments, same
+// accumulator layout and the same epilogue as the kernel above: bit-identical results (the order of a fragment's k steps is
+// unchanged: ks ascending inside a K tile, K tiles ascending).
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvGroup g)
+{
+#if __HIP_DEVICE_COMPILE__
+    int view = 0;
+#pragma unroll
+    for (int j = 1; j < CONV_MAX_VIEWS; ++j)
+        if (j < g.n && (int)blockIdx.x >= g.first[j]) view = j;
+    const ConvArgs &a = g.v[view];
+    constexpr int BM = 256, BN = 256, NW = 8, NT = 512, WP = 2, TP = 128, TC = 64, FP = 4, FC = 2;
+    constexpr int ES = sizeof(T), CPS = BK_BYTES / ES;
+    static_assert(ES == 2, "16-bit operands");
+    constexpr int HALF = 128 * BK_BYTES;                          // one half-tile: 128 rows x 128 B = 16 KB
+    constexpr int TILE = 4 * HALF;                                // X0 | W0 | W1 | X1
+    constexpr int ESZ = 2, OUT_BYTES = BM * BN * ESZ;
+    constexpr int LDS_BYTES = OUT_BYTES + BM * 4 > 2 * TILE ? OUT_BYTES + BM * 4 : 2 * TILE;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    unsigned *const s_pix = (unsigned *)(lds + OUT_BYTES);
+
+    const int id = (int)blockIdx.x - g.first[view], xcd = id & 7, local = id >> 3;
+    const int mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles, nt = local % a.n_tiles;
+    if (mt >= a.m_tiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K2 = 9 * a.Cin * ES;                                // bytes of one weight row
+    const int Wp = a.W + 2;
+
+    // ---- DMA source offsets.  Piece q (0 / 1) of a half-tile, this wave: LDS rows (q * 8 + wave) * 8 + (lane >> 3).
+    //   X half h: LDS row r -> tile pixel (r / 64) * 128 + h * 64 + r % 64      (r / 64 = the pixel half wp of the reading waves)
+    //   W half h: LDS row r -> tile cout  (r / 32) * 64 + h * 32 + r % 32       (r / 32 = the cout quarter wc of the reading waves)
+    const int gsel = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    const int last = ((a.Bn * (a.H + 2) - 3) * Wp + a.W - 1) * a.Cin * ES;         // pixel M - 1: rows past the end read it (never stored)
+    int xoff[2][2], woff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (q * 8 + wave) * 8 + (lane >> 3);
+            const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            const int b = m / a.HW, rr = m - b * a.HW, yy = rr / a.W, xx = rr - yy * a.W;
+            xoff[h][q] = (m < a.M ? ((b * (a.H + 2) + yy) * Wp + xx) * a.Cin * ES : last) + gsel * 16;
+            woff[h][q] = (n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * K2 + gsel * 16;
+        }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, (int)a.w_bytes, 0x00020000);
+
+    // the DMA stream, statically scheduled: X / W half-tile `h` of K tile `t` (scalar tap / slice offset sxt of that tile)
+    const int cpt = a.Cin / CPS, KT = 9 * cpt;
+    auto issue_x = [&](const int h, const int t, const int sxt) __attribute__((always_inline)) {
+        char *const dst = lds + __builtin_amdgcn_readfirstlane((t & 1) * TILE + (h ? 3 * HALF : 0));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t *)(dst + (q * 8 + wave) * 1024), 16, xoff[h][q], sxt, 0, 0);
+    };
+    auto issue_w = [&](const int h, const int t) __attribute__((always_inline)) {
+        char *const dst = lds + __builtin_amdgcn_readfirstlane((t & 1) * TILE + (1 + h) * HALF);
+        const int sw = __builtin_amdgcn_readfirstlane(t * BK_BYTES);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t *)(dst + (q * 8 + wave) * 1024), 16, woff[h][q], sw, 0, 0);
+    };
+    // scalar source offset of a K tile's tap / channel slice: tiles are walked in order, one cursor that runs two tiles ahead
+    int c_ty = 0, c_tx = 0, c_cc = 0;
+    auto next_sx = [&]() __attribute__((always_inline)) -> int {
+        const int v = __builtin_amdgcn_readfirstlane(((c_ty * Wp + c_tx) * a.Cin + c_cc * CPS) * ES);
+        if (++c_cc == cpt) { c_cc = 0; if (++c_tx == 3) { c_tx = 0; ++c_ty; } }
+        return v;
+    };
+
+    // ---- operand reads
+    const int wp = wave & 1, wc = (wave >> 1) & 3;                // pixel half, cout quarter of this wave's 128 x 64 tile
+    // (groups: waves {0..3} = group 0, {4..7} = group 1 -- a workgroup's waves go to the SIMDs in a cyclic order, so waves w and
+    // w + 4 share a SIMD: one of each group)
+    const int h5 = lane >> 5, sw7 = (lane >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = (lane & 31) * BK_BYTES + (((ks * 2 + h5) ^ sw7) << 4);
+    typedef typename OpVec<T>::type OV;
+    const int x_rows = wp * 64 * BK_BYTES, w_rows = wc * 32 * BK_BYTES;
+
+    f32x16 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int j = 0; j < FP; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_BAR() do { PP_SB(); __builtin_amdgcn_s_barrier(); PP_SB(); } while (0)
+#define PP_MFMA(ACC, FW, FX)                                                                                        \
+    do {                                                                                                            \
+        if constexpr (__is_same(T, _Float16)) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(FW, FX, ACC, 0, 0, 0);   \
+        else ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW, FX, ACC, 0, 0, 0);                                   \
+    } while (0)
+
+    // prologue: half-tiles X0 W0 W1 X1 of tile 0, X0 W0 of tile 1 (stream order; KT >= 9); the first two have to have landed
+    const int sx0 = next_sx();
+    int sx_a = next_sx(), sx_b = next_sx();                       // tap / slice offsets of tiles kt + 1 and kt + 2
+    issue_x(0, 0, sx0); issue_w(0, 0); issue_w(1, 0); issue_x(1, 0, sx0);
+    issue_x(0, 1, sx_a); issue_w(0, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    PP_BAR();
+    if (wave >= 4) PP_BAR();                                      // group 1 runs one barrier interval behind group 0
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const char *const st = lds + (kt & 1) * TILE;
+        OV fx[2][4], fw0[4], fw1[4];
+        // ---- P1: X0 + W0 -> (X0, W0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw0[ks] = *(const OV *)(st + HALF + w_rows + koff[ks]);
+        PP_SB();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fx[j][ks] = *(const OV *)(st + x_rows + j * 32 * BK_BYTES + koff[ks]);
+        const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT;      // (scalar)
+        if (more1) issue_w(1, kt + 1);                            // W1[kt + 1]
+        // counted wait: this wave's pieces of the FOUR youngest half-tiles stay in flight (nothing more is issued for the last
+        // two tiles: they wait for everything) -> W1[kt] has landed
+        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);                            // (the compiler's own counted lgkmcnt waits sit in front of each MFMA)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) PP_MFMA(acc[0][j], fw0[ks], fx[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- P2: W1 -> (X0, W1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw1[ks] = *(const OV *)(st + 2 * HALF + w_rows + koff[ks]);
+        if (more1) issue_x(1, kt + 1, sx_a);                      // X1[kt + 1]
+        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1[kt] has landed
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);                            // (the compiler's own counted lgkmcnt waits sit in front of each MFMA)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) PP_MFMA(acc[1][j], fw1[ks], fx[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- P3: X1 -> (X1, W1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fx[j][ks] = *(const OV *)(st + 3 * HALF + x_rows + j * 32 * BK_BYTES + koff[ks]);
+        if (more2) issue_x(0, kt + 2, sx_b);                      // X0[kt + 2]
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);                            // (the compiler's own counted lgkmcnt waits sit in front of each MFMA)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) PP_MFMA(acc[1][2 + j], fw1[ks], fx[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- P4: (X1, W0), W0's fragments still in registers
+        if (more2) issue_w(0, kt + 2);                            // W0[kt + 2]
+        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X0 / W0[kt + 1] have landed
+        sx_a = sx_b;
+        sx_b = next_sx();
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) PP_MFMA(acc[0][2 + j], fw0[ks], fx[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+    }
+    if (wave < 4) PP_BAR();                                       // group 0 waits for group 1's last interval
+#undef PP_MFMA
+    __syncthreads();                                              // every wave is done with the stages: reuse them for the tile
+    {   // output address of every pixel of the tile
+        const int b0 = m0 / a.HW, r0 = m0 - b0 * a.HW, y0 = r0 / a.W, x0 = r0 - y0 * a.W;
+        const int Ho = a.H + 2 * a.out_pad, Wo = a.W + 2 * a.out_pad;
+        for (int p = tid; p < BM; p += NT) {
+            int b = b0, yy = y0, xx = x0 + p;
+            while (xx >= a.W) { xx -= a.W; if (++yy == a.H) { yy = 0; ++b; } }
+            s_pix[p] = m0 + p < a.M ? (unsigned)(((b * Ho + yy + a.out_pad) * Wo + xx + a.out_pad)) * (unsigned)(a.Cout * ESZ) : 0xFFFFFFFFu;
+        }
+    }
+    // ---- epilogue (as above): + bias, ReLU, -> LDS tile [pixel][cout], -> 16-byte global stores [gated by the mask map]
+    constexpr int ROWB = BN * ESZ, SLOTS = ROWB / 16;
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = wc * TC + i * 32 + 8 * q + 4 * h5;
+            const f32x4 bv = *(const f32x4 *)(a.bias + n0 + c0);
+#pragma unroll
+            for (int j = 0; j < FP; ++j) {
+                const int P = wp * TP + j * 32 + (lane & 31);
+                typename Vec<T>::v4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e] + bv[e];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    hv[e] = (T)v;
+                }
+                *(typename Vec<T>::v4 *)(lds + P * ROWB + (((c0 >> 3) ^ (P & (SLOTS - 1))) << 4) + (c0 & 7) * 2) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    char *const yb = (char *)a.y + (size_t)n0 * ESZ;
+#pragma unroll 4
+    for (int u = tid; u < BM * SLOTS; u += NT) {
+        const int P = u / SLOTS, s = u % SLOTS;
+        const unsigned off = s_pix[P];
+        u32x4 v = *(const u32x4 *)(lds + P * ROWB + ((s ^ (P & (SLOTS - 1))) << 4));
+        if (off == 0xFFFFFFFFu) continue;
+        if (a.mask) {                                             // gate by the sign of the masking map's 8 values of this piece
+            typedef typename Vec<T>::v8 V8;
+            const V8 m = *(const V8 *)((const char *)a.mask + (size_t)n0 * ESZ + off + s * 16);
+            V8 o = __builtin_bit_cast(V8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (float)m[e] > 0.f ? o[e] : (T)0.f;
+            v = __builtin_bit_cast(u32x4, o);
+        }
+        *(u32x4 *)(yb + off + s * 16) = v;
+    }
+#endif
+}
+
 // the pools' views (one launch for the trunks of one depth, like ConvGroup): view k owns workgroups [first[k], first[k + 1])
 struct PoolView { const void *x, *g; void *y; int B, H, W, Ho, Wo; };
 struct PoolGroup { PoolView v[CONV_MAX_VIEWS]; int n, C8; int first[CONV_MAX_VIEWS + 1]; };
@@ -433,6 +687,23 @@ int launch_conv16(ConvGroup &g, hipStream_t s)
     return mv3d_launch_status();
 }
 
+// the wave-specialised 256 x 256 workgroup (conv3x3_pp_kernel): 16-bit framed / bare output, ordinary layers
+template <typename T>
+int launch_conv_pp(ConvGroup &g, hipStream_t s)
+{
+    int grid = 0;
+    for (int k = 0; k < g.n; ++k) {
+        ConvArgs &b = g.v[k];
+        b.m_tiles = (b.M + 255) / 256;
+        b.n_tiles = b.Cout / 256;
+        g.first[k] = grid;
+        grid += (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
+    }
+    for (int k = g.n; k < CONV_MAX_VIEWS; ++k) { g.v[k] = g.v[0]; g.first[k] = grid; }
+    hipLaunchKernelGGL((conv3x3_pp_kernel<T>), dim3(grid), dim3(512), 0, s, g);
+    return mv3d_launch_status();
+}
+
 template <typename T, int BM, int BN, int WP, int WC>
 int launch_conv_pool(ConvGroup &g, hipStream_t s)
 {
@@ -511,8 +782,16 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
 #else
         const int big_min = 640, big_wp = 2;
 #endif
-        if (!out_f32 && c_out % 256 == 0 && tiles256 >= big_min)
+        if (!out_f32 && c_out % 256 == 0 && tiles256 >= big_min) {
+#ifdef MV3D_TUNING
+            static const int pp = getenv("MV3D_CONV_PP") ? atoi(getenv("MV3D_CONV_PP")) : 1;
+#else
+            const int pp = 1;
+#endif
+            // the same tile with the wave-specialised K loop (two groups of four waves one barrier interval apart, counted waits)
+            if (pp) return launch_conv_pp<T>(g, s);
             return big_wp == 2 ? launch_conv16<T, 256, 256, 2, 4>(g, s) : launch_conv16<T, 256, 256, 4, 2>(g, s);
+        }
 #ifdef MV3D_TUNING                                                // experiment builds: the 256 x 256 workgroup, 8 waves of 128 x 64
         static const int big = getenv("MV3D_CONV_TILE") ? atoi(getenv("MV3D_CONV_TILE")) : 0;
         if (big == 256 && c_out % 256 == 0 && !out_f32) return launch_conv16<T, 256, 256, 2, 4>(g, s);

@@ -16,6 +16,7 @@
 #include <float.h>
 #include <stdlib.h>
 #include <math.h>
+#include <string.h>
 #include "common.h"
 #include "kernels.h"
 #include "roi_geom.h"
@@ -110,12 +111,12 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
 struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
 
 template <int FWD_PASSES>
-__device__ __forceinline__ void roi_pool_fwd_xcd_block(const unsigned block, const float *__restrict__ data, float scale,
+__device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
+                                                        const float *__restrict__ data, float scale,
                                                         int B, int R, int H, int W, int C, int PH, int PW,
                                                         const float *__restrict__ rois, float *__restrict__ top,
                                                         int *__restrict__ argmax, int tpb_shift)
 {
-    __shared__ BinGeom s_g[FWD_PASSES * 32];
     const int tpb = 1 << tpb_shift;                  // threads per bin = C/32 (8, 16 or 32 float4 lanes)
     const int bpp = 256 >> tpb_shift;                // bins per pass (32, 16 or 8)
     const int slice = block & 7;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_kernel(const float *__re
                                                                const float *__restrict__ rois, float *__restrict__ top,
                                                                int *__restrict__ argmax, int tpb_shift)
 {
-    roi_pool_fwd_xcd_block<FWD_PASSES>(blockIdx.x, data, scale, B, R, H, W, C, PH, PW, rois, top, argmax, tpb_shift);
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
+    roi_pool_fwd_xcd_block<FWD_PASSES>(s_g, blockIdx.x, data, scale, B, R, H, W, C, PH, PW, rois, top, argmax, tpb_shift);
 }
 
 // Several views (the BEV and RGB maps of one step) in ONE launch: the second view's workgroups fill the
@@ -218,12 +220,13 @@ struct RoiViewPack { RoiViewDev v[MV3D_MAX_ROI_VIEWS]; int n, PH, PW; };
 template <int FWD_PASSES>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack p)
 {
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES>(blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+    roi_pool_fwd_xcd_block<FWD_PASSES>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
                            v.argmax, v.tpb_shift);
 }
 
@@ -236,9 +239,10 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack
 // the memory-side cache (which every XCD reads) when those get there: 40 us for both together.  Same results.
 #define PF_PIX 16
 struct RoiPrefetchPack { unsigned first_block[MV3D_MAX_ROI_VIEWS]; unsigned blocks; };
-__device__ __forceinline__ void roi_prefetch_block(const RoiViewPack &p, const RoiPrefetchPack &pf, const unsigned block, int *sink)
+__device__ __forceinline__ void roi_prefetch_block(unsigned *s_mask_p /* LDS, one word */, const RoiViewPack &p, const RoiPrefetchPack &pf,
+                                                   const unsigned block, int *sink)
 {
-    __shared__ unsigned s_mask;
+    unsigned &s_mask = *s_mask_p;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
@@ -279,14 +283,16 @@ __device__ __forceinline__ void roi_prefetch_block(const RoiViewPack &p, const R
 template <int FWD_PASSES>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink)
 {
-    if (blockIdx.x < pf.blocks) { roi_prefetch_block(p, pf, blockIdx.x, sink); return; }
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
+    __shared__ unsigned s_mask;
+    if (blockIdx.x < pf.blocks) { roi_prefetch_block(&s_mask, p, pf, blockIdx.x, sink); return; }
     const unsigned blk = blockIdx.x - pf.blocks;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blk >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES>(blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+    roi_pool_fwd_xcd_block<FWD_PASSES>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
                            v.argmax, v.tpb_shift);
 }
 
@@ -635,28 +641,48 @@ __global__ __launch_bounds__(BW_THREADS) void roi_pool_bwd_sliced_kernel(RoiGrad
 // (floor / ceil slack), likewise over the columns.  Every word is written before it is read: no memset, no zero contract.
 #define BWI_PIX 16
 #define BWG_GROUPS 256                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
-struct RoiGradIdxPack { long long *trace; int4 *items; int *pool; int *header; int *seg_tot, *seg_ne; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; };
+#define BWI_SPIN_LIMIT (1 << 16)      // polls of one published word before a look-back gives up (and flags the index invalid)
+// header words of the workspace (ints): [0] look-back "done" counter of the fused forward (zero between calls), [1] number of items,
+// [2] signature of the index a fused forward built (0: none), [3] error flag of the fused forward's look-back
+struct RoiGradIdxPack {
+    long long *trace; int4 *items; int *pool; int *header;
+    int *seg_tot, *seg_mask;                         // per 16-pixel segment: candidates, 16-bit mask of the pixels that have any
+    unsigned long long *seg_word;                    // fused forward: the same two numbers published as one word (0 = not yet)
+    unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS];
+    unsigned nseg, sig;
+};
 
-// FILL = false: zero-fill + sizes (seg_tot / seg_ne per segment); FILL = true: slab offsets from the sizes of the preceding
-// segments (a plain sum: the sizing launch is complete), items and candidate lists.  No atomics on global memory, no state
-// that has to be zero on entry.
-template <bool FILL>
-__global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGradIdxPack ix)
+// LDS of one index workgroup (14.4 KB; the fused forward overlays it with the pooling role's bin table)
+struct RoiIdxShared {
+    int red[8];
+    int roi[BW_CHUNK], rsw[BW_CHUNK], rew[BW_CHUNK], prow[BW_CHUNK];
+    float bw[BW_CHUNK];
+    unsigned char nb[BW_CHUNK][BWI_PIX], xr[BW_CHUNK][BWI_PIX];
+    int wcnt[4], cnt[BWI_PIX], base[BWI_PIX], run[BWI_PIX];
+    int part[16][BWI_PIX];
+    int last;
+};
+
+// One index workgroup = one 16-pixel segment of a map row.
+// FILL = false: sizes (candidates of the segment, mask of its non-empty pixels); FILL = true: slab offsets from the sizes of the
+// preceding segments (a plain sum), items and candidate lists.  ZERO: the workgroup also zero-fills its pixels of bottom_diff
+// (the stand-alone two-launch RoiPoolGrad).  FUSED: both phases run inside ONE launch (the forward RoiPool's): the sizes are
+// published as one 64-bit word per segment with an agent-scope store, the lists phase looks back over the words of its
+// predecessors (the protocol of mv3d_grid_compact, common.h: 0 = not yet published; the words are zero on entry, and the lists
+// workgroup that finishes its look-back last clears them again) -- the sizes workgroups sit EARLIER in the grid than every lists
+// workgroup, so a word is missing only while its workgroup is still running; a look-back that waits more than BWI_SPIN_LIMIT polls
+// gives up and flags the index invalid (the backward then refuses it) instead of hanging.
+template <bool FILL, bool ZERO, bool FUSED>
+__device__ __forceinline__ void roi_bwd_index_block(RoiIdxShared &S, const RoiGradPack &p, const RoiGradIdxPack &ix, const unsigned block,
+                                                    const unsigned nblocks)
 {
-    __shared__ int s_red[8];
-    __shared__ int s_roi[BW_CHUNK], s_rsw[BW_CHUNK], s_rew[BW_CHUNK], s_prow[BW_CHUNK];
-    __shared__ float s_bw[BW_CHUNK];
-    __shared__ unsigned char s_nb[BW_CHUNK][BWI_PIX], s_xr[BW_CHUNK][BWI_PIX];
-    __shared__ int s_off[BW_CHUNK][BWI_PIX];
-    __shared__ int s_wcnt[4], s_cnt[BWI_PIX], s_base[BWI_PIX], s_run[BWI_PIX];
-    __shared__ int s_part[16][BWI_PIX];
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
-        if (j < p.n && blockIdx.x >= ix.first_block[j]) k = j;
+        if (j < p.n && block >= ix.first_block[j]) k = j;
     const RoiGradViewDev &v = p.v[k];
     const int PH = p.PH, PW = p.PW, H = v.H, W = v.W, R = v.R, C = v.C;
-    const unsigned g = blockIdx.x - ix.first_block[k];
+    const unsigned g = block - ix.first_block[k];
     const int gpr = ix.gpr[k];
     const int w0 = (int)(g % (unsigned)gpr) * BWI_PIX;
     const int npx = min(BWI_PIX, W - w0);
@@ -666,7 +692,7 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
     const int j = threadIdx.x & (BWI_PIX - 1), q = threadIdx.x / BWI_PIX;      // pixel of the segment, entry stripe
     const int npass = (R + BW_CHUNK - 1) / BW_CHUNK;
     const long long pix0 = ((long long)n * H + h) * W + w0;
-    if (FILL == ((h & 1) != 0)) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have
+    if (ZERO && FILL == ((h & 1) != 0)) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have
         // candidates); even rows by the sizing launch, odd rows by the list launch: each launch is a chain of barriers and LDS
         // round trips with the memory system idle, so half of the 55 MB of streaming stores hides under each.  The
         // segment's npx * C floats are contiguous
@@ -676,7 +702,7 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
         const int n4 = npx * (C / 4);
         for (int t = threadIdx.x; t < n4; t += 256) __builtin_nontemporal_store(z, dst + t);
     }
-    if (threadIdx.x < BWI_PIX) { s_cnt[threadIdx.x] = 0; s_run[threadIdx.x] = 0; }
+    if (threadIdx.x < BWI_PIX) { S.cnt[threadIdx.x] = 0; S.run[threadIdx.x] = 0; }
     int nlist = 0;
 
     // filter one pass of ROIs into the ordered LDS list, then evaluate every (entry, pixel) pair: number of candidate
@@ -702,34 +728,34 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
             }
         }
         const unsigned long long bal = __ballot(ok);
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        if (lane == 0) S.wcnt[wave] = __popcll(bal);
         __syncthreads();
         int pos = __popcll(bal & ((1ull << lane) - 1ull));
         int nl = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const int cw = s_wcnt[t]; if (t < wave) pos += cw; nl += cw; }
-        if (ok) { s_roi[pos] = r; s_rsw[pos] = rsw; s_rew[pos] = rew; s_prow[pos] = prow; s_bw[pos] = bw; }
+        for (int t = 0; t < 4; ++t) { const int cw = S.wcnt[t]; if (t < wave) pos += cw; nl += cw; }
+        if (ok) { S.roi[pos] = r; S.rsw[pos] = rsw; S.rew[pos] = rew; S.prow[pos] = prow; S.bw[pos] = bw; }
         __syncthreads();
         int local = 0;
         const int w = w0 + j;
         for (int e = q; e < nl; e += 256 / BWI_PIX) {
             int nb = 0, xr = 0;
-            const int xs = s_rsw[e], xe = s_rew[e];
+            const int xs = S.rsw[e], xe = S.rew[e];
             if (j < npx && w >= xs && w <= xe) {
-                const float fbw = s_bw[e];
+                const float fbw = S.bw[e];
                 int x0 = (int)floorf((float)(w - xs) / fbw), x1 = (int)ceilf((float)(w - xs + 1) / fbw);
                 x0 = min(max(x0, 0), PW); x1 = min(max(x1, 0), PW);
                 if (x1 > x0) {
-                    const int pr = s_prow[e];
+                    const int pr = S.prow[e];
                     nb = ((pr >> 8) - (pr & 255)) * (x1 - x0);
                     xr = x0 | (x1 << 4);
                 }
             }
-            s_nb[e][j] = (unsigned char)nb;
-            s_xr[e][j] = (unsigned char)xr;
+            S.nb[e][j] = (unsigned char)nb;
+            S.xr[e][j] = (unsigned char)xr;
             local += nb;
         }
-        if (local) atomicAdd(&s_cnt[j], local);
+        if (local) atomicAdd(&S.cnt[j], local);
         return nl;
     };
 
@@ -737,65 +763,104 @@ __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGr
     __syncthreads();
     if (!FILL) {
         if (threadIdx.x < 64) {
-            const int c = (lane < BWI_PIX) ? s_cnt[lane] : 0;
+            const int c = (lane < BWI_PIX) ? S.cnt[lane] : 0;
             int tot = c;
 #pragma unroll
             for (int m = 1; m < BWI_PIX; m <<= 1) tot += __shfl_xor(tot, m);
-            const unsigned long long ne = __ballot(c > 0);
-            if (lane == 0) { ix.seg_tot[blockIdx.x] = tot; ix.seg_ne[blockIdx.x] = __popcll(ne); }
+            const unsigned mask = (unsigned)(__ballot(c > 0) & 0xffffull);
+            if (lane == 0) {
+                if (FUSED) __hip_atomic_store(&ix.seg_word[block], ((unsigned long long)(unsigned)tot << 32) | ((unsigned long long)mask << 1) | 1ull,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else { ix.seg_tot[block] = tot; ix.seg_mask[block] = (int)mask; }
+            }
         }
         return;
     }
     {   // slab offsets = sums over the preceding segments' sizes
         int a = 0, b = 0;
-        for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) { a += ix.seg_tot[t]; b += ix.seg_ne[t]; }
+        bool gave_up = false;
+        for (int t = threadIdx.x; t < (int)block; t += 256) {
+            if (FUSED) {
+                unsigned long long w8 = __hip_atomic_load(&ix.seg_word[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; w8 == 0ull && spin < BWI_SPIN_LIMIT; ++spin) {
+                    __builtin_amdgcn_s_sleep(8);
+                    w8 = __hip_atomic_load(&ix.seg_word[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gave_up = gave_up || w8 == 0ull;
+                a += (int)(w8 >> 32); b += __popc((unsigned)(w8 >> 1) & 0xffffu);
+            } else {
+                a += ix.seg_tot[t]; b += __popc((unsigned)ix.seg_mask[t]);
+            }
+        }
+        if (FUSED && gave_up) { atomicOr(&ix.header[3], 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-        if (lane == 0) { s_red[wave] = a; s_red[4 + wave] = b; }
+        if (lane == 0) { S.red[wave] = a; S.red[4 + wave] = b; }
         __syncthreads();
     }
+    if (FUSED) {   // this workgroup's look-back is over; the one that gets there last clears the published words for the next call
+        if (threadIdx.x == 0)
+            S.last = (__hip_atomic_fetch_add(&ix.header[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)nblocks - 1);
+        __syncthreads();
+        if (S.last) {
+            for (int t = threadIdx.x; t < (int)nblocks; t += 256) __hip_atomic_store(&ix.seg_word[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                const int bad = __hip_atomic_load(&ix.header[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ix.header[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ix.header[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ix.header[2] = bad ? 0 : (int)ix.sig;          // the index of THIS forward (read by the backward launch)
+            }
+        }
+    }
     if (threadIdx.x < 64) {                      // sizes -> offsets inside the segment's slabs; items
-        const int base0 = s_red[0] + s_red[1] + s_red[2] + s_red[3], ibase = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-        const int c = (lane < BWI_PIX) ? s_cnt[lane] : 0;
+        const int base0 = S.red[0] + S.red[1] + S.red[2] + S.red[3], ibase = S.red[4] + S.red[5] + S.red[6] + S.red[7];
+        const int c = (lane < BWI_PIX) ? S.cnt[lane] : 0;
         int inc = c;
 #pragma unroll
         for (int m = 1; m < BWI_PIX; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
         const unsigned long long ne = __ballot(c > 0);
-        if (lane < BWI_PIX) s_base[lane] = base0 + inc - c;
+        if (lane < BWI_PIX) S.base[lane] = base0 + inc - c;
         if (c > 0) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, c, k);
-        if (lane == 0 && blockIdx.x == gridDim.x - 1) ix.header[1] = ibase + __popcll(ne);    // number of items of the launch
+        if (lane == 0) {
+            if (FUSED) ix.seg_mask[block] = (int)(ne & 0xffffull);                // (the fill workgroups of the backward launch)
+            if (block == nblocks - 1) ix.header[1] = ibase + __popcll(ne);        // number of items of the launch
+        }
     }
     __syncthreads();
     for (int pass = 0; pass < npass; ++pass) {
         if (npass > 1) { nlist = build(pass); }
         __syncthreads();
-        {   // per pixel: where each entry's bins go, in entry order = an exclusive prefix of s_nb over the entries.  16 stripes
-            // of entries per pixel (thread = (stripe, pixel)): stripe sums, a 16-step prefix over the stripes, then the
-            // stripe's own entries -- a serial walk by one thread per pixel was the slowest part of the launch on segments
-            // with a few hundred entries
-            const int sp = threadIdx.x & (BWI_PIX - 1), st = threadIdx.x / BWI_PIX;       // pixel, stripe
-            const int L = (nlist + 15) / 16, e0 = st * L, e1 = min(nlist, e0 + L);
-            int sum = 0;
-            for (int e = e0; e < e1; ++e) sum += s_nb[e][sp];
-            s_part[st][sp] = sum;
-            __syncthreads();
-            int run = s_run[sp];
-            for (int t = 0; t < st; ++t) run += s_part[t][sp];
-            for (int e = e0; e < e1; ++e) { s_off[e][sp] = run; run += s_nb[e][sp]; }
-            __syncthreads();
-            if (st == 15) s_run[sp] = run;                             // (the last stripe ends at the total)
-        }
+        // per pixel: where each entry's bins go, in entry order = an exclusive prefix of nb over the entries.  16 stripes of
+        // CONSECUTIVE entries per pixel (thread = (stripe, pixel)): stripe sums, a prefix over the stripes, then the thread walks
+        // its own entries with the running offset in a register and writes their records' byte offsets (a serial walk by one
+        // thread per pixel was the slowest part of the launch on segments with a few hundred entries)
+        const int sp = threadIdx.x & (BWI_PIX - 1), st = threadIdx.x / BWI_PIX;       // pixel, stripe
+        const int L = (nlist + 15) / 16, e0 = st * L, e1 = min(nlist, e0 + L);
+        int sum = 0;
+        for (int e = e0; e < e1; ++e) sum += S.nb[e][sp];
+        S.part[st][sp] = sum;
         __syncthreads();
-        for (int e = q; e < nlist; e += 256 / BWI_PIX) {
-            const int nb = s_nb[e][j];
+        int run = S.run[sp];
+        for (int t = 0; t < st; ++t) run += S.part[t][sp];
+        int *dst = ix.pool + S.base[sp] + run;
+        for (int e = e0; e < e1; ++e) {
+            const int nb = S.nb[e][sp];
             if (nb == 0) continue;
-            const int xr = s_xr[e][j], x0 = xr & 15, x1 = xr >> 4, pr = s_prow[e];
-            int *dst = ix.pool + s_base[j] + s_off[e][j];
-            const int rec0 = s_roi[e] * PH * PW;
+            const int xr = S.xr[e][sp], x0 = xr & 15, x1 = xr >> 4, pr = S.prow[e];
+            const int rec0 = S.roi[e] * PH * PW;
             for (int ph = pr & 255; ph < (pr >> 8); ++ph)
                 for (int pw = x0; pw < x1; ++pw) *dst++ = (rec0 + ph * PW + pw) * C * 4;     // the record's byte offset
         }
+        __syncthreads();
+        if (st == 15) S.run[sp] = run + sum;                         // (the last stripe ends at the pass's total)
     }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGradIdxPack ix)
+{
+    __shared__ RoiIdxShared S;
+    roi_bwd_index_block<FILL, true, false>(S, p, ix, blockIdx.x, gridDim.x);
 }
 
 // records u0 .. u0 + W - 1 of the 64 whose byte offsets sit in the lanes of `cur`: per record one v_readlane (-> SGPR) and two
@@ -835,19 +900,20 @@ __device__ __forceinline__ void bwd_drain_lanes(const int cur, const int u0, con
 // larger pieces do not.  A wave walks its items i, i + stride, ... software-pipelined: while item n's records are in flight,
 // the offsets of item n + 1 and the header of item n + 2 are already requested.
 template <int CPL>
-__global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl)
+__device__ __forceinline__ void roi_bwd_gather_block(const RoiGradPack &p, const RoiGradIdxPack &ix, const int nsl, const unsigned vblock,
+                                                     const unsigned vgrid)
 {
     const int lane = threadIdx.x & 63;
-    const int xcd = (int)(blockIdx.x & 7);
+    const int xcd = (int)(vblock & 7);
     const int slice = xcd % nsl, part = xcd / nsl, nparts = 8 / nsl;
     const int n_all = __builtin_amdgcn_readfirstlane(ix.header[1]);
     const int per = (n_all + nparts - 1) / nparts;
     const int i_end = min(n_all, (part + 1) * per);                     // this part's items: [part * per, i_end)
-    const int stride = (int)(gridDim.x >> 3) * 4;
-    int i = part * per + (int)(blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);
+    const int stride = (int)(vgrid >> 3) * 4;
+    int i = part * per + (int)(vblock >> 3) * 4 + (int)(threadIdx.x >> 6);
     // diagnostics (tools/roi_bwd_trace.py): 8 words per wave {start, items loaded, offsets loaded, first item done, end, items,
     // candidates, -}
-    long long *tr = ix.trace ? ix.trace + 8 * ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) : nullptr;
+    long long *tr = ix.trace ? ix.trace + 8 * ((long long)vblock * 4 + (threadIdx.x >> 6)) : nullptr;
     long long t_first = 0;
     int n_done = 0, n_cand = 0;
     if (tr && lane == 0) tr[0] = (long long)__builtin_readcyclecounter();
@@ -902,6 +968,102 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
         if (tr) { if (n_done == 0) t_first = (long long)__builtin_readcyclecounter(); ++n_done; n_cand += cnt; }
     }
     if (tr && lane == 0) { tr[3] = t_first; tr[4] = (long long)__builtin_readcyclecounter(); tr[5] = n_done; tr[6] = n_cand; tr[7] = 0; }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl)
+{
+    roi_bwd_gather_block<CPL>(p, ix, nsl, blockIdx.x, gridDim.x);
+}
+
+// RoiPoolGrad behind ONE launch, on the candidate index the forward launch of the same ROIs built (mv3d_roi_pool_forward_views_indexed):
+// the first `fill_blocks` workgroups (one per 16-pixel segment, a multiple of 8 so that the gather's workgroup -> XCD slice mapping
+// holds) zero the pixels that have no candidate (~80 % of the maps; the index kept a 16-bit mask per segment), the gather grid behind
+// them overwrites the others -- every pixel is written exactly once, by one role.  An index that is not the one of these views (the
+// signature the forward left does not match, or its look-back gave up) is refused loudly: the maps are filled with NaN.
+template <int CPL>
+__global__ __launch_bounds__(256) void roi_bwd_fill_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl, unsigned fill_blocks)
+{
+    const bool ok = __builtin_amdgcn_readfirstlane(ix.header[2]) == (int)ix.sig;
+    if (blockIdx.x < fill_blocks) {
+        const unsigned block = blockIdx.x;
+        if (block >= ix.nseg) return;
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+            if (j < p.n && block >= ix.first_block[j]) k = j;
+        const RoiGradViewDev &v = p.v[k];
+        const unsigned g = block - ix.first_block[k];
+        const int w0 = (int)(g % (unsigned)ix.gpr[k]) * BWI_PIX;
+        const int npx = min(BWI_PIX, v.W - w0);
+        const long long pix0 = (long long)(g / (unsigned)ix.gpr[k]) * v.W + w0;       // (frame, row) x W + w0
+        const unsigned mask = ok ? (unsigned)__builtin_amdgcn_readfirstlane(ix.seg_mask[block]) : 0u;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const float z = ok ? 0.0f : __builtin_nanf("");
+        const f4v zz = {z, z, z, z};
+        f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * v.C);
+        const int c4 = v.C / 4, n4 = npx * c4;
+        for (int t = threadIdx.x; t < n4; t += 256)
+            if (!((mask >> (t / c4)) & 1u)) __builtin_nontemporal_store(zz, dst + t);
+        return;
+    }
+    if (!ok) return;
+    roi_bwd_gather_block<CPL>(p, ix, nsl, blockIdx.x - fill_blocks, gridDim.x - fill_blocks);
+}
+
+// The forward RoiPool of all views AND the candidate index of their RoiPoolGrad in one launch.  Roles by workgroup index (after the
+// cold variant's prefetch workgroups): the pooling workgroups in their usual order, with the index workgroups spread between them
+// in chunks of 8 (so that a pooling workgroup's index and its physical XCD keep the same residue mod 8: the channel slicing) --
+// the sizes phase among the first third of the pooling chunks, the lists phase among the last third.  The pooling role is bound by
+// its 154 MB of output writes and leaves the vector ALUs and the LDS idle; the index role is LDS / ALU / latency work that touches
+// a few hundred KB: side by side on a CU they cost each other little.  Region r of the grid has n_r chunks of which NI8 are index
+// chunks, spread evenly: chunk c of the region is an index chunk iff floor((c + 1) NI8 / n_r) > floor(c NI8 / n_r).
+struct RoiFusedPlan { unsigned ni8, n1, p1, n2, n3, nseg; };
+template <int FWD_PASSES>
+union RoiFusedShared { BinGeom g[FWD_PASSES * 32]; RoiIdxShared ix; unsigned mask; };
+
+template <int FWD_PASSES, bool COLD>
+__global__ __launch_bounds__(256) void roi_pool_fwd_indexed_kernel(RoiViewPack p, RoiPrefetchPack pf, RoiGradPack gp, RoiGradIdxPack ix,
+                                                                   RoiFusedPlan pl, int *sink)
+{
+    __shared__ RoiFusedShared<FWD_PASSES> sh;
+    unsigned b = blockIdx.x;
+    if (COLD) {
+        if (b < pf.blocks) { roi_prefetch_block(&sh.mask, p, pf, b, sink); return; }
+        b -= pf.blocks;
+    }
+    unsigned c = b >> 3;
+    const unsigned l8 = b & 7;
+    unsigned pool_chunk;
+    int role = 0;                                   // 0: pooling, 1: index sizes, 2: index lists
+    unsigned idx_chunk = 0;
+    if (c < pl.n1) {
+        const unsigned i0 = c * pl.ni8 / pl.n1, i1 = (c + 1) * pl.ni8 / pl.n1;
+        if (i1 > i0) { role = 1; idx_chunk = i0; }
+        pool_chunk = c - i0;
+    } else if (c < pl.n1 + pl.n2) {
+        pool_chunk = pl.p1 + (c - pl.n1);
+    } else {
+        c -= pl.n1 + pl.n2;
+        const unsigned i0 = c * pl.ni8 / pl.n3, i1 = (c + 1) * pl.ni8 / pl.n3;
+        if (i1 > i0) { role = 2; idx_chunk = i0; }
+        pool_chunk = pl.p1 + pl.n2 + (c - i0);
+    }
+    if (role) {
+        const unsigned seg = idx_chunk * 8 + l8;
+        if (seg >= pl.nseg) return;
+        if (role == 1) roi_bwd_index_block<false, false, true>(sh.ix, gp, ix, seg, pl.nseg);
+        else roi_bwd_index_block<true, false, true>(sh.ix, gp, ix, seg, pl.nseg);
+        return;
+    }
+    const unsigned blk = pool_chunk * 8 + l8;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blk >= p.v[j].first_block) k = j;
+    const RoiViewDev &v = p.v[k];
+    roi_pool_fwd_xcd_block<FWD_PASSES>(sh.g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                                       v.argmax, v.tpb_shift);
 }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -1084,27 +1246,135 @@ static size_t bwd_pool_entries(const mv3d_roi_grad_view &w, int PH, int PW)
     return (size_t)w.num_rois * (size_t)(PH + 2 * w.height + 3) * (size_t)(PW + 2 * w.width + 3);
 }
 
+static unsigned bwd_segments(const mv3d_roi_grad_view &w) { return (unsigned)((long long)w.batch_size * w.height * ((w.width + BWI_PIX - 1) / BWI_PIX)); }
+
+// The candidate index of RoiPoolGrad (lists of (roi, bin) records per pixel) and who may use it: same C for all views, C in
+// {64, 128, 256, 512}, pooled sizes <= 15, 16-byte aligned buffers where given, everything inside 31-bit offsets.
+static bool bwd_index_eligible(int num_views, const mv3d_roi_grad_view *views, int PH, int PW)
+{
+    long long all_pix = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[k];
+        if (!bwd_fast_ok(w.channels, PH, PW, w.height, w.width, w.batch_size)) return false;
+        // (64-channel slices, one per XCD or XCD group: C = 64, 128, 256 or 512; other widths take the sliced kernel)
+        if (w.channels != views[0].channels || w.channels % 64 != 0 || w.channels > 512 || 512 % w.channels != 0) return false;
+        if ((w.bottom_diff && !aligned16(w.bottom_diff)) || (w.top_diff && !aligned16(w.top_diff)) || (w.argmax_data && !aligned16(w.argmax_data)))
+            return false;
+        // record byte offsets are 31-bit scalars in the gather kernel
+        if ((long long)w.num_rois * PH * PW * w.channels * 4 >= 0x7fffffffLL) return false;
+        all_pix += (long long)w.batch_size * w.height * w.width;
+    }
+    return all_pix < 0x7fffffffLL && PH <= 15 && PW <= 15 && PH * PW <= 255;
+}
+
 extern "C" size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height,
                                                          int pooled_width)
 {
     if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0) return 0;
-    size_t total = MV3D_ALIGN;
+    size_t total = MV3D_ALIGN, nseg = 0;
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_grad_view &w = views[k];
         if (w.batch_size <= 0 || w.height <= 0 || w.width <= 0 || w.num_rois < 0) return 0;
         total += mv3d_align_up((size_t)w.batch_size * w.height * w.width * sizeof(int4));
-        total += 2 * mv3d_align_up((size_t)w.batch_size * w.height * ((w.width + BWI_PIX - 1) / BWI_PIX) * sizeof(int) * MV3D_MAX_ROI_VIEWS);
         total += mv3d_align_up(bwd_pool_entries(w, pooled_height, pooled_width) * sizeof(int));
+        nseg += bwd_segments(w);
     }
-    return total + MV3D_ALIGN;
+    // header | candidates per segment | mask per segment | published words of the fused forward | items | pool
+    return total + 2 * mv3d_align_up(nseg * sizeof(int)) + mv3d_align_up(nseg * sizeof(unsigned long long)) + MV3D_ALIGN;
 }
 
-extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
-                                            void *workspace, size_t workspace_bytes, void *stream)
+// The views in index order (the densest view first -- candidates per pixel ~ R PH PW / pixels: the 8 x 64 front-view map carries
+// ~10 x the lists of the others -- so that its pixels head the item list and the gather's waves start with the long lists instead
+// of ending with them: the kernel's time is its slowest wave), the segment numbering and the workspace carved.
+struct BwdIndexPlan { RoiGradPack p; RoiGradIdxPack ix; unsigned iblocks; int ord[MV3D_MAX_ROI_VIEWS]; };
+static int bwd_index_plan(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, void *workspace, BwdIndexPlan &pl)
+{
+    RoiGradPack &p = pl.p;
+    RoiGradIdxPack &ix = pl.ix;
+    ix = RoiGradIdxPack{};
+    p.n = num_views; p.PH = PH; p.PW = PW;
+    int *ord = pl.ord;
+    for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) ord[k] = k;
+    for (int a = 0; a < num_views; ++a)
+        for (int b = a + 1; b < num_views; ++b) {
+            const mv3d_roi_grad_view &x = views[ord[a]], &y = views[ord[b]];
+            const double dx = (double)x.num_rois / ((double)x.batch_size * x.height * x.width);
+            const double dy = (double)y.num_rois / ((double)y.batch_size * y.height * y.width);
+            if (dy > dx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+        }
+    unsigned iblocks = 0;
+    size_t pool_entries = 0, n_items = 0;
+    unsigned sig = 2166136261u;                                         // FNV-1a over what the index depends on
+    auto mix = [&sig](unsigned long long x) { for (int i = 0; i < 8; ++i) { sig ^= (unsigned)(x & 255u); sig *= 16777619u; x >>= 8; } };
+    mix((unsigned long long)num_views); mix((unsigned long long)PH); mix((unsigned long long)PW);
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[ord[k]];
+        RoiGradViewDev &v = p.v[k];
+        v.top_diff = w.top_diff; v.rois = w.bottom_rois; v.argmax = w.argmax_data; v.bottom_diff = w.bottom_diff;
+        v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
+        v.nsl = w.channels / 64;
+        v.first_block = 0; v.pxg = 4; v.gpr = 0;
+        n_items += (size_t)w.batch_size * w.height * w.width;
+        ix.first_block[k] = iblocks;
+        ix.gpr[k] = (w.width + BWI_PIX - 1) / BWI_PIX;
+        iblocks += bwd_segments(w);
+        pool_entries += bwd_pool_entries(w, PH, PW);
+        unsigned sbits;
+        memcpy(&sbits, &w.spatial_scale, 4);
+        mix((unsigned long long)(uintptr_t)w.bottom_rois); mix(sbits); mix((unsigned long long)w.batch_size); mix((unsigned long long)w.num_rois);
+        mix((unsigned long long)w.height); mix((unsigned long long)w.width); mix((unsigned long long)w.channels); mix((unsigned long long)ord[k]);
+    }
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) { p.v[k] = p.v[0]; ix.first_block[k] = 0; ix.gpr[k] = 1; }
+    if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
+    char *ws = (char *)workspace;
+    size_t o = MV3D_ALIGN;
+    ix.header = (int *)ws;
+    ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
+    ix.seg_mask = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
+    ix.seg_word = (unsigned long long *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(unsigned long long));
+    ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
+    ix.pool = (int *)(ws + o);
+    ix.nseg = iblocks;
+    ix.sig = sig ? sig : 1u;
+    ix.trace = nullptr;
+#ifdef MV3D_TUNING                                                     // diagnostics (tools/roi_bwd_trace.py), experiment builds only
+    ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;
+#endif
+    pl.iblocks = iblocks;
+    return MV3D_OK;
+}
+
+// channels per lane of the gather: 1 (64-channel slices, 256-B pieces of a record per wave) measured best on the training batch:
+// 75 us for the three launches vs 82 (2 channels, 512-B pieces) and 105 (4 channels, 1-KB pieces, 8 records in flight): the
+// walk is bound by its dependent round trips, and a lane with more channels holds fewer records in flight
+static int bwd_gather_cpl(int channels)
+{
+#ifdef MV3D_TUNING                                                     // tuning hooks, experiment builds only
+    static const int cpl_env = getenv("MV3D_BWG_CPL") ? atoi(getenv("MV3D_BWG_CPL")) : 0;
+#else
+    const int cpl_env = 0;
+#endif
+    int cpl = 1;
+    if (cpl_env == 2 && channels % 128 == 0) cpl = 2;
+    if (cpl_env == 4 && channels % 256 == 0) cpl = 4;
+    if (8 % (channels / (64 * cpl)) != 0 || channels / (64 * cpl) > 8) cpl = 0;     // (C = 64 k, k not a divisor of 8)
+    return cpl;
+}
+
+static int bwd_gather_groups()
+{
+#ifdef MV3D_TUNING
+    static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;
+    return groups;
+#else
+    return BWG_GROUPS;
+#endif
+}
+
+static int grad_views_check(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width)
 {
     if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0)
         return MV3D_ERR_INVALID_ARG;
-    bool fast = true;
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_grad_view &w = views[k];
         if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_diff ||
@@ -1112,8 +1382,18 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
             (long long)w.height * w.width * w.channels > 0x7fffffffLL ||
             (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
             return MV3D_ERR_INVALID_ARG;
-        fast = fast && bwd_fast_ok(w.channels, pooled_height, pooled_width, w.height, w.width, w.batch_size);
     }
+    return MV3D_OK;
+}
+
+extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int rc0 = grad_views_check(num_views, views, pooled_height, pooled_width);
+    if (rc0 != MV3D_OK) return rc0;
+    bool fast = true;
+    for (int k = 0; k < num_views; ++k)
+        fast = fast && bwd_fast_ok(views[k].channels, pooled_height, pooled_width, views[k].height, views[k].width, views[k].batch_size);
     if (workspace && ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
     if (!fast) {                                          // generic shapes: one launch of the generic kernel per view
         for (int k = 0; k < num_views; ++k) {
@@ -1125,56 +1405,33 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
         }
         return MV3D_OK;
     }
+    const bool indexed = workspace && bwd_index_eligible(num_views, views, pooled_height, pooled_width) &&
+                         workspace_bytes >= mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width);
+    if (indexed) {
+        BwdIndexPlan pl;
+        const int rc = bwd_index_plan(num_views, views, pooled_height, pooled_width, workspace, pl);
+        if (rc != MV3D_OK) return rc;
+        hipLaunchKernelGGL(roi_bwd_index_kernel<false>, dim3(pl.iblocks), dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix);
+        hipLaunchKernelGGL(roi_bwd_index_kernel<true>, dim3(pl.iblocks), dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix);
+        const int cpl = bwd_gather_cpl(views[0].channels);
+        const dim3 gg((unsigned)(bwd_gather_groups() * 8));
+        if (cpl == 4) hipLaunchKernelGGL(roi_bwd_gather_kernel<4>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 256);
+        else if (cpl == 2) hipLaunchKernelGGL(roi_bwd_gather_kernel<2>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 128);
+        else if (cpl == 1) hipLaunchKernelGGL(roi_bwd_gather_kernel<1>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 64);
+        else return MV3D_ERR_INVALID_ARG;
+        return mv3d_launch_status();
+    }
     RoiGradPack p;
     p.n = num_views; p.PH = pooled_height; p.PW = pooled_width;
-    bool same_c = true;
-    long long all_pix = 0;
-    for (int k = 0; k < num_views; ++k) {
-        // (64-channel slices, one per XCD or XCD group: C = 64, 128, 256 or 512; other widths take the sliced kernel)
-        same_c = same_c && views[k].channels == views[0].channels && views[k].channels % 64 == 0 && views[k].channels <= 512 &&
-                 512 % views[k].channels == 0 && aligned16(views[k].bottom_diff) &&
-                 aligned16(views[k].top_diff) && aligned16(views[k].argmax_data);
-        all_pix += (long long)views[k].batch_size * views[k].height * views[k].width;
-    }
-    bool small = true;                                   // record byte offsets are 31-bit scalars in the gather kernel
-    for (int k = 0; k < num_views; ++k)
-        small = small && (long long)views[k].num_rois * pooled_height * pooled_width * views[k].channels * 4 < 0x7fffffffLL;
-    const bool indexed = workspace && same_c && small && all_pix < 0x7fffffffLL && pooled_height <= 15 && pooled_width <= 15 &&
-                         pooled_height * pooled_width <= 255 &&
-                         workspace_bytes >= mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width);
     unsigned blocks = 0;
     size_t carry = 0;
-    RoiGradIdxPack ix = {};
-    unsigned iblocks = 0;
-    char *ws = (char *)workspace;
-    size_t pool_entries = 0, n_items = 0;
-    // the densest view first (candidates per pixel ~ R PH PW / pixels: the 8 x 64 front-view map carries ~10 x the lists of
-    // the others): its pixels then head the item list and the gather's waves start with the long lists instead of ending
-    // with them -- the kernel's time is its slowest wave
-    int ord[MV3D_MAX_ROI_VIEWS] = {0, 1, 2, 3};
-    for (int a = 0; a < num_views; ++a)
-        for (int b = a + 1; b < num_views; ++b) {
-            const mv3d_roi_grad_view &x = views[ord[a]], &y = views[ord[b]];
-            const double dx = (double)x.num_rois / ((double)x.batch_size * x.height * x.width);
-            const double dy = (double)y.num_rois / ((double)y.batch_size * y.height * y.width);
-            if (dy > dx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
-        }
     for (int k = 0; k < num_views; ++k) {
-        const mv3d_roi_grad_view &w = views[ord[k]];
+        const mv3d_roi_grad_view &w = views[k];
         RoiGradViewDev &v = p.v[k];
         v.top_diff = w.top_diff; v.rois = w.bottom_rois; v.argmax = w.argmax_data; v.bottom_diff = w.bottom_diff;
         v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
         v.nsl = w.channels / 64;
         v.first_block = blocks;
-        if (indexed) {
-            v.pxg = 4; v.gpr = 0;
-            n_items += (size_t)w.batch_size * w.height * w.width;
-            ix.first_block[k] = iblocks;
-            ix.gpr[k] = (w.width + BWI_PIX - 1) / BWI_PIX;
-            iblocks += (unsigned)((long long)w.batch_size * w.height * ix.gpr[k]);
-            pool_entries += bwd_pool_entries(w, pooled_height, pooled_width);
-            continue;
-        }
         // sliced kernel: a workgroup = one row segment x one slice.  Long segments amortise the ROI filter and the launch
         // of a workgroup over many (mostly empty) pixels; small maps get short segments so that the launch still fills the chip
         const long long rows = (long long)w.batch_size * w.height * v.nsl;
@@ -1186,42 +1443,151 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
         blocks += (unsigned)(rows * v.gpr);
         if (w.num_rois > BW_CHUNK && (size_t)v.pxg * 64 * sizeof(float) > carry) carry = (size_t)v.pxg * 64 * sizeof(float);
     }
-    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) { p.v[k] = p.v[0]; ix.first_block[k] = 0; ix.gpr[k] = 1; }
-    if (indexed) {
-        size_t o = MV3D_ALIGN;
-        ix.header = (int *)ws;
-        ix.trace = nullptr;
-#ifdef MV3D_TUNING                                                     // diagnostics (tools/roi_bwd_trace.py), experiment builds only
-        ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;
-#endif
-        ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
-        ix.seg_ne = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
-        ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
-        ix.pool = (int *)(ws + o);
-        if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
-        hipLaunchKernelGGL(roi_bwd_index_kernel<false>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
-        hipLaunchKernelGGL(roi_bwd_index_kernel<true>, dim3(iblocks), dim3(256), 0, (hipStream_t)stream, p, ix);
-#ifdef MV3D_TUNING                                                     // tuning hooks, experiment builds only
-        static const int groups = getenv("MV3D_BWG_GROUPS") ? atoi(getenv("MV3D_BWG_GROUPS")) : BWG_GROUPS;
-        static const int cpl_env = getenv("MV3D_BWG_CPL") ? atoi(getenv("MV3D_BWG_CPL")) : 0;
-#else
-        const int groups = BWG_GROUPS, cpl_env = 0;
-#endif
-        // channels per lane: 1 (64-channel slices, 256-B pieces of a record per wave) measured best on the training batch:
-        // 75 us for the three launches vs 82 (2 channels, 512-B pieces) and 105 (4 channels, 1-KB pieces, 8 records in flight):
-        // the walk is bound by its dependent round trips, and a lane with more channels holds fewer records in flight
-        int cpl = 1;
-        if (cpl_env == 2 && views[0].channels % 128 == 0) cpl = 2;
-        if (cpl_env == 4 && views[0].channels % 256 == 0) cpl = 4;
-        if (8 % (views[0].channels / (64 * cpl)) != 0 || views[0].channels / (64 * cpl) > 8) cpl = 0;     // (C = 64 k, k not a divisor of 8)
-        const dim3 gg((unsigned)(groups * 8));
-        if (cpl == 4) hipLaunchKernelGGL(roi_bwd_gather_kernel<4>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 256);
-        else if (cpl == 2) hipLaunchKernelGGL(roi_bwd_gather_kernel<2>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 128);
-        else if (cpl == 1) hipLaunchKernelGGL(roi_bwd_gather_kernel<1>, gg, dim3(256), 0, (hipStream_t)stream, p, ix, views[0].channels / 64);
-        else return MV3D_ERR_INVALID_ARG;
-        return mv3d_launch_status();
-    }
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
     hipLaunchKernelGGL(roi_pool_bwd_sliced_kernel, dim3(blocks), dim3(BW_THREADS), carry, (hipStream_t)stream, p);
+    return mv3d_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoiPool forward + the candidate index of its gradient in ONE launch, RoiPoolGrad in ONE launch.
+static void grad_views_of(int num_views, const mv3d_roi_view *views, mv3d_roi_grad_view *g)
+{
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        g[k].bottom_diff = nullptr; g[k].bottom_rois = w.bottom_rois; g[k].top_diff = nullptr; g[k].argmax_data = nullptr;
+        g[k].spatial_scale = w.spatial_scale; g[k].batch_size = w.batch_size; g[k].num_rois = w.num_rois; g[k].height = w.height;
+        g[k].width = w.width; g[k].channels = w.channels;
+    }
+}
+
+// Is the candidate index of these views built by the forward launch?  Decided from the SHAPES alone (channel widths the XCD-sliced
+// forward handles, at least one ROI per view, the index's own conditions, chunk counts inside the kernel's 32-bit arithmetic), so
+// that mv3d_roi_pool_forward_views_indexed and mv3d_roi_pool_backward_views_indexed take the same decision independently.
+static bool roi_fused_plan(int num_views, const mv3d_roi_grad_view *g, int PH, int PW, RoiFusedPlan &fp, int &passes)
+{
+    if (!bwd_index_eligible(num_views, g, PH, PW)) return false;
+    long long total_bins = 0;
+    unsigned nseg = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const int cv4 = g[k].channels / 4;
+        if (g[k].channels % 4 != 0 || !(cv4 == 64 || cv4 == 128 || cv4 == 256) || g[k].num_rois <= 0) return false;
+        total_bins += (long long)g[k].num_rois * PH * PW;
+        nseg += bwd_segments(g[k]);
+    }
+    passes = fwd_passes(total_bins);
+    unsigned long long np8 = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const int cv4 = g[k].channels / 4;
+        const int tpb_shift = cv4 == 64 ? 3 : (cv4 == 128 ? 4 : 5);
+        const long long per_block = (long long)passes * (256 >> tpb_shift);
+        np8 += (unsigned long long)(((long long)g[k].num_rois * PH * PW + per_block - 1) / per_block);
+    }
+    fp.nseg = nseg;
+    fp.ni8 = (nseg + 7) / 8;
+    if (fp.ni8 >= 32768u || np8 >= 32768ull) return false;
+    fp.p1 = (unsigned)np8 / 3;
+    const unsigned p3 = (unsigned)np8 / 3;
+    fp.n2 = (unsigned)np8 - fp.p1 - p3;
+    fp.n1 = fp.ni8 + fp.p1;
+    fp.n3 = fp.ni8 + p3;
+    return true;
+}
+
+extern "C" size_t mv3d_roi_pool_index_workspace_bytes(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views) return 0;
+    mv3d_roi_grad_view g[MV3D_MAX_ROI_VIEWS];
+    grad_views_of(num_views, views, g);
+    return mv3d_roi_pool_backward_workspace_bytes(num_views, g, pooled_height, pooled_width);
+}
+
+extern "C" int mv3d_roi_pool_forward_views_indexed(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                                   int cold_maps, void *index_ws, size_t index_ws_bytes, void *stream)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0 || !index_ws)
+        return MV3D_ERR_INVALID_ARG;
+    if ((uintptr_t)index_ws % MV3D_ALIGN) return MV3D_ERR_WORKSPACE;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_data ||
+            (w.num_rois > 0 && (!w.bottom_rois || !w.top_data)) ||
+            (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
+            return MV3D_ERR_INVALID_ARG;
+    }
+    mv3d_roi_grad_view g[MV3D_MAX_ROI_VIEWS];
+    grad_views_of(num_views, views, g);
+    const size_t need = mv3d_roi_pool_backward_workspace_bytes(num_views, g, pooled_height, pooled_width);
+    if (need == 0 || index_ws_bytes < need) return MV3D_ERR_WORKSPACE;
+    RoiFusedPlan fp;
+    int passes = 2;
+    bool fused = roi_fused_plan(num_views, g, pooled_height, pooled_width, fp, passes);
+    for (int k = 0; k < num_views && fused; ++k)            // (pointer conditions: a caller that misses them gets an error, not a silent other path)
+        if (!aligned16(views[k].bottom_data) || !aligned16(views[k].top_data) || !views[k].argmax_data || !aligned16(views[k].argmax_data))
+            return MV3D_ERR_INVALID_ARG;
+    if (!fused)
+        // shapes outside the fused kernel: the plain forward; mv3d_roi_pool_backward_views_indexed takes the same decision from
+        // the same shapes and builds the index itself
+        return roi_pool_forward_views_impl(num_views, views, pooled_height, pooled_width, cold_maps != 0, stream);
+    BwdIndexPlan ip;
+    const int rc = bwd_index_plan(num_views, g, pooled_height, pooled_width, index_ws, ip);
+    if (rc != MV3D_OK) return rc;
+    RoiViewPack p;
+    p.n = num_views; p.PH = pooled_height; p.PW = pooled_width;
+    unsigned blocks = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        const int cv4 = w.channels / 4;
+        RoiViewDev &v = p.v[k];
+        v.data = w.bottom_data; v.rois = w.bottom_rois; v.top = w.top_data; v.argmax = w.argmax_data; v.scale = w.spatial_scale;
+        v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
+        v.tpb_shift = cv4 == 64 ? 3 : (cv4 == 128 ? 4 : 5);
+        v.first_block = blocks;
+        const long long nbins = (long long)w.num_rois * pooled_height * pooled_width;
+        const long long per_block = (long long)passes * (256 >> v.tpb_shift);
+        blocks += (unsigned)(((nbins + per_block - 1) / per_block) * 8);
+    }
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
+    if (blocks / 8 != fp.p1 + fp.n2 + (fp.n3 - fp.ni8) || fp.nseg != ip.iblocks) return MV3D_ERR_INVALID_ARG;      // (plan and packs agree)
+    const unsigned long long chunks = (unsigned long long)fp.n1 + fp.n2 + fp.n3;
+    RoiPrefetchPack pf;
+    pf.blocks = 0;
+    for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) pf.first_block[k] = 0;
+    const bool cold = cold_maps && roi_prefetch_plan(num_views, views, pf);
+    if (cold) pf.blocks = (pf.blocks + 7u) & ~7u; else pf.blocks = 0;
+    const dim3 grid((unsigned)(pf.blocks + chunks * 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (cold) {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<4, true>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
+        else hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<2, true>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
+    } else {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<4, false>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
+        else hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<2, false>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
+    }
+    return mv3d_launch_status();
+}
+
+extern "C" int mv3d_roi_pool_backward_views_indexed(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                                    void *index_ws, size_t index_ws_bytes, void *stream)
+{
+    const int rc0 = grad_views_check(num_views, views, pooled_height, pooled_width);
+    if (rc0 != MV3D_OK) return rc0;
+    if (!index_ws || ((uintptr_t)index_ws % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    if (index_ws_bytes < mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
+    // the decision mv3d_roi_pool_forward_views_indexed took from the same shapes: was the index built by the forward launch?
+    RoiFusedPlan fp;
+    int passes = 2;
+    const bool fused = roi_fused_plan(num_views, views, pooled_height, pooled_width, fp, passes);
+    if (!fused) return mv3d_roi_pool_backward_views(num_views, views, pooled_height, pooled_width, index_ws, index_ws_bytes, stream);
+    BwdIndexPlan pl;
+    const int rc = bwd_index_plan(num_views, views, pooled_height, pooled_width, index_ws, pl);
+    if (rc != MV3D_OK) return rc;
+    const int cpl = bwd_gather_cpl(views[0].channels);
+    const unsigned fill_blocks = (pl.iblocks + 7u) & ~7u;
+    const dim3 gg((unsigned)(fill_blocks + bwd_gather_groups() * 8));
+    if (cpl == 4) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<4>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 256, fill_blocks);
+    else if (cpl == 2) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<2>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 128, fill_blocks);
+    else if (cpl == 1) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<1>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 64, fill_blocks);
+    else return MV3D_ERR_INVALID_ARG;
     return mv3d_launch_status();
 }
 
@@ -1235,4 +1601,21 @@ extern "C" int mv3d_roi_pool_backward(const float *top_diff, float spatial_scale
     w.spatial_scale = spatial_scale; w.batch_size = batch_size; w.num_rois = num_rois; w.height = height; w.width = width;
     w.channels = channels;
     return mv3d_roi_pool_backward_views(1, &w, pooled_height, pooled_width, nullptr, 0, stream);
+}
+
+// roi_pooling_op_gpu.h:18-27, argument for argument: 1 = launched, 0 = refused / launch error
+extern "C" int mv3d_ROIPoolForwardLaucher(const float *bottom_data, float spatial_scale, int num_rois, int height, int width,
+                                          int channels, int pooled_height, int pooled_width, const float *bottom_rois,
+                                          float *top_data, int32_t *argmax_data, void *stream)
+{
+    return mv3d_roi_pool_forward(bottom_data, spatial_scale, 0x7fffffff, num_rois, height, width, channels, pooled_height, pooled_width,
+                                 bottom_rois, top_data, argmax_data, stream) == MV3D_OK;
+}
+
+extern "C" int mv3d_ROIPoolBackwardLaucher(const float *top_diff, float spatial_scale, int batch_size, int num_rois, int height,
+                                           int width, int channels, int pooled_height, int pooled_width, const float *bottom_rois,
+                                           float *bottom_diff, const int32_t *argmax_data, void *stream)
+{
+    return mv3d_roi_pool_backward(top_diff, spatial_scale, batch_size, num_rois, height, width, channels, pooled_height, pooled_width,
+                                  bottom_rois, bottom_diff, argmax_data, stream) == MV3D_OK;
 }

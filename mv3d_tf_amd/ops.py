@@ -335,6 +335,63 @@ def roi_pool_backward_views(views, pooled_height, pooled_width, outs=None):
     return res
 
 
+# ---- RoiPool + the candidate index of its gradient in one launch, RoiPoolGrad in one launch (mv3d_roi_pool_*_views_indexed)
+_INDEX_WS_FREE = {}                # (device, bytes) -> index workspaces that no forward / backward pair holds
+
+
+def roi_index_workspace(nbytes, device):
+    """An index workspace for one forward -> backward pair: zeroed once when it is made (the contract of
+    mv3d_roi_pool_forward_views_indexed; the library leaves its look-back words zero after every call), then recycled through
+    release_roi_index_workspace."""
+    free = _INDEX_WS_FREE.setdefault((str(device), int(nbytes)), [])
+    return free.pop() if free else torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def release_roi_index_workspace(ws):
+    free = _INDEX_WS_FREE.setdefault((str(ws.device), int(ws.numel())), [])
+    if len(free) < 4:
+        free.append(ws)
+
+
+def roi_pool_forward_views_indexed(views, pooled_height, pooled_width, outs=None, cold_maps=False, index_ws=None):
+    """views as roi_pool_forward_views; ONE launch pools every view AND builds the per-pixel candidate index RoiPoolGrad gathers
+    over into `index_ws` (made here when None).  Returns ([(top, argmax), ...], index_ws): hand both to
+    roi_pool_backward_views_indexed."""
+    arr = (RoiView * len(views))()
+    res = []
+    for k, (data, rois, scale) in enumerate(views):
+        B, H, W, Cc = data.shape
+        R = rois.shape[0]
+        if outs is not None:
+            top, am = outs[k]
+        else:
+            top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.float32, device=data.device)
+            am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device)
+        arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, R, H, W, Cc)
+        res.append((top, am))
+    if index_ws is None:
+        index_ws = roi_index_workspace(lib().mv3d_roi_pool_index_workspace_bytes(len(views), arr, pooled_height, pooled_width), views[0][0].device)
+    check(lib().mv3d_roi_pool_forward_views_indexed(len(views), arr, pooled_height, pooled_width, 1 if cold_maps else 0, _ptr(index_ws),
+                                                    index_ws.numel(), _stream()), "mv3d_roi_pool_forward_views_indexed")
+    return res, index_ws
+
+
+def roi_pool_backward_views_indexed(views, pooled_height, pooled_width, index_ws, outs=None):
+    """views as roi_pool_backward_views, of the forward that filled `index_ws` (the same rois TENSORS, the argmax planes it wrote):
+    RoiPoolGrad of all of them in ONE launch.  Returns [bottom_diff, ...]."""
+    arr = (RoiGradView * len(views))()
+    res = []
+    for k, (top_diff, rois, argmax, shape, scale) in enumerate(views):
+        B, H, W, Cc = shape
+        out = outs[k] if outs is not None else torch.empty((B, H, W, Cc), dtype=torch.float32, device=top_diff.device)
+        arr[k] = RoiGradView(out.data_ptr(), rois.data_ptr(), top_diff.data_ptr(), argmax.data_ptr(), float(scale), B,
+                             rois.shape[0], H, W, Cc)
+        res.append(out)
+    check(lib().mv3d_roi_pool_backward_views_indexed(len(views), arr, pooled_height, pooled_width, _ptr(index_ws), index_ws.numel(), _stream()),
+          "mv3d_roi_pool_backward_views_indexed")
+    return res
+
+
 def rois_3d_to_fv(rois_3d, out=None):
     """rois_3d (R,7) device f32 [b,x,y,z,l,w,h] -> rois_fv (R,5) [b,x1,y1,x2,y2] on the 64 x 512 front-view map."""
     r3 = rois_3d.contiguous()

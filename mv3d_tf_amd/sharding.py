@@ -38,6 +38,16 @@ def sum_over_ranks(value, dist=None, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, dist=None, device="cpu"):
+    """a python float of every rank, in rank order, on every rank (per-rank diagnostics of the bench line)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def gather_frame_results(local, num_frames, dist=None, device="cpu"):
     """local: dict {frame index: 1-D int64 tensor} for the frames this rank owns.  Returns on
     every rank the list of per-frame tensors in frame order (None if no process group: local only).

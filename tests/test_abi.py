@@ -21,7 +21,7 @@ def hiplib():
 def test_header_symbols_are_exported(hiplib):
     hdr = open(os.path.join(ROOT, "include", "mv3d_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(mv3d_[a-z0-9_]+|_nms)\s*\(", hdr))
+    declared = set(re.findall(r"\b(mv3d_[A-Za-z0-9_]+|_nms)\s*\(", hdr))
     assert declared, "no declarations parsed"
     handle = hiplib.lib()
     for name in declared:

@@ -84,6 +84,50 @@ def test_bench_line_contract_on_the_gpu():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the line verifies what it timed and reports the roofline in the mode it timed
+    v = d["verified"]
+    assert v["bit_exact"] is True and v["batches"] == 2 and v["rows"] > 0 and v["mismatches"] == []
+    fl = r["in_flight"]
+    assert fl["batches_in_flight"] == 8 and fl["forward_us"] > 0 and fl["backward_us"] > 0
+    assert d["config"]["host_cpu_s_per_step"] > 0 and d["config"]["host_cores"]["usable"] >= 1 and d["config"]["host_cores"]["pinned"] is None
+    assert all("in_flight_us" in e for e in d["roofline_kernels"])
+
+
+@pytest.mark.gpu
+def test_path_driver_depth8_equals_the_oracle(bench):
+    """the headline's own driver (bench.PathDriver, depth 8: eight batches in flight on eight streams, argument structs at capacity
+    with the row count set per batch) against the oracle, after it has been run the way the timed loop runs it"""
+    import torch
+    from mv3d_tf_amd import build, hot_path, synth
+    from mv3d_tf_amd.fast_rcnn.config import apply_end2end_yml, cfg
+    build.build()
+    saved = {k: cfg.TRAIN[k] for k in ("BG_THRESH_LO", "BG_THRESH_HI", "FG_THRESH")}
+    apply_end2end_yml()
+    try:
+        dev = torch.device("cuda")
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+        host, inputs, maps = [], [], []
+        for k in range(5):
+            frames = [synth.rpn_head(7700 + 2 * k + b, 76, 76, "peaky", return_gt=True) for b in range(2)]
+            host.append(frames)
+            inputs.append((t(np.concatenate([f[0] for f in frames])), t(np.concatenate([f[1] for f in frames])),
+                           t(np.concatenate([f[2] for f in frames])), t(np.stack([f[3] for f in frames])),
+                           [tuple(t(a) for a in f[4]) for f in frames]))
+            maps.append(hot_path.synth_maps(2, 60 + k, dev))
+        drv = bench.PathDriver(inputs, maps, depth=8)
+        np.random.seed(11)
+        drv.run(37)                                                  # (every slot reused several times, cursor not a multiple of anything)
+        v = drv.verify(host, nbatches=5, seed=77)
+        assert v["bit_exact"], v["mismatches"]
+        assert v["batches"] == 5 and v["rows"] > 5 * 2 * 64
+        fl = drv.in_flight_us(nb=24)
+        assert fl["forward_us"] > 0 and fl["backward_us"] > 0 and fl["calls_timed"] == 16
+        v2 = drv.verify(host, nbatches=2, seed=78)                   # ... and still right after the event-marked run
+        assert v2["bit_exact"], v2["mismatches"]
+        drv.close()
+    finally:
+        for k, val in saved.items():
+            cfg.TRAIN[k] = val
 
 
 @pytest.mark.gpu
@@ -165,3 +209,20 @@ def test_cpu_baseline_worker_and_usable_cores(tmp_path):
         out, _ = p.communicate(timeout=120)
         frames, secs = out.split()
         assert int(frames) >= 1 and 0.0 < float(secs) < 30.0
+
+
+def test_host_thread_plan_pins_core_pairs_or_falls_back(bench):
+    """VERDICT r04 #6b: N ranks share a node's cores -- every rank's submitting + drawing thread get their own core pair, or the
+    bench says that the host cannot carry `--launch path` and times the frozen-batch replay instead"""
+    one = bench.plan_host_threads(1, 0, 16, range(16))
+    assert one["launch"] == "path" and one["cores"] is None
+    mask = [3, 4, 5, 6, 7, 8, 9, 10, 40, 41, 42, 43, 44, 45, 46, 47]            # a 16-core affinity mask, not starting at 0
+    plans = [bench.plan_host_threads(8, r, 16, mask) for r in range(8)]
+    assert all(p["launch"] == "path" for p in plans)
+    pairs = [tuple(p["cores"]) for p in plans]
+    assert pairs[0] == (3, 4) and pairs[7] == (46, 47) and len({c for pr in pairs for c in pr}) == 16      # disjoint pairs
+    few = bench.plan_host_threads(8, 2, 12, mask)                               # quota 12 < 2 x 8
+    assert few["launch"] == "graph" and few["cores"] is None and "12 usable host cores for 8 ranks" in few["note"]
+    assert bench.plan_host_threads(8, 2, 16, mask[:10])["launch"] == "graph"      # the mask itself is too small
+    n, note = bench.usable_cores()
+    assert n >= 1 and isinstance(note, str)
