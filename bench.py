@@ -8,8 +8,8 @@ Default workload = BASELINE configs[2], path only (the largest single-GPU config
       mv3d_anchor_target_*       RPN labels / 6-d targets of every frame
       mv3d_proposal_target_*     <= 128 sampled ROIs / frame (fg first), corner targets, image boxes
       mv3d_rois_3d_to_fv         third (front-view) ROIs
-      mv3d_roi_pool_forward_views   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7
-      mv3d_roi_pool_backward_views  the same three layers, RoiPoolGrad
+      mv3d_roi_pool_forward_views_pair   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7 (private 16-bit argmax plane)
+      mv3d_roi_pool_backward_views_pair  the same three layers, RoiPoolGrad (candidate index + zero fill, ordered gather)
 
 A "step" = one pass over `--batches-per-step` such batches (default 1664 batches = 3328 frames: `--steps 20` is a SUSTAINED
 ~5 s timed region, not a burst), cycling through a ring of `--ring` (default 16) DISTINCT batches per GPU -- distinct frames
@@ -196,7 +196,7 @@ class PathDriver:
         self.rows = 0
 
     def roi(self, out, k, marks=None):
-        """RoiPool forward (+ the gradient's candidate index, same launch) and backward (one launch) on the batch's ROIs: the
+        """The RoiPool pair (forward with the private compact argmax plane; backward = index + fill, gather) on the batch's ROIs: the
         argument structs of a (maps, slot) combination are built once (every buffer has the slots' fixed capacity), a batch only
         sets its row count -- a caller's steady state, no per-batch slicing.  marks: {"fwd": [], "bwd": []} gets a HIP event pair
         per call, recorded on the batch's own stream (the calls' durations with the other batches in flight)."""
@@ -215,7 +215,7 @@ class PathDriver:
                 bwd[i] = self.RoiGradView(d[v][3].data_ptr(), r, d[v][2].data_ptr(), d[v][1].data_ptr(), 0.125, Bm, self.cap, H, W, Cc)
             ws = self.bufs[j].get("ws")
             if ws is None:
-                wsz = L.mv3d_roi_pool_index_workspace_bytes(NV, fwd, 7, 7)          # (at the slots' capacity)
+                wsz = L.mv3d_roi_pool_pair_workspace_bytes(NV, bwd, 7, 7)           # (at the slots' capacity; zeroed once: the entry's contract)
                 ws = self.bufs[j]["ws"] = torch.zeros(max(wsz, 256), dtype=torch.uint8, device=maps[self.views[0]].device)
             hit = self.structs[key] = (fwd, bwd, ws)
         fwd, bwd, ws = hit
@@ -228,10 +228,10 @@ class PathDriver:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
         if ev:
             ev[0].record(stream)
-        self.check(L.mv3d_roi_pool_forward_views_indexed(NV, fwd, 7, 7, self.cold, wp, wn, st), "mv3d_roi_pool_forward_views_indexed")
+        self.check(L.mv3d_roi_pool_forward_views_pair(NV, fwd, 7, 7, self.cold, st), "mv3d_roi_pool_forward_views_pair")
         if ev:
             ev[1].record(stream)
-        self.check(L.mv3d_roi_pool_backward_views_indexed(NV, bwd, 7, 7, wp, wn, st), "mv3d_roi_pool_backward_views_indexed")
+        self.check(L.mv3d_roi_pool_backward_views_pair(NV, bwd, 7, 7, wp, wn, st), "mv3d_roi_pool_backward_views_pair")
         if ev:
             ev[2].record(stream)
             marks["fwd"].append((ev[0], ev[1]))
@@ -296,16 +296,24 @@ class PathDriver:
                 want["bev"].append(r_bv); want["rgb"].append(r_img); want["fv"].append(oracle.rois_3d_to_fv(r_3d))
             St = out["rois"]["bev"].shape[0]
             rows += St
-            for v in self.views:
+            # the pair keeps its argmax plane as private 16-bit codes: decoded to the reference's int32 plane for the comparison
+            from mv3d_tf_amd import ops
+            mp = self.maps[k % len(self.inputs)]
+            fviews = [(mp[v], out["rois"][v], 0.125) for v in self.views]
+            with torch.cuda.stream(out["stream"]):
+                dec = ops.roi_pool_argmax_decode(fviews, [(self.bufs[j][v][0][:St], self.bufs[j][v][1]) for v in self.views], 7, 7)
+            torch.cuda.synchronize()
+            for vi, v in enumerate(self.views):
                 rois = np.concatenate(want[v])
                 if rois.shape[0] != St or not np.array_equal(out["rois"][v].cpu().numpy(), rois):
                     bad.append("batch %d rois_%s" % (k, v))
                     continue
-                m = self.maps[k % len(self.inputs)][v].cpu().numpy()
-                top, am, td, bd = (t.cpu().numpy() for t in self.bufs[j][v])
+                m = mp[v].cpu().numpy()
+                top, _, td, bd = (t.cpu().numpy() for t in self.bufs[j][v])
+                am = dec[vi].cpu().numpy()
                 o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
                 o_bd = oracle.roi_pool_grad(m, rois, o_am, td[:St], 7, 7, 0.125)
-                for name, a, b_ in (("top", top[:St], o_top), ("argmax", am[:St], o_am), ("bottom_diff", bd, o_bd)):
+                for name, a, b_ in (("top", top[:St], o_top), ("argmax", am, o_am), ("bottom_diff", bd, o_bd)):
                     if not np.array_equal(a, b_):
                         bad.append("batch %d %s_%s" % (k, name, v))
         return {"batches": len(cap), "rows": rows, "bit_exact": not bad, "mismatches": bad[:8],
@@ -361,9 +369,10 @@ def roofline_entries(ring, workload, signature):
     s0 = ring.slots[0].stream
     mine = [s for s in ring.slots if s.stream is s0]
     if workload == "train":
-        # RoiPool + the gradient's candidate index in one launch, RoiPoolGrad (zero fill + gather) in one launch
-        legs = [("roi_pool_fwd_indexed_kernel", "mv3d_roi_pool_forward_views_indexed", "roi_forward_bytes"),
-                ("roi_bwd_fill_gather_kernel", "mv3d_roi_pool_backward_views_indexed", "roi_backward_bytes")]
+        # the RoiPool pair: forward with 16-bit argmax codes; RoiPoolGrad = index + zero fill launch, gather launch behind one call
+        legs = [("roi_pool_fwd_pair_cold_kernel" if getattr(mine[0], "cold_maps", False) else "roi_pool_fwd_pair_kernel",
+                 "mv3d_roi_pool_forward_views_pair", "roi_forward_bytes"),
+                ("roi_pair_index_kernel + roi_pair_gather_kernel", "mv3d_roi_pool_backward_views_pair", "roi_backward_bytes")]
     else:
         legs = [("roi_pool_fwd_xcd_multi%s_kernel" % ("_cold" if getattr(mine[0], "cold_maps", False) else ""),
                  mine[0].fwd_fn.__name__, "roi_forward_bytes")]
@@ -384,7 +393,7 @@ def roofline_entries(ring, workload, signature):
         out.append({"kernel": "%s (BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512 views, R=%d rows each, batch %d)"
                               % (kname, mine[0].num_rois, mine[0].B),
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kname, signature),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("roi_pair_" if "roi_pair_" in kname else kname, signature),
                     "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(marks[fn])})
     return out
 
@@ -712,7 +721,8 @@ def main():
         res["config"]["one_batch_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         entries = roofline_entries(ring, wl, signature)
         dom = max(entries, key=lambda e: e["avg_launch_us"]) if entries else {}
-        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = index + gather kernels behind one C call); "
+        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = index + fill and gather kernels behind one C call; algorithmic "
+                                         "bytes as SURVEY 8(d) defines them -- 8 B per pooled value -- while the pair moves 6: its argmax plane is 16-bit); "
                                          "HIP event pairs on the launch stream around the call inside the batch's eager launch "
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "
                                          "configuration or null")
@@ -723,7 +733,7 @@ def main():
             res["roofline"]["in_flight"] = dict(fl, note="HIP event pairs on each batch's own stream around the RoiPool calls while the "
                                                          "path driver keeps its batches in flight (the mode `value` is measured in)")
             for e in entries:
-                us = fl["backward_us"] if "bwd" in e["kernel"] else fl["forward_us"]
+                us = fl["backward_us"] if "roi_pair_" in e["kernel"] else fl["forward_us"]
                 e["in_flight_us"] = us
                 e["in_flight_frac"] = round(e["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             res["verified"] = ring.driver.verify(ring.host_frames_all)

@@ -180,27 +180,37 @@ size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv3d_roi_grad
 int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
                                  void *workspace, size_t workspace_bytes, void *stream);
 
-/* RoiPool and the candidate index of its gradient in ONE launch, RoiPoolGrad in ONE launch (the fast training path).
- * The per-pixel candidate lists RoiPoolGrad gathers over (roi_pooling_op.cc:392-431: which (roi, ph, pw) bins may name a pixel)
- * are a function of the ROIs alone, so mv3d_roi_pool_forward_views_indexed builds them while it pools -- index workgroups spread
- * between the pooling workgroups of the same launch: the pooling is bound by its output writes, the index is LDS / ALU work -- into
- * `index_ws`, and mv3d_roi_pool_backward_views_indexed is then one launch: fill workgroups zero the pixels without candidates,
- * the gather writes the others.  Results are bit-identical to mv3d_roi_pool_forward_views / mv3d_roi_pool_backward_views.
- *   index_ws        caller-owned, 256-B aligned, >= mv3d_roi_pool_index_workspace_bytes(); its FIRST 256 + 24 * segments bytes
- *                   (simply: the whole buffer) must be ZERO before the first call that uses it -- the library leaves them zero
- *                   again after every call (the look-back words of the in-launch index are cleared by the launch itself);
- *                   one forward -> backward pair at a time per buffer, both on streams ordered after each other.
- *   backward        the views must be the forward's (same order, shapes, spatial_scale and the SAME bottom_rois pointers); an
- *                   index that is not theirs is refused loudly: bottom_diff is filled with NaN.  `argmax_data` must be the plane
- *                   the forward wrote (for a foreign argmax use mv3d_roi_pool_backward_views, which builds its index on demand).
+/* The PAIR: RoiPool and RoiPoolGrad of a training step with a PRIVATE argmax plane between them (the fast training path).
+ * `top_data` and `bottom_diff` are bit-identical to mv3d_roi_pool_forward_views / mv3d_roi_pool_backward_views.
+ *   argmax_data     (required) belongs to the pair: the forward writes it, the backward reads it, nobody else needs it (the
+ *                   reference's own graph uses the op's second output only in RoiPoolGrad, roi_pooling_op_grad.py:7-43).  The
+ *                   pair's kernels store it as 16-bit codes -- the position of the first maximum in its bin's scan order
+ *                   (h - hstart) * (wend - wstart) + (w - wstart), 0xFFFF for the reference's -1 -- in the first half of the
+ *                   caller's (num_rois, PH, PW, C) int32 buffer: a quarter of the record bytes (8 -> 6 B per pooled value) is
+ *                   neither written by the forward nor read by the backward.  mv3d_roi_pool_argmax_decode returns the reference's
+ *                   int32 plane (tests, verification).
+ *   backward        three launches: one workgroup per 16 pixels of a map row sizes (1) and then writes (2) the per-pixel candidate
+ *                   lists of roi_pooling_op.cc:392-431 -- only bins whose forward rectangle contains the pixel, each with the
+ *                   code the pixel has in that bin -- both zero-filling half of bottom_diff under their latency chains; (3) the
+ *                   ordered gather: `code == pixel's code ? top_diff : +0` per record, the reference's summation order.  The
+ *                   views must be the forward's (same order, shapes, scale, ROIs) with the argmax buffers it wrote.  (For a
+ *                   foreign argmax plane use mv3d_roi_pool_backward_views: int32 argmax.)
+ *   workspace       caller-owned, 256-B aligned, >= mv3d_roi_pool_pair_workspace_bytes(); needs no initialisation (every word is
+ *                   written before it is read).
  *   cold_maps       != 0: as mv3d_roi_pool_forward_views_cold.
- * Shapes outside the fused kernels (C not in {256, 512, 1024} / not the same for all views, pooled sizes > 15, an empty view) take
- * the plain forward and the index-on-demand backward behind the same two entries. */
-size_t mv3d_roi_pool_index_workspace_bytes(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width);
-int mv3d_roi_pool_forward_views_indexed(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
-                                        int cold_maps, void *index_ws, size_t index_ws_bytes, void *stream);
-int mv3d_roi_pool_backward_views_indexed(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
-                                         void *index_ws, size_t index_ws_bytes, void *stream);
+ * Shapes outside the pair's kernels (C not in {256, 512} / not the same for all views, pooled sizes > 15, a map of more than 65534
+ * pixels, an empty view) take the plain forward (int32 argmax) and mv3d_roi_pool_backward_views behind the same entries.
+ * (Measured and dropped, round 5: the candidate index built by workgroups inside the FORWARD launch, and a single-pass index with
+ * an in-launch look-back -- DESIGN.md.) */
+size_t mv3d_roi_pool_pair_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width);
+int mv3d_roi_pool_forward_views_pair(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                     int cold_maps, void *stream);
+int mv3d_roi_pool_backward_views_pair(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+/* views: as passed to mv3d_roi_pool_forward_views_pair (after it ran); argmax_out[k]: (num_rois, PH, PW, C) int32, a buffer of its
+ * own: the reference's argmax plane of view k (flat index inside the frame, -1 for an empty bin). */
+int mv3d_roi_pool_argmax_decode(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                int32_t *const *argmax_out, void *stream);
 
 /* Call-compatible aliases of the reference's two launchers (roi_pooling_op_gpu.h:18-27): EXACTLY their argument order -- the
  * forward WITHOUT a batch size (out-of-range batch indices are then the caller's problem, as in the reference) -- with `void *stream`

@@ -151,9 +151,10 @@ _SIGS = {
     "mv3d_roi_pool_forward_views_cold": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
     "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
     "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
-    "mv3d_roi_pool_index_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int]),
-    "mv3d_roi_pool_forward_views_indexed": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
-    "mv3d_roi_pool_backward_views_indexed": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_roi_pool_pair_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
+    "mv3d_roi_pool_forward_views_pair": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_roi_pool_backward_views_pair": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mv3d_roi_pool_argmax_decode": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, C.POINTER(C.c_void_p), _P]),
     "mv3d_ROIPoolForwardLaucher": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "mv3d_ROIPoolBackwardLaucher": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "mv3d_rois_3d_to_fv": (C.c_int, [_P, C.c_int, _P, _P]),

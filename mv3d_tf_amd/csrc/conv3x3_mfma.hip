@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvGroup g)
     for (int j = 1; j < CONV_MAX_VIEWS; ++j)
         if (j < g.n && (int)blockIdx.x >= g.first[j]) view = j;
     const ConvArgs &a = g.v[view];
-    constexpr int BM = 256, BN = 256, NW = 8, NT = 512, WP = 2, TP = 128, TC = 64, FP = 4, FC = 2;
+    constexpr int BM = 256, BN = 256, NT = 512, TP = 128, TC = 64, FP = 4, FC = 2;   // 8 waves = 2 pixel halves x 4 cout quarters
     constexpr int ES = sizeof(T), CPS = BK_BYTES / ES;
     static_assert(ES == 2, "16-bit operands");
     constexpr int HALF = 128 * BK_BYTES;                          // one half-tile: 128 rows x 128 B = 16 KB

@@ -16,7 +16,6 @@
 #include <float.h>
 #include <stdlib.h>
 #include <math.h>
-#include <string.h>
 #include "common.h"
 #include "kernels.h"
 #include "roi_geom.h"
@@ -110,7 +109,21 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const float *__restri
 #define LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local")
 struct BinGeom { int hs, he, ws, we; int base; int pad0, pad1, pad2; };   // base < 0: empty / bad batch index
 
-template <int FWD_PASSES>
+__device__ __forceinline__ void upd4pos(const float4 x, int pos, float4 &mv, int4 &mi)
+{
+    upd(x.x, pos, mv.x, mi.x);
+    upd(x.y, pos, mv.y, mi.y);
+    upd(x.z, pos, mv.z, mi.z);
+    upd(x.w, pos, mv.w, mi.w);
+}
+
+// COMPACT (the indexed pair, mv3d_roi_pool_forward_views_indexed): the argmax plane is PRIVATE to the pair -- only its own
+// RoiPoolGrad reads it -- and is written as 16-bit codes instead of the reference's int32 flat indices: the position of the first
+// maximum in the bin's scan order, (h - hstart) * (wend - wstart) + (w - wstart), 0xFFFF for "none" (the reference's -1).  A quarter
+// of the pair's record bytes (8 -> 6 B per pooled value) is neither written here nor read by the gradient; the gradient's
+// candidate index carries the code each candidate pixel has inside each of its bins, so the test `argmax == this pixel`
+// (roi_pooling_op.cc:433) is one 16-bit compare.  mv3d_roi_pool_argmax_decode gives the reference's plane back (tests, bench).
+template <int FWD_PASSES, bool COMPACT = false>
 __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
                                                         const float *__restrict__ data, float scale,
                                                         int B, int R, int H, int W, int C, int PH, int PW,
@@ -162,6 +175,7 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
             if (g.base >= 0) {
                 mv = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
                 const float *d = data + (long long)g.base * H * W * C + c0;
+                int pos = 0;                         // (COMPACT) position in the bin's scan order
                 for (int h = g.hs; h < g.he; ++h) {
                     int w = g.ws;
                     // four independent 16-byte loads in flight, consumed in scan order (first max wins)
@@ -171,14 +185,20 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
                         const float4 x1 = *reinterpret_cast<const float4 *>(d + idx + C);
                         const float4 x2 = *reinterpret_cast<const float4 *>(d + idx + 2 * C);
                         const float4 x3 = *reinterpret_cast<const float4 *>(d + idx + 3 * C);
-                        upd4(x0, idx + c0, mv, mi);
-                        upd4(x1, idx + C + c0, mv, mi);
-                        upd4(x2, idx + 2 * C + c0, mv, mi);
-                        upd4(x3, idx + 3 * C + c0, mv, mi);
+                        if (COMPACT) {
+                            upd4pos(x0, pos, mv, mi); upd4pos(x1, pos + 1, mv, mi); upd4pos(x2, pos + 2, mv, mi); upd4pos(x3, pos + 3, mv, mi);
+                            pos += 4;
+                        } else {
+                            upd4(x0, idx + c0, mv, mi);
+                            upd4(x1, idx + C + c0, mv, mi);
+                            upd4(x2, idx + 2 * C + c0, mv, mi);
+                            upd4(x3, idx + 3 * C + c0, mv, mi);
+                        }
                     }
                     for (; w < g.we; ++w) {
                         const int idx = (h * W + w) * C;
-                        upd4(*reinterpret_cast<const float4 *>(d + idx), idx + c0, mv, mi);
+                        if (COMPACT) upd4pos(*reinterpret_cast<const float4 *>(d + idx), pos++, mv, mi);
+                        else upd4(*reinterpret_cast<const float4 *>(d + idx), idx + c0, mv, mi);
                     }
                 }
             }
@@ -188,9 +208,15 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef int i4v __attribute__((ext_vector_type(4)));
             const f4v mvv = {mv.x, mv.y, mv.z, mv.w};
-            const i4v miv = {mi.x, mi.y, mi.z, mi.w};
             __builtin_nontemporal_store(mvv, reinterpret_cast<f4v *>(top + o));
-            if (argmax) __builtin_nontemporal_store(miv, reinterpret_cast<i4v *>(argmax + o));
+            if (COMPACT) {                           // four 16-bit codes (-1 -> 0xFFFF), 8 bytes per lane
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                const u2v cv = {((unsigned)mi.x & 0xffffu) | ((unsigned)mi.y << 16), ((unsigned)mi.z & 0xffffu) | ((unsigned)mi.w << 16)};
+                __builtin_nontemporal_store(cv, reinterpret_cast<u2v *>(reinterpret_cast<unsigned short *>(argmax) + o));
+            } else {
+                const i4v miv = {mi.x, mi.y, mi.z, mi.w};
+                if (argmax) __builtin_nontemporal_store(miv, reinterpret_cast<i4v *>(argmax + o));
+            }
         }
     }
 }
@@ -642,17 +668,13 @@ __global__ __launch_bounds__(BW_THREADS) void roi_pool_bwd_sliced_kernel(RoiGrad
 #define BWI_PIX 16
 #define BWG_GROUPS 256                // gather grid = BWG_GROUPS x nsl workgroups of 4 waves (~ what the chip holds at once)
 #define BWI_SPIN_LIMIT (1 << 16)      // polls of one published word before a look-back gives up (and flags the index invalid)
-// header words of the workspace (ints): [0] look-back "done" counter of the fused forward (zero between calls), [1] number of items,
-// [2] signature of the index a fused forward built (0: none), [3] error flag of the fused forward's look-back
 struct RoiGradIdxPack {
     long long *trace; int4 *items; int *pool; int *header;
     int *seg_tot, *seg_mask;                         // per 16-pixel segment: candidates, 16-bit mask of the pixels that have any
-    unsigned long long *seg_word;                    // fused forward: the same two numbers published as one word (0 = not yet)
     unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS];
-    unsigned nseg, sig;
 };
 
-// LDS of one index workgroup (14.4 KB; the fused forward overlays it with the pooling role's bin table)
+// LDS of one index workgroup
 struct RoiIdxShared {
     int red[8];
     int roi[BW_CHUNK], rsw[BW_CHUNK], rew[BW_CHUNK], prow[BW_CHUNK];
@@ -660,19 +682,13 @@ struct RoiIdxShared {
     unsigned char nb[BW_CHUNK][BWI_PIX], xr[BW_CHUNK][BWI_PIX];
     int wcnt[4], cnt[BWI_PIX], base[BWI_PIX], run[BWI_PIX];
     int part[16][BWI_PIX];
-    int last;
 };
 
 // One index workgroup = one 16-pixel segment of a map row.
-// FILL = false: sizes (candidates of the segment, mask of its non-empty pixels); FILL = true: slab offsets from the sizes of the
-// preceding segments (a plain sum), items and candidate lists.  ZERO: the workgroup also zero-fills its pixels of bottom_diff
-// (the stand-alone two-launch RoiPoolGrad).  FUSED: both phases run inside ONE launch (the forward RoiPool's): the sizes are
-// published as one 64-bit word per segment with an agent-scope store, the lists phase looks back over the words of its
-// predecessors (the protocol of mv3d_grid_compact, common.h: 0 = not yet published; the words are zero on entry, and the lists
-// workgroup that finishes its look-back last clears them again) -- the sizes workgroups sit EARLIER in the grid than every lists
-// workgroup, so a word is missing only while its workgroup is still running; a look-back that waits more than BWI_SPIN_LIMIT polls
-// gives up and flags the index invalid (the backward then refuses it) instead of hanging.
-template <bool FILL, bool ZERO, bool FUSED>
+// FILL = false: zero-fill + sizes (candidates of the segment, mask of its non-empty pixels); FILL = true: slab offsets from the
+// sizes of the preceding segments (a plain sum: the sizing launch is complete), items and candidate lists.  No atomics on global
+// memory, no state that has to be zero on entry.
+template <bool FILL>
 __device__ __forceinline__ void roi_bwd_index_block(RoiIdxShared &S, const RoiGradPack &p, const RoiGradIdxPack &ix, const unsigned block,
                                                     const unsigned nblocks)
 {
@@ -692,7 +708,7 @@ __device__ __forceinline__ void roi_bwd_index_block(RoiIdxShared &S, const RoiGr
     const int j = threadIdx.x & (BWI_PIX - 1), q = threadIdx.x / BWI_PIX;      // pixel of the segment, entry stripe
     const int npass = (R + BW_CHUNK - 1) / BW_CHUNK;
     const long long pix0 = ((long long)n * H + h) * W + w0;
-    if (ZERO && FILL == ((h & 1) != 0)) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have
+    if (FILL == ((h & 1) != 0)) {   // every pixel of the segment starts as zeros (the gather kernel overwrites the ones that have
         // candidates); even rows by the sizing launch, odd rows by the list launch: each launch is a chain of barriers and LDS
         // round trips with the memory system idle, so half of the 55 MB of streaming stores hides under each.  The
         // segment's npx * C floats are contiguous
@@ -768,49 +784,27 @@ __device__ __forceinline__ void roi_bwd_index_block(RoiIdxShared &S, const RoiGr
 #pragma unroll
             for (int m = 1; m < BWI_PIX; m <<= 1) tot += __shfl_xor(tot, m);
             const unsigned mask = (unsigned)(__ballot(c > 0) & 0xffffull);
-            if (lane == 0) {
-                if (FUSED) __hip_atomic_store(&ix.seg_word[block], ((unsigned long long)(unsigned)tot << 32) | ((unsigned long long)mask << 1) | 1ull,
-                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else { ix.seg_tot[block] = tot; ix.seg_mask[block] = (int)mask; }
-            }
+            if (lane == 0) { ix.seg_tot[block] = (tot << 5) | __popc(mask); ix.seg_mask[block] = (int)mask; }
         }
         return;
     }
-    {   // slab offsets = sums over the preceding segments' sizes
+    {   // slab offsets = sums over the preceding segments' sizes (candidates << 5 | pixels with any; eight words per thread requested
+        // together: one word at a time the loop was a chain of dependent round trips at the head of every workgroup)
         int a = 0, b = 0;
-        bool gave_up = false;
-        for (int t = threadIdx.x; t < (int)block; t += 256) {
-            if (FUSED) {
-                unsigned long long w8 = __hip_atomic_load(&ix.seg_word[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int spin = 0; w8 == 0ull && spin < BWI_SPIN_LIMIT; ++spin) {
-                    __builtin_amdgcn_s_sleep(8);
-                    w8 = __hip_atomic_load(&ix.seg_word[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                gave_up = gave_up || w8 == 0ull;
-                a += (int)(w8 >> 32); b += __popc((unsigned)(w8 >> 1) & 0xffffu);
-            } else {
-                a += ix.seg_tot[t]; b += __popc((unsigned)ix.seg_mask[t]);
+        for (int t0 = 0; t0 < (int)block; t0 += 256 * 8) {
+            int pk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256 + (int)threadIdx.x;
+                pk[u] = t < (int)block ? ix.seg_tot[t] : 0;
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += pk[u] >> 5; b += pk[u] & 31; }
         }
-        if (FUSED && gave_up) { atomicOr(&ix.header[3], 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
         if (lane == 0) { S.red[wave] = a; S.red[4 + wave] = b; }
         __syncthreads();
-    }
-    if (FUSED) {   // this workgroup's look-back is over; the one that gets there last clears the published words for the next call
-        if (threadIdx.x == 0)
-            S.last = (__hip_atomic_fetch_add(&ix.header[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)nblocks - 1);
-        __syncthreads();
-        if (S.last) {
-            for (int t = threadIdx.x; t < (int)nblocks; t += 256) __hip_atomic_store(&ix.seg_word[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (threadIdx.x == 0) {
-                const int bad = __hip_atomic_load(&ix.header[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ix.header[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ix.header[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ix.header[2] = bad ? 0 : (int)ix.sig;          // the index of THIS forward (read by the backward launch)
-            }
-        }
     }
     if (threadIdx.x < 64) {                      // sizes -> offsets inside the segment's slabs; items
         const int base0 = S.red[0] + S.red[1] + S.red[2] + S.red[3], ibase = S.red[4] + S.red[5] + S.red[6] + S.red[7];
@@ -821,10 +815,7 @@ __device__ __forceinline__ void roi_bwd_index_block(RoiIdxShared &S, const RoiGr
         const unsigned long long ne = __ballot(c > 0);
         if (lane < BWI_PIX) S.base[lane] = base0 + inc - c;
         if (c > 0) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, c, k);
-        if (lane == 0) {
-            if (FUSED) ix.seg_mask[block] = (int)(ne & 0xffffull);                // (the fill workgroups of the backward launch)
-            if (block == nblocks - 1) ix.header[1] = ibase + __popcll(ne);        // number of items of the launch
-        }
+        if (lane == 0 && block == nblocks - 1) ix.header[1] = ibase + __popcll(ne);        // number of items of the launch
     }
     __syncthreads();
     for (int pass = 0; pass < npass; ++pass) {
@@ -860,7 +851,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void roi_bwd_index_kernel(RoiGradPack p, RoiGradIdxPack ix)
 {
     __shared__ RoiIdxShared S;
-    roi_bwd_index_block<FILL, true, false>(S, p, ix, blockIdx.x, gridDim.x);
+    roi_bwd_index_block<FILL>(S, p, ix, blockIdx.x, gridDim.x);
 }
 
 // records u0 .. u0 + W - 1 of the 64 whose byte offsets sit in the lanes of `cur`: per record one v_readlane (-> SGPR) and two
@@ -976,94 +967,421 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
     roi_bwd_gather_block<CPL>(p, ix, nsl, blockIdx.x, gridDim.x);
 }
 
-// RoiPoolGrad behind ONE launch, on the candidate index the forward launch of the same ROIs built (mv3d_roi_pool_forward_views_indexed):
-// the first `fill_blocks` workgroups (one per 16-pixel segment, a multiple of 8 so that the gather's workgroup -> XCD slice mapping
-// holds) zero the pixels that have no candidate (~80 % of the maps; the index kept a 16-bit mask per segment), the gather grid behind
-// them overwrites the others -- every pixel is written exactly once, by one role.  An index that is not the one of these views (the
-// signature the forward left does not match, or its look-back gave up) is refused loudly: the maps are filled with NaN.
-template <int CPL>
-__global__ __launch_bounds__(256) void roi_bwd_fill_gather_kernel(RoiGradPack p, RoiGradIdxPack ix, int nsl, unsigned fill_blocks)
+// ===============================================================================================================================
+// The PAIR (mv3d_roi_pool_forward_views_pair / mv3d_roi_pool_backward_views_pair): RoiPool and its gradient with a private 16-bit
+// argmax plane between them.
+//
+//   forward          the XCD-sliced pooling kernels above with COMPACT codes: 6 instead of 8 bytes per pooled value are written.
+//   backward, launches 1 + 2  one workgroup per 16-pixel segment of a map row, as the plain indexed RoiPoolGrad above: SIZES
+//                    (filter the ROIs by frame, row, column span; an upper bound of every pixel's list: all bins the reference's
+//                    test lets through), then LISTS (slab offsets = plain sums over the preceding segments' sizes -- the sizing
+//                    launch is complete -- items, and the candidate lists themselves); each launch zero-fills half of the maps'
+//                    rows under its latency chain (the ROI loads are issued BEFORE the fill's stores: a load's wait would
+//                    otherwise wait for every older store as well).  No atomics, no state that has to be zero on entry.
+//   candidate lists  entries {record byte offset into top_diff, code of THIS pixel inside THAT bin} in the reference's order
+//                    roi -> ph -> pw; only bins whose forward rectangle [hstart, hend) x [wstart, wend) (roi_pooling_op.cc:153-162)
+//                    contains the pixel are listed: the forward scans nothing else, so a bin outside of which the pixel lies can
+//                    never name it (roi_pooling_op.cc:433 is false for it whatever top_diff holds) -- and a bin that covers the
+//                    pixel without passing the reference's candidate test (:401-431: the test uses the UNCLAMPED rounded ROI, a
+//                    last bin's ceil() may reach one pixel past it) stays out, as the reference leaves it out.
+//   backward, launch 3  the gather sums each candidate pixel's records in list order (= the reference's f32 summation order): per
+//                    record one 16-bit code + one f32 per lane, `code == this pixel's code ? top_diff : +0`, and overwrites the pixel.
+// Bit-identical to the plain entries (tests/test_roi_pair.py).  Measured and dropped in round 5 (tools/experiments/
+// roi_pair_index_in_forward_r05.hip.txt, profiles/r05_c_*, r05_d_*): the index built by workgroups INSIDE the forward launch
+// (forward 39 -> 56 us: latency-bound workgroups under a write-saturated memory system), and a single-pass index with a look-back
+// over agent-scope words (38 - 49 us for the launch: 1744 workgroups x ~870 predecessor words through the memory side).
+// header words of the workspace (ints): [1] number of items
+struct RoiPairIdx {
+    int4 *items; int2 *pool; int *header; int *seg_tot, *seg_mask;
+    unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS];
+    unsigned nseg;
+    int dbg;                                         // experiment builds (MV3D_TUNING): parts of the index launches switched off, 0 otherwise
+    long long *trace;                                // experiment builds: 8 cycle stamps per workgroup of the lists launch (tools/roi_idx_trace.py)
+};
+
+struct RoiPairShared {
+    int red[8];
+    int roi[BW_CHUNK], rsw[BW_CHUNK], rew[BW_CHUNK], rsh[BW_CHUNK], prow[BW_CHUNK];
+    float bw[BW_CHUNK], bh[BW_CHUNK];
+    unsigned char nb[BW_CHUNK][BWI_PIX], xr[BW_CHUNK][BWI_PIX];
+    int wcnt[4], cnt[BWI_PIX], base[BWI_PIX], run[BWI_PIX];
+    int part[16][BWI_PIX];
+    int last;
+};
+
+// The forward's rectangle of a bin is a product of a row range and a column range (roi_pooling_op.cc:153-162), and so is the
+// reference's candidate set of a pixel (:423-431), so the listed bins of pixel (h, w) under one ROI are [pa, pb) x [qa, qb): the
+// bins ph of the reference's range whose rows hstart(ph) <= h < hend(ph) contain the pixel's row -- a contiguous run, the bins being
+// ordered -- times the same for the columns.  The row run is found once per (ROI, segment) by the thread that filters the ROI, the
+// column run once per (ROI, pixel); a bin's code is then (h - hstart(ph)) * (wend(pw) - wstart(pw)) + (w - wstart(pw)).
+__device__ __forceinline__ int roi_pair_lo(const int p, const float bin, const int start, const int limit)
 {
-    const bool ok = __builtin_amdgcn_readfirstlane(ix.header[2]) == (int)ix.sig;
-    if (blockIdx.x < fill_blocks) {
-        const unsigned block = blockIdx.x;
-        if (block >= ix.nseg) return;
-        int k = 0;
-#pragma unroll
-        for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
-            if (j < p.n && block >= ix.first_block[j]) k = j;
-        const RoiGradViewDev &v = p.v[k];
-        const unsigned g = block - ix.first_block[k];
-        const int w0 = (int)(g % (unsigned)ix.gpr[k]) * BWI_PIX;
-        const int npx = min(BWI_PIX, v.W - w0);
-        const long long pix0 = (long long)(g / (unsigned)ix.gpr[k]) * v.W + w0;       // (frame, row) x W + w0
-        const unsigned mask = ok ? (unsigned)__builtin_amdgcn_readfirstlane(ix.seg_mask[block]) : 0u;
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        const float z = ok ? 0.0f : __builtin_nanf("");
-        const f4v zz = {z, z, z, z};
-        f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * v.C);
-        const int c4 = v.C / 4, n4 = npx * c4;
-        for (int t = threadIdx.x; t < n4; t += 256)
-            if (!((mask >> (t / c4)) & 1u)) __builtin_nontemporal_store(zz, dst + t);
-        return;
+    return min(max((int)floorf(__fmul_rn((float)p, bin)) + start, 0), limit);        // hstart / wstart as roi_pool_fwd_xcd_block computes them
+}
+__device__ __forceinline__ int roi_pair_hi(const int p, const float bin, const int start, const int limit)
+{
+    return min(max((int)ceilf(__fmul_rn((float)(p + 1), bin)) + start, 0), limit);    // hend / wend
+}
+// the run [a, b) of bins of [p0, p1) whose extent contains coordinate x; packed a | b << 8 (a == b: none)
+__device__ __forceinline__ int roi_pair_run(const int p0, const int p1, const float bin, const int start, const int limit, const int x)
+{
+    int a = p1, b = p1;
+    for (int p = p0; p < p1; ++p) {
+        const bool in = x >= roi_pair_lo(p, bin, start, limit) && x < roi_pair_hi(p, bin, start, limit);
+        if (in && a == p1) a = p;
+        if (!in && a != p1) { b = p; break; }
     }
-    if (!ok) return;
-    roi_bwd_gather_block<CPL>(p, ix, nsl, blockIdx.x - fill_blocks, gridDim.x - fill_blocks);
+    return a | (b << 8);
 }
 
-// The forward RoiPool of all views AND the candidate index of their RoiPoolGrad in one launch.  Roles by workgroup index (after the
-// cold variant's prefetch workgroups): the pooling workgroups in their usual order, with the index workgroups spread between them
-// in chunks of 8 (so that a pooling workgroup's index and its physical XCD keep the same residue mod 8: the channel slicing) --
-// the sizes phase among the first third of the pooling chunks, the lists phase among the last third.  The pooling role is bound by
-// its 154 MB of output writes and leaves the vector ALUs and the LDS idle; the index role is LDS / ALU / latency work that touches
-// a few hundred KB: side by side on a CU they cost each other little.  Region r of the grid has n_r chunks of which NI8 are index
-// chunks, spread evenly: chunk c of the region is an index chunk iff floor((c + 1) NI8 / n_r) > floor(c NI8 / n_r).
-struct RoiFusedPlan { unsigned ni8, n1, p1, n2, n3, nseg; };
-template <int FWD_PASSES>
-union RoiFusedShared { BinGeom g[FWD_PASSES * 32]; RoiIdxShared ix; unsigned mask; };
-
-template <int FWD_PASSES, bool COLD>
-__global__ __launch_bounds__(256) void roi_pool_fwd_indexed_kernel(RoiViewPack p, RoiPrefetchPack pf, RoiGradPack gp, RoiGradIdxPack ix,
-                                                                   RoiFusedPlan pl, int *sink)
+// FILL = false: sizes -- the UNPRUNED number of candidate bins of every pixel (an upper bound of its list, cheap: no per-bin
+// arithmetic) and the mask of pixels that have any; FILL = true: offsets, items, the pruned lists with their codes.
+template <bool FILL>
+__device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const RoiGradPack &p, const RoiPairIdx &ix, const unsigned block)
 {
-    __shared__ RoiFusedShared<FWD_PASSES> sh;
-    unsigned b = blockIdx.x;
-    if (COLD) {
-        if (b < pf.blocks) { roi_prefetch_block(&sh.mask, p, pf, b, sink); return; }
-        b -= pf.blocks;
+    const unsigned nblocks = ix.nseg;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && block >= ix.first_block[j]) k = j;
+    const RoiGradViewDev &v = p.v[k];
+    const int PH = p.PH, PW = p.PW, H = v.H, W = v.W, R = v.R, C = v.C;
+    const unsigned g = block - ix.first_block[k];
+    const int gpr = ix.gpr[k];
+    const int w0 = (int)(g % (unsigned)gpr) * BWI_PIX;
+    const int npx = min(BWI_PIX, W - w0);
+    const unsigned gh = g / (unsigned)gpr;
+    const int h = (int)(gh % (unsigned)H), n = (int)(gh / (unsigned)H);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = threadIdx.x & (BWI_PIX - 1), q = threadIdx.x / BWI_PIX;      // pixel of the segment, entry stripe
+    const int npass = (R + BW_CHUNK - 1) / BW_CHUNK;
+    const long long pix0 = ((long long)n * H + h) * W + w0;
+    long long *tr = (FILL && ix.trace) ? ix.trace + 8 * (long long)block : nullptr;
+#define RPI_STAMP(K) do { if (tr && threadIdx.x == 0) tr[K] = (long long)__builtin_readcyclecounter(); } while (0)
+    RPI_STAMP(0);
+    // the first pass's ROI of this thread: requested BEFORE the fill's stores (a wait for a load also waits for every older store)
+    float r0[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if ((int)threadIdx.x < R) {
+        const float *roi = v.rois + 5 * (long long)threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) r0[u] = roi[u];
     }
-    unsigned c = b >> 3;
-    const unsigned l8 = b & 7;
-    unsigned pool_chunk;
-    int role = 0;                                   // 0: pooling, 1: index sizes, 2: index lists
-    unsigned idx_chunk = 0;
-    if (c < pl.n1) {
-        const unsigned i0 = c * pl.ni8 / pl.n1, i1 = (c + 1) * pl.ni8 / pl.n1;
-        if (i1 > i0) { role = 1; idx_chunk = i0; }
-        pool_chunk = c - i0;
-    } else if (c < pl.n1 + pl.n2) {
-        pool_chunk = pl.p1 + (c - pl.n1);
-    } else {
-        c -= pl.n1 + pl.n2;
-        const unsigned i0 = c * pl.ni8 / pl.n3, i1 = (c + 1) * pl.ni8 / pl.n3;
-        if (i1 > i0) { role = 2; idx_chunk = i0; }
-        pool_chunk = pl.p1 + pl.n2 + (c - i0);
+    // (lists) the segment's slab and item offsets = sums over the preceding segments' sizes: requested before the fill as well
+    int a = 0, b = 0;
+    unsigned my_mask = 0;
+    if (FILL) {
+        // (seg_tot holds candidates << 5 | pixels with any; eight words per thread requested together: summed one word at a time the
+        // loop was a chain of dependent round trips -- ~2 us each -- at the head of every workgroup)
+        for (int t0 = 0; t0 < ((ix.dbg & 2) ? 0 : (int)block); t0 += 256 * 8) {
+            int pk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 256 + (int)threadIdx.x;
+                pk[u] = t < (int)block ? ix.seg_tot[t] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += pk[u] >> 5; b += pk[u] & 31; }
+        }
+        my_mask = (unsigned)ix.seg_mask[block];                        // the pixels the sizing launch gave an item (upper bound > 0)
     }
-    if (role) {
-        const unsigned seg = idx_chunk * 8 + l8;
-        if (seg >= pl.nseg) return;
-        if (role == 1) roi_bwd_index_block<false, false, true>(sh.ix, gp, ix, seg, pl.nseg);
-        else roi_bwd_index_block<true, false, true>(sh.ix, gp, ix, seg, pl.nseg);
+    if (FILL == ((h & 1) != 0) && !(ix.dbg & 1)) {   // every pixel of the segment starts as zeros (the gather overwrites the ones that have candidates);
+        // even rows by the sizing launch, odd rows by the list launch.  npx * C contiguous floats, streaming stores
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * C);
+        const int n4 = npx * (C / 4);
+        for (int t = threadIdx.x; t < n4; t += 256) __builtin_nontemporal_store(z, dst + t);
+    }
+    if (threadIdx.x < BWI_PIX) { S.cnt[threadIdx.x] = 0; S.run[threadIdx.x] = 0; }
+    int nlist = 0;
+
+    // filter one pass of ROIs into the ordered LDS list (roi_pooling_op.cc:392-403, :423-426 for the rows), then count every
+    // (entry, pixel) pair's bins: all the reference's test lets through (sizes), or the ones the lists will hold (lists)
+    auto build = [&](const int pass) -> int {
+        __syncthreads();
+        const int r = pass * BW_CHUNK + (int)threadIdx.x;
+        bool ok = false;
+        int rsw = 0, rew = 0, rsh = 0, prow = 0;
+        float bw = 1.0f, bh = 1.0f;
+        if (r < R) {
+            float rr[5];
+            if (pass == 0) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) rr[u] = r0[u];
+            } else {
+                const float *roi = v.rois + 5 * (long long)r;
+#pragma unroll
+                for (int u = 0; u < 5; ++u) rr[u] = roi[u];
+            }
+            const RoiGeom t = roi_geom(rr, v.scale);
+            ok = ((int)rr[0] == n) && h >= t.rsh && h <= t.reh && t.rew >= w0 && t.rsw < w0 + npx;
+            if (ok) {
+                const int rh = max(t.reh - t.rsh + 1, 1), rw = max(t.rew - t.rsw + 1, 1);
+                bh = (float)rh / (float)PH;
+                int phs = (int)floorf((float)(h - t.rsh) / bh), phe = (int)ceilf((float)(h - t.rsh + 1) / bh);
+                phs = min(max(phs, 0), PH); phe = min(max(phe, 0), PH);
+                ok = phe > phs;
+                rsw = t.rsw; rew = t.rew; rsh = t.rsh; prow = phs | (phe << 8);
+                bw = (float)rw / (float)PW;
+                if (FILL && ok && !(ix.dbg & 8)) { // the lists hold only the bins whose forward rows contain h
+                    prow = roi_pair_run(phs, phe, bh, rsh, H, h);
+                    ok = (prow >> 8) > (prow & 255);
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) S.wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1ull));
+        int nl = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int cw = S.wcnt[t]; if (t < wave) pos += cw; nl += cw; }
+        if (ok) { S.roi[pos] = r; S.rsw[pos] = rsw; S.rew[pos] = rew; S.rsh[pos] = rsh; S.prow[pos] = prow; S.bw[pos] = bw; S.bh[pos] = bh; }
+        __syncthreads();
+        int local = 0;
+        const int w = w0 + j;
+        for (int e = q; e < nl; e += 256 / BWI_PIX) {
+            int nb = 0, xr = 0;
+            const int xs = S.rsw[e], xe = S.rew[e];
+            if (j < npx && w >= xs && w <= xe) {
+                const float fbw = S.bw[e];
+                int x0 = (int)floorf((float)(w - xs) / fbw), x1 = (int)ceilf((float)(w - xs + 1) / fbw);      // :425-426
+                x0 = min(max(x0, 0), PW); x1 = min(max(x1, 0), PW);
+                if (x1 > x0) {
+                    const int pr = S.prow[e];
+                    if (FILL && !(ix.dbg & 8)) {    // ... and whose forward columns contain w
+                        const int run = roi_pair_run(x0, x1, fbw, xs, W, w);
+                        x0 = run & 255; x1 = run >> 8;
+                    }
+                    nb = ((pr >> 8) - (pr & 255)) * (x1 - x0);
+                    xr = x0 | (x1 << 4);
+                }
+            }
+            if (FILL) { S.nb[e][j] = (unsigned char)nb; S.xr[e][j] = (unsigned char)xr; }
+            local += nb;
+        }
+        if (local) atomicAdd(&S.cnt[j], local);
+        return nl;
+    };
+
+    if (!FILL) {
+        for (int pass = 0; pass < npass; ++pass) nlist = build(pass);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int c = (lane < BWI_PIX) ? S.cnt[lane] : 0;
+            int tot = c;
+#pragma unroll
+            for (int m = 1; m < BWI_PIX; m <<= 1) tot += __shfl_xor(tot, m);
+            const unsigned mask = (unsigned)(__ballot(c > 0) & 0xffffull);
+            if (lane == 0) { ix.seg_tot[block] = (tot << 5) | __popc(mask); ix.seg_mask[block] = (int)mask; }
+        }
         return;
     }
-    const unsigned blk = pool_chunk * 8 + l8;
+    // ---- lists
+    RPI_STAMP(1);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+    RPI_STAMP(2);                                     // (the prefix words have arrived)
+    if (lane == 0) { S.red[wave] = a; S.red[4 + wave] = b; }
+    // the pruned counts of every pass: a pixel's list is written pass after pass, its length is known after the last one
+    if (npass == 1) nlist = build(0);
+    else {
+        // (R > 256: the pixel counts of all passes first, then the passes again for the lists -- rare on this path)
+        for (int pass = 0; pass < npass; ++pass) nlist = build(pass);
+    }
+    __syncthreads();
+    RPI_STAMP(3);                                     // (filter + counts done)
+    if (tr && threadIdx.x == 0) tr[7] = nlist;
+    if (threadIdx.x < 64) {                      // upper-bound slab offsets of the segment's pixels come from the SIZES launch's rule
+        const int base0 = S.red[0] + S.red[1] + S.red[2] + S.red[3], ibase = S.red[4] + S.red[5] + S.red[6] + S.red[7];
+        // this pixel's slab: the unpruned counts are not kept, so the pixels share the segment's slab in pixel order by their PRUNED
+        // counts (pruned <= unpruned, pixel by pixel: the slab is never overrun)
+        const int c = (lane < BWI_PIX) ? S.cnt[lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int m = 1; m < BWI_PIX; m <<= 1) { const int t = __shfl_up(inc, m); if (lane >= m) inc += t; }
+        const bool has = lane < BWI_PIX && ((my_mask >> lane) & 1u);
+        const unsigned long long ne = __ballot(has);
+        if (lane < BWI_PIX) S.base[lane] = base0 + inc - c;
+        // an item per pixel the sizing launch counted (its list may turn out empty: count 0, the gather then writes the zero again)
+        if (has) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, c, k);
+        if (lane == 0 && block == nblocks - 1) ix.header[1] = ibase + __popcll(ne);        // number of items of the launch
+    }
+    __syncthreads();
+    for (int pass = 0; pass < npass; ++pass) {
+        if (npass > 1) { nlist = build(pass); }
+        __syncthreads();
+        // per pixel: where each entry's bins go = an exclusive prefix of nb over the entries: 16 stripes of consecutive entries per
+        // pixel (thread = (stripe, pixel)), stripe sums, a prefix over the stripes, then the thread walks its own entries
+        const int sp = threadIdx.x & (BWI_PIX - 1), st = threadIdx.x / BWI_PIX;       // pixel, stripe
+        const int L = (nlist + 15) / 16, e0 = st * L, e1 = min(nlist, e0 + L);
+        int sum = 0;
+        for (int e = e0; e < e1; ++e) sum += S.nb[e][sp];
+        S.part[st][sp] = sum;
+        __syncthreads();
+        int run = S.run[sp];
+        for (int t = 0; t < st; ++t) run += S.part[t][sp];
+        int2 *dst = ix.pool + S.base[sp] + run;
+        for (int e = e0; e < ((ix.dbg & 4) ? e0 : e1); ++e) {
+            if (S.nb[e][sp] == 0) continue;
+            const int xr = S.xr[e][sp], pr = S.prow[e], ys = S.rsh[e], xs = S.rsw[e];
+            const float fbh = S.bh[e], fbw = S.bw[e];
+            const int rec0 = S.roi[e] * PH * PW, w = w0 + sp;
+            for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
+                const int dh = h - roi_pair_lo(ph, fbh, ys, H);
+                for (int pw = xr & 15; pw < (xr >> 4); ++pw) {
+                    const int ws = roi_pair_lo(pw, fbw, xs, W), we = roi_pair_hi(pw, fbw, xs, W);
+                    *dst++ = make_int2((rec0 + ph * PW + pw) * C * 4, dh * (we - ws) + (w - ws));
+                }
+            }
+        }
+        __syncthreads();
+        if (st == 15) S.run[sp] = run + sum;                         // (the last stripe ends at the pass's total)
+    }
+    RPI_STAMP(4);
+#undef RPI_STAMP
+}
+
+// the gather of the pair: wave = (item, 64-channel slice) as roi_bwd_gather_block; per record one 16-bit code and one f32 per lane
+template <int W, bool MASKED>
+__device__ __forceinline__ void roi_pair_drain(const int cur_o, const int cur_k, const int u0, const int m, const __amdgpu_buffer_rsrc_t rc,
+                                               const __amdgpu_buffer_rsrc_t rt, const int lane, float &a)
+{
+    unsigned short cd[W];
+    float td[W];
+    int sk[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const int l = MASKED ? min(u0 + u, 63) : u0 + u;
+        const int so = __builtin_amdgcn_readlane(cur_o, l);
+        sk[u] = __builtin_amdgcn_readlane(cur_k, l);
+        cd[u] = __builtin_amdgcn_raw_buffer_load_b16(rc, lane * 2, so >> 1, 0);
+        td[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, lane * 4, so, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < W; ++u)
+        if (!MASKED || u0 + u < m) a += ((int)cd[u] == sk[u]) ? td[u] : 0.0f;
+}
+
+__device__ __forceinline__ void roi_pair_gather_block(const RoiGradPack &p, const RoiPairIdx &ix, const int nsl, const unsigned vblock,
+                                                      const unsigned vgrid)
+{
+    const int lane = threadIdx.x & 63;
+    const int xcd = (int)(vblock & 7);
+    const int slice = xcd % nsl, part = xcd / nsl, nparts = 8 / nsl;
+    const int n_all = __builtin_amdgcn_readfirstlane(ix.header[1]);
+    const int per = (n_all + nparts - 1) / nparts;
+    const int i_end = min(n_all, (part + 1) * per);                     // this part's items: [part * per, i_end)
+    const int stride = (int)(vgrid >> 3) * 4;
+    int i = part * per + (int)(vblock >> 3) * 4 + (int)(threadIdx.x >> 6);
+    if (i >= i_end) return;
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int4 it = ix.items[i];
+    int4 it1 = (i + stride < i_end) ? ix.items[i + stride] : zero4;
+    int2 idx = ix.pool[it.y + max(min(lane, it.z - 1), 0)];       // (a list may be empty: every bin of the pixel pruned)
+    constexpr int W = 32;
+    for (; i < i_end; i += stride) {
+        const int pix = __builtin_amdgcn_readfirstlane(it.x), off = __builtin_amdgcn_readfirstlane(it.y);
+        const int cnt = __builtin_amdgcn_readfirstlane(it.z), k = __builtin_amdgcn_readfirstlane(it.w);
+        const bool more = i + stride < i_end;                              // wave-uniform
+        const int4 nxt = it1;
+        if (i + 2 * stride < i_end) it1 = ix.items[i + 2 * stride];
+        int2 idx1 = make_int2(0, 0);
+        if (more) idx1 = ix.pool[__builtin_amdgcn_readfirstlane(nxt.y) + max(min(lane, __builtin_amdgcn_readfirstlane(nxt.z) - 1), 0)];
+        const RoiGradViewDev &v = p.v[k];
+        const int C = v.C;
+        const int c = slice * 64 + lane;
+        const int2 *cand = ix.pool + off;
+        // the slice lives in the (wave-uniform) base address, the lane in the vector offset, the record's byte offset is the scalar
+        // offset of the load (halved for the 16-bit code plane, which the forward wrote into the caller's argmax buffer)
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((const unsigned short *)v.argmax + slice * 64), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64), 0, 0x7fffffff, 0x00020000);
+        float a = 0.0f;
+        for (int t0 = 0; t0 < cnt; t0 += 64) {
+            const int2 cur = idx;
+            if (t0 + 64 < cnt) idx = cand[min(t0 + 64 + lane, cnt - 1)];
+            const int m = min(64, cnt - t0);
+            int u0 = 0;
+            for (; u0 + W <= m; u0 += W) roi_pair_drain<W, false>(cur.x, cur.y, u0, m, rc, rt, lane, a);
+            if (u0 + 16 <= m) { roi_pair_drain<16, false>(cur.x, cur.y, u0, m, rc, rt, lane, a); u0 += 16; }
+            if (u0 + 8 <= m) { roi_pair_drain<8, false>(cur.x, cur.y, u0, m, rc, rt, lane, a); u0 += 8; }
+            if (u0 + 4 <= m) { roi_pair_drain<4, false>(cur.x, cur.y, u0, m, rc, rt, lane, a); u0 += 4; }
+            if (u0 < m) roi_pair_drain<4, true>(cur.x, cur.y, u0, m, rc, rt, lane, a);
+        }
+        __builtin_nontemporal_store(a, v.bottom_diff + (long long)pix * C + c);
+        it = nxt; idx = idx1;
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void roi_pair_index_kernel(RoiGradPack p, RoiPairIdx ix)
+{
+    __shared__ RoiPairShared S;
+    roi_pair_index_block<FILL>(S, p, ix, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void roi_pair_gather_kernel(RoiGradPack p, RoiPairIdx ix, int nsl)
+{
+    roi_pair_gather_block(p, ix, nsl, blockIdx.x, gridDim.x);
+}
+
+// the pair's forward: the multi-view pooling kernels with COMPACT argmax codes
+template <int FWD_PASSES>
+__global__ __launch_bounds__(256) void roi_pool_fwd_pair_kernel(RoiViewPack p)
+{
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
+    const RoiViewDev &v = p.v[k];
+    roi_pool_fwd_xcd_block<FWD_PASSES, true>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                                             v.argmax, v.tpb_shift);
+}
+
+template <int FWD_PASSES>
+__global__ __launch_bounds__(256) void roi_pool_fwd_pair_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink)
+{
+    __shared__ BinGeom s_g[FWD_PASSES * 32];
+    __shared__ unsigned s_mask;
+    if (blockIdx.x < pf.blocks) { roi_prefetch_block(&s_mask, p, pf, blockIdx.x, sink); return; }
+    const unsigned blk = blockIdx.x - pf.blocks;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blk >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES>(sh.g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
-                                       v.argmax, v.tpb_shift);
+    roi_pool_fwd_xcd_block<FWD_PASSES, true>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                                             v.argmax, v.tpb_shift);
+}
+
+// the pair's private 16-bit argmax plane -> the reference's int32 plane (flat index inside the frame, -1 for none); tests and
+// bench.py's verification only.  One thread per pooled value; the bin geometry as the forward computes it.
+__global__ __launch_bounds__(256) void roi_argmax_decode_kernel(const unsigned short *__restrict__ codes, const float *__restrict__ rois,
+                                                                float scale, int R, int H, int W, int C, int PH, int PW, int *__restrict__ out)
+{
+    const long long total = (long long)R * PH * PW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int pw = (int)(t % PW); t /= PW;
+        const int ph = (int)(t % PH);
+        const int n = (int)(t / PH);
+        const unsigned code = codes[i];
+        int res = -1;
+        if (code != 0xffffu) {
+            const float *roi = rois + 5 * (long long)n;
+            const RoiGeom q = roi_geom(roi, scale);
+            const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);
+            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+            const int hs = min(max((int)floorf(__fmul_rn((float)ph, bh)) + q.rsh, 0), H);
+            const int ws = min(max((int)floorf(__fmul_rn((float)pw, bw)) + q.rsw, 0), W);
+            const int we = min(max((int)ceilf(__fmul_rn((float)(pw + 1), bw)) + q.rsw, 0), W);
+            const int bwid = max(we - ws, 1);
+            res = ((hs + (int)code / bwid) * W + ws + (int)code % bwid) * C + c;
+        }
+        out[i] = res;
+    }
 }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -1279,21 +1597,19 @@ extern "C" size_t mv3d_roi_pool_backward_workspace_bytes(int num_views, const mv
         total += mv3d_align_up(bwd_pool_entries(w, pooled_height, pooled_width) * sizeof(int));
         nseg += bwd_segments(w);
     }
-    // header | candidates per segment | mask per segment | published words of the fused forward | items | pool
-    return total + 2 * mv3d_align_up(nseg * sizeof(int)) + mv3d_align_up(nseg * sizeof(unsigned long long)) + MV3D_ALIGN;
+    // header | candidates per segment | mask per segment | items | pool
+    return total + 2 * mv3d_align_up(nseg * sizeof(int)) + MV3D_ALIGN;
 }
 
 // The views in index order (the densest view first -- candidates per pixel ~ R PH PW / pixels: the 8 x 64 front-view map carries
 // ~10 x the lists of the others -- so that its pixels head the item list and the gather's waves start with the long lists instead
-// of ending with them: the kernel's time is its slowest wave), the segment numbering and the workspace carved.
-struct BwdIndexPlan { RoiGradPack p; RoiGradIdxPack ix; unsigned iblocks; int ord[MV3D_MAX_ROI_VIEWS]; };
-static int bwd_index_plan(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, void *workspace, BwdIndexPlan &pl)
+// of ending with them: the kernel's time is its slowest wave) and the segment numbering
+struct BwdOrder { RoiGradPack p; unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS]; unsigned iblocks; size_t n_items, pool_entries; };
+static void bwd_order(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, BwdOrder &o)
 {
-    RoiGradPack &p = pl.p;
-    RoiGradIdxPack &ix = pl.ix;
-    ix = RoiGradIdxPack{};
+    RoiGradPack &p = o.p;
     p.n = num_views; p.PH = PH; p.PW = PW;
-    int *ord = pl.ord;
+    int ord[MV3D_MAX_ROI_VIEWS];
     for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) ord[k] = k;
     for (int a = 0; a < num_views; ++a)
         for (int b = a + 1; b < num_views; ++b) {
@@ -1302,11 +1618,7 @@ static int bwd_index_plan(int num_views, const mv3d_roi_grad_view *views, int PH
             const double dy = (double)y.num_rois / ((double)y.batch_size * y.height * y.width);
             if (dy > dx) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
         }
-    unsigned iblocks = 0;
-    size_t pool_entries = 0, n_items = 0;
-    unsigned sig = 2166136261u;                                         // FNV-1a over what the index depends on
-    auto mix = [&sig](unsigned long long x) { for (int i = 0; i < 8; ++i) { sig ^= (unsigned)(x & 255u); sig *= 16777619u; x >>= 8; } };
-    mix((unsigned long long)num_views); mix((unsigned long long)PH); mix((unsigned long long)PW);
+    o.iblocks = 0; o.n_items = 0; o.pool_entries = 0;
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_grad_view &w = views[ord[k]];
         RoiGradViewDev &v = p.v[k];
@@ -1314,33 +1626,77 @@ static int bwd_index_plan(int num_views, const mv3d_roi_grad_view *views, int PH
         v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
         v.nsl = w.channels / 64;
         v.first_block = 0; v.pxg = 4; v.gpr = 0;
-        n_items += (size_t)w.batch_size * w.height * w.width;
-        ix.first_block[k] = iblocks;
-        ix.gpr[k] = (w.width + BWI_PIX - 1) / BWI_PIX;
-        iblocks += bwd_segments(w);
-        pool_entries += bwd_pool_entries(w, PH, PW);
-        unsigned sbits;
-        memcpy(&sbits, &w.spatial_scale, 4);
-        mix((unsigned long long)(uintptr_t)w.bottom_rois); mix(sbits); mix((unsigned long long)w.batch_size); mix((unsigned long long)w.num_rois);
-        mix((unsigned long long)w.height); mix((unsigned long long)w.width); mix((unsigned long long)w.channels); mix((unsigned long long)ord[k]);
+        o.n_items += (size_t)w.batch_size * w.height * w.width;
+        o.first_block[k] = o.iblocks;
+        o.gpr[k] = (w.width + BWI_PIX - 1) / BWI_PIX;
+        o.iblocks += bwd_segments(w);
+        o.pool_entries += bwd_pool_entries(w, PH, PW);
     }
-    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) { p.v[k] = p.v[0]; ix.first_block[k] = 0; ix.gpr[k] = 1; }
-    if (pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
+    for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) { p.v[k] = p.v[0]; o.first_block[k] = 0; o.gpr[k] = 1; }
+}
+
+struct BwdIndexPlan { RoiGradPack p; RoiGradIdxPack ix; unsigned iblocks; };
+static int bwd_index_plan(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, void *workspace, BwdIndexPlan &pl)
+{
+    BwdOrder o;
+    bwd_order(num_views, views, PH, PW, o);
+    if (o.pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
+    pl.p = o.p;
+    RoiGradIdxPack &ix = pl.ix;
+    ix = RoiGradIdxPack{};
+    for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) { ix.first_block[k] = o.first_block[k]; ix.gpr[k] = o.gpr[k]; }
     char *ws = (char *)workspace;
-    size_t o = MV3D_ALIGN;
+    size_t off = MV3D_ALIGN;
     ix.header = (int *)ws;
-    ix.seg_tot = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
-    ix.seg_mask = (int *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(int));
-    ix.seg_word = (unsigned long long *)(ws + o); o += mv3d_align_up((size_t)iblocks * sizeof(unsigned long long));
-    ix.items = (int4 *)(ws + o); o += mv3d_align_up(n_items * sizeof(int4));
-    ix.pool = (int *)(ws + o);
-    ix.nseg = iblocks;
-    ix.sig = sig ? sig : 1u;
+    ix.seg_tot = (int *)(ws + off); off += mv3d_align_up((size_t)o.iblocks * sizeof(int));
+    ix.seg_mask = (int *)(ws + off); off += mv3d_align_up((size_t)o.iblocks * sizeof(int));
+    ix.items = (int4 *)(ws + off); off += mv3d_align_up(o.n_items * sizeof(int4));
+    ix.pool = (int *)(ws + off);
     ix.trace = nullptr;
 #ifdef MV3D_TUNING                                                     // diagnostics (tools/roi_bwd_trace.py), experiment builds only
     ix.trace = getenv("MV3D_BWD_TRACE") ? (long long *)strtoull(getenv("MV3D_BWD_TRACE"), nullptr, 10) : nullptr;
 #endif
-    pl.iblocks = iblocks;
+    pl.iblocks = o.iblocks;
+    return MV3D_OK;
+}
+
+// the pair's workspace: header | upper-bound sizes per segment | masks per segment | items | pool of {record offset, code} entries
+static size_t roi_pair_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int PH, int PW)
+{
+    size_t total = MV3D_ALIGN, nseg = 0;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_grad_view &w = views[k];
+        total += mv3d_align_up((size_t)w.batch_size * w.height * w.width * sizeof(int4));
+        total += mv3d_align_up(bwd_pool_entries(w, PH, PW) * sizeof(int2));
+        nseg += bwd_segments(w);
+    }
+    return total + 2 * mv3d_align_up(nseg * sizeof(int)) + MV3D_ALIGN;
+}
+
+struct RoiPairPlan { RoiGradPack p; RoiPairIdx ix; };
+static int roi_pair_plan(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, void *workspace, RoiPairPlan &pl)
+{
+    BwdOrder o;
+    bwd_order(num_views, views, PH, PW, o);
+    if (o.pool_entries > 0x7fffffffull) return MV3D_ERR_INVALID_ARG;
+    pl.p = o.p;
+    RoiPairIdx &ix = pl.ix;
+    ix = RoiPairIdx{};
+    for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) { ix.first_block[k] = o.first_block[k]; ix.gpr[k] = o.gpr[k]; }
+    char *ws = (char *)workspace;
+    size_t off = MV3D_ALIGN;
+    ix.header = (int *)ws;
+    ix.seg_tot = (int *)(ws + off); off += mv3d_align_up((size_t)o.iblocks * sizeof(int));
+    ix.seg_mask = (int *)(ws + off); off += mv3d_align_up((size_t)o.iblocks * sizeof(int));
+    ix.items = (int4 *)(ws + off); off += mv3d_align_up(o.n_items * sizeof(int4));
+    ix.pool = (int2 *)(ws + off);
+    ix.nseg = o.iblocks;
+    ix.dbg = 0;
+    ix.trace = nullptr;
+#ifdef MV3D_TUNING
+    ix.dbg = getenv("MV3D_IDX_DBG") ? atoi(getenv("MV3D_IDX_DBG")) : 0;
+    ix.trace = getenv("MV3D_IDX_TRACE") ? (long long *)strtoull(getenv("MV3D_IDX_TRACE"), nullptr, 10) : nullptr;
+#endif
     return MV3D_OK;
 }
 
@@ -1449,7 +1805,7 @@ extern "C" int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_v
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RoiPool forward + the candidate index of its gradient in ONE launch, RoiPoolGrad in ONE launch.
+// The pair: RoiPool with a private compact argmax plane, RoiPoolGrad = index + zero fill (one launch) and gather (one launch).
 static void grad_views_of(int num_views, const mv3d_roi_view *views, mv3d_roi_grad_view *g)
 {
     for (int k = 0; k < num_views; ++k) {
@@ -1460,80 +1816,53 @@ static void grad_views_of(int num_views, const mv3d_roi_view *views, mv3d_roi_gr
     }
 }
 
-// Is the candidate index of these views built by the forward launch?  Decided from the SHAPES alone (channel widths the XCD-sliced
-// forward handles, at least one ROI per view, the index's own conditions, chunk counts inside the kernel's 32-bit arithmetic), so
-// that mv3d_roi_pool_forward_views_indexed and mv3d_roi_pool_backward_views_indexed take the same decision independently.
-static bool roi_fused_plan(int num_views, const mv3d_roi_grad_view *g, int PH, int PW, RoiFusedPlan &fp, int &passes)
+// Do these views go through the pair's own kernels (compact argmax codes)?  Decided from the SHAPES alone (channel widths the
+// XCD-sliced forward handles, at least one ROI per view, the index's own conditions, bins whose scan positions fit 16 bits), so that
+// the forward, the backward and the decode entries take the same decision independently.
+static bool roi_pair_shapes(int num_views, const mv3d_roi_grad_view *g, int PH, int PW)
 {
     if (!bwd_index_eligible(num_views, g, PH, PW)) return false;
-    long long total_bins = 0;
-    unsigned nseg = 0;
     for (int k = 0; k < num_views; ++k) {
         const int cv4 = g[k].channels / 4;
         if (g[k].channels % 4 != 0 || !(cv4 == 64 || cv4 == 128 || cv4 == 256) || g[k].num_rois <= 0) return false;
-        total_bins += (long long)g[k].num_rois * PH * PW;
-        nseg += bwd_segments(g[k]);
+        if ((long long)g[k].height * g[k].width > 0xfffeLL) return false;           // a bin never has more scan positions than the map has pixels
     }
-    passes = fwd_passes(total_bins);
-    unsigned long long np8 = 0;
-    for (int k = 0; k < num_views; ++k) {
-        const int cv4 = g[k].channels / 4;
-        const int tpb_shift = cv4 == 64 ? 3 : (cv4 == 128 ? 4 : 5);
-        const long long per_block = (long long)passes * (256 >> tpb_shift);
-        np8 += (unsigned long long)(((long long)g[k].num_rois * PH * PW + per_block - 1) / per_block);
-    }
-    fp.nseg = nseg;
-    fp.ni8 = (nseg + 7) / 8;
-    if (fp.ni8 >= 32768u || np8 >= 32768ull) return false;
-    fp.p1 = (unsigned)np8 / 3;
-    const unsigned p3 = (unsigned)np8 / 3;
-    fp.n2 = (unsigned)np8 - fp.p1 - p3;
-    fp.n1 = fp.ni8 + fp.p1;
-    fp.n3 = fp.ni8 + p3;
     return true;
 }
 
-extern "C" size_t mv3d_roi_pool_index_workspace_bytes(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width)
+extern "C" size_t mv3d_roi_pool_pair_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width)
 {
-    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views) return 0;
-    mv3d_roi_grad_view g[MV3D_MAX_ROI_VIEWS];
-    grad_views_of(num_views, views, g);
-    return mv3d_roi_pool_backward_workspace_bytes(num_views, g, pooled_height, pooled_width);
+    const size_t plain = mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width);      // (validates)
+    if (plain == 0) return 0;
+    const size_t pair = roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width);
+    return pair > plain ? pair : plain;                   // (shapes outside the pair's kernels use the plain layout in the same buffer)
 }
 
-extern "C" int mv3d_roi_pool_forward_views_indexed(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
-                                                   int cold_maps, void *index_ws, size_t index_ws_bytes, void *stream)
+extern "C" int mv3d_roi_pool_forward_views_pair(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                                int cold_maps, void *stream)
 {
-    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0 || !index_ws)
-        return MV3D_ERR_INVALID_ARG;
-    if ((uintptr_t)index_ws % MV3D_ALIGN) return MV3D_ERR_WORKSPACE;
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0) return MV3D_ERR_INVALID_ARG;
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_view &w = views[k];
         if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 || !w.bottom_data ||
-            (w.num_rois > 0 && (!w.bottom_rois || !w.top_data)) ||
+            (w.num_rois > 0 && (!w.bottom_rois || !w.top_data || !w.argmax_data)) ||
             (long long)w.num_rois * pooled_height * pooled_width > 0x7fffffffLL)
             return MV3D_ERR_INVALID_ARG;
     }
     mv3d_roi_grad_view g[MV3D_MAX_ROI_VIEWS];
     grad_views_of(num_views, views, g);
-    const size_t need = mv3d_roi_pool_backward_workspace_bytes(num_views, g, pooled_height, pooled_width);
-    if (need == 0 || index_ws_bytes < need) return MV3D_ERR_WORKSPACE;
-    RoiFusedPlan fp;
-    int passes = 2;
-    bool fused = roi_fused_plan(num_views, g, pooled_height, pooled_width, fp, passes);
-    for (int k = 0; k < num_views && fused; ++k)            // (pointer conditions: a caller that misses them gets an error, not a silent other path)
-        if (!aligned16(views[k].bottom_data) || !aligned16(views[k].top_data) || !views[k].argmax_data || !aligned16(views[k].argmax_data))
-            return MV3D_ERR_INVALID_ARG;
-    if (!fused)
-        // shapes outside the fused kernel: the plain forward; mv3d_roi_pool_backward_views_indexed takes the same decision from
-        // the same shapes and builds the index itself
+    if (!roi_pair_shapes(num_views, g, pooled_height, pooled_width))
+        // shapes outside the pair's kernels: the plain forward (int32 argmax plane); mv3d_roi_pool_backward_views_pair takes the same
+        // decision from the same shapes
         return roi_pool_forward_views_impl(num_views, views, pooled_height, pooled_width, cold_maps != 0, stream);
-    BwdIndexPlan ip;
-    const int rc = bwd_index_plan(num_views, g, pooled_height, pooled_width, index_ws, ip);
-    if (rc != MV3D_OK) return rc;
+    for (int k = 0; k < num_views; ++k)                    // (pointer conditions: a caller that misses them gets an error, not a silent other path)
+        if (!aligned16(views[k].bottom_data) || !aligned16(views[k].top_data) || !aligned16(views[k].argmax_data)) return MV3D_ERR_INVALID_ARG;
     RoiViewPack p;
     p.n = num_views; p.PH = pooled_height; p.PW = pooled_width;
     unsigned blocks = 0;
+    long long total_bins = 0;
+    for (int k = 0; k < num_views; ++k) total_bins += (long long)views[k].num_rois * pooled_height * pooled_width;
+    const int passes = fwd_passes(total_bins);
     for (int k = 0; k < num_views; ++k) {
         const mv3d_roi_view &w = views[k];
         const int cv4 = w.channels / 4;
@@ -1547,47 +1876,73 @@ extern "C" int mv3d_roi_pool_forward_views_indexed(int num_views, const mv3d_roi
         blocks += (unsigned)(((nbins + per_block - 1) / per_block) * 8);
     }
     for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
-    if (blocks / 8 != fp.p1 + fp.n2 + (fp.n3 - fp.ni8) || fp.nseg != ip.iblocks) return MV3D_ERR_INVALID_ARG;      // (plan and packs agree)
-    const unsigned long long chunks = (unsigned long long)fp.n1 + fp.n2 + fp.n3;
-    RoiPrefetchPack pf;
-    pf.blocks = 0;
-    for (int k = 0; k < MV3D_MAX_ROI_VIEWS; ++k) pf.first_block[k] = 0;
-    const bool cold = cold_maps && roi_prefetch_plan(num_views, views, pf);
-    if (cold) pf.blocks = (pf.blocks + 7u) & ~7u; else pf.blocks = 0;
-    const dim3 grid((unsigned)(pf.blocks + chunks * 8));
     hipStream_t s = (hipStream_t)stream;
-    if (cold) {
-        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<4, true>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
-        else hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<2, true>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
-    } else {
-        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<4, false>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
-        else hipLaunchKernelGGL((roi_pool_fwd_indexed_kernel<2, false>), grid, dim3(256), 0, s, p, pf, ip.p, ip.ix, fp, (int *)nullptr);
+    RoiPrefetchPack pf;
+    if (cold_maps && roi_prefetch_plan(num_views, views, pf)) {
+        pf.blocks = (pf.blocks + 7u) & ~7u;
+        if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<4>, dim3(blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr);
+        else hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<2>, dim3(blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr);
+        return mv3d_launch_status();
     }
+    if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<4>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
     return mv3d_launch_status();
 }
 
-extern "C" int mv3d_roi_pool_backward_views_indexed(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
-                                                    void *index_ws, size_t index_ws_bytes, void *stream)
+extern "C" int mv3d_roi_pool_backward_views_pair(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width,
+                                                 void *workspace, size_t workspace_bytes, void *stream)
 {
     const int rc0 = grad_views_check(num_views, views, pooled_height, pooled_width);
     if (rc0 != MV3D_OK) return rc0;
-    if (!index_ws || ((uintptr_t)index_ws % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
-    if (index_ws_bytes < mv3d_roi_pool_backward_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
-    // the decision mv3d_roi_pool_forward_views_indexed took from the same shapes: was the index built by the forward launch?
-    RoiFusedPlan fp;
-    int passes = 2;
-    const bool fused = roi_fused_plan(num_views, views, pooled_height, pooled_width, fp, passes);
-    if (!fused) return mv3d_roi_pool_backward_views(num_views, views, pooled_height, pooled_width, index_ws, index_ws_bytes, stream);
-    BwdIndexPlan pl;
-    const int rc = bwd_index_plan(num_views, views, pooled_height, pooled_width, index_ws, pl);
+    if (!workspace || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    // the decision mv3d_roi_pool_forward_views_pair took from the same shapes: compact codes in argmax_data?
+    if (!roi_pair_shapes(num_views, views, pooled_height, pooled_width))
+        return mv3d_roi_pool_backward_views(num_views, views, pooled_height, pooled_width, workspace, workspace_bytes, stream);
+    if (workspace_bytes < roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
+    for (int k = 0; k < num_views; ++k)
+        if (!aligned16(views[k].bottom_diff) || !aligned16(views[k].top_diff) || !aligned16(views[k].argmax_data)) return MV3D_ERR_INVALID_ARG;
+    RoiPairPlan pl;
+    const int rc = roi_pair_plan(num_views, views, pooled_height, pooled_width, workspace, pl);
     if (rc != MV3D_OK) return rc;
-    const int cpl = bwd_gather_cpl(views[0].channels);
-    const unsigned fill_blocks = (pl.iblocks + 7u) & ~7u;
-    const dim3 gg((unsigned)(fill_blocks + bwd_gather_groups() * 8));
-    if (cpl == 4) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<4>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 256, fill_blocks);
-    else if (cpl == 2) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<2>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 128, fill_blocks);
-    else if (cpl == 1) hipLaunchKernelGGL(roi_bwd_fill_gather_kernel<1>, gg, dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix, views[0].channels / 64, fill_blocks);
-    else return MV3D_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(roi_pair_index_kernel<false>, dim3(pl.ix.nseg), dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix);
+    hipLaunchKernelGGL(roi_pair_index_kernel<true>, dim3(pl.ix.nseg), dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix);
+    hipLaunchKernelGGL(roi_pair_gather_kernel, dim3((unsigned)(bwd_gather_groups() * 8)), dim3(256), 0, (hipStream_t)stream, pl.p, pl.ix,
+                       views[0].channels / 64);
+    return mv3d_launch_status();
+}
+
+// The argmax plane a forward of the pair left in `argmax_data` -> the reference's int32 plane (num_rois, PH, PW, C) in `argmax_out`
+// (a buffer of its own).  For views outside the pair's kernels the plane already IS the reference's: copied.  Tests / verification:
+// the pair itself never needs it.
+extern "C" int mv3d_roi_pool_argmax_decode(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                           int32_t *const *argmax_out, void *stream)
+{
+    if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0 || !argmax_out)
+        return MV3D_ERR_INVALID_ARG;
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        if (w.batch_size <= 0 || w.num_rois < 0 || w.height <= 0 || w.width <= 0 || w.channels <= 0 ||
+            (w.num_rois > 0 && (!w.bottom_rois || !w.argmax_data || !argmax_out[k])))
+            return MV3D_ERR_INVALID_ARG;
+    }
+    mv3d_roi_grad_view g[MV3D_MAX_ROI_VIEWS];
+    grad_views_of(num_views, views, g);
+    const bool pair = roi_pair_shapes(num_views, g, pooled_height, pooled_width);
+    for (int k = 0; k < num_views; ++k) {
+        const mv3d_roi_view &w = views[k];
+        const long long total = (long long)w.num_rois * pooled_height * pooled_width * w.channels;
+        if (total == 0) continue;
+        if (!pair) {
+            if (argmax_out[k] != w.argmax_data &&
+                hipMemcpyAsync(argmax_out[k], w.argmax_data, (size_t)total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                return MV3D_ERR_HIP;
+            continue;
+        }
+        if ((void *)argmax_out[k] == (void *)w.argmax_data) return MV3D_ERR_INVALID_ARG;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(roi_argmax_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)w.argmax_data,
+                           w.bottom_rois, w.spatial_scale, w.num_rois, w.height, w.width, w.channels, pooled_height, pooled_width, argmax_out[k]);
+    }
     return mv3d_launch_status();
 }
 

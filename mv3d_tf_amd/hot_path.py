@@ -6,8 +6,8 @@ and replayed as plain kernel launches -- what bench.py times and what a training
         per frame: mv3d_anchor_target_stage1 / stage2                       lib/rpn_msr/anchor_target_layer_tf.py:21-250
         per frame: mv3d_proposal_target_stage1 / stage2 (<= 128 sampled)    lib/rpn_msr/proposal_target_layer_tf.py:19-94
         mv3d_rois_3d_to_fv                                                  (third view; network.py:293-315 is a TODO)
-        mv3d_roi_pool_forward_views_indexed  BEV + RGB + FV (+ the gradient's index)  roi_pooling_op.cc:74-190 x 3 layers
-        mv3d_roi_pool_backward_views_indexed BEV + RGB + FV, one launch              roi_pooling_op.cc:319-452 x 3 layers
+        mv3d_roi_pool_forward_views_pair   BEV + RGB + FV, private 16-bit argmax plane  roi_pooling_op.cc:74-190 x 3 layers
+        mv3d_roi_pool_backward_views_pair  BEV + RGB + FV: index + fill, gather         roi_pooling_op.cc:319-452 x 3 layers
     TestPathBatch    BASELINE configs[1] / configs[4] path: mv3d_proposal_3d (TEST cfg 6000 -> 300), FV ROIs,
         RoiPool forward on the three views.
 
@@ -265,17 +265,16 @@ class TrainPathBatch:
             self.tops[v], self.top_diff[v], self.bottom_diff[v] = (top, am), td, bd
             fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
             bwd[k] = RoiGradView(bd.data_ptr(), self.rois[v].data_ptr(), td.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
-        # RoiPool forward + the gradient's candidate index in ONE launch, RoiPoolGrad in ONE launch (mv3d_roi_pool_*_views_indexed)
-        bws = torch.zeros(max(L.mv3d_roi_pool_index_workspace_bytes(len(self.views), fwd, 7, 7), 256), dtype=torch.uint8, device=dev)
-        af = (len(self.views), fwd, 7, 7, 1 if self.cold_maps else 0, _P(bws), C.c_size_t(bws.numel()), st)
+        # the RoiPool pair: forward with the private compact argmax plane, backward = index + zero fill, gather (mv3d_roi_pool_*_views_pair)
+        bws = torch.zeros(max(L.mv3d_roi_pool_pair_workspace_bytes(len(self.views), bwd, 7, 7), 256), dtype=torch.uint8, device=dev)
+        af = (len(self.views), fwd, 7, 7, 1 if self.cold_maps else 0, st)
         ab = (len(self.views), bwd, 7, 7, _P(bws), C.c_size_t(bws.numel()), st)
         bnd.keep += [bws]
-        self.index_ws = bws
-        self.fwd_fn = L.mv3d_roi_pool_forward_views_indexed
-        check(self.fwd_fn(*af), "mv3d_roi_pool_forward_views_indexed")
-        check(L.mv3d_roi_pool_backward_views_indexed(*ab), "mv3d_roi_pool_backward_views_indexed")
+        self.fwd_fn = L.mv3d_roi_pool_forward_views_pair
+        check(self.fwd_fn(*af), "mv3d_roi_pool_forward_views_pair")
+        check(L.mv3d_roi_pool_backward_views_pair(*ab), "mv3d_roi_pool_backward_views_pair")
         bnd.add(self.fwd_fn, *af)
-        bnd.add(L.mv3d_roi_pool_backward_views_indexed, *ab)
+        bnd.add(L.mv3d_roi_pool_backward_views_pair, *ab)
         bnd.keep += [fwd, bwd]
         self.fwd_args, self.bwd_args = af, ab
         self.num_rois = St
@@ -290,10 +289,10 @@ class TrainPathBatch:
         self.bound.run()
 
     def roi_forward(self):
-        check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views_indexed")
+        check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views_pair")
 
     def roi_backward(self):
-        check(lib().mv3d_roi_pool_backward_views_indexed(*self.bwd_args), "mv3d_roi_pool_backward_views_indexed")
+        check(lib().mv3d_roi_pool_backward_views_pair(*self.bwd_args), "mv3d_roi_pool_backward_views_pair")
 
     # algorithmic HBM bytes: maps once + rois + (top f32 + argmax i32) / (grad + argmax) + map write
     def roi_forward_bytes(self):

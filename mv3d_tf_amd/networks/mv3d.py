@@ -4,8 +4,8 @@ by a small executor, with the hot-path layers bound to libmv3d_hip.so:
     proposal_layer_3d                                                     mv3d_tf_amd.rpn_msr (device tensors, any batch)
     anchor_target_layer + proposal_target_layer_3d (TRAIN)                mv3d_tf_amd.train_path.TrainPathStream: the batched
                                                                           C entries, ONE host round trip per step for the draws
-    roi_pool of every view (+ gradient)                                   roi_pooling_layer.roi_pool_views: one launch forward, the
-                                                                          indexed RoiPoolGrad (with workspace) backward
+    roi_pool of every view (+ gradient)                                   roi_pooling_layer.roi_pool_views: the library's RoiPool pair
+                                                                          (one launch forward, index + gather backward)
     proposal_transform                                                    tuple element 0 ('bv') / 1 ('img')
 
 `forward(feed)` takes B >= 1 frames (B > 1: lists of per-frame ground-truth arrays, im_info (B,3), calib (B,4,12)); the ROI
@@ -332,7 +332,7 @@ class MV3D:
             L["rois"] = rois
             L["roi_data_bv"], L["roi_data_img"] = rois[0], rois[1]
             r3, rois_fv = rois[2], None
-        # RoI pooling of every view in one launch (+ the indexed gradient) and the fusion head (MV3D_test.py:95-123)
+        # RoI pooling of every view in one launch (+ the pair's gradient) and the fusion head (MV3D_test.py:95-123)
         views = [(L["conv5_3"], L["roi_data_bv"]), (L["conv5_3_2"], L["roi_data_img"])]
         names = ["pool_5", "pool_5_2"]
         if self.views == 3:

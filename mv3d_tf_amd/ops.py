@@ -335,28 +335,26 @@ def roi_pool_backward_views(views, pooled_height, pooled_width, outs=None):
     return res
 
 
-# ---- RoiPool + the candidate index of its gradient in one launch, RoiPoolGrad in one launch (mv3d_roi_pool_*_views_indexed)
-_INDEX_WS_FREE = {}                # (device, bytes) -> index workspaces that no forward / backward pair holds
+# ---- the RoiPool pair of a training step: private compact argmax plane, index + fill and gather behind one backward call
+_PAIR_WS_FREE = {}                 # (device, bytes) -> workspaces no backward call is using
 
 
-def roi_index_workspace(nbytes, device):
-    """An index workspace for one forward -> backward pair: zeroed once when it is made (the contract of
-    mv3d_roi_pool_forward_views_indexed; the library leaves its look-back words zero after every call), then recycled through
-    release_roi_index_workspace."""
-    free = _INDEX_WS_FREE.setdefault((str(device), int(nbytes)), [])
-    return free.pop() if free else torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+def roi_pair_workspace(nbytes, device):
+    """A workspace for mv3d_roi_pool_backward_views_pair (no initialisation needed), recycled through release_roi_pair_workspace."""
+    free = _PAIR_WS_FREE.setdefault((str(device), int(nbytes)), [])
+    return free.pop() if free else torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def release_roi_index_workspace(ws):
-    free = _INDEX_WS_FREE.setdefault((str(ws.device), int(ws.numel())), [])
+def release_roi_pair_workspace(ws):
+    free = _PAIR_WS_FREE.setdefault((str(ws.device), int(ws.numel())), [])
     if len(free) < 4:
         free.append(ws)
 
 
-def roi_pool_forward_views_indexed(views, pooled_height, pooled_width, outs=None, cold_maps=False, index_ws=None):
-    """views as roi_pool_forward_views; ONE launch pools every view AND builds the per-pixel candidate index RoiPoolGrad gathers
-    over into `index_ws` (made here when None).  Returns ([(top, argmax), ...], index_ws): hand both to
-    roi_pool_backward_views_indexed."""
+def roi_pool_forward_views_pair(views, pooled_height, pooled_width, outs=None, cold_maps=False):
+    """views as roi_pool_forward_views; one launch.  Returns [(top, argmax_private), ...]: the second tensor is the pair's PRIVATE
+    argmax plane (16-bit codes in an int32-shaped buffer for the shapes the pair's kernels take) -- hand it to
+    roi_pool_backward_views_pair only; roi_pool_argmax_decode gives the reference's int32 plane."""
     arr = (RoiView * len(views))()
     res = []
     for k, (data, rois, scale) in enumerate(views):
@@ -369,16 +367,28 @@ def roi_pool_forward_views_indexed(views, pooled_height, pooled_width, outs=None
             am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device)
         arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, R, H, W, Cc)
         res.append((top, am))
-    if index_ws is None:
-        index_ws = roi_index_workspace(lib().mv3d_roi_pool_index_workspace_bytes(len(views), arr, pooled_height, pooled_width), views[0][0].device)
-    check(lib().mv3d_roi_pool_forward_views_indexed(len(views), arr, pooled_height, pooled_width, 1 if cold_maps else 0, _ptr(index_ws),
-                                                    index_ws.numel(), _stream()), "mv3d_roi_pool_forward_views_indexed")
-    return res, index_ws
+    check(lib().mv3d_roi_pool_forward_views_pair(len(views), arr, pooled_height, pooled_width, 1 if cold_maps else 0, _stream()),
+          "mv3d_roi_pool_forward_views_pair")
+    return res
 
 
-def roi_pool_backward_views_indexed(views, pooled_height, pooled_width, index_ws, outs=None):
-    """views as roi_pool_backward_views, of the forward that filled `index_ws` (the same rois TENSORS, the argmax planes it wrote):
-    RoiPoolGrad of all of them in ONE launch.  Returns [bottom_diff, ...]."""
+def roi_pool_argmax_decode(views, res, pooled_height, pooled_width):
+    """The reference's int32 argmax planes of a roi_pool_forward_views_pair call: views / res as given to / returned by it.  Tests and
+    verification only."""
+    arr = (RoiView * len(views))()
+    outs = []
+    for k, ((data, rois, scale), (top, am)) in enumerate(zip(views, res)):
+        B, H, W, Cc = data.shape
+        arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr(), float(scale), B, rois.shape[0], H, W, Cc)
+        outs.append(torch.empty(tuple(top.shape), dtype=torch.int32, device=data.device))
+    ptrs = (C.c_void_p * len(views))(*[o.data_ptr() for o in outs])
+    check(lib().mv3d_roi_pool_argmax_decode(len(views), arr, pooled_height, pooled_width, ptrs, _stream()), "mv3d_roi_pool_argmax_decode")
+    return outs
+
+
+def roi_pool_backward_views_pair(views, pooled_height, pooled_width, outs=None, workspace=None):
+    """views as roi_pool_backward_views, of a roi_pool_forward_views_pair call (the argmax tensors it returned): RoiPoolGrad of all of
+    them behind one call (index + zero fill, gather).  Returns [bottom_diff, ...]."""
     arr = (RoiGradView * len(views))()
     res = []
     for k, (top_diff, rois, argmax, shape, scale) in enumerate(views):
@@ -387,8 +397,13 @@ def roi_pool_backward_views_indexed(views, pooled_height, pooled_width, index_ws
         arr[k] = RoiGradView(out.data_ptr(), rois.data_ptr(), top_diff.data_ptr(), argmax.data_ptr(), float(scale), B,
                              rois.shape[0], H, W, Cc)
         res.append(out)
-    check(lib().mv3d_roi_pool_backward_views_indexed(len(views), arr, pooled_height, pooled_width, _ptr(index_ws), index_ws.numel(), _stream()),
-          "mv3d_roi_pool_backward_views_indexed")
+    ws = workspace
+    if ws is None:
+        ws = roi_pair_workspace(lib().mv3d_roi_pool_pair_workspace_bytes(len(views), arr, pooled_height, pooled_width), views[0][0].device)
+    check(lib().mv3d_roi_pool_backward_views_pair(len(views), arr, pooled_height, pooled_width, _ptr(ws), ws.numel(), _stream()),
+          "mv3d_roi_pool_backward_views_pair")
+    if workspace is None:
+        release_roi_pair_workspace(ws)        # (stream-ordered reuse: the next call on this stream runs behind these launches)
     return res
 
 

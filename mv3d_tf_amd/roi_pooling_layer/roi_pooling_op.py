@@ -33,20 +33,19 @@ class RoiPoolFunction(torch.autograd.Function):
 
 
 class RoiPoolViewsFunction(torch.autograd.Function):
-    """The RoiPool layers of one step (`pool_5`, `pool_5_2` [, `pool_5_3`]: network.py:199-213 called once per view) behind
-    ONE launch forward (mv3d_roi_pool_forward_views_indexed: pools every view and builds the candidate index of the gradient
-    between the pooling workgroups) and ONE launch backward (mv3d_roi_pool_backward_views_indexed: zero fill + the ordered gather
-    of roi_pooling_op.cc:319-452 for every view).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...) -> (top_0, top_1,
-    ...); gradients for the data tensors only (roi_pooling_op_grad.py:43).  A view whose output gets no gradient (unused in the
-    loss) contributes zeros, like an unconnected tf.gradients branch."""
+    """The RoiPool layers of one step (`pool_5`, `pool_5_2` [, `pool_5_3`]: network.py:199-213 called once per view) as the library's
+    PAIR: ONE launch forward (mv3d_roi_pool_forward_views_pair: every view, the argmax plane kept as private 16-bit codes) and one
+    call backward (mv3d_roi_pool_backward_views_pair: candidate index + zero fill, then the ordered gather of
+    roi_pooling_op.cc:319-452 for every view).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...) -> (top_0, top_1, ...);
+    gradients for the data tensors only (roi_pooling_op_grad.py:43).  A view whose output gets no gradient (unused in the loss)
+    contributes zeros, like an unconnected tf.gradients branch."""
 
     @staticmethod
     def forward(ctx, pooled_height, pooled_width, spatial_scale, *tensors):
         datas = [t.contiguous() for t in tensors[0::2]]
         rois = [t.contiguous() for t in tensors[1::2]]
-        res, ws = ops.roi_pool_forward_views_indexed([(d, r, spatial_scale) for d, r in zip(datas, rois)], pooled_height, pooled_width)
+        res = ops.roi_pool_forward_views_pair([(d, r, spatial_scale) for d, r in zip(datas, rois)], pooled_height, pooled_width)
         ctx.save_for_backward(*rois, *[am for _, am in res])
-        ctx.index_ws = ws
         ctx.meta = ([tuple(d.shape) for d in datas], pooled_height, pooled_width, spatial_scale)
         return tuple(top for top, _ in res)
 
@@ -62,10 +61,7 @@ class RoiPoolViewsFunction(torch.autograd.Function):
             if g is None:
                 g = torch.zeros((rois[k].shape[0], ph, pw, shapes[k][3]), dtype=torch.float32, device=rois[k].device)
             views.append((g.contiguous(), rois[k], argmax[k], shapes[k], scale))
-        outs = ops.roi_pool_backward_views_indexed(views, ph, pw, ctx.index_ws)
-        ws, ctx.index_ws = ctx.index_ws, None
-        if ws is not None:
-            ops.release_roi_index_workspace(ws)        # (stream-ordered reuse: the next forward on this stream runs behind this launch)
+        outs = ops.roi_pool_backward_views_pair(views, ph, pw)
         ret = [None, None, None]
         for k in range(n):
             ret += [outs[k], None]

@@ -1,11 +1,12 @@
 """-m gpu tests of the fast training-side RoiPool pair:
 
-    mv3d_roi_pool_forward_views_indexed     pools every view AND builds the candidate index of the gradient in one launch
-    mv3d_roi_pool_backward_views_indexed    zero fill + the ordered gather (roi_pooling_op.cc:319-452) in one launch
+    mv3d_roi_pool_forward_views_pair     pools every view in one launch, the argmax plane kept as private 16-bit codes
+    mv3d_roi_pool_backward_views_pair    candidate index + zero fill (one launch), the ordered gather (roi_pooling_op.cc:319-452)
 
-Bit-identical to the plain entries and to the oracle on BASELINE configs[2]'s full-size workload, on the pinned fixtures
-(tests/golden/roipool_*), across channel widths, on a workspace that is reused call after call (the in-launch look-back cleans
-up after itself), and loud -- NaN -- when handed an index that is not the views'.  Plus the call-compatible launcher aliases of
+top / bottom_diff bit-identical to the plain entries and to the oracle (the pair's private 16-bit argmax plane through
+mv3d_roi_pool_argmax_decode) on BASELINE configs[2]'s full-size workload, on the pinned fixtures
+(tests/golden/roipool_*), across channel widths, on a workspace that is reused call after call (nothing in it has to be
+zero on entry: it is filled with garbage first).  Plus the call-compatible launcher aliases of
 roi_pooling_op_gpu.h:18-27.  All calls go through the C-ABI (ctypes, mv3d_tf_amd.ops)."""
 import ctypes as C
 
@@ -30,9 +31,9 @@ def gpu():
 
 
 @pytest.mark.parametrize("cold", [False, True])
-def test_config2_indexed_pair_equals_plain_entries_and_oracle(gpu, oracle, cold):
-    """BASELINE configs[2] at full size (3 maps x batch 2, R = 256 rows per view): forward + index in one launch, backward in one
-    launch; top / argmax / bottom_diff equal to the oracle AND to the plain entries, five batches through ONE workspace."""
+def test_config2_pair_equals_plain_entries_and_oracle(gpu, oracle, cold):
+    """BASELINE configs[2] at full size (3 maps x batch 2, R = 256 rows per view): top / argmax (decoded) / bottom_diff equal to the
+    oracle AND to the plain entries, five batches through ONE workspace."""
     torch, ops = gpu
     B, per = 2, 128
     maps = {k: synth.feature_map(170 + i, H, W, 512, B) for i, (k, (H, W)) in enumerate(VIEWS.items())}
@@ -41,46 +42,49 @@ def test_config2_indexed_pair_equals_plain_entries_and_oracle(gpu, oracle, cold)
     for it in range(5):
         rois = three_view_rois(oracle, B, per if it != 3 else 37, 900 + 10 * it)          # (one batch with fewer rows)
         d_rois = {k: dev(torch, v) for k, v in rois.items()}
-        outs, ws = ops.roi_pool_forward_views_indexed([(d_maps[k], d_rois[k], 0.125) for k in VIEWS], 7, 7, cold_maps=cold, index_ws=ws)
-        plain = ops.roi_pool_forward_views([(d_maps[k], d_rois[k], 0.125) for k in VIEWS], 7, 7)
+        fv = [(d_maps[k], d_rois[k], 0.125) for k in VIEWS]
+        outs = ops.roi_pool_forward_views_pair(fv, 7, 7, cold_maps=cold)
+        dec = ops.roi_pool_argmax_decode(fv, outs, 7, 7)              # the pair's private 16-bit plane -> the reference's int32 plane
+        plain = ops.roi_pool_forward_views(fv, 7, 7)
         grads = {}
-        for k, (top, am), (ptop, pam) in zip(VIEWS, outs, plain):
+        for k, (top, _), am, (ptop, pam) in zip(VIEWS, outs, dec, plain):
             assert torch.equal(top, ptop) and torch.equal(am, pam), k
             if it < 2:
                 o_top, o_am = oracle.roi_pool(maps[k], rois[k], 7, 7, 0.125)
                 assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am), k
             grads[k] = dev(torch, np.random.RandomState(31 + it).uniform(-1, 1, tuple(top.shape)).astype(np.float32))
-        views = [(grads[k], d_rois[k], am, maps[k].shape, 0.125) for k, (_, am) in zip(VIEWS, outs)]
-        got = ops.roi_pool_backward_views_indexed(views, 7, 7, ws)
-        want = ops.roi_pool_backward_views(views, 7, 7)
-        for k, a, b in zip(VIEWS, got, want):
+        if ws is None:
+            from mv3d_tf_amd._lib import RoiGradView, lib
+            arr = (RoiGradView * 3)(*[RoiGradView(0, 0, 0, 0, 0.125, B, 2 * per, H, W, 512) for H, W in VIEWS.values()])
+            ws = torch.randint(0, 255, (lib().mv3d_roi_pool_pair_workspace_bytes(3, arr, 7, 7),), dtype=torch.uint8, device="cuda")
+        got = ops.roi_pool_backward_views_pair([(grads[k], d_rois[k], am, maps[k].shape, 0.125) for k, (_, am) in zip(VIEWS, outs)], 7, 7, workspace=ws)
+        want = ops.roi_pool_backward_views([(grads[k], d_rois[k], pam, maps[k].shape, 0.125) for k, (_, pam) in zip(VIEWS, plain)], 7, 7)
+        for k, a, b, (_, pam) in zip(VIEWS, got, want, plain):
             assert torch.equal(a, b), (it, k)
             if it < 2:
-                o = oracle.roi_pool_grad(maps[k], rois[k], outs[list(VIEWS).index(k)][1].cpu().numpy(), grads[k].cpu().numpy(), 7, 7, 0.125)
+                o = oracle.roi_pool_grad(maps[k], rois[k], pam.cpu().numpy(), grads[k].cpu().numpy(), 7, 7, 0.125)
                 assert np.array_equal(a.cpu().numpy(), o), (it, k)
-        # the look-back words and the done counter are zero again after every forward (the workspace's contract)
-        head = ws[:256].view(torch.int32).cpu().numpy()
-        assert head[0] == 0 and head[3] == 0 and head[2] != 0
 
 
 @pytest.mark.parametrize("name", SMALL + HASHED)
-def test_indexed_pair_on_the_pinned_fixtures(gpu, name):
+def test_pair_on_the_pinned_fixtures(gpu, name):
     """the Appendix-D fixtures (real proposal boxes, the edge cases: out-of-map, 1x1, negative, +-.5 rounding, batch index > 0,
-    ties, NaN, a stack of ROIs on one pixel) through the indexed pair; widths below 256 channels take the entries' plain path"""
+    ties, NaN, a stack of ROIs on one pixel) through the pair; widths below 256 channels take the entries' plain path"""
     torch, ops = gpu
     g, data, rois, grad = load_case(name)
     d, r = dev(torch, data), dev(torch, rois)
-    (res,), ws = ops.roi_pool_forward_views_indexed([(d, r, 0.125)], 7, 7)
-    top, am = res
-    bd, = ops.roi_pool_backward_views_indexed([(dev(torch, grad), r, am, data.shape, 0.125)], 7, 7, ws)
-    check_outputs(g, top.cpu().numpy(), am.cpu().numpy(), bd.cpu().numpy())
+    res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
+    top, am = res[0]
+    dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
+    bd, = ops.roi_pool_backward_views_pair([(dev(torch, grad), r, am, data.shape, 0.125)], 7, 7)
+    check_outputs(g, top.cpu().numpy(), dec.cpu().numpy(), bd.cpu().numpy())
 
 
 @pytest.mark.parametrize("C", [64, 256, 320, 512, 1024])
 @pytest.mark.parametrize("R", [40, 700])
-def test_indexed_pair_other_widths_and_many_rois(gpu, oracle, C, R):
-    """256 / 512 channels: the fused kernels (R = 700: three passes of the index's 256-ROI filter); 64 / 320 / 1024: the plain forward
-    and the index-on-demand / sliced / generic backward behind the same two entries"""
+def test_pair_other_widths_and_many_rois(gpu, oracle, C, R):
+    """256 / 512 channels: the pair's kernels (R = 700: three passes of the index's 256-ROI filter); 64 / 320 / 1024: the plain forward
+    and the plain indexed / sliced / generic backward behind the same two entries"""
     torch, ops = gpu
     rs = np.random.RandomState(C + R)
     B = 2
@@ -91,36 +95,46 @@ def test_indexed_pair_other_widths_and_many_rois(gpu, oracle, C, R):
         x1, y1 = rs.randint(-8, w - 8, R), rs.randint(-8, h - 8, R)
         rois.append(np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.randint(0, w // 2, R), y1 + rs.randint(0, h // 2, R)], 1).astype(np.float32))
     d_maps, d_rois = [dev(torch, m) for m in maps], [dev(torch, r) for r in rois]
-    outs, ws = ops.roi_pool_forward_views_indexed([(m, r, 0.125) for m, r in zip(d_maps, d_rois)], 7, 7)
-    grads = []
-    for m, r, (top, am) in zip(maps, rois, outs):
+    fv = [(m, r, 0.125) for m, r in zip(d_maps, d_rois)]
+    outs = ops.roi_pool_forward_views_pair(fv, 7, 7)
+    dec = ops.roi_pool_argmax_decode(fv, outs, 7, 7)
+    grads, ams = [], []
+    for m, r, (top, _), am in zip(maps, rois, outs, dec):
         o_top, o_am = oracle.roi_pool(m, r, 7, 7, 0.125)
         assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am)
-        grads.append(rs.uniform(-1, 1, o_top.shape).astype(np.float32))
-    bds = ops.roi_pool_backward_views_indexed([(dev(torch, g), r, am, m.shape, 0.125) for g, r, (_, am), m in zip(grads, d_rois, outs, maps)], 7, 7, ws)
-    for m, r, (_, am), g, bd in zip(maps, rois, outs, grads, bds):
-        assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, r, am.cpu().numpy(), g, 7, 7, 0.125))
+        grads.append(rs.uniform(-1, 1, o_top.shape).astype(np.float32)); ams.append(o_am)
+    bds = ops.roi_pool_backward_views_pair([(dev(torch, g), r, am, m.shape, 0.125) for g, r, (_, am), m in zip(grads, d_rois, outs, maps)], 7, 7)
+    for m, r, o_am, g, bd in zip(maps, rois, ams, grads, bds):
+        assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, r, o_am, g, 7, 7, 0.125))
 
 
-def test_an_index_of_other_views_is_refused_with_nan(gpu):
+def test_pair_huge_rois_ties_and_nan(gpu, oracle):
+    """ROIs larger than the map (one bin = up to the whole map: the largest scan positions a 16-bit code has to hold), ROIs of one
+    pixel, ties (first maximum wins), NaN pixels (never win), a stack of identical ROIs on one spot, rows past the rounded end"""
     torch, ops = gpu
-    rs = np.random.RandomState(5)
-    m = dev(torch, rs.uniform(-1, 1, (1, 10, 12, 256)).astype(np.float32))
-    mk = lambda n: dev(torch, np.stack([np.zeros(n), rs.randint(0, 40, n), rs.randint(0, 30, n), rs.randint(40, 90, n), rs.randint(30, 70, n)], 1).astype(np.float32))
-    r1, r2 = mk(20), mk(20)
-    (res1,), ws = ops.roi_pool_forward_views_indexed([(m, r1, 0.125)], 7, 7)
-    (res2,), ws2 = ops.roi_pool_forward_views_indexed([(m, r2, 0.125)], 7, 7)
-    g = torch.ones_like(res1[0])
-    ok, = ops.roi_pool_backward_views_indexed([(g, r1, res1[1], tuple(m.shape), 0.125)], 7, 7, ws)
-    assert torch.isfinite(ok).all()
-    bad, = ops.roi_pool_backward_views_indexed([(g, r2, res2[1], tuple(m.shape), 0.125)], 7, 7, ws)     # ws holds r1's index
-    assert torch.isnan(bad).all()
-    fresh = torch.zeros_like(ws)                                                                       # no forward at all
-    bad2, = ops.roi_pool_backward_views_indexed([(g, r1, res1[1], tuple(m.shape), 0.125)], 7, 7, fresh)
-    assert torch.isnan(bad2).all()
+    rs = np.random.RandomState(77)
+    B, H, W, C = 2, 46, 155, 256
+    m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    m[0, 3:9, 10:30, :] = 0.75                                       # ties
+    m[1, 20, 40, :7] = np.nan
+    m[1, 21:23, 41:44, 5] = np.nan
+    rois = [[0, -4000, -3000, 9000, 7000], [1, 0, 0, W * 8 - 1, H * 8 - 1], [0, 80, 24, 80, 24], [1, 300, 160, 330, 180],
+            [1, 159.5, 83.5, 344.5, 183.5], [0, 1236, 364, 1300, 400], [1, -50, -50, 10, 10]] + [[0, 64, 32, 200, 120]] * 40
+    for _ in range(150):
+        x1, y1 = rs.randint(-40, W * 8), rs.randint(-40, H * 8)
+        rois.append([rs.randint(0, B), x1, y1, x1 + rs.randint(0, 900), y1 + rs.randint(0, 300)])
+    rois = np.asarray(rois, np.float32)
+    d, r = dev(torch, m), dev(torch, rois)
+    res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
+    dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
+    o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
+    assert np.array_equal(res[0][0].cpu().numpy(), o_top, equal_nan=True) and np.array_equal(dec.cpu().numpy(), o_am)
+    g = rs.uniform(-1, 1, o_top.shape).astype(np.float32)
+    bd, = ops.roi_pool_backward_views_pair([(dev(torch, g), r, res[0][1], m.shape, 0.125)], 7, 7)
+    assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, rois, o_am, g, 7, 7, 0.125))
 
 
-def test_autograd_views_function_uses_the_indexed_pair(gpu, oracle):
+def test_autograd_views_function_uses_the_pair(gpu, oracle):
     torch, ops = gpu
     from mv3d_tf_amd.roi_pooling_layer.roi_pooling_op import roi_pool_views
     rs = np.random.RandomState(9)

@@ -2,8 +2,8 @@
 
   * N consecutive FRESH batches through submit() / finish() (pipelined: batch i + 1 submitted before batch i is finished)
     equal the oracle run frame by frame with the same numpy seed, draw for draw;
-  * a batch-2 step of the MV3D_train graph goes through the batched C entries (`*_batch`, `*_views_indexed`: RoiPool + the
-    gradient's index in one launch, RoiPoolGrad in one launch: a call counter on the ctypes handle) and its target layers / ROIs equal the per-frame oracle."""
+  * a batch-2 step of the MV3D_train graph goes through the batched C entries (`*_batch`, `*_views_pair`: the RoiPool pair with its private
+    compact argmax plane: a call counter on the ctypes handle) and its target layers / ROIs equal the per-frame oracle."""
 import numpy as np
 import pytest
 
@@ -143,7 +143,7 @@ def test_batch2_train_graph_uses_batched_entries_and_matches_oracle(gpu, oracle)
     L_ = _lib.lib()
     # (the target layers + proposal layer of a batch are ONE submit / finish pair of the C object mv3d_train_path, which issues the
     # batched entries itself; none of the per-frame or per-stage entries is called from Python any more)
-    counted = ("mv3d_train_path_submit", "mv3d_train_path_finish", "mv3d_roi_pool_forward_views_indexed", "mv3d_roi_pool_backward_views_indexed",
+    counted = ("mv3d_train_path_submit", "mv3d_train_path_finish", "mv3d_roi_pool_forward_views_pair", "mv3d_roi_pool_backward_views_pair",
                "mv3d_roi_pool_forward_views", "mv3d_roi_pool_backward_views", "mv3d_proposal_3d", "mv3d_anchor_target_stage1_batch", "mv3d_anchor_target_stage2_batch",
                "mv3d_proposal_target_stage1_batch_devn", "mv3d_proposal_target_stage2_batch_devn",
                "mv3d_roi_pool_forward", "mv3d_roi_pool_backward", "mv3d_anchor_target_stage1", "mv3d_proposal_target_stage1")
@@ -180,9 +180,9 @@ def test_batch2_train_graph_uses_batched_entries_and_matches_oracle(gpu, oracle)
         for name in counted[4:]:
             assert len(calls[name]) == 0, (name, len(calls[name]))
         assert len(L["roi_rows"]) == B
-        fw = calls["mv3d_roi_pool_forward_views_indexed"][0]
-        bw = calls["mv3d_roi_pool_backward_views_indexed"][0]
-        assert fw[0] == 2 and bw[0] == 2 and bw[4].value not in (None, 0) and bw[4].value == fw[5].value and bw[5] > 0   # the forward's index
+        fw = calls["mv3d_roi_pool_forward_views_pair"][0]
+        bw = calls["mv3d_roi_pool_backward_views_pair"][0]
+        assert fw[0] == 2 and bw[0] == 2 and bw[4].value not in (None, 0) and bw[5] > 0        # (the pair's workspace)
         # ---- the layers equal the per-frame oracle on the graph's own RPN head (same seed, draw for draw)
         prob = L["rpn_cls_prob_reshape"].detach().cpu().numpy()
         pred = L["rpn_bbox_pred"].detach().cpu().numpy()

@@ -3,7 +3,7 @@
 views), kernel-only, cycling over NB resident batches (distinct maps / records, so consecutive launches are cold):
 
     plain    mv3d_roi_pool_forward_views_cold + mv3d_roi_pool_backward_views (workspace: index x 2 launches + gather)
-    indexed  mv3d_roi_pool_forward_views_indexed (cold) + mv3d_roi_pool_backward_views_indexed (fill + gather, one launch)
+    pair     mv3d_roi_pool_forward_views_pair (cold; 16-bit argmax codes) + mv3d_roi_pool_backward_views_pair (index + fill, gather)
 
 forward and backward are timed alternating (fwd b0, bwd b0, fwd b1, ...) -- the order a step runs them in -- with HIP events
 around every call, and back to back per kind."""
@@ -15,11 +15,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from mv3d_tf_amd import build, hot_path, synth
+from mv3d_tf_amd import _lib, build, hot_path, synth
 from mv3d_tf_amd._lib import RoiGradView, RoiView, check, lib
 from mv3d_tf_amd.fast_rcnn.config import apply_end2end_yml
 
-build.build()
+if "--lib" in sys.argv:                      # an experiment build of the library (tools only)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+else:
+    build.build()
 apply_end2end_yml()
 NB = int(os.environ.get("NB", "12"))
 ROUNDS = int(os.environ.get("ROUNDS", "6"))
@@ -42,12 +45,12 @@ def calls(bt, indexed):
         fwd[k] = RoiView(m.data_ptr(), bt.rois[v].data_ptr(), bt.tops[v][0].data_ptr(), bt.tops[v][1].data_ptr(), 0.125, B, bt.num_rois, H, W, Cc)
         bwd[k] = RoiGradView(bt.bottom_diff[v].data_ptr(), bt.rois[v].data_ptr(), bt.top_diff[v].data_ptr(), bt.tops[v][1].data_ptr(), 0.125, B,
                              bt.num_rois, H, W, Cc)
-    ws = torch.zeros(L.mv3d_roi_pool_index_workspace_bytes(3, fwd, 7, 7), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(L.mv3d_roi_pool_pair_workspace_bytes(3, bwd, 7, 7), dtype=torch.uint8, device=dev)
     wp, wn = C.c_void_p(ws.data_ptr()), ws.numel()
     keep = (fwd, bwd, ws)
     if indexed:
-        return (lambda: check(L.mv3d_roi_pool_forward_views_indexed(3, fwd, 7, 7, 1, wp, wn, st), "fwd"),
-                lambda: check(L.mv3d_roi_pool_backward_views_indexed(3, bwd, 7, 7, wp, wn, st), "bwd"), keep)
+        return (lambda: check(L.mv3d_roi_pool_forward_views_pair(3, fwd, 7, 7, 1, st), "fwd"),
+                lambda: check(L.mv3d_roi_pool_backward_views_pair(3, bwd, 7, 7, wp, wn, st), "bwd"), keep)
     return (lambda: check(L.mv3d_roi_pool_forward_views_cold(3, fwd, 7, 7, st), "fwd"),
             lambda: check(L.mv3d_roi_pool_backward_views(3, bwd, 7, 7, wp, wn, st), "bwd"), keep)
 
@@ -82,12 +85,13 @@ def run(indexed):
 
 
 want = None
-for name, indexed in (("plain", False), ("indexed", True), ("plain", False), ("indexed", True)):
+ORDER = (("pair", True),) * 2 if os.environ.get("PAIR_ONLY") else (("plain", False), ("pair", True), ("plain", False), ("pair", True))
+for name, indexed in ORDER:
     f, b, f2, b2 = run(indexed)
     print("%-8s alternating: fwd %6.1f us  bwd %6.1f us  sum %6.1f   back-to-back: fwd %6.1f  bwd %6.1f" % (name, f, b, f + b, f2, b2), flush=True)
     snap = [batches[0].bottom_diff[v].clone() for v in VIEWS] + [batches[0].tops[v][0].clone() for v in VIEWS]
     if want is None:
         want = snap
-    else:
-        assert all(torch.equal(a, b_) for a, b_ in zip(want, snap)), "plain and indexed outputs differ"
+    elif not os.environ.get("MV3D_IDX_DBG"):
+        assert all(torch.equal(a, b_) for a, b_ in zip(want, snap)), "plain and pair outputs differ"
 print("outputs of both pairs bit-identical on batch 0")
