@@ -975,8 +975,8 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
 //   backward, launches 1 + 2  one workgroup per 16-pixel segment of a map row, as the plain indexed RoiPoolGrad above: SIZES
 //                    (filter the ROIs by frame, row, column span; an upper bound of every pixel's list: all bins the reference's
 //                    test lets through), then LISTS (slab offsets = plain sums over the preceding segments' sizes -- the sizing
-//                    launch is complete -- items, and the candidate lists themselves); each launch zero-fills half of the maps'
-//                    rows under its latency chain (the ROI loads are issued BEFORE the fill's stores: a load's wait would
+//                    launch is complete -- items, and the candidate lists themselves); the LISTS launch zero-fills the maps under
+//                    its latency chain (the ROI and size loads are issued BEFORE the fill's stores: a load's wait would
 //                    otherwise wait for every older store as well).  No atomics, no state that has to be zero on entry.
 //   candidate lists  entries {record byte offset into top_diff, code of THIS pixel inside THAT bin} in the reference's order
 //                    roi -> ph -> pw; only bins whose forward rectangle [hstart, hend) x [wstart, wend) (roi_pooling_op.cc:153-162)
@@ -1084,8 +1084,9 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
         }
         my_mask = (unsigned)ix.seg_mask[block];                        // the pixels the sizing launch gave an item (upper bound > 0)
     }
-    if (FILL == ((h & 1) != 0) && !(ix.dbg & 1)) {   // every pixel of the segment starts as zeros (the gather overwrites the ones that have candidates);
-        // even rows by the sizing launch, odd rows by the list launch.  npx * C contiguous floats, streaming stores
+    if (FILL && !(ix.dbg & 1)) {    // every pixel of the segment starts as zeros (the gather overwrites the ones that have candidates): the
+        // list launch is a ~15 us chain of barriers, LDS round trips and little memory traffic, the 55 MB of streaming stores ride
+        // under it (the sizing launch is short and stays short without them).  npx * C contiguous floats
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
         f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * C);
@@ -1190,6 +1191,14 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
         for (int pass = 0; pass < npass; ++pass) nlist = build(pass);
     }
     __syncthreads();
+    if (npass == 1 && nlist == 0 && my_mask == 0u) {  // no ROI touches the segment (half of them): no item, nothing to list
+        if (threadIdx.x == 0 && block == nblocks - 1) {
+            int bt = 0;
+            for (int u = 0; u < 4; ++u) bt += S.red[4 + u];
+            ix.header[1] = bt;                        // (the sizing launch gave this segment no item either)
+        }
+        return;
+    }
     RPI_STAMP(3);                                     // (filter + counts done)
     if (tr && threadIdx.x == 0) tr[7] = nlist;
     if (threadIdx.x < 64) {                      // upper-bound slab offsets of the segment's pixels come from the SIZES launch's rule
@@ -1227,11 +1236,33 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
             const int xr = S.xr[e][sp], pr = S.prow[e], ys = S.rsh[e], xs = S.rsw[e];
             const float fbh = S.bh[e], fbw = S.bw[e];
             const int rec0 = S.roi[e] * PH * PW, w = w0 + sp;
-            for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
-                const int dh = h - roi_pair_lo(ph, fbh, ys, H);
-                for (int pw = xr & 15; pw < (xr >> 4); ++pw) {
-                    const int ws = roi_pair_lo(pw, fbw, xs, W), we = roi_pair_hi(pw, fbw, xs, W);
-                    *dst++ = make_int2((rec0 + ph * PW + pw) * C * 4, dh * (we - ws) + (w - ws));
+            const int qa = xr & 15, ncols = (xr >> 4) - qa;
+            // (a tiny ROI -- far objects on the 8 x 64 front-view map -- puts all PH x PW bins on one pixel: up to 49 entries per (ROI,
+            // pixel), and such segments are the launch's long pole.  The columns' start / width are the same for every row of bins:
+            // up to eight of them are kept in registers, so that an entry costs a multiply-add and a store)
+            if (ncols <= 8) {
+                int cw[8], cd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int pw = min(qa + u, PW - 1);
+                    const int ws = roi_pair_lo(pw, fbw, xs, W);
+                    cw[u] = roi_pair_hi(pw, fbw, xs, W) - ws;
+                    cd[u] = w - ws;
+                }
+                for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
+                    const int dh = h - roi_pair_lo(ph, fbh, ys, H), rb = (rec0 + ph * PW + qa) * C * 4;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < ncols) dst[u] = make_int2(rb + u * C * 4, dh * cw[u] + cd[u]);
+                    dst += ncols;
+                }
+            } else {
+                for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
+                    const int dh = h - roi_pair_lo(ph, fbh, ys, H);
+                    for (int pw = qa; pw < qa + ncols; ++pw) {
+                        const int ws = roi_pair_lo(pw, fbw, xs, W), we = roi_pair_hi(pw, fbw, xs, W);
+                        *dst++ = make_int2((rec0 + ph * PW + pw) * C * 4, dh * (we - ws) + (w - ws));
+                    }
                 }
             }
         }
@@ -1269,14 +1300,19 @@ __device__ __forceinline__ void roi_pair_gather_block(const RoiGradPack &p, cons
     const int lane = threadIdx.x & 63;
     const int xcd = (int)(vblock & 7);
     const int slice = xcd % nsl, part = xcd / nsl, nparts = 8 / nsl;
+    const int stride = (int)(vgrid >> 3) * 4;
+    const int i0 = (int)(vblock >> 3) * 4 + (int)(threadIdx.x >> 6);
+    // (eight slices: this wave's first item does not depend on the number of items -- its header is requested together with that
+    // number, one dependent round trip less at the head of every wave; the item array has a slot per pixel, so the read is in bounds)
+    int4 it = make_int4(0, 0, 0, 0);
+    if (nparts == 1) it = ix.items[i0];
     const int n_all = __builtin_amdgcn_readfirstlane(ix.header[1]);
     const int per = (n_all + nparts - 1) / nparts;
     const int i_end = min(n_all, (part + 1) * per);                     // this part's items: [part * per, i_end)
-    const int stride = (int)(vgrid >> 3) * 4;
-    int i = part * per + (int)(vblock >> 3) * 4 + (int)(threadIdx.x >> 6);
+    int i = part * per + i0;
     if (i >= i_end) return;
     const int4 zero4 = make_int4(0, 0, 0, 0);
-    int4 it = ix.items[i];
+    if (nparts != 1) it = ix.items[i];
     int4 it1 = (i + stride < i_end) ? ix.items[i + stride] : zero4;
     int2 idx = ix.pool[it.y + max(min(lane, it.z - 1), 0)];       // (a list may be empty: every bin of the pixel pruned)
     constexpr int W = 32;
