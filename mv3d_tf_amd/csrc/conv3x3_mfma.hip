@@ -41,7 +41,6 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes;
     int m_tiles, n_tiles;
     int Ho, Wo, xtiles;           // POOL mode: pooled size (H / 2, W / 2) and 2-row tiles per pair of rows
-    int nsplit;                   // 1: two n-tiles, each on its own half of the XCDs (conv3x3_pp_kernel)
 };
 
 // Several views (the BEV / image / front-view trunks at one VGG depth: same channel counts, different map sizes) behind ONE
@@ -349,14 +348,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvGroup g)
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     unsigned *const s_pix = (unsigned *)(lds + OUT_BYTES);
 
-    // workgroup -> tile.  Default: XCD x owns a band of m-tiles and runs a tile's n-tiles back to back (they share the activation
-    // rows in that XCD's L2).  nsplit (c_out = 512: two 256-cout n-tiles whose weight panels, 2 x 2.4 MB, do not fit one 4 MB L2
-    // together and evict each other): n-tile x & 1 lives on XCDs of that parity, bands of m-tiles over x >> 1 -- each L2 keeps ONE
-    // weight panel resident; the activation rows are then fetched by two XCDs instead of one.
+    // workgroup -> tile as in the kernel above: XCD x owns a band of m-tiles and runs a tile's n-tiles back to back.  (Measured and
+    // dropped, profiles/r05_conv_mfma.txt: the two 256-cout n-tiles of a 512-cout layer on XCD halves, so that each L2 keeps one
+    // weight panel -- 3 - 7 % slower: the activation rows then cross the fabric twice.)
     const int id = (int)blockIdx.x - g.first[view], xcd = id & 7, local = id >> 3;
-    int mt, nt;
-    if (a.nsplit) { nt = xcd & 1; mt = (xcd >> 1) * ((a.m_tiles + 3) >> 2) + local; if (local >= ((a.m_tiles + 3) >> 2)) return; }
-    else { mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles; nt = local % a.n_tiles; }
+    const int mt = xcd * ((a.m_tiles + 7) >> 3) + local / a.n_tiles, nt = local % a.n_tiles;
     if (mt >= a.m_tiles) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -699,16 +695,10 @@ template <typename T>
 int launch_conv_pp(ConvGroup &g, hipStream_t s)
 {
     int grid = 0;
-#ifdef MV3D_TUNING
-    static const int nsplit_env = getenv("MV3D_CONV_NSPLIT") ? atoi(getenv("MV3D_CONV_NSPLIT")) : 0;
-#else
-    const int nsplit_env = 0;
-#endif
     for (int k = 0; k < g.n; ++k) {
         ConvArgs &b = g.v[k];
         b.m_tiles = (b.M + 255) / 256;
         b.n_tiles = b.Cout / 256;
-        b.nsplit = (nsplit_env && b.n_tiles == 2) ? 1 : 0;
         g.first[k] = grid;
         grid += (b.m_tiles + 7) / 8 * 8 * b.n_tiles;
     }
@@ -753,7 +743,6 @@ static bool conv_view_args(ConvArgs &a, const mv3d_conv_view &w, int c_in, int c
     a.out_pad = out_framed != 0; a.relu = relu != 0;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     a.m_tiles = a.n_tiles = 0;
-    a.nsplit = 0;
     return true;
 }
 
