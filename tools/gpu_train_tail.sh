@@ -33,6 +33,14 @@ for (s, e, n), (ps, pe, pn) in zip(tw[1:], tw[:-1]):
     if g > 0:
         k = (pn[:60], n[:60])
         a = gaps.setdefault(k, [0, 0]); a[0] += 1; a[1] += g
+# ... and by who owns the two launches: the library's kernels (mv3d_* / roi_* / loss_* / at_* / pt_* / nms_*) or torch / rocBLAS
+own = lambda n: any(t in n for t in ("mv3d", "roi_", "loss_", "at_", "pt_", "nms_", "proposal", "rgt_"))
+cls = {}
+for (pn, n), v in gaps.items():
+    k = ("library" if own(pn) else "torch") + " -> " + ("library" if own(n) else "torch")
+    a = cls.setdefault(k, [0, 0]); a[0] += v[0]; a[1] += v[1]
+for k, v in sorted(cls.items()):
+    print("gaps %-20s %6.1f / step, %.3f ms / step" % (k, v[0] / steps, v[1] / 1e6 / steps))
 print("idle between kernels: %.2f ms per step; largest contributors (previous kernel -> next kernel):" % (sum(v[1] for v in gaps.values()) / 1e6 / steps))
 for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
     print("  %6.1f us x %5.1f / step   %s  ->  %s" % (v[1] / v[0] / 1e3, v[0] / steps, k[0], k[1]))
