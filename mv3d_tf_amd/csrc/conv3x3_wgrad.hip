@@ -377,8 +377,18 @@ __global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const
     if ((int)blockIdx.x >= cob * ciq) {                           // the bias gradient's partial sums
         const int co = ((int)blockIdx.x - cob * ciq) * (144 * RED_G) + tid;
         if (v.db && co < c_out) {
-            float s = v.bpart[co];
-            for (int k = 1; k < splits; ++k) s += v.bpart[(long)k * c_out + co];
+            // (eight loads in flight, added in split order: the 64-channel layers have 300+ splits and this block was the launch's
+            // long pole when it walked them one round trip at a time)
+            float s = 0.f;
+            int k = 0;
+            for (; k + 8 <= splits; k += 8) {
+                float b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b[u] = v.bpart[(long)(k + u) * c_out + co];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += b[u];
+            }
+            for (; k < splits; ++k) s += v.bpart[(long)k * c_out + co];
             v.db[co] = s;
         }
         return;
@@ -392,6 +402,13 @@ __global__ __launch_bounds__(144 * RED_G) void conv3x3_wgrad_reduce_kernel(const
     const int per = (splits + RED_G - 1) / RED_G, k0 = grp * per, k1 = min(splits, k0 + per);
     f32x4r s = {0.f, 0.f, 0.f, 0.f};
     int k = k0;
+    for (; k + 8 <= k1; k += 8) {                                 // eight 16-byte loads in flight (a 64 -> 64 layer: ~80 splits per group)
+        f32x4r a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = p[(long)(k + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+    }
     for (; k + 4 <= k1; k += 4) {
         const f32x4r a0 = p[(long)k * n4], a1 = p[(long)(k + 1) * n4], a2 = p[(long)(k + 2) * n4], a3 = p[(long)(k + 3) * n4];
         s += a0; s += a1; s += a2; s += a3;

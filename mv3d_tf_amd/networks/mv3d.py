@@ -64,6 +64,10 @@ class MV3D:
         self._mfma = None
         self._train_pool = None
         self._wcache = {}
+        self._step_half = None      # {name: (w, b)} in amp_dtype for the current training step (amp_cast.cast_params)
+        # amp training: the dense head's reduced-precision parameter copies of a step from ONE multi-tensor launch (amp_cast.CastMany)
+        # instead of one autocast cast per tensor and use; False = autocast's own casts (tools' A / B)
+        self.cast_many = True
         self.params = {}
         g = torch.Generator().manual_seed(seed)
 
@@ -185,8 +189,8 @@ class MV3D:
             self._wcache[key] = hit
         return hit[1], hit[2]
 
-    def _fc(self, x, name, relu=True):
-        if not torch.is_grad_enabled():                             # serving: cached weights, no flattening copy
+    def _fc(self, x, name, relu=True, wb=None):
+        if wb is None and not torch.is_grad_enabled():              # serving: cached weights, no flattening copy
             nhwc = tuple(x.shape[1:]) if x.ndim == 4 else None
             w, b = self._serving_weights(name, nhwc)
             # (a plain GEMM: rocBLAS / hipBLASLt.  The convolution kernel run without taps measured 617 vs 943 TFLOP/s on fc6.)
@@ -194,10 +198,36 @@ class MV3D:
             return F.relu(y) if relu else y
         if x.ndim == 4:                                             # NHWC -> (c,h,w) flattening (network.py:373-377)
             x = x.permute(0, 3, 1, 2).reshape(x.shape[0], -1)
-        w, b = self.params[name]
+        w, b = wb if wb is not None else self._half_or_master(name)
         with self._amp():
             y = F.linear(x, w, b)
             return F.relu(y) if relu else y
+
+    def _head_fn(self, pools, P, keep_prob):
+        """The fusion head (MV3D_train.py:108-136 / MV3D_test.py:95-123) on the pooled maps: per view fc6 -> (dropout) -> fc7 ->
+        (dropout), concatenated, cls_score (+ softmax) and bbox_pred.  P(name) -> (w, b) | None (= this network's own).  Returns
+        ([fc7 per view], cls_score f32, cls_prob, bbox_pred f32)."""
+        tower = []
+        for t, x in zip(("_1", "_2", "_3"), pools):
+            x = self._fc(x, "fc6" + t, wb=P("fc6" + t))
+            if self.phase == "TRAIN":
+                x = F.dropout(x, 1.0 - keep_prob, training=True)
+            x = self._fc(x, "fc7" + t, wb=P("fc7" + t))
+            if self.phase == "TRAIN":
+                x = F.dropout(x, 1.0 - keep_prob, training=True)
+            tower.append(x)
+        fused = torch.cat(tower, dim=1)
+        cls = self._fc(fused, "cls_score", relu=False, wb=P("cls_score")).float()
+        return tower, cls, F.softmax(cls, dim=1), self._fc(fused, "bbox_pred", relu=False, wb=P("bbox_pred")).float()
+
+    _HEAD_LAYERS = ("rpn_cls_score", "rpn_bbox_pred", "fc6_1", "fc7_1", "fc6_2", "fc7_2", "fc6_3", "fc7_3", "cls_score", "bbox_pred")
+
+    def _half_or_master(self, name):
+        """(w, b) of a dense head layer for this training step: under amp the copies in amp_dtype that ONE multi-tensor launch made
+        for all head layers (amp_cast.CastMany; autocast then finds nothing to cast), otherwise the fp32 parameters themselves"""
+        if self._step_half is not None and name in self._step_half:
+            return self._step_half[name]
+        return self.params[name]
 
     # ---- hot-path plumbing
     _TP_CACHE = 4                 # TrainPathStream objects kept alive (KITTI has four image sizes -> four sub-batch shapes)
@@ -248,6 +278,10 @@ class MV3D:
             if k in feed and feed[k] is not None:
                 L[k] = [to_dev(a) for a in feed[k]] if isinstance(feed[k], (list, tuple)) else to_dev(feed[k])
         keep_prob = float(feed.get("keep_prob", self.keep_prob))
+        self._step_half = None
+        if self.cast_many and self.amp_dtype is not None and self.phase == "TRAIN" and torch.is_grad_enabled():
+            from ..amp_cast import cast_params
+            self._step_half = cast_params(self.params, [n for n in self._HEAD_LAYERS if n in self.params], self.amp_dtype)
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
@@ -271,7 +305,7 @@ class MV3D:
             L["rpn_conv/3x3"] = rpn_nhwc
             heads = []
             for name in ("rpn_cls_score", "rpn_bbox_pred"):                       # 1x1 convolutions = a matmul over the channel axis
-                w, b = self.params[name]
+                w, b = self._half_or_master(name)
                 with self._amp():
                     heads.append(F.linear(rpn_nhwc, w.reshape(w.shape[0], -1), b).float().contiguous())
             score, L["rpn_bbox_pred"] = heads
@@ -344,19 +378,8 @@ class MV3D:
             names.append("pool_5_3")
         for name, top in zip(names, roi_pool_views([(d.contiguous(), r.contiguous()) for d, r in views], 7, 7, 1.0 / 8)):
             L[name] = top
-        pools = list(zip(("_1", "_2", "_3"), names))
-        tower = []
-        for t, pool in pools:
-            x = self._fc(L[pool], "fc6" + t)
-            if self.phase == "TRAIN":
-                x = F.dropout(x, 1.0 - keep_prob, training=True)
-            x = self._fc(x, "fc7" + t)
-            if self.phase == "TRAIN":
-                x = F.dropout(x, 1.0 - keep_prob, training=True)
+        tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)
+        for t, x in zip(("_1", "_2", "_3"), tower):
             L["fc7" + t] = x
-            tower.append(x)
-        fused = torch.cat(tower, dim=1)
-        L["cls_score"] = self._fc(fused, "cls_score", relu=False).float()
-        L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
-        L["bbox_pred"] = self._fc(fused, "bbox_pred", relu=False).float()
+        self._step_half = None                                                      # (the autograd graph keeps what backward needs)
         return L

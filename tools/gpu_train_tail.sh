@@ -2,17 +2,17 @@
 # GPU box: steady-state kernel totals of one training-step configuration (rocprofv3 kernel trace of tools/train_probe.py, the last
 # 40 % of the trace = the timed steps).   tools/gpu_train_tail.sh <tag> <fp32|bf16|bf16_mfma|fp32_mfma> [steps]
 set -u
-TAG=$1; CFG=$2; STEPS=${3:-8}
+TAG=$1; CFG=$2; STEPS=${3:-8}; SFX=${4:-}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace -d $OUT/tr -o r -- python $GRAFT_REPO_ROOT/tools/train_probe.py $CFG $STEPS > $OUT/$CFG.log 2>&1
 tail -1 $OUT/$CFG.log
-python - $OUT/tr/r_results.db $STEPS > $OUT/${CFG}_tail.txt <<'PY'
+python - $OUT/tr/r_results.db $STEPS > $OUT/${CFG}${SFX}_tail.txt <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1]); steps = float(sys.argv[2])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # the timed steps = the last `steps` of steps + 2 warm-up: cut at the Adam launch (multi_tensor_apply) that ends warm-up step 2
-adam = [r[1] for r in rows if "multi_tensor_apply" in r[0]]
+adam = [r[1] for r in rows if "multi_tensor_apply" in r[0] and "Adam" in r[0]]        # (not the multi-tensor casts)
 per = len(adam) / (steps + 2)
 cut = adam[int(round(2 * per)) - 1] if adam else rows[0][1]
 agg = {}
@@ -46,4 +46,4 @@ for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
     print("  %6.1f us x %5.1f / step   %s  ->  %s" % (v[1] / v[0] / 1e3, v[0] / steps, k[0], k[1]))
 PY
 rm -rf $OUT/tr
-head -24 $OUT/${CFG}_tail.txt | cut -c1-170; grep -A15 '^idle between' $OUT/${CFG}_tail.txt | cut -c1-200
+head -24 $OUT/${CFG}${SFX}_tail.txt | cut -c1-170; grep -A15 '^idle between' $OUT/${CFG}${SFX}_tail.txt | cut -c1-200

@@ -15,5 +15,6 @@ from mv3d_tf_amd.fast_rcnn.train_mv import bench_train_step  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bf16_mfma"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-r = bench_train_step(0, 1, None, steps=steps, warmup=2, amp=None if name.startswith("fp32") else torch.bfloat16, mfma=name.endswith("_mfma"))
+cm = os.environ.get("MV3D_CAST_MANY", "1") == "1"      # (A / B of the multi-tensor parameter casts)
+r = bench_train_step(0, 1, None, steps=steps, warmup=2, cast_many=cm, amp=None if name.startswith("fp32") else torch.bfloat16, mfma=name.endswith("_mfma"))
 print(json.dumps({"config": name, "ms_per_step": r["ms_per_step"], "frames_per_s": r["frames_per_s"]}))
