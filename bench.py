@@ -8,7 +8,7 @@ Default workload = BASELINE configs[2], path only (the largest single-GPU config
       mv3d_anchor_target_*       RPN labels / 6-d targets of every frame
       mv3d_proposal_target_*     <= 128 sampled ROIs / frame (fg first), corner targets, image boxes
       mv3d_rois_3d_to_fv         third (front-view) ROIs
-      mv3d_roi_pool_forward_views_pair   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7 (private 16-bit argmax plane)
+      mv3d_roi_pool_forward_views_pair   BEV 76x76x512 + RGB 46x155x512 + FV 8x64x512, 7x7 (private one-byte argmax plane)
       mv3d_roi_pool_backward_views_pair  the same three layers, RoiPoolGrad (candidate index + zero fill, ordered gather)
 
 A "step" = one pass over `--batches-per-step` such batches (default 1664 batches = 3328 frames: `--steps 20` is a SUSTAINED
@@ -296,7 +296,7 @@ class PathDriver:
                 want["bev"].append(r_bv); want["rgb"].append(r_img); want["fv"].append(oracle.rois_3d_to_fv(r_3d))
             St = out["rois"]["bev"].shape[0]
             rows += St
-            # the pair keeps its argmax plane as private 16-bit codes: decoded to the reference's int32 plane for the comparison
+            # the pair keeps its argmax plane as private one-byte codes: decoded to the reference's int32 plane for the comparison
             from mv3d_tf_amd import ops
             mp = self.maps[k % len(self.inputs)]
             fviews = [(mp[v], out["rois"][v], 0.125) for v in self.views]
@@ -369,7 +369,7 @@ def roofline_entries(ring, workload, signature):
     s0 = ring.slots[0].stream
     mine = [s for s in ring.slots if s.stream is s0]
     if workload == "train":
-        # the RoiPool pair: forward with 16-bit argmax codes; RoiPoolGrad = index + zero fill launch, gather launch behind one call
+        # the RoiPool pair: forward with one-byte argmax codes; RoiPoolGrad = index + zero fill launch, gather launch behind one call
         legs = [("roi_pool_fwd_pair_cold_kernel" if getattr(mine[0], "cold_maps", False) else "roi_pool_fwd_pair_kernel",
                  "mv3d_roi_pool_forward_views_pair", "roi_forward_bytes"),
                 ("roi_pair_index_kernel + roi_pair_gather_kernel", "mv3d_roi_pool_backward_views_pair", "roi_backward_bytes")]
@@ -722,7 +722,7 @@ def main():
         entries = roofline_entries(ring, wl, signature)
         dom = max(entries, key=lambda e: e["avg_launch_us"]) if entries else {}
         res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = index + fill and gather kernels behind one C call; algorithmic "
-                                         "bytes as SURVEY 8(d) defines them -- 8 B per pooled value -- while the pair moves 6: its argmax plane is 16-bit); "
+                                         "bytes as SURVEY 8(d) defines them -- 8 B per pooled value -- while the pair moves 5: its argmax plane holds one-byte codes); "
                                          "HIP event pairs on the launch stream around the call inside the batch's eager launch "
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "
                                          "configuration or null")

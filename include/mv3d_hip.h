@@ -184,14 +184,15 @@ int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views,
  * `top_data` and `bottom_diff` are bit-identical to mv3d_roi_pool_forward_views / mv3d_roi_pool_backward_views.
  *   argmax_data     (required) belongs to the pair: the forward writes it, the backward reads it, nobody else needs it (the
  *                   reference's own graph uses the op's second output only in RoiPoolGrad, roi_pooling_op_grad.py:7-43).  The
- *                   pair's kernels store it as 16-bit codes -- the position of the first maximum in its bin's scan order
- *                   (h - hstart) * (wend - wstart) + (w - wstart), 0xFFFF for the reference's -1 -- in the first half of the
- *                   caller's (num_rois, PH, PW, C) int32 buffer: a quarter of the record bytes (8 -> 6 B per pooled value) is
- *                   neither written by the forward nor read by the backward.  mv3d_roi_pool_argmax_decode returns the reference's
+ *                   pair's kernels store it as ONE-BYTE codes -- the position of the first maximum in its bin's scan order
+ *                   (h - hstart) * (wend - wstart) + (w - wstart), 0xFF for the reference's -1 -- in the first quarter of the
+ *                   caller's (num_rois, PH, PW, C) int32 buffer (bins of more than 255 pixels, i.e. ROIs far larger than the
+ *                   map: 16-bit codes in the two quarters behind it): 3 / 8 of the record bytes (8 -> 5 B per pooled value)
+ *                   are neither written by the forward nor read by the backward.  mv3d_roi_pool_argmax_decode returns the reference's
  *                   int32 plane (tests, verification).
  *   backward        three launches: one workgroup per 16 pixels of a map row sizes (1) and then writes (2) the per-pixel candidate
  *                   lists of roi_pooling_op.cc:392-431 -- only bins whose forward rectangle contains the pixel, each with the
- *                   code the pixel has in that bin -- both zero-filling half of bottom_diff under their latency chains; (3) the
+ *                   code the pixel has in that bin --, (2) also zero-filling the pixels without a list under its latency chain; (3) the
  *                   ordered gather: `code == pixel's code ? top_diff : +0` per record, the reference's summation order.  The
  *                   views must be the forward's (same order, shapes, scale, ROIs) with the argmax buffers it wrote.  (For a
  *                   foreign argmax plane use mv3d_roi_pool_backward_views: int32 argmax.)

@@ -117,12 +117,17 @@ __device__ __forceinline__ void upd4pos(const float4 x, int pos, float4 &mv, int
     upd(x.w, pos, mv.w, mi.w);
 }
 
-// COMPACT (the indexed pair, mv3d_roi_pool_forward_views_indexed): the argmax plane is PRIVATE to the pair -- only its own
-// RoiPoolGrad reads it -- and is written as 16-bit codes instead of the reference's int32 flat indices: the position of the first
-// maximum in the bin's scan order, (h - hstart) * (wend - wstart) + (w - wstart), 0xFFFF for "none" (the reference's -1).  A quarter
-// of the pair's record bytes (8 -> 6 B per pooled value) is neither written here nor read by the gradient; the gradient's
-// candidate index carries the code each candidate pixel has inside each of its bins, so the test `argmax == this pixel`
-// (roi_pooling_op.cc:433) is one 16-bit compare.  mv3d_roi_pool_argmax_decode gives the reference's plane back (tests, bench).
+// COMPACT (the pair, mv3d_roi_pool_forward_views_pair): the argmax plane is PRIVATE to the pair -- only its own RoiPoolGrad reads
+// it -- and holds, instead of the reference's int32 flat indices, the position of the first maximum in the bin's scan order,
+// (h - hstart) * (wend - wstart) + (w - wstart):
+//   bins of <= 255 pixels (every bin of a ROI smaller than ~100 x 100 feature pixels): ONE BYTE per pooled value, 0xFF = "none"
+//       (the reference's -1), in the byte plane at the front of the caller's argmax buffer, [0, N), N = R * PH * PW * C;
+//   larger bins (ROIs far larger than the map): 16-bit codes, 0xFFFF = none, in the escape plane behind it, bytes [N, 3 N).
+// Which plane a bin uses follows from its geometry alone, so the gradient's index knows it (RPC_BIG in a list entry).  3 / 8 of the
+// pair's record bytes (8 -> 5 B per pooled value) are neither written here nor read by the gradient; the index carries the code each
+// candidate pixel has inside each of its bins, so the test `argmax == this pixel` (roi_pooling_op.cc:433) is one compare.
+// mv3d_roi_pool_argmax_decode gives the reference's plane back (tests, bench).
+#define RPC_BIG 0x10000              // list entry: the bin has more than 255 pixels -- its codes are in the 16-bit escape plane
 template <int FWD_PASSES, bool COMPACT = false>
 __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
                                                         const float *__restrict__ data, float scale,
@@ -209,10 +214,16 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
             typedef int i4v __attribute__((ext_vector_type(4)));
             const f4v mvv = {mv.x, mv.y, mv.z, mv.w};
             __builtin_nontemporal_store(mvv, reinterpret_cast<f4v *>(top + o));
-            if (COMPACT) {                           // four 16-bit codes (-1 -> 0xFFFF), 8 bytes per lane
-                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-                const u2v cv = {((unsigned)mi.x & 0xffffu) | ((unsigned)mi.y << 16), ((unsigned)mi.z & 0xffffu) | ((unsigned)mi.w << 16)};
-                __builtin_nontemporal_store(cv, reinterpret_cast<u2v *>(reinterpret_cast<unsigned short *>(argmax) + o));
+            if (COMPACT) {
+                unsigned char *const plane8 = reinterpret_cast<unsigned char *>(argmax);
+                if (g.base < 0 || (g.he - g.hs) * (g.we - g.ws) <= 255) {      // four one-byte codes (-1 -> 0xFF), 4 bytes per lane
+                    const unsigned cv = ((unsigned)mi.x & 0xffu) | (((unsigned)mi.y & 0xffu) << 8) | (((unsigned)mi.z & 0xffu) << 16) | ((unsigned)mi.w << 24);
+                    __builtin_nontemporal_store(cv, reinterpret_cast<unsigned *>(plane8 + o));
+                } else {                             // a bin of more than 255 pixels: four 16-bit codes in the escape plane
+                    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                    const u2v cv = {((unsigned)mi.x & 0xffffu) | ((unsigned)mi.y << 16), ((unsigned)mi.z & 0xffffu) | ((unsigned)mi.w << 16)};
+                    __builtin_nontemporal_store(cv, reinterpret_cast<u2v *>(reinterpret_cast<unsigned short *>(plane8 + nbins * C) + o));
+                }
             } else {
                 const i4v miv = {mi.x, mi.y, mi.z, mi.w};
                 if (argmax) __builtin_nontemporal_store(miv, reinterpret_cast<i4v *>(argmax + o));
@@ -968,15 +979,15 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
 }
 
 // ===============================================================================================================================
-// The PAIR (mv3d_roi_pool_forward_views_pair / mv3d_roi_pool_backward_views_pair): RoiPool and its gradient with a private 16-bit
-// argmax plane between them.
+// The PAIR (mv3d_roi_pool_forward_views_pair / mv3d_roi_pool_backward_views_pair): RoiPool and its gradient with a private
+// argmax plane of one-byte codes between them (16-bit codes for bins of more than 255 pixels: COMPACT above).
 //
-//   forward          the XCD-sliced pooling kernels above with COMPACT codes: 6 instead of 8 bytes per pooled value are written.
+//   forward          the XCD-sliced pooling kernels above with COMPACT codes: 5 instead of 8 bytes per pooled value are written.
 //   backward, launches 1 + 2  one workgroup per 16-pixel segment of a map row, as the plain indexed RoiPoolGrad above: SIZES
 //                    (filter the ROIs by frame, row, column span; an upper bound of every pixel's list: all bins the reference's
 //                    test lets through), then LISTS (slab offsets = plain sums over the preceding segments' sizes -- the sizing
-//                    launch is complete -- items, and the candidate lists themselves); the LISTS launch zero-fills the maps under
-//                    its latency chain (the ROI and size loads are issued BEFORE the fill's stores: a load's wait would
+//                    launch is complete -- items, and the candidate lists themselves); the LISTS launch zero-fills the pixels
+//                    WITHOUT an item under its latency chain (the ROI and size loads are issued BEFORE the fill's stores: a load's wait would
 //                    otherwise wait for every older store as well).  No atomics, no state that has to be zero on entry.
 //   candidate lists  entries {record byte offset into top_diff, code of THIS pixel inside THAT bin} in the reference's order
 //                    roi -> ph -> pw; only bins whose forward rectangle [hstart, hend) x [wstart, wend) (roi_pooling_op.cc:153-162)
@@ -985,7 +996,7 @@ __global__ __launch_bounds__(256) void roi_bwd_gather_kernel(RoiGradPack p, RoiG
 //                    pixel without passing the reference's candidate test (:401-431: the test uses the UNCLAMPED rounded ROI, a
 //                    last bin's ceil() may reach one pixel past it) stays out, as the reference leaves it out.
 //   backward, launch 3  the gather sums each candidate pixel's records in list order (= the reference's f32 summation order): per
-//                    record one 16-bit code + one f32 per lane, `code == this pixel's code ? top_diff : +0`, and overwrites the pixel.
+//                    record one code byte + one f32 per lane, `code == this pixel's code ? top_diff : +0`, and writes the pixel.
 // Bit-identical to the plain entries (tests/test_roi_pair.py).  Measured and dropped in round 5 (tools/experiments/
 // roi_pair_index_in_forward_r05.hip.txt, profiles/r05_c_*, r05_d_*): the index built by workgroups INSIDE the forward launch
 // (forward 39 -> 56 us: latency-bound workgroups under a write-saturated memory system), and a single-pass index with a look-back
@@ -1059,6 +1070,10 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
     long long *tr = (FILL && ix.trace) ? ix.trace + 8 * (long long)block : nullptr;
 #define RPI_STAMP(K) do { if (tr && threadIdx.x == 0) tr[K] = (long long)__builtin_readcyclecounter(); } while (0)
     RPI_STAMP(0);
+    // (lists) the pixels the sizing launch gave an item (upper bound > 0): the FIRST request of the workgroup -- the fill below skips
+    // those pixels and should not have to wait for the younger requests as well
+    unsigned my_mask = 0;
+    if (FILL) my_mask = (unsigned)ix.seg_mask[block];
     // the first pass's ROI of this thread: requested BEFORE the fill's stores (a wait for a load also waits for every older store)
     float r0[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if ((int)threadIdx.x < R) {
@@ -1068,7 +1083,6 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
     }
     // (lists) the segment's slab and item offsets = sums over the preceding segments' sizes: requested before the fill as well
     int a = 0, b = 0;
-    unsigned my_mask = 0;
     if (FILL) {
         // (seg_tot holds candidates << 5 | pixels with any; eight words per thread requested together: summed one word at a time the
         // loop was a chain of dependent round trips -- ~2 us each -- at the head of every workgroup)
@@ -1082,16 +1096,17 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a += pk[u] >> 5; b += pk[u] & 31; }
         }
-        my_mask = (unsigned)ix.seg_mask[block];                        // the pixels the sizing launch gave an item (upper bound > 0)
     }
-    if (FILL && !(ix.dbg & 1)) {    // every pixel of the segment starts as zeros (the gather overwrites the ones that have candidates): the
-        // list launch is a ~15 us chain of barriers, LDS round trips and little memory traffic, the 55 MB of streaming stores ride
-        // under it (the sizing launch is short and stays short without them).  npx * C contiguous floats
+    if (FILL && !(ix.dbg & 1)) {    // the pixels of the segment WITHOUT an item become zeros here (every item's pixel is written by the
+        // gather, an empty pruned list as +0): the list launch is a ~15 us chain of barriers, LDS round trips and little memory traffic,
+        // the ~40 MB of streaming stores ride under it (the sizing launch is short and stays short without them).  npx * C floats
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
         f4v *dst = reinterpret_cast<f4v *>(v.bottom_diff + pix0 * C);
-        const int n4 = npx * (C / 4);
-        for (int t = threadIdx.x; t < n4; t += 256) __builtin_nontemporal_store(z, dst + t);
+        const int n4 = npx * (C / 4), psh = C == 512 ? 7 : 6;          // (the pair takes C = 256 | 512: roi_pair_shapes)
+        const unsigned skip = (ix.dbg & 16) ? 0u : my_mask;            // (dbg 16, experiment builds: zero every pixel as before)
+        for (int t = threadIdx.x; t < n4; t += 256)
+            if (!((skip >> (t >> psh)) & 1u)) __builtin_nontemporal_store(z, dst + t);
     }
     if (threadIdx.x < BWI_PIX) { S.cnt[threadIdx.x] = 0; S.run[threadIdx.x] = 0; }
     int nlist = 0;
@@ -1250,18 +1265,19 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
                     cd[u] = w - ws;
                 }
                 for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
-                    const int dh = h - roi_pair_lo(ph, fbh, ys, H), rb = (rec0 + ph * PW + qa) * C * 4;
+                    const int hs = roi_pair_lo(ph, fbh, ys, H), bhgt = roi_pair_hi(ph, fbh, ys, H) - hs;
+                    const int dh = h - hs, rb = (rec0 + ph * PW + qa) * C * 4;
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (u < ncols) dst[u] = make_int2(rb + u * C * 4, dh * cw[u] + cd[u]);
+                        if (u < ncols) dst[u] = make_int2(rb + u * C * 4, (dh * cw[u] + cd[u]) | (bhgt * cw[u] > 255 ? RPC_BIG : 0));
                     dst += ncols;
                 }
             } else {
                 for (int ph = pr & 255; ph < (pr >> 8); ++ph) {
-                    const int dh = h - roi_pair_lo(ph, fbh, ys, H);
+                    const int hs = roi_pair_lo(ph, fbh, ys, H), bhgt = roi_pair_hi(ph, fbh, ys, H) - hs, dh = h - hs;
                     for (int pw = qa; pw < qa + ncols; ++pw) {
                         const int ws = roi_pair_lo(pw, fbw, xs, W), we = roi_pair_hi(pw, fbw, xs, W);
-                        *dst++ = make_int2((rec0 + ph * PW + pw) * C * 4, dh * (we - ws) + (w - ws));
+                        *dst++ = make_int2((rec0 + ph * PW + pw) * C * 4, (dh * (we - ws) + (w - ws)) | (bhgt * (we - ws) > 255 ? RPC_BIG : 0));
                     }
                 }
             }
@@ -1273,12 +1289,12 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
 #undef RPI_STAMP
 }
 
-// the gather of the pair: wave = (item, 64-channel slice) as roi_bwd_gather_block; per record one 16-bit code and one f32 per lane
+// the gather of the pair: wave = (item, 64-channel slice) as roi_bwd_gather_block; per record one code byte and one f32 per lane
 template <int W, bool MASKED>
 __device__ __forceinline__ void roi_pair_drain(const int cur_o, const int cur_k, const int u0, const int m, const __amdgpu_buffer_rsrc_t rc,
                                                const __amdgpu_buffer_rsrc_t rt, const int lane, float &a)
 {
-    unsigned short cd[W];
+    unsigned char cd[W];
     float td[W];
     int sk[W];
 #pragma unroll
@@ -1286,12 +1302,25 @@ __device__ __forceinline__ void roi_pair_drain(const int cur_o, const int cur_k,
         const int l = MASKED ? min(u0 + u, 63) : u0 + u;
         const int so = __builtin_amdgcn_readlane(cur_o, l);
         sk[u] = __builtin_amdgcn_readlane(cur_k, l);
-        cd[u] = __builtin_amdgcn_raw_buffer_load_b16(rc, lane * 2, so >> 1, 0);
+        cd[u] = __builtin_amdgcn_raw_buffer_load_b8(rc, lane, so >> 2, 0);
         td[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, lane * 4, so, 0));
     }
 #pragma unroll
     for (int u = 0; u < W; ++u)
         if (!MASKED || u0 + u < m) a += ((int)cd[u] == sk[u]) ? td[u] : 0.0f;
+}
+// a batch of entries with bins of more than 255 pixels among them (ROIs far larger than the map: rare): entry by entry, each from
+// its own plane, in the same order
+__device__ __forceinline__ void roi_pair_drain_mixed(const int cur_o, const int cur_k, const int m, const __amdgpu_buffer_rsrc_t rc,
+                                                     const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt, const int lane, float &a)
+{
+    for (int u = 0; u < m; ++u) {
+        const int so = __builtin_amdgcn_readlane(cur_o, u), k = __builtin_amdgcn_readlane(cur_k, u);
+        const int code = (k & RPC_BIG) ? (int)__builtin_amdgcn_raw_buffer_load_b16(rc16, lane * 2, so >> 1, 0)
+                                       : (int)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, so >> 2, 0);
+        const float td = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, lane * 4, so, 0));
+        a += (code == (k & 0xffff)) ? td : 0.0f;
+    }
 }
 
 __device__ __forceinline__ void roi_pair_gather_block(const RoiGradPack &p, const RoiPairIdx &ix, const int nsl, const unsigned vblock,
@@ -1329,14 +1358,21 @@ __device__ __forceinline__ void roi_pair_gather_block(const RoiGradPack &p, cons
         const int c = slice * 64 + lane;
         const int2 *cand = ix.pool + off;
         // the slice lives in the (wave-uniform) base address, the lane in the vector offset, the record's byte offset is the scalar
-        // offset of the load (halved for the 16-bit code plane, which the forward wrote into the caller's argmax buffer)
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((const unsigned short *)v.argmax + slice * 64), 0, 0x7fffffff, 0x00020000);
+        // offset of the load (a quarter of it for the byte plane, half for the escape plane: both in the caller's argmax buffer)
+        const unsigned char *const plane8 = (const unsigned char *)v.argmax;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(plane8 + slice * 64), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rc16 = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((const unsigned short *)(plane8 + (long long)v.R * p.PH * p.PW * C) + slice * 64), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64), 0, 0x7fffffff, 0x00020000);
         float a = 0.0f;
         for (int t0 = 0; t0 < cnt; t0 += 64) {
             const int2 cur = idx;
             if (t0 + 64 < cnt) idx = cand[min(t0 + 64 + lane, cnt - 1)];
             const int m = min(64, cnt - t0);
+            if (__ballot((cur.y & RPC_BIG) != 0 && lane < m) != 0ull) {      // (wave-uniform; never taken on the proposal path's ROIs)
+                roi_pair_drain_mixed(cur.x, cur.y, m, rc, rc16, rt, lane, a);
+                continue;
+            }
             int u0 = 0;
             for (; u0 + W <= m; u0 += W) roi_pair_drain<W, false>(cur.x, cur.y, u0, m, rc, rt, lane, a);
             if (u0 + 16 <= m) { roi_pair_drain<16, false>(cur.x, cur.y, u0, m, rc, rt, lane, a); u0 += 16; }
@@ -1391,28 +1427,32 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_pair_cold_kernel(RoiViewPack
                                              v.argmax, v.tpb_shift);
 }
 
-// the pair's private 16-bit argmax plane -> the reference's int32 plane (flat index inside the frame, -1 for none); tests and
-// bench.py's verification only.  One thread per pooled value; the bin geometry as the forward computes it.
-__global__ __launch_bounds__(256) void roi_argmax_decode_kernel(const unsigned short *__restrict__ codes, const float *__restrict__ rois,
+// the pair's private argmax planes (byte codes; 16-bit codes for bins of more than 255 pixels) -> the reference's int32 plane (flat
+// index inside the frame, -1 for none); tests and bench.py's verification only.  One thread per pooled value; the bin geometry as
+// the forward computes it.
+__global__ __launch_bounds__(256) void roi_argmax_decode_kernel(const unsigned char *__restrict__ plane8, const float *__restrict__ rois,
                                                                 float scale, int R, int H, int W, int C, int PH, int PW, int *__restrict__ out)
 {
     const long long total = (long long)R * PH * PW * C;
+    const unsigned short *const plane16 = reinterpret_cast<const unsigned short *>(plane8 + total);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         long long t = i / C;
         const int pw = (int)(t % PW); t /= PW;
         const int ph = (int)(t % PH);
         const int n = (int)(t / PH);
-        const unsigned code = codes[i];
+        const float *roi = rois + 5 * (long long)n;
+        const RoiGeom q = roi_geom(roi, scale);
+        const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);
+        const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+        const int hs = min(max((int)floorf(__fmul_rn((float)ph, bh)) + q.rsh, 0), H);
+        const int he = min(max((int)ceilf(__fmul_rn((float)(ph + 1), bh)) + q.rsh, 0), H);
+        const int ws = min(max((int)floorf(__fmul_rn((float)pw, bw)) + q.rsw, 0), W);
+        const int we = min(max((int)ceilf(__fmul_rn((float)(pw + 1), bw)) + q.rsw, 0), W);
+        const bool big = he > hs && we > ws && (he - hs) * (we - ws) > 255;
+        const unsigned code = big ? (unsigned)plane16[i] : (unsigned)plane8[i];
         int res = -1;
-        if (code != 0xffffu) {
-            const float *roi = rois + 5 * (long long)n;
-            const RoiGeom q = roi_geom(roi, scale);
-            const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);
-            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-            const int hs = min(max((int)floorf(__fmul_rn((float)ph, bh)) + q.rsh, 0), H);
-            const int ws = min(max((int)floorf(__fmul_rn((float)pw, bw)) + q.rsw, 0), W);
-            const int we = min(max((int)ceilf(__fmul_rn((float)(pw + 1), bw)) + q.rsw, 0), W);
+        if (code != (big ? 0xffffu : 0xffu)) {
             const int bwid = max(we - ws, 1);
             res = ((hs + (int)code / bwid) * W + ws + (int)code % bwid) * C + c;
         }
@@ -1976,7 +2016,7 @@ extern "C" int mv3d_roi_pool_argmax_decode(int num_views, const mv3d_roi_view *v
         }
         if ((void *)argmax_out[k] == (void *)w.argmax_data) return MV3D_ERR_INVALID_ARG;
         const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-        hipLaunchKernelGGL(roi_argmax_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)w.argmax_data,
+        hipLaunchKernelGGL(roi_argmax_decode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)w.argmax_data,
                            w.bottom_rois, w.spatial_scale, w.num_rois, w.height, w.width, w.channels, pooled_height, pooled_width, argmax_out[k]);
     }
     return mv3d_launch_status();

@@ -353,7 +353,7 @@ def release_roi_pair_workspace(ws):
 
 def roi_pool_forward_views_pair(views, pooled_height, pooled_width, outs=None, cold_maps=False):
     """views as roi_pool_forward_views; one launch.  Returns [(top, argmax_private), ...]: the second tensor is the pair's PRIVATE
-    argmax plane (16-bit codes in an int32-shaped buffer for the shapes the pair's kernels take) -- hand it to
+    argmax plane (one-byte codes, 16-bit for bins of > 255 pixels, in an int32-shaped buffer for the shapes the pair's kernels take) -- hand it to
     roi_pool_backward_views_pair only; roi_pool_argmax_decode gives the reference's int32 plane."""
     arr = (RoiView * len(views))()
     res = []

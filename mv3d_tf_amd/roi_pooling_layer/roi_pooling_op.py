@@ -34,7 +34,7 @@ class RoiPoolFunction(torch.autograd.Function):
 
 class RoiPoolViewsFunction(torch.autograd.Function):
     """The RoiPool layers of one step (`pool_5`, `pool_5_2` [, `pool_5_3`]: network.py:199-213 called once per view) as the library's
-    PAIR: ONE launch forward (mv3d_roi_pool_forward_views_pair: every view, the argmax plane kept as private 16-bit codes) and one
+    PAIR: ONE launch forward (mv3d_roi_pool_forward_views_pair: every view, the argmax plane kept as private one-byte codes) and one
     call backward (mv3d_roi_pool_backward_views_pair: candidate index + zero fill, then the ordered gather of
     roi_pooling_op.cc:319-452 for every view).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...) -> (top_0, top_1, ...);
     gradients for the data tensors only (roi_pooling_op_grad.py:43).  A view whose output gets no gradient (unused in the loss)
