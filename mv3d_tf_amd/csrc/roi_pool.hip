@@ -128,6 +128,55 @@ __device__ __forceinline__ void upd4pos(const float4 x, int pos, float4 &mv, int
 // candidate pixel has inside each of its bins, so the test `argmax == this pixel` (roi_pooling_op.cc:433) is one compare.
 // mv3d_roi_pool_argmax_decode gives the reference's plane back (tests, bench).
 #define RPC_BIG 0x10000              // list entry: the bin has more than 255 pixels -- its codes are in the 16-bit escape plane
+// the rectangle of bin (ph, pw) of the ROI row rr[5] as roi_pooling_op.cc:139-162 computes it
+__device__ __forceinline__ BinGeom fwd_bin_rect(const float rr[5], const int ph, const int pw, const float scale, const int B, const int H, const int W,
+                                                const int PH, const int PW)
+{
+    BinGeom g;
+    g.pad0 = g.pad1 = g.pad2 = 0;
+    const int bi = (int)rr[0];
+    const RoiGeom q = roi_geom(rr, scale);
+    const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);   // roi_pooling_op.cc:146-147
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;        // :148-151
+    int hs = (int)floorf(__fmul_rn((float)ph, bh)), ws = (int)floorf(__fmul_rn((float)pw, bw));
+    int he = (int)ceilf(__fmul_rn((float)(ph + 1), bh)), we = (int)ceilf(__fmul_rn((float)(pw + 1), bw));
+    g.hs = min(max(hs + q.rsh, 0), H); g.he = min(max(he + q.rsh, 0), H);      // :159-162
+    g.ws = min(max(ws + q.rsw, 0), W); g.we = min(max(we + q.rsw, 0), W);
+    const bool empty = (g.he <= g.hs) || (g.we <= g.ws) || bi < 0 || bi >= B;
+    g.base = empty ? -1 : bi;
+    return g;
+}
+// the rectangle of pooled bin `bin` (= (roi n, ph, pw) flattened)
+__device__ __forceinline__ BinGeom fwd_bin_geom(const long long bin, const long long nbins, const float *__restrict__ rois, const float scale,
+                                                const int B, const int H, const int W, const int PH, const int PW)
+{
+    BinGeom g;
+    g.hs = g.he = g.ws = g.we = 0; g.base = -1; g.pad0 = g.pad1 = g.pad2 = 0;
+    if (bin < nbins) {
+        // 32-bit divisions (the launcher guarantees R*PH*PW < 2^31): a 64-bit divide is ~100 instructions,
+        // three of them in front of the barrier were the long pole of every workgroup
+        const unsigned ub = (unsigned)bin, upw = (unsigned)PW, uph = (unsigned)PH;
+        const unsigned t = ub / upw;
+        const int pw = (int)(ub - t * upw);
+        const unsigned n = t / uph;
+        const int ph = (int)(t - n * uph);
+        const float *roi = rois + 5 * (long long)n;
+        float rr[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) rr[u] = roi[u];
+        g = fwd_bin_rect(rr, ph, pw, scale, B, H, W, PH, PW);
+    }
+    return g;
+}
+
+template <int FWD_PASSES, bool COMPACT>
+__device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
+                                                       int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
+                                                       int *__restrict__ argmax, int tpb_shift);
+
+// (Round 5, measured and dropped: the rectangles computed per thread in registers -- no LDS, no barrier, the 8 - 32 lanes of a bin
+// redundantly: 42 - 46 us instead of 35, profiles/r05_fwd_local_ab.txt; a persistent grid that requests the next group's ROI rows
+// while it pools the current one: 39 - 41 us, profiles/r05_v_fwd_persist_ab.txt, tools/experiments/roi_pool_fwd_persistent_r05.hip.txt.)
 template <int FWD_PASSES, bool COMPACT = false>
 __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
                                                         const float *__restrict__ data, float scale,
@@ -135,38 +184,23 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
                                                         const float *__restrict__ rois, float *__restrict__ top,
                                                         int *__restrict__ argmax, int tpb_shift)
 {
-    const int tpb = 1 << tpb_shift;                  // threads per bin = C/32 (8, 16 or 32 float4 lanes)
-    const int bpp = 256 >> tpb_shift;                // bins per pass (32, 16 or 8)
-    const int slice = block & 7;
+    const int bpp = 256 >> tpb_shift;                // bins per pass (32, 16 or 8): C/32 = 8, 16 or 32 float4 lanes per bin
     const long long nbins = (long long)R * PH * PW;
     const long long bin0 = (long long)(block >> 3) * (FWD_PASSES * bpp);
-    if (threadIdx.x < FWD_PASSES * bpp) {
-        BinGeom g;
-        g.hs = g.he = g.ws = g.we = 0; g.base = -1; g.pad0 = g.pad1 = g.pad2 = 0;
-        const long long bin = bin0 + threadIdx.x;
-        if (bin < nbins) {
-            // 32-bit divisions (the launcher guarantees R*PH*PW < 2^31): a 64-bit divide is ~100 instructions,
-            // three of them in front of the barrier were the long pole of every workgroup
-            const unsigned ub = (unsigned)bin, upw = (unsigned)PW, uph = (unsigned)PH;
-            const unsigned t = ub / upw;
-            const int pw = (int)(ub - t * upw);
-            const unsigned n = t / uph;
-            const int ph = (int)(t - n * uph);
-            const float *roi = rois + 5 * (long long)n;
-            const int bi = (int)roi[0];
-            const RoiGeom q = roi_geom(roi, scale);
-            const int rw = max(q.rew - q.rsw + 1, 1), rh = max(q.reh - q.rsh + 1, 1);   // roi_pooling_op.cc:146-147
-            const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;        // :148-151
-            int hs = (int)floorf(__fmul_rn((float)ph, bh)), ws = (int)floorf(__fmul_rn((float)pw, bw));
-            int he = (int)ceilf(__fmul_rn((float)(ph + 1), bh)), we = (int)ceilf(__fmul_rn((float)(pw + 1), bw));
-            g.hs = min(max(hs + q.rsh, 0), H); g.he = min(max(he + q.rsh, 0), H);      // :159-162
-            g.ws = min(max(ws + q.rsw, 0), W); g.we = min(max(we + q.rsw, 0), W);
-            const bool empty = (g.he <= g.hs) || (g.we <= g.ws) || bi < 0 || bi >= B;
-            g.base = empty ? -1 : bi;
-        }
-        s_g[threadIdx.x] = g;
-    }
+    if (threadIdx.x < FWD_PASSES * bpp) s_g[threadIdx.x] = fwd_bin_geom(bin0 + threadIdx.x, nbins, rois, scale, B, H, W, PH, PW);
     __syncthreads();
+    roi_pool_fwd_xcd_pool<FWD_PASSES, COMPACT>(s_g, block, data, B, R, H, W, C, PH, PW, top, argmax, tpb_shift);
+}
+
+// the pooling phase of roi_pool_fwd_xcd_block: the workgroup's bins from their rectangles in LDS
+template <int FWD_PASSES, bool COMPACT>
+__device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
+                                                       int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
+                                                       int *__restrict__ argmax, int tpb_shift)
+{
+    const int tpb = 1 << tpb_shift, bpp = 256 >> tpb_shift, slice = block & 7;
+    const long long nbins = (long long)R * PH * PW;
+    const long long bin0 = (long long)(block >> 3) * (FWD_PASSES * bpp);
     const int sub = threadIdx.x >> tpb_shift;        // bin inside the pass
     const int c0 = (slice * tpb + (threadIdx.x & (tpb - 1))) * 4;
 #pragma unroll
@@ -181,6 +215,10 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
                 mv = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
                 const float *d = data + (long long)g.base * H * W * C + c0;
                 int pos = 0;                         // (COMPACT) position in the bin's scan order
+                // (Measured and dropped in round 5, profiles/r05_u_fwd_clamped_rows_probe.txt: row steps of four with the offsets clamped
+                // to the row's last pixel -- no one-pixel tail loop, one round trip per row of a 1 - 4 pixel wide bin.  36.3 vs 35.4 us
+                // here, 708 vs 658 us on the TEST-cfg batch: at eight waves per SIMD the tail's round trips are hidden, the compares of
+                // the re-read pixels are not -- the kernel is bound by vector-ALU issue and stores, not by load latency.)
                 for (int h = g.hs; h < g.he; ++h) {
                     int w = g.ws;
                     // four independent 16-byte loads in flight, consumed in scan order (first max wins)
