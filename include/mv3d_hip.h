@@ -370,6 +370,18 @@ int mv3d_proposal_target_stage2_batch_devn(int batch, const float *const *rois_b
  * 8 = reflectance of the last point of the highest slice (numpy fancy-assignment order). */
 int mv3d_point_cloud_2_top(const float *points_dev, int num_points, float *top_dev, void *stream);
 
+/* The same function with its own parameters (lib/utils/read_lidar.py:10-16: res, zres, side_range, fwd_range, height_range).
+ * mv3d_point_cloud_2_top_shape: dims[3] = (y_max + 1, x_max + 1, z_max + 1) of the map (read_lidar.py:49-52), host arithmetic only.
+ * mv3d_point_cloud_2_top_ranges: top_dev of that shape; *status_dev (one int32 on the device, written by the call) becomes 1 when a
+ * point's cell falls outside the map after numpy's wrap of negative indices -- where the reference's fancy assignment raises
+ * IndexError (the point is skipped here; the host mirror raises).  MV3D_ERR_INVALID_ARG: empty or inverted ranges, more than
+ * 32767 cells per axis or more than 31 height slices, P >= 2^27. */
+int mv3d_point_cloud_2_top_shape(double res, double zres, double side_lo, double side_hi, double fwd_lo, double fwd_hi,
+                                 double height_lo, double height_hi, int *dims);
+int mv3d_point_cloud_2_top_ranges(const float *points_dev, int num_points, double res, double zres, double side_lo, double side_hi,
+                                  double fwd_lo, double fwd_hi, double height_lo, double height_hi, float *top_dev,
+                                  int *status_dev, void *stream);
+
 /* ------------------------------------------------------------------ the target layers' random subsamplings (HOST code)
  * The reference subsamples with `npr.choice(inds, size=k, replace=False)` on the numpy GLOBAL legacy RandomState
  * (lib/rpn_msr/anchor_target_layer_tf.py:146-159,178-183; lib/rpn_msr/proposal_target_layer_tf.py:246-269) = 

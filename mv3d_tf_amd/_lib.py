@@ -143,6 +143,8 @@ _SIGS = {
     "mv3d_proposal_target_stage2": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.POINTER(ProposalTargetParams),
                                               _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_point_cloud_2_top": (C.c_int, [_P, C.c_int, _P, _P]),
+    "mv3d_point_cloud_2_top_shape": (C.c_int, [C.c_double] * 8 + [_P]),
+    "mv3d_point_cloud_2_top_ranges": (C.c_int, [_P, C.c_int] + [C.c_double] * 8 + [_P, _P, _P]),
     "mv3d_box_detect_tail": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "mv3d_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mv3d_rpn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),

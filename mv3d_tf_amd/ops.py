@@ -275,11 +275,23 @@ def proposal_target_stage2(rois_bv, rois_3d, gt_bv, gt_3d, gt_cnr, calib, params
 
 
 # ------------------------------------------------------------------ SURVEY §8(f) next rows
-def point_cloud_2_top(points):
-    """points (P,4) f32 device tensor -> top (601,601,9) f32 device tensor."""
+def point_cloud_2_top(points, ranges=None):
+    """points (P,4) f32 device tensor -> top f32 device tensor: (601,601,9) for the call MV3D makes (ranges=None), or the map of
+    ranges = (res, zres, side_lo, side_hi, fwd_lo, fwd_hi, height_lo, height_hi) (lib/utils/read_lidar.py:10-16); that form reads
+    one status word back and raises IndexError where numpy's fancy assignment would (a cell outside the map)."""
     pts = points.contiguous()
-    top = torch.empty((601, 601, 9), dtype=torch.float32, device=pts.device)
-    check(lib().mv3d_point_cloud_2_top(_ptr(pts), pts.shape[0], _ptr(top), _stream()), "mv3d_point_cloud_2_top")
+    if ranges is None:
+        top = torch.empty((601, 601, 9), dtype=torch.float32, device=pts.device)
+        check(lib().mv3d_point_cloud_2_top(_ptr(pts), pts.shape[0], _ptr(top), _stream()), "mv3d_point_cloud_2_top")
+        return top
+    r = [float(v) for v in ranges]
+    dims = (C.c_int * 3)()
+    check(lib().mv3d_point_cloud_2_top_shape(*r, dims), "mv3d_point_cloud_2_top_shape")
+    top = torch.empty(tuple(dims), dtype=torch.float32, device=pts.device)
+    status = torch.empty(1, dtype=torch.int32, device=pts.device)
+    check(lib().mv3d_point_cloud_2_top_ranges(_ptr(pts), pts.shape[0], *r, _ptr(top), _ptr(status), _stream()), "mv3d_point_cloud_2_top_ranges")
+    if int(status.item()):
+        raise IndexError("point_cloud_2_top: a point's cell lies outside the map (numpy raises IndexError there)")
     return top
 
 

@@ -721,31 +721,54 @@ void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc,
     }
 }
 
-void mv3d_ref_point_cloud_2_top(const float *pts, int P, float *top)
+/* read_lidar.py:10-115 with its own parameters.  What numpy (2.2, NEP 50) does with the dtypes, restated:
+ *   x_points > fwd_range[0] ...   f32 array against a Python float: compared in f32 (the bound rounded to f32)      (:58-61)
+ *   np.arange(h0, h1, zres)       length ceil((h1 - h0) / zres); values h0, h0 + zres, then h0 + i * ((h0 + zres) - h0) -- numpy fills
+ *                                 from the first two elements, so the step is the ROUNDED difference, not zres                (:80)
+ *   z_points >= height            f32 array against an np.float64 scalar: compared in f64; height + zres in f64               (:82-83)
+ *   (-y / res).astype(int32)      f32 divide by f32(res), truncation                                                         (:96-97)
+ *   z - height_range[0]           f32                                                                                        (:106)
+ *   top[y, x, i] = ...            last assignment wins (point order inside a slice, slices in order); channel z_max = reflectance;
+ *                                 negative indices wrap once, anything else out of range is numpy's IndexError: *err = 1      (:109-112)
+ * dims[3] = (y_max + 1, x_max + 1, z_max + 1) of the output (top must hold them; call with top = NULL to get the shape only). */
+void mv3d_ref_point_cloud_2_top_ranges(const float *pts, int P, double res, double zres, double side0, double side1, double fwd0, double fwd1,
+                                       double h0, double h1, int *dims, float *top, int *err)
 {
-    /* read_lidar.py:48-113 with side_range=(-30,30), fwd_range=(0,60), height_range=(-2,0.4), res=0.1, zres=0.3 */
-    const double side0 = -30.0, side1 = 30.0, fwd0 = 0.0, fwd1 = 60.0, h0 = -2.0, h1 = 0.4, res = 0.1, zres = 0.3;
     const int x_max = (int)((side1 - side0) / res), y_max = (int)((fwd1 - fwd0) / res), z_max = (int)((h1 - h0) / zres);
     const int Wd = x_max + 1, Hd = y_max + 1, Cd = z_max + 1;
+    if (dims) { dims[0] = Hd; dims[1] = Wd; dims[2] = Cd; }
+    if (err) *err = 0;
+    if (!top) return;
     memset(top, 0, sizeof(float) * (size_t)Wd * Hd * Cd);
     const int xoff = (int)floor(side0 / res), yoff = (int)floor(fwd1 / res);
-    const int nslice = (int)ceil((h1 - h0) / zres);               /* len(np.arange(h0, h1, zres)) */
-    const float resf = (float)res;
+    int nslice = (int)ceil((h1 - h0) / zres);
+    if (nslice < 0) nslice = 0;
+    const double next = h0 + zres, delta = next - h0;
+    const float resf = (float)res, fwd0f = (float)fwd0, fwd1f = (float)fwd1, ylo = (float)(-side1), yhi = (float)(-side0), h0f = (float)h0;
     for (int i = 0; i < nslice; ++i) {
-        const double height = h0 + i * zres;                       /* np.arange: start + i*step */
+        const double height = i == 0 ? h0 : (i == 1 ? next : h0 + (double)i * delta);
+        const double upper = height + zres;
         for (int p = 0; p < P; ++p) {
             const float x = pts[4 * p], y = pts[4 * p + 1], z = pts[4 * p + 2], r = pts[4 * p + 3];
-            if (!((double)x > fwd0 && (double)x < fwd1)) continue;
-            if (!((double)y > -side1 && (double)y < -side0)) continue;
-            if (!((double)z >= height && (double)z < height + zres)) continue;
-            int x_img = (int)(-y / resf), y_img = (int)(-x / resf);   /* f32 divide, trunc */
+            if (!(x > fwd0f && x < fwd1f)) continue;
+            if (!(y > ylo && y < yhi)) continue;
+            if (!((double)z >= height && (double)z < upper)) continue;
+            int x_img = (int)(-y / resf), y_img = (int)(-x / resf);
             x_img -= xoff; y_img += yoff;
-            /* numpy negative indices wrap; the ranges above keep both in [0, 600] */
+            if (x_img < 0) x_img += Wd;
+            if (y_img < 0) y_img += Hd;
+            if (x_img < 0 || x_img >= Wd || y_img < 0 || y_img >= Hd) { if (err) *err = 1; continue; }
             float *cell = top + ((size_t)y_img * Wd + x_img) * Cd;
-            cell[i] = z - (float)h0;
+            cell[i] = z - h0f;
             cell[z_max] = r;
         }
     }
+}
+
+void mv3d_ref_point_cloud_2_top(const float *pts, int P, float *top)
+{
+    /* the call MV3D makes (tools/read_lidar.py:121-133): (601, 601, 9) */
+    mv3d_ref_point_cloud_2_top_ranges(pts, P, 0.1, 0.3, -30.0, 30.0, 0.0, 60.0, -2.0, 0.4, NULL, top, NULL);
 }
 
 /* ------------------------------------------------------------------ X1: third (front-view) ROI

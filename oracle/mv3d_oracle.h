@@ -128,6 +128,10 @@ void mv3d_ref_box_tail(const float *rois_3d, const float *deltas, int R, int nc,
  * points (P,4) f32 -> top (601,601,9) f32; later point (then later height slice, for the
  * reflectance channel) wins a cell, as numpy fancy assignment does. */
 void mv3d_ref_point_cloud_2_top(const float *points, int P, float *top);
+/* ... with its own parameters (read_lidar.py:10-16); dims[3] = the map's shape (top may be NULL to ask for it), *err = 1 where numpy
+ * raises IndexError (a cell outside the map after the wrap of negative indices) */
+void mv3d_ref_point_cloud_2_top_ranges(const float *points, int P, double res, double zres, double side0, double side1, double fwd0,
+                                       double fwd1, double h0, double h1, int *dims, float *top, int *err);
 
 /* lib/datasets/kitti_mv3d.py:240-272 + lib/utils/transform.py:441-465,502-524,172-187,113-142: camera label boxes -> camera /
  * LIDAR corners, LIDAR box, BEV pixel box (f32 outputs as stored in the roidb).  cos_sin (G,2) f64 = np.cos / np.sin of the

@@ -343,10 +343,19 @@ def box_tail(rois_3d, deltas, nc=2):
     return cnr, np.hstack([cnr] * nc), pr, bv.astype(np.float64), bvr.astype(np.float64)
 
 
-def point_cloud_2_top(points):
+def point_cloud_2_top(points, res=0.1, zres=0.3, side_range=(-30., 30.), fwd_range=(0., 60.), height_range=(-2., 0.4)):
+    """lib/utils/read_lidar.py:10-115 (defaults: the call MV3D makes); raises IndexError where numpy's fancy assignment would"""
     p = _f32(points)
-    top = np.zeros((601, 601, 9), np.float32)
-    lib().mv3d_ref_point_cloud_2_top(_p(p), C.c_int(p.shape[0]), _p(top))
+    d = [C.c_double(float(v)) for v in (res, zres, side_range[0], side_range[1], fwd_range[0], fwd_range[1], height_range[0], height_range[1])]
+    dims = (C.c_int * 3)()
+    err = C.c_int(0)
+    fn = lib().mv3d_ref_point_cloud_2_top_ranges
+    fn.restype = None
+    fn(_p(p), C.c_int(p.shape[0]), *d, dims, None, C.byref(err))
+    top = np.zeros(tuple(dims), np.float32)
+    fn(_p(p), C.c_int(p.shape[0]), *d, dims, _p(top), C.byref(err))
+    if err.value:
+        raise IndexError("point_cloud_2_top: a point's cell lies outside the map (numpy raises IndexError there)")
     return top
 
 

@@ -217,16 +217,33 @@ def save(name, **kw):
     print(f"{name:42s} {os.path.getsize(path) / 1024:8.1f} KB")
 
 
+def gen_bev_ranges():
+    """point_cloud_2_top with its own parameters (lib/utils/read_lidar.py:10-16) on clouds with points ON the limits (round 5)"""
+    from utils.read_lidar import point_cloud_2_top
+    for k, case in enumerate(sorted(synth.BEV_RANGE_CASES)):
+        res, zres, side, fwd, hr = synth.BEV_RANGE_CASES[case]
+        pts = synth.point_cloud_ranges(70 + k, 30000, case)
+        top = point_cloud_2_top(pts, res=res, zres=zres, side_range=side, fwd_range=fwd, height_range=hr)
+        nz = np.flatnonzero(top)
+        save(f"point_cloud_top_ranges_{case}", seed=70 + k, P=30000, sha_points=synth.sha256(pts), shape=np.array(top.shape),
+             nz_index=nz.astype(np.int32), nz_value=top.ravel()[nz], sha_top=synth.sha256(top))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep-scratch", action="store_true")
-    ap.add_argument("--only", default="", help="'kitti': regenerate only the KITTI label / calib fixture; 'extra': write only "
+    ap.add_argument("--only", default="", help="'kitti': regenerate only the KITTI label / calib fixture; 'bev': only the rasteriser's parameter cases; 'extra': write only "
                                                "the fixtures added in round 3 (EXTRA_R03)")
     args = ap.parse_args()
     d = tempfile.mkdtemp(prefix="mv3d_ref_")
     build_scratch(d)
     if args.only == "kitti":
         gen_kitti(d)
+        if not args.keep_scratch:
+            shutil.rmtree(d, ignore_errors=True)
+        return
+    if args.only == "bev":
+        gen_bev_ranges()
         if not args.keep_scratch:
             shutil.rmtree(d, ignore_errors=True)
         return
@@ -412,6 +429,7 @@ def main():
         save(f"point_cloud_top_{name}", seed=seed, P=P, sha_points=synth.sha256(pts), shape=np.array(top.shape),
              nz_index=nz.astype(np.int32), nz_value=top.ravel()[nz], sha_top=synth.sha256(top))
 
+    gen_bev_ranges()
     gen_kitti(d)
 
     if args.keep_scratch:

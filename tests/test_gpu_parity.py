@@ -533,8 +533,24 @@ def test_point_cloud_2_top_matches_reference(ops, name):
     nz = np.flatnonzero(top)
     assert np.array_equal(nz, g["nz_index"]) and np.array_equal(top.ravel()[nz], g["nz_value"])
     assert synth.sha256(top) == str(g["sha_top"])
-    with pytest.raises(NotImplementedError):
-        point_cloud_2_top(pts, side_range=(-10., 10.))
+
+
+@pytest.mark.parametrize("case", sorted(synth.BEV_RANGE_CASES))
+def test_point_cloud_2_top_with_its_own_parameters(ops, oracle, case):
+    """mv3d_point_cloud_2_top_ranges against the reference-generated fixtures of lib/utils/read_lidar.py:10-16's parameters (and the
+    oracle): the function's defaults, unrepresentable limits, points exactly on numpy's slice limits"""
+    from mv3d_tf_amd.utils.read_lidar import point_cloud_2_top
+    g = golden("point_cloud_top_ranges_" + case)
+    res, zres, side, fwd, hr = synth.BEV_RANGE_CASES[case]
+    pts = synth.point_cloud_ranges(int(g["seed"]), int(g["P"]), case)
+    top = point_cloud_2_top(pts, res=res, zres=zres, side_range=side, fwd_range=fwd, height_range=hr)
+    assert top.shape == tuple(g["shape"]) and top.dtype == np.float32
+    nz = np.flatnonzero(top)
+    assert np.array_equal(nz, g["nz_index"]) and np.array_equal(top.ravel()[nz], g["nz_value"])
+    assert synth.sha256(top) == str(g["sha_top"])
+    assert np.array_equal(top, oracle.point_cloud_2_top(pts, res, zres, side, fwd, hr))
+    if case == "defaults":                                              # the function's own defaults (read_lidar.py:10-16)
+        assert np.array_equal(top, point_cloud_2_top(pts))
 
 
 def test_point_cloud_2_top_empty_and_repeat(ops, torch_cuda, oracle):

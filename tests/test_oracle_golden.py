@@ -161,6 +161,22 @@ def test_box_tail(oracle):
     assert np.array_equal(bv_r, g["pred_bv_r"])
 
 
+@pytest.mark.parametrize("case", sorted(synth.BEV_RANGE_CASES))
+def test_point_cloud_2_top_with_its_own_parameters(oracle, case):
+    """lib/utils/read_lidar.py:10-16's parameters (reference-generated): the function's defaults, unrepresentable limits, a slice
+    count that is not an integer, and points exactly ON numpy's slice limits for the MV3D ranges (np.arange's values are
+    h0 + i * ((h0 + zres) - h0), not h0 + i * zres: z = -0.5 lands one slice lower than the naive restatement puts it)"""
+    g = golden("point_cloud_top_ranges_" + case)
+    res, zres, side, fwd, hr = synth.BEV_RANGE_CASES[case]
+    pts = synth.point_cloud_ranges(int(g["seed"]), int(g["P"]), case)
+    assert synth.sha256(pts) == str(g["sha_points"])
+    top = oracle.point_cloud_2_top(pts, res, zres, side, fwd, hr)
+    assert tuple(g["shape"]) == top.shape
+    nz = np.flatnonzero(top)
+    assert np.array_equal(nz, g["nz_index"]) and np.array_equal(top.ravel()[nz], g["nz_value"])
+    assert synth.sha256(top) == str(g["sha_top"])
+
+
 @pytest.mark.parametrize("name", ["point_cloud_top_small", "point_cloud_top_kitti"])
 def test_point_cloud_2_top(oracle, name):
     g = golden(name)
