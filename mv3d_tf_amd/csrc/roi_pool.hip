@@ -1044,6 +1044,7 @@ struct RoiPairIdx {
     int4 *items; int2 *pool; int *header; int *seg_tot, *seg_mask;
     unsigned first_block[MV3D_MAX_ROI_VIEWS]; int gpr[MV3D_MAX_ROI_VIEWS];
     unsigned nseg;
+    int nslots;                                      // item slots (one per pixel of every view)
     int dbg;                                         // experiment builds (MV3D_TUNING): parts of the index launches switched off, 0 otherwise
     long long *trace;                                // experiment builds: 8 cycle stamps per workgroup of the lists launch (tools/roi_idx_trace.py)
 };
@@ -1266,7 +1267,9 @@ __device__ __forceinline__ void roi_pair_index_block(RoiPairShared &S, const Roi
         const unsigned long long ne = __ballot(has);
         if (lane < BWI_PIX) S.base[lane] = base0 + inc - c;
         // an item per pixel the sizing launch counted (its list may turn out empty: count 0, the gather then writes the zero again)
-        if (has) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, c, k);
+        // (dbg 32 / 64, experiment builds: lists cut to 32 / 8 entries -- wrong sums, the gather's time without its long items)
+        const int cc = (ix.dbg & 32) ? min(c, 32) : ((ix.dbg & 64) ? min(c, 8) : c);
+        if (has) ix.items[ibase + __popcll(ne & ((1ull << lane) - 1ull))] = make_int4((int)(pix0 + lane), base0 + inc - c, cc, k);
         if (lane == 0 && block == nblocks - 1) ix.header[1] = ibase + __popcll(ne);        // number of items of the launch
     }
     __syncthreads();
@@ -1805,6 +1808,7 @@ static int roi_pair_plan(int num_views, const mv3d_roi_grad_view *views, int PH,
     ix.items = (int4 *)(ws + off); off += mv3d_align_up(o.n_items * sizeof(int4));
     ix.pool = (int2 *)(ws + off);
     ix.nseg = o.iblocks;
+    ix.nslots = (int)o.n_items;
     ix.dbg = 0;
     ix.trace = nullptr;
 #ifdef MV3D_TUNING
