@@ -1364,6 +1364,9 @@ __device__ __forceinline__ void roi_pair_drain_mixed(const int cur_o, const int 
     }
 }
 
+// (Round 5, measured and dropped -- profiles/r05_z_gather_whole_ab.txt: the eight waves of a 512-thread workgroup taking ONE item and a
+// slice each, any workgroup any item -- a record's 2 KB requested by one CU at one time instead of as 256-byte pieces by eight XCDs:
+// RoiPoolGrad 79 - 103 us for grids of 4096 - 512 workgroups against 68 us.  The slices stay on their XCDs.)
 __device__ __forceinline__ void roi_pair_gather_block(const RoiGradPack &p, const RoiPairIdx &ix, const int nsl, const unsigned vblock,
                                                       const unsigned vgrid)
 {
@@ -1437,6 +1440,7 @@ __global__ __launch_bounds__(256) void roi_pair_gather_kernel(RoiGradPack p, Roi
 {
     roi_pair_gather_block(p, ix, nsl, blockIdx.x, gridDim.x);
 }
+
 
 // the pair's forward: the multi-view pooling kernels with COMPACT argmax codes
 template <int FWD_PASSES>
