@@ -49,6 +49,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -84,6 +85,7 @@ def parse():
     ap.add_argument("--with-trunk", action="store_true", help="(default since r03; kept for old command lines)")
     ap.add_argument("--no-trunk", action="store_true", help="skip secondary.with_trunk (the full training step with the torch VGG16 trunks)")
     ap.add_argument("--no-fresh", action="store_true", help="skip secondary.fresh_inputs")
+    ap.add_argument("--secondary-timeout", type=int, default=1500, help="seconds the secondary legs may take before the line is printed without the rest")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests)")
     return ap.parse_args()
 
@@ -739,93 +741,117 @@ def main():
             res["verified"] = ring.driver.verify(ring.host_frames_all)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(ring, wl, args.cpu_seconds)
+    failed_here = False
     if not args.no_secondary and wl == "train":
         sec = {}
-        if not args.no_fresh and args.launch == "path":
-            # the figure rounds 1-4 headlined: the same ring with every batch's index lists drawn during set-up, each batch one
-            # hipGraph replayed on three streams (no host stage inside the timed region)
-            host = host_draws
-            ring.driver.close()
-            ring.make_graphs()
-            dt_r, _, _ = timed(ring, nb, 3, 1, barrier)
-            rep = sharding.sum_over_ranks(3 * nb * batch / dt_r, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            if rank == 0:
-                sec["resident_replay"] = {"frames_per_s": round(rep, 2), "launch": "hipGraph replay of frozen batches, 3 streams",
-                                          "note": "rounds 1-4 reported this as `value`: index lists of the two target layers drawn during "
-                                                  "set-up and resident, so no host stage in the timed region"}
-                nfr = (args.steps + args.warmup) * nb * batch
-                sec["fresh_inputs"] = {"frames_per_s": res["value"], "fraction_of_resident_replay": round(res["value"] / rep, 4),
-                                       "host_draw_ms_per_frame": round(host[1] / nfr * 1e3, 4),
-                                       "host_wait_for_device_ms_per_frame": round(host[0] / nfr * 1e3, 4),
-                                       "note": "= the headline since round 4 (the path on new inputs, draws in the loop); host_* = the "
-                                               "library's helper thread on rank 0: drawing / waiting for a batch's stage 1"}
-        elif not args.no_fresh:
-            fr = fresh_inputs_line(rank, args.variant)
-            fr["frames_per_s"] = round(sharding.sum_over_ranks(fr["frames_per_s"], dist, device="cuda" if args.dist_backend == "nccl" else "cpu"), 2)
-            if rank == 0:
-                fr["fraction_of_resident_replay"] = round(fr["frames_per_s"] / res["value"], 4)
-                sec["fresh_inputs"] = fr
-            torch.cuda.empty_cache()
-        if ring.driver is not None:
-            ring.driver.close()
-        del ring
-        torch.cuda.empty_cache()
-        args2 = argparse.Namespace(**vars(args))
-        if args2.launch == "path":
-            args2.launch = "graph"
-        r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
-        nb2, st2 = 48, max(2, args.steps // 2)
-        dt2, _, _ = timed(r2, nb2, st2, 1, barrier)
-        dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        if rank == 0:
-            sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
-                                           "views, ring of 3 batches on the step's streams (%s launches)" % args2.launch,
-                               "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
-                               "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
-        del r2
-        torch.cuda.empty_cache()
-        if not args.no_trunk:
-            if rank == 0:
-                # BASELINE configs[1]: one frame, BEV-only RPN + HIP NMS with the VGG16 trunk on the MFMA convolution, batch 1
-                from mv3d_tf_amd.fast_rcnn import test_mv as _tm
-                sec["config1_latency"] = _tm.bench_config1_latency()
+        # The secondaries must never cost the line: an exception in one of them (they hold the only RCCL collectives of the bench at
+        # N > 1) is recorded in secondary.error, and a watchdog prints the line without the unfinished part and leaves if they hang
+        # (a rank that failed inside a collective leaves the others waiting).
+        done = threading.Lock()
+
+        def emit_and_leave():
+            if done.acquire(blocking=False):
+                sec.setdefault("error", "secondary legs still running after %d s: line printed without the unfinished ones" % args.secondary_timeout)
+                if rank == 0:
+                    res["secondary"] = sec
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+
+        watchdog = threading.Timer(args.secondary_timeout, emit_and_leave)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if not args.no_fresh and args.launch == "path":
+                # the figure rounds 1-4 headlined: the same ring with every batch's index lists drawn during set-up, each batch one
+                # hipGraph replayed on three streams (no host stage inside the timed region)
+                host = host_draws
+                ring.driver.close()
+                ring.make_graphs()
+                dt_r, _, _ = timed(ring, nb, 3, 1, barrier)
+                rep = sharding.sum_over_ranks(3 * nb * batch / dt_r, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+                if rank == 0:
+                    sec["resident_replay"] = {"frames_per_s": round(rep, 2), "launch": "hipGraph replay of frozen batches, 3 streams",
+                                              "note": "rounds 1-4 reported this as `value`: index lists of the two target layers drawn during "
+                                                      "set-up and resident, so no host stage in the timed region"}
+                    nfr = (args.steps + args.warmup) * nb * batch
+                    sec["fresh_inputs"] = {"frames_per_s": res["value"], "fraction_of_resident_replay": round(res["value"] / rep, 4),
+                                           "host_draw_ms_per_frame": round(host[1] / nfr * 1e3, 4),
+                                           "host_wait_for_device_ms_per_frame": round(host[0] / nfr * 1e3, 4),
+                                           "note": "= the headline since round 4 (the path on new inputs, draws in the loop); host_* = the "
+                                                   "library's helper thread on rank 0: drawing / waiting for a batch's stage 1"}
+            elif not args.no_fresh:
+                fr = fresh_inputs_line(rank, args.variant)
+                fr["frames_per_s"] = round(sharding.sum_over_ranks(fr["frames_per_s"], dist, device="cuda" if args.dist_backend == "nccl" else "cpu"), 2)
+                if rank == 0:
+                    fr["fraction_of_resident_replay"] = round(fr["frames_per_s"] / res["value"], 4)
+                    sec["fresh_inputs"] = fr
                 torch.cuda.empty_cache()
-            from mv3d_tf_amd.fast_rcnn import train_mv
-            sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
+            if ring.driver is not None:
+                ring.driver.close()
+            del ring
             torch.cuda.empty_cache()
-            # the same step with the trunks' forward AND backward convolutions on this library's bf16 MFMA kernels (mixed precision:
-            # a lower precision than the reference's fp32 training, reported next to it)
-            mp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=torch.bfloat16, mfma=True)
-            torch.cuda.empty_cache()
-            # ... and in the reference's fp32 with the trunks' forward / data-gradient convolutions on the exact-f32 MFMA kernel
-            fp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=None, mfma=True)
-            torch.cuda.empty_cache()
+            args2 = argparse.Namespace(**vars(args))
+            if args2.launch == "path":
+                args2.launch = "graph"
+            r2 = Ring(args2, rank, "test", 16, 3, streams[:3])
+            nb2, st2 = 48, max(2, args.steps // 2)
+            dt2, _, _ = timed(r2, nb2, st2, 1, barrier)
+            dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
             if rank == 0:
-                from mv3d_tf_amd import trunk_train
-                from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
-                sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"],
-                                                         "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers, dtype=torch.float32)]}
-                sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
-                                                         "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
-            if dist is not None:
-                dist.barrier()
+                sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
+                                               "views, ring of 3 batches on the step's streams (%s launches)" % args2.launch,
+                                   "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
+                                   "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
+            del r2
             torch.cuda.empty_cache()
-            from mv3d_tf_amd.fast_rcnn import test_mv
-            sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
-            torch.cuda.empty_cache()
-            if rank == 0:
-                # the hand-written MFMA convolution against the dense f16 matrix-core peak (rank 0 only: a per-kernel figure)
-                from mv3d_tf_amd import trunk
-                from mv3d_tf_amd.networks.mv3d import _VGG
-                import torch as _t
-                sec["serving_with_trunk"]["roofline_kernels"] = [trunk.bench_conv_layers(_VGG), trunk.bench_conv_layers(_VGG, dtype=_t.float32)]
-            if dist is not None:
-                dist.barrier()
+            if not args.no_trunk:
+                if rank == 0:
+                    # BASELINE configs[1]: one frame, BEV-only RPN + HIP NMS with the VGG16 trunk on the MFMA convolution, batch 1
+                    from mv3d_tf_amd.fast_rcnn import test_mv as _tm
+                    sec["config1_latency"] = _tm.bench_config1_latency()
+                    torch.cuda.empty_cache()
+                from mv3d_tf_amd.fast_rcnn import train_mv
+                sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
+                torch.cuda.empty_cache()
+                # the same step with the trunks' forward AND backward convolutions on this library's bf16 MFMA kernels (mixed precision:
+                # a lower precision than the reference's fp32 training, reported next to it)
+                mp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=torch.bfloat16, mfma=True)
+                torch.cuda.empty_cache()
+                # ... and in the reference's fp32 with the trunks' forward / data-gradient convolutions on the exact-f32 MFMA kernel
+                fp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=None, mfma=True)
+                torch.cuda.empty_cache()
+                if rank == 0:
+                    from mv3d_tf_amd import trunk_train
+                    from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
+                    sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"],
+                                                             "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers, dtype=torch.float32)]}
+                    sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
+                                                             "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.empty_cache()
+                from mv3d_tf_amd.fast_rcnn import test_mv
+                sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
+                torch.cuda.empty_cache()
+                if rank == 0:
+                    # the hand-written MFMA convolution against the dense f16 matrix-core peak (rank 0 only: a per-kernel figure)
+                    from mv3d_tf_amd import trunk
+                    from mv3d_tf_amd.networks.mv3d import _VGG
+                    import torch as _t
+                    sec["serving_with_trunk"]["roofline_kernels"] = [trunk.bench_conv_layers(_VGG), trunk.bench_conv_layers(_VGG, dtype=_t.float32)]
+                if dist is not None:
+                    dist.barrier()
+        except Exception as e:                                   # (KeyboardInterrupt / SystemExit pass)
+            sec["error"] = "%s: %s" % (type(e).__name__, str(e)[:500])
+            failed_here = True
+        watchdog.cancel()
+        if not done.acquire(blocking=False):                     # the watchdog is printing the line
+            time.sleep(3600)
         if rank == 0:
             res["secondary"] = sec
     if rank == 0:
-        print(json.dumps(res))
-    if dist is not None:
+        print(json.dumps(res), flush=True)
+    if dist is not None and not failed_here:                      # (a rank whose secondaries raised does not wait for the others)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and "verified" in res and not res["verified"]["bit_exact"]:
