@@ -202,7 +202,7 @@ int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views,
  * Shapes outside the pair's kernels (C not in {256, 512} / not the same for all views, pooled sizes > 15, a map of more than 65534
  * pixels, an empty view) take the plain forward (int32 argmax) and mv3d_roi_pool_backward_views behind the same entries.
  * (Measured and dropped, round 5: the candidate index built by workgroups inside the FORWARD launch, and a single-pass index with
- * an in-launch look-back -- DESIGN.md.) */
+ * an in-launch look-back -- profiles/EXPERIMENTS.md, round 5.) */
 size_t mv3d_roi_pool_pair_workspace_bytes(int num_views, const mv3d_roi_grad_view *views, int pooled_height, int pooled_width);
 int mv3d_roi_pool_forward_views_pair(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
                                      int cold_maps, void *stream);
