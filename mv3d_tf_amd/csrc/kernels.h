@@ -57,3 +57,7 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
                      hipStream_t stream, const float4 *gather_src = nullptr, float4 *gather_dst = nullptr);
 
 
+
+// ---- RoiPoolGrad of the pair as one launch of LDS-resident map tiles (roi_grad_tiles.hip) -----------------
+// views validated by the caller (roi_pair_shapes of roi_pool.hip); argmax_data holds the pair's compact codes
+int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, hipStream_t stream);

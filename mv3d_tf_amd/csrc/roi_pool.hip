@@ -2023,6 +2023,12 @@ extern "C" int mv3d_roi_pool_backward_views_pair(int num_views, const mv3d_roi_g
     if (workspace_bytes < roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
     for (int k = 0; k < num_views; ++k)
         if (!aligned16(views[k].bottom_diff) || !aligned16(views[k].top_diff) || !aligned16(views[k].argmax_data)) return MV3D_ERR_INVALID_ARG;
+#ifdef MV3D_TUNING
+    static const int tiles_env = getenv("MV3D_PAIR_TILES") ? atoi(getenv("MV3D_PAIR_TILES")) : 0;
+#else
+    const int tiles_env = 0;                         // (work in progress: roi_grad_tiles.hip, correct, 88 us against 68)
+#endif
+    if (tiles_env) return mv3d_launch_roi_pair_tiles(num_views, views, pooled_height, pooled_width, (hipStream_t)stream);
     RoiPairPlan pl;
     const int rc = roi_pair_plan(num_views, views, pooled_height, pooled_width, workspace, pl);
     if (rc != MV3D_OK) return rc;
