@@ -2016,19 +2016,22 @@ extern "C" int mv3d_roi_pool_backward_views_pair(int num_views, const mv3d_roi_g
 {
     const int rc0 = grad_views_check(num_views, views, pooled_height, pooled_width);
     if (rc0 != MV3D_OK) return rc0;
-    if (!workspace || ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
+    if (workspace && ((uintptr_t)workspace % MV3D_ALIGN)) return MV3D_ERR_WORKSPACE;
     // the decision mv3d_roi_pool_forward_views_pair took from the same shapes: compact codes in argmax_data?
     if (!roi_pair_shapes(num_views, views, pooled_height, pooled_width))
         return mv3d_roi_pool_backward_views(num_views, views, pooled_height, pooled_width, workspace, workspace_bytes, stream);
-    if (workspace_bytes < roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
     for (int k = 0; k < num_views; ++k)
         if (!aligned16(views[k].bottom_diff) || !aligned16(views[k].top_diff) || !aligned16(views[k].argmax_data)) return MV3D_ERR_INVALID_ARG;
 #ifdef MV3D_TUNING
-    static const int tiles_env = getenv("MV3D_PAIR_TILES") ? atoi(getenv("MV3D_PAIR_TILES")) : 0;
+    static const int tiles_env = getenv("MV3D_PAIR_TILES") ? atoi(getenv("MV3D_PAIR_TILES")) : -1;
 #else
-    const int tiles_env = 0;                         // (work in progress: roi_grad_tiles.hip, correct, 88 us against 68)
+    const int tiles_env = -1;
 #endif
-    if (tiles_env) return mv3d_launch_roi_pair_tiles(num_views, views, pooled_height, pooled_width, (hipStream_t)stream);
+    // without a workspace: ONE launch of map tiles, no index, no fill (roi_grad_tiles.hip); with one: index + gather
+    if (tiles_env == 1 || (tiles_env < 0 && !workspace))
+        return mv3d_launch_roi_pair_tiles(num_views, views, pooled_height, pooled_width, (hipStream_t)stream);
+    if (!workspace) return MV3D_ERR_WORKSPACE;
+    if (workspace_bytes < roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;
     RoiPairPlan pl;
     const int rc = roi_pair_plan(num_views, views, pooled_height, pooled_width, workspace, pl);
     if (rc != MV3D_OK) return rc;

@@ -400,7 +400,9 @@ def roi_pool_argmax_decode(views, res, pooled_height, pooled_width):
 
 def roi_pool_backward_views_pair(views, pooled_height, pooled_width, outs=None, workspace=None):
     """views as roi_pool_backward_views, of a roi_pool_forward_views_pair call (the argmax tensors it returned): RoiPoolGrad of all of
-    them behind one call (index + zero fill, gather).  Returns [bottom_diff, ...]."""
+    them behind one call.  workspace = None: a recycled workspace (index + zero fill, gather); a uint8 tensor: that workspace;
+    False: NO workspace -- the entry's single-launch path (map tiles in LDS, csrc/roi_grad_tiles.hip), same results.
+    Returns [bottom_diff, ...]."""
     arr = (RoiGradView * len(views))()
     res = []
     for k, (top_diff, rois, argmax, shape, scale) in enumerate(views):
@@ -409,6 +411,10 @@ def roi_pool_backward_views_pair(views, pooled_height, pooled_width, outs=None, 
         arr[k] = RoiGradView(out.data_ptr(), rois.data_ptr(), top_diff.data_ptr(), argmax.data_ptr(), float(scale), B,
                              rois.shape[0], H, W, Cc)
         res.append(out)
+    if workspace is False:
+        check(lib().mv3d_roi_pool_backward_views_pair(len(views), arr, pooled_height, pooled_width, None, 0, _stream()),
+              "mv3d_roi_pool_backward_views_pair")
+        return res
     ws = workspace
     if ws is None:
         ws = roi_pair_workspace(lib().mv3d_roi_pool_pair_workspace_bytes(len(views), arr, pooled_height, pooled_width), views[0][0].device)

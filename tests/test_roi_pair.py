@@ -30,8 +30,13 @@ def gpu():
     return torch, ops
 
 
+# RoiPoolGrad of the pair with a workspace (index + fill, gather) and without one (ONE launch of map tiles, csrc/roi_grad_tiles.hip)
+WS = pytest.mark.parametrize("no_ws", [False, True], ids=["workspace", "no-workspace"])
+
+
+@WS
 @pytest.mark.parametrize("cold", [False, True])
-def test_config2_pair_equals_plain_entries_and_oracle(gpu, oracle, cold):
+def test_config2_pair_equals_plain_entries_and_oracle(gpu, oracle, cold, no_ws):
     """BASELINE configs[2] at full size (3 maps x batch 2, R = 256 rows per view): top / argmax (decoded) / bottom_diff equal to the
     oracle AND to the plain entries, five batches through ONE workspace."""
     torch, ops = gpu
@@ -53,7 +58,9 @@ def test_config2_pair_equals_plain_entries_and_oracle(gpu, oracle, cold):
                 o_top, o_am = oracle.roi_pool(maps[k], rois[k], 7, 7, 0.125)
                 assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am), k
             grads[k] = dev(torch, np.random.RandomState(31 + it).uniform(-1, 1, tuple(top.shape)).astype(np.float32))
-        if ws is None:
+        if no_ws:
+            ws = False
+        elif ws is None:
             from mv3d_tf_amd._lib import RoiGradView, lib
             arr = (RoiGradView * 3)(*[RoiGradView(0, 0, 0, 0, 0.125, B, 2 * per, H, W, 512) for H, W in VIEWS.values()])
             ws = torch.randint(0, 255, (lib().mv3d_roi_pool_pair_workspace_bytes(3, arr, 7, 7),), dtype=torch.uint8, device="cuda")
@@ -66,8 +73,9 @@ def test_config2_pair_equals_plain_entries_and_oracle(gpu, oracle, cold):
                 assert np.array_equal(a.cpu().numpy(), o), (it, k)
 
 
+@WS
 @pytest.mark.parametrize("name", SMALL + HASHED)
-def test_pair_on_the_pinned_fixtures(gpu, name):
+def test_pair_on_the_pinned_fixtures(gpu, name, no_ws):
     """the Appendix-D fixtures (real proposal boxes, the edge cases: out-of-map, 1x1, negative, +-.5 rounding, batch index > 0,
     ties, NaN, a stack of ROIs on one pixel) through the pair; widths below 256 channels take the entries' plain path"""
     torch, ops = gpu
@@ -76,13 +84,14 @@ def test_pair_on_the_pinned_fixtures(gpu, name):
     res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
     top, am = res[0]
     dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
-    bd, = ops.roi_pool_backward_views_pair([(dev(torch, grad), r, am, data.shape, 0.125)], 7, 7)
+    bd, = ops.roi_pool_backward_views_pair([(dev(torch, grad), r, am, data.shape, 0.125)], 7, 7, workspace=False if no_ws else None)
     check_outputs(g, top.cpu().numpy(), dec.cpu().numpy(), bd.cpu().numpy())
 
 
+@WS
 @pytest.mark.parametrize("C", [64, 256, 320, 512, 1024])
 @pytest.mark.parametrize("R", [40, 700])
-def test_pair_other_widths_and_many_rois(gpu, oracle, C, R):
+def test_pair_other_widths_and_many_rois(gpu, oracle, C, R, no_ws):
     """256 / 512 channels: the pair's kernels (R = 700: three passes of the index's 256-ROI filter); 64 / 320 / 1024: the plain forward
     and the plain indexed / sliced / generic backward behind the same two entries"""
     torch, ops = gpu
@@ -103,12 +112,14 @@ def test_pair_other_widths_and_many_rois(gpu, oracle, C, R):
         o_top, o_am = oracle.roi_pool(m, r, 7, 7, 0.125)
         assert np.array_equal(top.cpu().numpy(), o_top) and np.array_equal(am.cpu().numpy(), o_am)
         grads.append(rs.uniform(-1, 1, o_top.shape).astype(np.float32)); ams.append(o_am)
-    bds = ops.roi_pool_backward_views_pair([(dev(torch, g), r, am, m.shape, 0.125) for g, r, (_, am), m in zip(grads, d_rois, outs, maps)], 7, 7)
+    bds = ops.roi_pool_backward_views_pair([(dev(torch, g), r, am, m.shape, 0.125) for g, r, (_, am), m in zip(grads, d_rois, outs, maps)], 7, 7,
+                                           workspace=False if no_ws else None)
     for m, r, o_am, g, bd in zip(maps, rois, ams, grads, bds):
         assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, r, o_am, g, 7, 7, 0.125))
 
 
-def test_pair_huge_rois_ties_and_nan(gpu, oracle):
+@WS
+def test_pair_huge_rois_ties_and_nan(gpu, oracle, no_ws):
     """ROIs larger than the map (one bin = up to the whole map: the largest scan positions a 16-bit code has to hold), ROIs of one
     pixel, ties (first maximum wins), NaN pixels (never win), a stack of identical ROIs on one spot, rows past the rounded end"""
     torch, ops = gpu
@@ -130,7 +141,7 @@ def test_pair_huge_rois_ties_and_nan(gpu, oracle):
     o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
     assert np.array_equal(res[0][0].cpu().numpy(), o_top, equal_nan=True) and np.array_equal(dec.cpu().numpy(), o_am)
     g = rs.uniform(-1, 1, o_top.shape).astype(np.float32)
-    bd, = ops.roi_pool_backward_views_pair([(dev(torch, g), r, res[0][1], m.shape, 0.125)], 7, 7)
+    bd, = ops.roi_pool_backward_views_pair([(dev(torch, g), r, res[0][1], m.shape, 0.125)], 7, 7, workspace=False if no_ws else None)
     assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, rois, o_am, g, 7, 7, 0.125))
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave wall-clock stamps (100 MHz) of the pair's tile RoiPoolGrad (roi_pair_tiles_kernel) on one bench batch (experiment build,
-MV3D_RGT_TRACE): 0 start, 1 ROI rows filtered, 2 hit list ready (two barriers), 3 expansion + full drains done, 4 last drain done,
-5 end; word 6 = ring entries of the wave's tile."""
+MV3D_RGT_TRACE): 0 start, 1 first 64 ROI rows filtered, 3 expansion + full drains done, 4 last drain done, 5 end; word 6 = ring
+entries of the wave's tile."""
 import ctypes as C
 import os
 import sys
@@ -47,7 +47,7 @@ for _ in range(2):
     for fwd, arr in cs:
         bwd(arr)
 torch.cuda.synchronize()
-NW = 1 << 16
+NW = 1 << 17
 trace = torch.zeros((NW, 8), dtype=torch.int64, device=dev)
 os.environ["MV3D_RGT_TRACE"] = str(trace.data_ptr())
 bwd(cs[0][1])                                    # cold: five other batches went through since
@@ -61,8 +61,7 @@ live = t[:, 5] != 0
 t = t[live]
 print("   start - t0       :", q(t[:, 0] - t0))
 print("   ROI rows filtered:", q(t[:, 1] - t[:, 0]))
-print("   hit list ready   :", q(t[:, 2] - t[:, 1]))
-print("   expand + drains  :", q(t[:, 3] - t[:, 2]))
+print("   expand + drains  :", q(t[:, 3] - t[:, 1]))
 print("   last drain       :", q(t[:, 4] - t[:, 3]))
 print("   write-out        :", q(t[:, 5] - t[:, 4]))
 print("   whole wave       :", q(t[:, 5] - t[:, 0]))
@@ -70,7 +69,7 @@ print("   end - t0         :", q(t[:, 5] - t0))
 print("   ring entries     :", q(t[:, 6]), " total", t[:, 6].sum())
 ne = t[t[:, 6] > 0]
 print("waves with entries: %d" % len(ne))
-print("   expand + drains  :", q(ne[:, 3] - ne[:, 2]))
+print("   expand + drains  :", q(ne[:, 3] - ne[:, 1]))
 print("   last drain       :", q(ne[:, 4] - ne[:, 3]))
 print("   whole wave       :", q(ne[:, 5] - ne[:, 0]))
 # occupancy over time: waves alive per microsecond
