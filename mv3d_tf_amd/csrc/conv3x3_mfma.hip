@@ -17,6 +17,7 @@
 // Accumulators go back through LDS so that every global store is a full 16-byte piece of a pixel's channel row.
 #include <stdlib.h>
 #include "common.h"
+#include "kernels.h"
 
 namespace mv3d_conv {
 
@@ -759,6 +760,15 @@ static int conv3x3_views_entry(int num_views, const mv3d_conv_view *views, int c
     for (int k = 0; k < num_views; ++k)
         if (!conv_view_args(g.v[k], views[k], c_in, c_out, out_framed, out_f32, relu, 2, first, gated)) return MV3D_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+#ifdef MV3D_TUNING
+    static const int input_env = getenv("MV3D_CONV_INPUT") ? atoi(getenv("MV3D_CONV_INPUT")) : 1;
+#else
+    const int input_env = 1;
+#endif
+    if (first && c_out == 64 && !out_f32 && !gated && input_env) {   // the input layer's own kernel (conv_input.hip)
+        if constexpr (__is_same(T, _Float16)) return mv3d_launch_conv_input_f16(num_views, views, out_framed, relu, s);
+        else return mv3d_launch_conv_input_bf16(num_views, views, out_framed, relu, s);
+    }
     if (first) return c_out % 128 == 0 ? launch_conv<T, 128, 128, 2, 2, 2, true>(g, out_f32, s) : launch_conv<T, 256, 64, 4, 1, 2, true>(g, out_f32, s);
     // 128x128 / 4 waves / 2 stages, two workgroups per CU.  (256x128 / 8 waves / 3 stages, one workgroup per CU with the DMA two
     // steps ahead, measured equal on the 512-channel layers and 3-5 % slower on the 128 / 256-channel ones: profiles/r03_conv_mfma.txt)

@@ -61,3 +61,7 @@ int mv3d_launch_rank(const uint32_t *keys, int N, int key_stride, int batch, int
 // ---- RoiPoolGrad of the pair as one launch of LDS-resident map tiles (roi_grad_tiles.hip) -----------------
 // views validated by the caller (roi_pair_shapes of roi_pool.hip); argmax_data holds the pair's compact codes
 int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, hipStream_t stream);
+
+// ---- the trunks' input layer (c_in = 16, c_out = 64, 16-bit maps) as a kernel of its own (conv_input.hip) ------------------
+int mv3d_launch_conv_input_f16(int num_views, const mv3d_conv_view *views, int out_framed, int relu, hipStream_t stream);
+int mv3d_launch_conv_input_bf16(int num_views, const mv3d_conv_view *views, int out_framed, int relu, hipStream_t stream);

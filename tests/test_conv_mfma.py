@@ -76,6 +76,42 @@ def test_input_layer_variant(gpu, B, H, W, cin, cout):
     assert float((got.float() - want).abs().max()) <= 2e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("half", ["float16", "bfloat16"])
+def test_input_layer_kernel_at_full_occupancy(gpu, half):
+    """csrc/conv_input.hip on maps large enough that every CU holds a full workgroup (two waves per SIMD: 1444 + 120 + 64 column strips),
+    three views in one launch, bare and framed outputs, no ReLU: every pixel against torch's f32 convolution of the rounded operands, no
+    NaN anywhere, the output's frame untouched.  (The second wave of a SIMD once stored garbage here: a 128-bit store's data registers
+    were rewritten while the store waited for the bus behind the other wave -- profiles/EXPERIMENTS.md R5.13.)"""
+    torch = gpu
+    import torch.nn.functional as F
+    from mv3d_tf_amd import ops
+    T = getattr(torch, half)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    views = [(2, 608, 608, 9), (2, 96, 320, 3), (1, 64, 512, 3)]
+    for relu in (True, False):
+        xs, ws, bs, refs = [], [], [], []
+        for B, H, W, cin in views:
+            x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+            w = torch.randn((64, cin, 3, 3), device="cuda", generator=g) * 0.2
+            b = torch.randn(64, device="cuda", generator=g)
+            xs.append(ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 16, "cuda", T)))
+            ws.append(ops.pack_conv3x3_weights_input_layer(w, dtype=T))
+            bs.append(b)
+            r = F.conv2d(x.to(T).float().permute(0, 3, 1, 2), w.to(T).float(), b, padding=1).permute(0, 2, 3, 1)
+            refs.append(F.relu(r) if relu else r)
+        outs = [ops.framed_buffer(B, H, W, 64, "cuda", T) for B, H, W, _ in views]
+        ops.conv3x3_views([(x, w, b, None, o) for x, w, b, o in zip(xs, ws, bs, outs)], relu=relu)
+        torch.cuda.synchronize()
+        tol = 4e-3 if half == "float16" else 3e-2
+        for o, r in zip(outs, refs):
+            inner = o[:, 1:-1, 1:-1].float()
+            assert not bool(torch.isnan(inner).any())
+            assert float((inner - r).abs().max()) <= tol * float(r.abs().max())
+            frame = o.clone()
+            frame[:, 1:-1, 1:-1] = 0
+            assert float(frame.abs().max()) == 0.0
+
+
 def test_maxpool_and_two_layer_chain(gpu):
     torch = gpu
     from mv3d_tf_amd import ops
