@@ -226,7 +226,9 @@ class PathDriver:
             bwd[i].num_rois = St
         stream = out["stream"]
         st = C.c_void_p(stream.cuda_stream)
-        wp, wn = C.c_void_p(ws.data_ptr()), ws.numel()
+        # RoiPoolGrad without a workspace = ONE launch of LDS map tiles (csrc/roi_grad_tiles.hip): +3 % over index + gather with eight
+        # batches in flight (profiles/r05_as_bench_ws_ab.txt); MV3D_BENCH_ROI_GRAD_WS=1 takes the workspace path for an A / B
+        wp, wn = (C.c_void_p(ws.data_ptr()), ws.numel()) if os.environ.get("MV3D_BENCH_ROI_GRAD_WS") else (None, 0)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if marks is not None else None
         if ev:
             ev[0].record(stream)
@@ -371,10 +373,10 @@ def roofline_entries(ring, workload, signature):
     s0 = ring.slots[0].stream
     mine = [s for s in ring.slots if s.stream is s0]
     if workload == "train":
-        # the RoiPool pair: forward with one-byte argmax codes; RoiPoolGrad = index + zero fill launch, gather launch behind one call
+        # the RoiPool pair: forward with one-byte argmax codes; RoiPoolGrad = ONE launch of LDS map tiles (no workspace)
         legs = [("roi_pool_fwd_pair_cold_kernel" if getattr(mine[0], "cold_maps", False) else "roi_pool_fwd_pair_kernel",
                  "mv3d_roi_pool_forward_views_pair", "roi_forward_bytes"),
-                ("roi_pair_index_kernel + roi_pair_gather_kernel", "mv3d_roi_pool_backward_views_pair", "roi_backward_bytes")]
+                ("roi_pair_tiles_kernel", "mv3d_roi_pool_backward_views_pair", "roi_backward_bytes")]
     else:
         legs = [("roi_pool_fwd_xcd_multi%s_kernel" % ("_cold" if getattr(mine[0], "cold_maps", False) else ""),
                  mine[0].fwd_fn.__name__, "roi_forward_bytes")]
@@ -723,7 +725,7 @@ def main():
         res["config"]["one_batch_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         entries = roofline_entries(ring, wl, signature)
         dom = max(entries, key=lambda e: e["avg_launch_us"]) if entries else {}
-        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = index + fill and gather kernels behind one C call; algorithmic "
+        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = one launch of LDS map tiles, no workspace; algorithmic "
                                          "bytes as SURVEY 8(d) defines them -- 8 B per pooled value -- while the pair moves 5: its argmax plane holds one-byte codes); "
                                          "HIP event pairs on the launch stream around the call inside the batch's eager launch "
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "

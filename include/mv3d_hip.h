@@ -200,8 +200,9 @@ int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views,
  *                   written before it is read).  workspace == NULL: the backward runs WITHOUT scratch memory as ONE launch -- a wave
  *                   owns a tile of <= 16 map pixels x 64 channels in LDS, finds the ROIs that reach it, streams their (roi, bin)
  *                   records in the reference's order and routes every value to the pixel its code names (csrc/roi_grad_tiles.hip;
- *                   no index, no fill: a tile is written out whole).  Same results; on the training batch 69 us against 68 with a
- *                   workspace (profiles/r05_ai_*.txt), and nothing to allocate or capture besides one kernel.
+ *                   no index, no fill: a tile is written out whole).  Same results; on the training batch 66 us against 69 with a
+ *                   workspace, and 3 - 6 % more frames/s with eight batches in flight (profiles/r05_as_*.txt, r05_at_*.txt): the mode
+ *                   the library's own train graph and bench.py use.
  *   cold_maps       != 0: as mv3d_roi_pool_forward_views_cold.
  * Shapes outside the pair's kernels (C not in {256, 512} / not the same for all views, pooled sizes > 15, a map of more than 65534
  * pixels, an empty view) take the plain forward (int32 argmax) and mv3d_roi_pool_backward_views behind the same entries.

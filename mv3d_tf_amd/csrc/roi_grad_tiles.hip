@@ -341,8 +341,9 @@ int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, i
         v.scale = w.spatial_scale; v.B = w.batch_size; v.R = w.num_rois; v.H = w.height; v.W = w.width; v.C = w.channels;
         // tile size from the record density: a tile's record stream is one wave's serial work
         const double d = dens[order[i]];
-        // (measured on the training batch, profiles/r05_ai / r05_ak: dense view 2 x 2, the first sparse view 2 x 4, the others 4 x 4)
-        int px = d >= 1.5 ? 4 : (i == 0 || dens[order[i - 1]] >= 1.5 ? 8 : 16);
+        // (measured with eight batches in flight, profiles/r05_at_tiles_in_path.txt: 2 x 2 on a dense view, 4 x 4 on the sparse ones;
+        // alone the first sparse view likes 2 x 4 by ~2 us, in the path 4 x 4 is 4 % faster)
+        int px = d >= 1.5 ? 4 : 16;
         if (force_px) px = i == 0 ? (force_px & 0xff) : (i == 1 ? (force_px >> 8) & 0xff : (force_px >> 16) & 0xff);
         if (px != 1 && px != 2 && px != 4 && px != 8 && px != 16) px = 16;
         int lg = 0;
@@ -364,6 +365,10 @@ int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, i
 #endif
     // 16 records in flight per wave (6 waves per SIMD); 32 (4 waves per SIMD) is 3 % faster alone and 4 % slower with eight batches
     // in flight (profiles/r05_am_tiles_w32_bench_ab.txt)
+#ifdef MV3D_TUNING
+    if (rgt_env("MV3D_RGT_W", 16) == 8) { hipLaunchKernelGGL((roi_pair_tiles_kernel<8, 1>), dim3(blocks), dim3(64), 0, stream, p); return mv3d_launch_status(); }
+    if (rgt_env("MV3D_RGT_W", 16) == 24) { hipLaunchKernelGGL((roi_pair_tiles_kernel<24, 1>), dim3(blocks), dim3(64), 0, stream, p); return mv3d_launch_status(); }
+#endif
     hipLaunchKernelGGL((roi_pair_tiles_kernel<16, 1>), dim3(blocks), dim3(64), 0, stream, p);
     return mv3d_launch_status();
 }

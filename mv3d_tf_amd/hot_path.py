@@ -7,7 +7,7 @@ and replayed as plain kernel launches -- what bench.py times and what a training
         per frame: mv3d_proposal_target_stage1 / stage2 (<= 128 sampled)    lib/rpn_msr/proposal_target_layer_tf.py:19-94
         mv3d_rois_3d_to_fv                                                  (third view; network.py:293-315 is a TODO)
         mv3d_roi_pool_forward_views_pair   BEV + RGB + FV, private 16-bit argmax plane  roi_pooling_op.cc:74-190 x 3 layers
-        mv3d_roi_pool_backward_views_pair  BEV + RGB + FV: index + fill, gather         roi_pooling_op.cc:319-452 x 3 layers
+        mv3d_roi_pool_backward_views_pair  BEV + RGB + FV: one launch of tiles          roi_pooling_op.cc:319-452 x 3 layers
     TestPathBatch    BASELINE configs[1] / configs[4] path: mv3d_proposal_3d (TEST cfg 6000 -> 300), FV ROIs,
         RoiPool forward on the three views.
 
@@ -265,11 +265,10 @@ class TrainPathBatch:
             self.tops[v], self.top_diff[v], self.bottom_diff[v] = (top, am), td, bd
             fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
             bwd[k] = RoiGradView(bd.data_ptr(), self.rois[v].data_ptr(), td.data_ptr(), am.data_ptr(), 0.125, Bm, St, Hm, Wm, Cm)
-        # the RoiPool pair: forward with the private compact argmax plane, backward = index + zero fill, gather (mv3d_roi_pool_*_views_pair)
-        bws = torch.zeros(max(L.mv3d_roi_pool_pair_workspace_bytes(len(self.views), bwd, 7, 7), 256), dtype=torch.uint8, device=dev)
+        # the RoiPool pair: forward with the private compact argmax plane, backward WITHOUT a workspace = one launch of LDS map tiles
+        # (mv3d_roi_pool_*_views_pair; with a workspace the same entry runs index + zero fill, gather: same bits)
         af = (len(self.views), fwd, 7, 7, 1 if self.cold_maps else 0, st)
-        ab = (len(self.views), bwd, 7, 7, _P(bws), C.c_size_t(bws.numel()), st)
-        bnd.keep += [bws]
+        ab = (len(self.views), bwd, 7, 7, None, C.c_size_t(0), st)
         self.fwd_fn = L.mv3d_roi_pool_forward_views_pair
         check(self.fwd_fn(*af), "mv3d_roi_pool_forward_views_pair")
         check(L.mv3d_roi_pool_backward_views_pair(*ab), "mv3d_roi_pool_backward_views_pair")

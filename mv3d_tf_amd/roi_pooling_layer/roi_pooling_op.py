@@ -35,8 +35,8 @@ class RoiPoolFunction(torch.autograd.Function):
 class RoiPoolViewsFunction(torch.autograd.Function):
     """The RoiPool layers of one step (`pool_5`, `pool_5_2` [, `pool_5_3`]: network.py:199-213 called once per view) as the library's
     PAIR: ONE launch forward (mv3d_roi_pool_forward_views_pair: every view, the argmax plane kept as private one-byte codes) and one
-    call backward (mv3d_roi_pool_backward_views_pair: candidate index + zero fill, then the ordered gather of
-    roi_pooling_op.cc:319-452 for every view).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...) -> (top_0, top_1, ...);
+    call backward (mv3d_roi_pool_backward_views_pair without a workspace: ONE launch, every view's map tiles in LDS, the ordered
+    sums of roi_pooling_op.cc:319-452).  apply(ph, pw, scale, data_0, rois_0, data_1, rois_1, ...) -> (top_0, top_1, ...);
     gradients for the data tensors only (roi_pooling_op_grad.py:43).  A view whose output gets no gradient (unused in the loss)
     contributes zeros, like an unconnected tf.gradients branch."""
 
@@ -61,7 +61,7 @@ class RoiPoolViewsFunction(torch.autograd.Function):
             if g is None:
                 g = torch.zeros((rois[k].shape[0], ph, pw, shapes[k][3]), dtype=torch.float32, device=rois[k].device)
             views.append((g.contiguous(), rois[k], argmax[k], shapes[k], scale))
-        outs = ops.roi_pool_backward_views_pair(views, ph, pw)
+        outs = ops.roi_pool_backward_views_pair(views, ph, pw, workspace=False)   # (one launch, no scratch memory)
         ret = [None, None, None]
         for k in range(n):
             ret += [outs[k], None]
