@@ -76,6 +76,36 @@ def test_input_layer_variant(gpu, B, H, W, cin, cout):
     assert float((got.float() - want).abs().max()) <= 2e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,cin,framed,relu", [(3, 33, 71, 9, False, True), (1, 17, 31, 3, False, False), (2, 50, 97, 3, True, False),
+                                                  (5, 1, 1, 9, True, True), (1, 3, 200, 9, False, True)])
+def test_input_layer_kernel_odd_shapes_and_bare_output(gpu, B, H, W, cin, framed, relu):
+    """csrc/conv_input.hip: widths that are no multiple of its 32-pixel blocks, heights that are no multiple of its 16-row strips (rows past
+    the map are computed from clamped rows and dropped by the store's range check), a 1 x 1 map, bare (unframed) outputs, no ReLU -- every
+    pixel against torch's f32 convolution of the rounded operands, and a framed output's frame left untouched"""
+    torch = gpu
+    import torch.nn.functional as F
+    from mv3d_tf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn((B, H, W, cin), device="cuda", generator=g)
+    w = torch.randn((64, cin, 3, 3), device="cuda", generator=g) * 0.25
+    b = torch.randn((64,), device="cuda", generator=g)
+    T = torch.float16
+    want = F.conv2d(x.to(T).float().permute(0, 3, 1, 2), w.to(T).float(), b, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        want = F.relu(want)
+    xf = ops.frame_nhwc_f16(x, ops.framed_buffer(B, H, W, 16, x.device))
+    out = ops.framed_buffer(B, H, W, 64, x.device) if framed else torch.full((B, H, W, 64), 7.0, dtype=T, device="cuda")
+    got = ops.conv3x3_f16(xf, ops.pack_conv3x3_weights_input_layer(w), b, out=out, out_framed=framed, relu=relu)
+    torch.cuda.synchronize()
+    inner = got[:, 1:-1, 1:-1] if framed else got
+    assert not bool(torch.isnan(inner.float()).any())
+    assert float((inner.float() - want).abs().max()) <= 4e-3 * max(1.0, float(want.abs().max()))
+    if framed:
+        fr = got.clone()
+        fr[:, 1:-1, 1:-1] = 0
+        assert float(fr.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("half", ["float16", "bfloat16"])
 def test_input_layer_kernel_at_full_occupancy(gpu, half):
     """csrc/conv_input.hip on maps large enough that every CU holds a full workgroup (two waves per SIMD: 1444 + 120 + 64 column strips),
