@@ -79,6 +79,8 @@ def parse():
                          "(index lists drawn during set-up) is captured once into a hipGraph on its stream and replayed; eager: the "
                          "same frozen batches as plain in-order launches from Python")
     ap.add_argument("--variant", default="peaky", choices=["peaky", "rand"])
+    ap.add_argument("--test-argmax", action="store_true", help="--workload test / secondary.test_cfg: RoiPool writes the op's argmax plane too "
+                    "(default: the inference graph's call, top only -- nothing reads argmax without a backward pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--no-secondary", action="store_true")
@@ -120,7 +122,8 @@ class Ring:
             if workload == "train":
                 slot = hot_path.TrainPathBatch(frames, maps, stream=st, top_diff_seed=k, cold_maps=True)   # ring maps: written long ago
             else:
-                slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st, cold_maps=True)
+                slot = hot_path.TestPathBatch([f[:4] for f in frames], maps, stream=st, cold_maps=True,
+                                              want_argmax=bool(getattr(args, "test_argmax", False)))
             self.slots.append(slot.setup())
             self.host_frames_all.append(frames)
             if k == 0:
@@ -801,7 +804,8 @@ def main():
             dt2 = sharding.max_over_ranks(dt2, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
             if rank == 0:
                 sec["test_cfg"] = {"workload": "BASELINE configs[4] per-GPU path: batch 16, TEST cfg 6000->300, FV ROIs, RoiPool fwd x3 "
-                                               "views, ring of 3 batches on the step's streams (%s launches)" % args2.launch,
+                                               "views (the inference call: top only%s), ring of 3 batches on the step's streams (%s launches)"
+                                               % ("" if not getattr(args2, "test_argmax", False) else " + argmax", args2.launch),
                                    "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
                                    "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
             del r2

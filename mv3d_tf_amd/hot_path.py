@@ -313,12 +313,15 @@ class TestPathBatch:
     """proposal_layer_3d (TEST cfg) -> FV ROIs -> RoiPool forward on the views, B frames; R = B * 300 ROI rows
     (rows past a frame's count are zero boxes, as the fixed-shape serving graph pools them)."""
 
-    def __init__(self, frames, maps, stream=None, views=VIEWS, cold_maps=False):
+    def __init__(self, frames, maps, stream=None, views=VIEWS, cold_maps=False, want_argmax=True):
+        """want_argmax=False: the inference graph's call (roi_pooling_op.roi_pool under no_grad: argmax_data = NULL -- the op's second
+        output only feeds RoiPoolGrad, roi_pooling_op_grad.py:7-43); True: both outputs of the op, as the reference's kernel writes them"""
         self.B = len(frames)
         self.views = tuple(views)
         self.stream = stream
         self.maps = maps
         self.cold_maps = bool(cold_maps)
+        self.want_argmax = bool(want_argmax)
         dev = next(iter(maps.values())).device
         self.dev = dev
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
@@ -356,9 +359,9 @@ class TestPathBatch:
                 m = self.maps[v]
                 Bm, Hm, Wm, Cm = m.shape
                 top = torch.empty((R, 7, 7, Cm), dtype=torch.float32, device=dev)
-                am = torch.empty((R, 7, 7, Cm), dtype=torch.int32, device=dev)
+                am = torch.empty((R, 7, 7, Cm), dtype=torch.int32, device=dev) if self.want_argmax else None
                 self.tops[v] = (top, am)
-                fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr(), 0.125, Bm, R, Hm, Wm, Cm)
+                fwd[k] = RoiView(m.data_ptr(), self.rois[v].data_ptr(), top.data_ptr(), am.data_ptr() if am is not None else None, 0.125, Bm, R, Hm, Wm, Cm)
             self.fwd_args = (len(self.views), fwd, 7, 7, st)
             self.fwd_fn = L.mv3d_roi_pool_forward_views_cold if self.cold_maps else L.mv3d_roi_pool_forward_views
             bnd.add(self.fwd_fn, *self.fwd_args)
@@ -376,7 +379,8 @@ class TestPathBatch:
         check(self.fwd_fn(*self.fwd_args), "mv3d_roi_pool_forward_views")
 
     def roi_forward_bytes(self):
-        return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 8 for v in self.views)
+        per = 8 if self.want_argmax else 4                         # top f32 (+ argmax i32)
+        return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * per for v in self.views)
 
 
 class _Null:
