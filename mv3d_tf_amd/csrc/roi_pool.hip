@@ -117,6 +117,13 @@ __device__ __forceinline__ void upd4pos(const float4 x, int pos, float4 &mv, int
     upd(x.w, pos, mv.w, mi.w);
 }
 
+// NOARG (inference: argmax_data = NULL in every view): the maximum alone, same strict > (first maximum, NaN never wins): half the
+// vector-ALU work of the scan and no index registers
+__device__ __forceinline__ void upd4max(const float4 x, float4 &mv)
+{
+    mv.x = x.x > mv.x ? x.x : mv.x; mv.y = x.y > mv.y ? x.y : mv.y; mv.z = x.z > mv.z ? x.z : mv.z; mv.w = x.w > mv.w ? x.w : mv.w;
+}
+
 // COMPACT (the pair, mv3d_roi_pool_forward_views_pair): the argmax plane is PRIVATE to the pair -- only its own RoiPoolGrad reads
 // it -- and holds, instead of the reference's int32 flat indices, the position of the first maximum in the bin's scan order,
 // (h - hstart) * (wend - wstart) + (w - wstart):
@@ -169,7 +176,7 @@ __device__ __forceinline__ BinGeom fwd_bin_geom(const long long bin, const long 
     return g;
 }
 
-template <int FWD_PASSES, bool COMPACT>
+template <int FWD_PASSES, bool COMPACT, bool NOARG>
 __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
                                                        int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
                                                        int *__restrict__ argmax, int tpb_shift);
@@ -177,7 +184,7 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
 // (Round 5, measured and dropped: the rectangles computed per thread in registers -- no LDS, no barrier, the 8 - 32 lanes of a bin
 // redundantly: 42 - 46 us instead of 35, profiles/r05_fwd_local_ab.txt; a persistent grid that requests the next group's ROI rows
 // while it pools the current one: 39 - 41 us, profiles/r05_v_fwd_persist_ab.txt, tools/experiments/roi_pool_fwd_persistent_r05.hip.txt.)
-template <int FWD_PASSES, bool COMPACT = false>
+template <int FWD_PASSES, bool COMPACT = false, bool NOARG = false>
 __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
                                                         const float *__restrict__ data, float scale,
                                                         int B, int R, int H, int W, int C, int PH, int PW,
@@ -189,11 +196,11 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
     const long long bin0 = (long long)(block >> 3) * (FWD_PASSES * bpp);
     if (threadIdx.x < FWD_PASSES * bpp) s_g[threadIdx.x] = fwd_bin_geom(bin0 + threadIdx.x, nbins, rois, scale, B, H, W, PH, PW);
     __syncthreads();
-    roi_pool_fwd_xcd_pool<FWD_PASSES, COMPACT>(s_g, block, data, B, R, H, W, C, PH, PW, top, argmax, tpb_shift);
+    roi_pool_fwd_xcd_pool<FWD_PASSES, COMPACT, NOARG>(s_g, block, data, B, R, H, W, C, PH, PW, top, argmax, tpb_shift);
 }
 
 // the pooling phase of roi_pool_fwd_xcd_block: the workgroup's bins from their rectangles in LDS
-template <int FWD_PASSES, bool COMPACT>
+template <int FWD_PASSES, bool COMPACT, bool NOARG>
 __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
                                                        int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
                                                        int *__restrict__ argmax, int tpb_shift)
@@ -228,7 +235,9 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
                         const float4 x1 = *reinterpret_cast<const float4 *>(d + idx + C);
                         const float4 x2 = *reinterpret_cast<const float4 *>(d + idx + 2 * C);
                         const float4 x3 = *reinterpret_cast<const float4 *>(d + idx + 3 * C);
-                        if (COMPACT) {
+                        if (NOARG) {
+                            upd4max(x0, mv); upd4max(x1, mv); upd4max(x2, mv); upd4max(x3, mv);
+                        } else if (COMPACT) {
                             upd4pos(x0, pos, mv, mi); upd4pos(x1, pos + 1, mv, mi); upd4pos(x2, pos + 2, mv, mi); upd4pos(x3, pos + 3, mv, mi);
                             pos += 4;
                         } else {
@@ -240,7 +249,8 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
                     }
                     for (; w < g.we; ++w) {
                         const int idx = (h * W + w) * C;
-                        if (COMPACT) upd4pos(*reinterpret_cast<const float4 *>(d + idx), pos++, mv, mi);
+                        if (NOARG) upd4max(*reinterpret_cast<const float4 *>(d + idx), mv);
+                        else if (COMPACT) upd4pos(*reinterpret_cast<const float4 *>(d + idx), pos++, mv, mi);
                         else upd4(*reinterpret_cast<const float4 *>(d + idx), idx + c0, mv, mi);
                     }
                 }
@@ -252,7 +262,8 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
             typedef int i4v __attribute__((ext_vector_type(4)));
             const f4v mvv = {mv.x, mv.y, mv.z, mv.w};
             __builtin_nontemporal_store(mvv, reinterpret_cast<f4v *>(top + o));
-            if (COMPACT) {
+            if (NOARG) {
+            } else if (COMPACT) {
                 unsigned char *const plane8 = reinterpret_cast<unsigned char *>(argmax);
                 if (g.base < 0 || (g.he - g.hs) * (g.we - g.ws) <= 255) {      // four one-byte codes (-1 -> 0xFF), 4 bytes per lane
                     const unsigned cv = ((unsigned)mi.x & 0xffu) | (((unsigned)mi.y & 0xffu) << 8) | (((unsigned)mi.z & 0xffu) << 16) | ((unsigned)mi.w << 24);
@@ -292,7 +303,7 @@ struct RoiViewDev {
 };
 struct RoiViewPack { RoiViewDev v[MV3D_MAX_ROI_VIEWS]; int n, PH, PW; };
 
-template <int FWD_PASSES>
+template <int FWD_PASSES, bool NOARG = false>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack p)
 {
     __shared__ BinGeom s_g[FWD_PASSES * 32];
@@ -301,8 +312,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
-                           v.argmax, v.tpb_shift);
+    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois,
+                                                     v.top, v.argmax, v.tpb_shift);
 }
 
 // Forward on maps that are NOT cache-resident (mv3d_roi_pool_forward_views_cold).  The forward reads a map in 256-B
@@ -355,7 +366,7 @@ __device__ __forceinline__ void roi_prefetch_block(unsigned *s_mask_p /* LDS, on
 
 // forward with the prefetch workgroups at the front of the same grid (pf.blocks is a multiple of 8: the forward's
 // workgroup -> XCD slice mapping is kept)
-template <int FWD_PASSES>
+template <int FWD_PASSES, bool NOARG = false>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink)
 {
     __shared__ BinGeom s_g[FWD_PASSES * 32];
@@ -367,8 +378,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_cold_kernel(RoiVie
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blk >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
-                           v.argmax, v.tpb_shift);
+    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                                                     v.argmax, v.tpb_shift);
 }
 
 #define BWD_CHUNK 1024      // ROIs whose geometry is staged in LDS at a time
@@ -1636,15 +1647,29 @@ static int roi_pool_forward_views_impl(int num_views, const mv3d_roi_view *views
     }
     for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
     if (blocks == 0) return MV3D_OK;
+    bool noarg = true;                                    // inference: no view wants the argmax plane -> the maximum-only scan
+    for (int k = 0; k < num_views; ++k) noarg = noarg && !views[k].argmax_data;
+    hipStream_t s = (hipStream_t)stream;
     RoiPrefetchPack pf;
     if (cold && roi_prefetch_plan(num_views, views, pf)) {
         pf.blocks = (pf.blocks + 7u) & ~7u;
-        if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_cold_kernel<4>, dim3(blocks + pf.blocks), dim3(256), 0, (hipStream_t)stream, p, pf, (int *)nullptr);
-        else hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_cold_kernel<2>, dim3(blocks + pf.blocks), dim3(256), 0, (hipStream_t)stream, p, pf, (int *)nullptr);
+        const dim3 grid(blocks + pf.blocks);
+        if (noarg) {
+            if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<4, true>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+            else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<2, true>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+        } else {
+            if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<4>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+            else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<2>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+        }
         return mv3d_launch_status();
     }
-    if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(roi_pool_fwd_xcd_multi_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if (noarg) {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<4, true>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<2, true>), dim3(blocks), dim3(256), 0, s, p);
+    } else {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<4>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<2>), dim3(blocks), dim3(256), 0, s, p);
+    }
     return mv3d_launch_status();
 }
 

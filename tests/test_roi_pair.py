@@ -185,3 +185,36 @@ def test_reference_launcher_aliases(gpu, oracle):
     assert L.mv3d_ROIPoolBackwardLaucher(P(dev(torch, g)), C.c_float(0.125), 2, 12, 9, 11, 24, 7, 7, P(r), P(bd), P(am), st) == 1
     assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(data, rois, o_am, g, 7, 7, 0.125))
     assert L.mv3d_ROIPoolForwardLaucher(None, C.c_float(0.125), 12, 9, 11, 24, 7, 7, P(r), P(top), P(am), st) == 0       # refused, not exit(-1)
+
+
+@pytest.mark.parametrize("R", [150, 2000])
+@pytest.mark.parametrize("cold", [False, True])
+def test_forward_views_without_argmax_is_the_same_top(gpu, oracle, R, cold):
+    """inference (argmax_data = NULL in every view: the maximum-only scan of mv3d_roi_pool_forward_views[_cold]) gives the bits of the
+    full op's `top` -- with -0.0 / +0.0 ties (the first one met stays), NaN pixels (never win), ROIs larger than the map, empty bins;
+    R = 2000 rows per view takes the four-pass workgroups"""
+    torch, ops = gpu
+    rs = np.random.RandomState(R)
+    B = 2
+    maps = [rs.uniform(-1, 1, (B, 20, 31, 512)).astype(np.float32), rs.uniform(-1, 1, (B, 9, 40, 512)).astype(np.float32)]
+    maps[0][0, 2:6, 3:9, :] = 0.0
+    maps[0][0, 2:6, 3:9, ::2] = -0.0                                   # signed zeros under the pooling windows
+    maps[0][1, 5, 7, :9] = np.nan
+    maps[1][maps[1] < -0.2] = -0.0
+    rois = []
+    for m in maps:
+        h, w = m.shape[1] * 8, m.shape[2] * 8
+        x1, y1 = rs.randint(-30, w, R), rs.randint(-30, h, R)
+        r = np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.randint(0, w, R), y1 + rs.randint(0, h, R)], 1).astype(np.float32)
+        r[:5] = [[0, -4000, -3000, 9000, 7000], [1, 0, 0, w - 1, h - 1], [0, 24, 16, 24, 16], [1, 9999, 9999, 10005, 10005], [0, 16, 16, 71, 47]]
+        rois.append(r)
+    fv = [(dev(torch, m), dev(torch, r), 0.125) for m, r in zip(maps, rois)]
+    full = ops.roi_pool_forward_views(fv, 7, 7, cold_maps=cold)
+    none = ops.roi_pool_forward_views(fv, 7, 7, cold_maps=cold, want_argmax=False)
+    for m, r, (top, am), (top2, am2) in zip(maps, rois, full, none):
+        assert am2 is None
+        a, b = top.cpu().numpy(), top2.cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))    # bit for bit, signs of zero included
+        if R == 150:
+            o_top, _ = oracle.roi_pool(m, r, 7, 7, 0.125)
+            assert np.array_equal(b.view(np.uint32), o_top.view(np.uint32))
