@@ -142,6 +142,27 @@ def test_input_layer_kernel_at_full_occupancy(gpu, half):
             assert float(frame.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", ["float16", "bfloat16", "float32"])
+@pytest.mark.parametrize("B,H,W,C,Co", [(2, 37, 53, 9, 16), (1, 5, 7, 3, 16), (3, 16, 20, 64, 64), (1, 9, 9, 40, 40), (2, 8, 8, 9, 32), (1, 1, 1, 3, 16)])
+def test_frame_nhwc_in_16_byte_pieces(gpu, dt, B, H, W, C, Co):
+    """mv3d_frame_nhwc_*: the interior of the framed map = the input rounded to the map's type, channels past C and the frame zero -- through
+    the 16-byte-piece kernel (C_out a multiple of the piece) and the element kernel (the rest), on a buffer that held garbage in its interior"""
+    torch = gpu
+    from mv3d_tf_amd import ops
+    T = getattr(torch, dt)
+    g = torch.Generator(device="cuda").manual_seed(C * 100 + W)
+    x = torch.randn((B, H, W, C), device="cuda", generator=g) * 3.0
+    out = ops.framed_buffer(B, H, W, Co, "cuda", T)
+    out[:, 1:-1, 1:-1, :C] = 7.0                                       # (the owner zeroes frame and padding channels once; the interior is rewritten)
+    ops.frame_nhwc_f16(x, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 1:-1, 1:-1, :C], x.to(T))
+    assert float(out[:, 1:-1, 1:-1, C:].abs().max()) == 0.0 if Co > C else True
+    fr = out.clone()
+    fr[:, 1:-1, 1:-1] = 0
+    assert float(fr.abs().max()) == 0.0
+
+
 def test_maxpool_and_two_layer_chain(gpu):
     torch = gpu
     from mv3d_tf_amd import ops
