@@ -156,6 +156,12 @@ int mv3d_roi_pool_forward_views(int num_views, const mv3d_roi_view *views, int p
  * maps were just produced by the previous layer.  (No counterpart in the reference.) */
 int mv3d_roi_pool_forward_views_cold(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
                                      void *stream);
+/* Inference in 16-bit mode: the same pooling with `top_data` written as f16 (top_type 1) or bf16 (top_type 2) -- exactly the values a
+ * cast of the f32 output gives (the maximum is taken in f32, then rounded once), without the f32 output and without the cast launch in
+ * front of the head's first GEMM.  Every view's argmax_data must be NULL and the shapes must be the XCD-sliced kernels'
+ * (C in {256, 512, 1024}, 16-byte aligned buffers): INVALID_ARG otherwise.  (No counterpart in the reference: its op is f32.) */
+int mv3d_roi_pool_forward_views_half(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                     int top_type, int cold_maps, void *stream);
 
 /* RoiPoolGrad of several views behind one call (the three RoiPool layers of a training step): same results as
  * one mv3d_roi_pool_backward per view.  In a backward view `top_data` is READ (top_diff, (num_rois,PH,PW,C)),

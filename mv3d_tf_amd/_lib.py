@@ -151,6 +151,7 @@ _SIGS = {
     "mv3d_rcnn_loss": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_forward_views": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
     "mv3d_roi_pool_forward_views_cold": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, _P]),
+    "mv3d_roi_pool_forward_views_half": (C.c_int, [C.c_int, C.POINTER(RoiView), C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_roi_pool_backward_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),
     "mv3d_roi_pool_backward_views": (C.c_int, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mv3d_roi_pool_pair_workspace_bytes": (C.c_size_t, [C.c_int, C.POINTER(RoiGradView), C.c_int, C.c_int]),

@@ -176,7 +176,7 @@ __device__ __forceinline__ BinGeom fwd_bin_geom(const long long bin, const long 
     return g;
 }
 
-template <int FWD_PASSES, bool COMPACT, bool NOARG>
+template <int FWD_PASSES, bool COMPACT, bool NOARG, int TOPT>
 __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
                                                        int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
                                                        int *__restrict__ argmax, int tpb_shift);
@@ -184,7 +184,9 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
 // (Round 5, measured and dropped: the rectangles computed per thread in registers -- no LDS, no barrier, the 8 - 32 lanes of a bin
 // redundantly: 42 - 46 us instead of 35, profiles/r05_fwd_local_ab.txt; a persistent grid that requests the next group's ROI rows
 // while it pools the current one: 39 - 41 us, profiles/r05_v_fwd_persist_ab.txt, tools/experiments/roi_pool_fwd_persistent_r05.hip.txt.)
-template <int FWD_PASSES, bool COMPACT = false, bool NOARG = false>
+// TOPT (with NOARG, the serving graph in 16-bit mode): the pooled maximum stored as f16 (1) / bf16 (2) -- the values a cast of the f32
+// output would give, without the f32 output and the cast launch
+template <int FWD_PASSES, bool COMPACT = false, bool NOARG = false, int TOPT = 0>
 __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_PASSES * 32 entries */, const unsigned block,
                                                         const float *__restrict__ data, float scale,
                                                         int B, int R, int H, int W, int C, int PH, int PW,
@@ -196,11 +198,11 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_block(BinGeom *s_g /* LDS, FWD_
     const long long bin0 = (long long)(block >> 3) * (FWD_PASSES * bpp);
     if (threadIdx.x < FWD_PASSES * bpp) s_g[threadIdx.x] = fwd_bin_geom(bin0 + threadIdx.x, nbins, rois, scale, B, H, W, PH, PW);
     __syncthreads();
-    roi_pool_fwd_xcd_pool<FWD_PASSES, COMPACT, NOARG>(s_g, block, data, B, R, H, W, C, PH, PW, top, argmax, tpb_shift);
+    roi_pool_fwd_xcd_pool<FWD_PASSES, COMPACT, NOARG, TOPT>(s_g, block, data, B, R, H, W, C, PH, PW, top, argmax, tpb_shift);
 }
 
 // the pooling phase of roi_pool_fwd_xcd_block: the workgroup's bins from their rectangles in LDS
-template <int FWD_PASSES, bool COMPACT, bool NOARG>
+template <int FWD_PASSES, bool COMPACT, bool NOARG, int TOPT>
 __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const unsigned block, const float *__restrict__ data,
                                                        int B, int R, int H, int W, int C, int PH, int PW, float *__restrict__ top,
                                                        int *__restrict__ argmax, int tpb_shift)
@@ -261,7 +263,16 @@ __device__ __forceinline__ void roi_pool_fwd_xcd_pool(const BinGeom *s_g, const 
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef int i4v __attribute__((ext_vector_type(4)));
             const f4v mvv = {mv.x, mv.y, mv.z, mv.w};
-            __builtin_nontemporal_store(mvv, reinterpret_cast<f4v *>(top + o));
+            if (TOPT == 1) {
+                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                const h4v hv = {(_Float16)mv.x, (_Float16)mv.y, (_Float16)mv.z, (_Float16)mv.w};
+                __builtin_nontemporal_store(hv, reinterpret_cast<h4v *>(reinterpret_cast<_Float16 *>(top) + o));
+            } else if (TOPT == 2) {
+                typedef __bf16 b4v __attribute__((ext_vector_type(4)));
+                const b4v hv = {(__bf16)mv.x, (__bf16)mv.y, (__bf16)mv.z, (__bf16)mv.w};
+                __builtin_nontemporal_store(hv, reinterpret_cast<b4v *>(reinterpret_cast<__bf16 *>(top) + o));
+            } else
+                __builtin_nontemporal_store(mvv, reinterpret_cast<f4v *>(top + o));
             if (NOARG) {
             } else if (COMPACT) {
                 unsigned char *const plane8 = reinterpret_cast<unsigned char *>(argmax);
@@ -303,7 +314,7 @@ struct RoiViewDev {
 };
 struct RoiViewPack { RoiViewDev v[MV3D_MAX_ROI_VIEWS]; int n, PH, PW; };
 
-template <int FWD_PASSES, bool NOARG = false>
+template <int FWD_PASSES, bool NOARG = false, int TOPT = 0>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack p)
 {
     __shared__ BinGeom s_g[FWD_PASSES * 32];
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_kernel(RoiViewPack
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois,
+    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG, TOPT>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois,
                                                      v.top, v.argmax, v.tpb_shift);
 }
 
@@ -366,7 +377,7 @@ __device__ __forceinline__ void roi_prefetch_block(unsigned *s_mask_p /* LDS, on
 
 // forward with the prefetch workgroups at the front of the same grid (pf.blocks is a multiple of 8: the forward's
 // workgroup -> XCD slice mapping is kept)
-template <int FWD_PASSES, bool NOARG = false>
+template <int FWD_PASSES, bool NOARG = false, int TOPT = 0>
 __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink)
 {
     __shared__ BinGeom s_g[FWD_PASSES * 32];
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_xcd_multi_cold_kernel(RoiVie
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blk >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+    roi_pool_fwd_xcd_block<FWD_PASSES, false, NOARG, TOPT>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
                                                      v.argmax, v.tpb_shift);
 }
 
@@ -1602,7 +1613,7 @@ static int roi_pool_backward_generic(const float *top_diff, float spatial_scale,
 }
 
 static int roi_pool_forward_views_impl(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
-                                       bool cold, void *stream)
+                                       bool cold, void *stream, int top_type = 0)
 {
     if (num_views <= 0 || num_views > MV3D_MAX_ROI_VIEWS || !views || pooled_height <= 0 || pooled_width <= 0)
         return MV3D_ERR_INVALID_ARG;
@@ -1616,6 +1627,11 @@ static int roi_pool_forward_views_impl(int num_views, const mv3d_roi_view *views
         const int cv4 = w.channels / 4;
         fast = fast && (w.channels % 4 == 0) && (cv4 == 64 || cv4 == 128 || cv4 == 256) && aligned16(w.bottom_data) &&
                aligned16(w.top_data) && (!w.argmax_data || aligned16(w.argmax_data));
+    }
+    if (top_type != 0) {                                  // 16-bit tops: the XCD-sliced maximum-only kernels or nothing
+        for (int k = 0; k < num_views; ++k)
+            if (views[k].argmax_data) return MV3D_ERR_INVALID_ARG;
+        if (!fast || (top_type != 1 && top_type != 2)) return MV3D_ERR_INVALID_ARG;
     }
     if (!fast) {                                          // generic shapes: one launch per view
         for (int k = 0; k < num_views; ++k) {
@@ -1654,7 +1670,13 @@ static int roi_pool_forward_views_impl(int num_views, const mv3d_roi_view *views
     if (cold && roi_prefetch_plan(num_views, views, pf)) {
         pf.blocks = (pf.blocks + 7u) & ~7u;
         const dim3 grid(blocks + pf.blocks);
-        if (noarg) {
+        if (top_type == 1) {
+            if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<4, true, 1>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+            else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<2, true, 1>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+        } else if (top_type == 2) {
+            if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<4, true, 2>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+            else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<2, true, 2>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
+        } else if (noarg) {
             if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<4, true>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
             else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_cold_kernel<2, true>), grid, dim3(256), 0, s, p, pf, (int *)nullptr);
         } else {
@@ -1663,7 +1685,13 @@ static int roi_pool_forward_views_impl(int num_views, const mv3d_roi_view *views
         }
         return mv3d_launch_status();
     }
-    if (noarg) {
+    if (top_type == 1) {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<4, true, 1>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<2, true, 1>), dim3(blocks), dim3(256), 0, s, p);
+    } else if (top_type == 2) {
+        if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<4, true, 2>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<2, true, 2>), dim3(blocks), dim3(256), 0, s, p);
+    } else if (noarg) {
         if (passes == 4) hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<4, true>), dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((roi_pool_fwd_xcd_multi_kernel<2, true>), dim3(blocks), dim3(256), 0, s, p);
     } else {
@@ -1683,6 +1711,13 @@ extern "C" int mv3d_roi_pool_forward_views_cold(int num_views, const mv3d_roi_vi
                                                 void *stream)
 {
     return roi_pool_forward_views_impl(num_views, views, pooled_height, pooled_width, true, stream);
+}
+
+extern "C" int mv3d_roi_pool_forward_views_half(int num_views, const mv3d_roi_view *views, int pooled_height, int pooled_width,
+                                                int top_type, int cold_maps, void *stream)
+{
+    if (top_type != 1 && top_type != 2) return MV3D_ERR_INVALID_ARG;
+    return roi_pool_forward_views_impl(num_views, views, pooled_height, pooled_width, cold_maps != 0, stream, top_type);
 }
 
 static bool roi_prefetch_plan(int num_views, const mv3d_roi_view *views, RoiPrefetchPack &pf)

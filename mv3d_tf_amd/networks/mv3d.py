@@ -376,7 +376,8 @@ class MV3D:
             L["roi_data_fv"] = rois_fv
             views.append((L["conv5_3_3"], rois_fv))
             names.append("pool_5_3")
-        for name, top in zip(names, roi_pool_views([(d.contiguous(), r.contiguous()) for d, r in views], 7, 7, 1.0 / 8)):
+        # (serving in 16-bit mode: the pooled maps in the head's type straight from the pooling launch -- no f32 copy, no cast launch)
+        for name, top in zip(names, roi_pool_views([(d.contiguous(), r.contiguous()) for d, r in views], 7, 7, 1.0 / 8, top_dtype=self.amp_dtype)):
             L[name] = top
         tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)
         for t, x in zip(("_1", "_2", "_3"), tower):

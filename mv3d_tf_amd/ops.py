@@ -307,11 +307,15 @@ def box_detect_tail(rois_3d, bbox_pred, num_classes):
     return cnr, pr, bv, bvr
 
 
-def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_maps=False, want_argmax=True):
+def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_maps=False, want_argmax=True, top_dtype=None):
     """views: list of (data (B,H,W,C), rois (R,5), spatial_scale); one launch for all of them.
     Returns [(top, argmax), ...]; pass `outs` (same structure) to reuse output tensors.  cold_maps: the maps are not
     cache-resident (mv3d_roi_pool_forward_views_cold: same results, prefetch workgroups in front of the launch).
-    want_argmax=False (inference): argmax_data = NULL, the entries are (top, None)."""
+    want_argmax=False (inference): argmax_data = NULL, the entries are (top, None).  top_dtype = torch.float16 / bfloat16 (inference,
+    want_argmax=False): `top` in that type (mv3d_roi_pool_forward_views_half: the values a cast of the f32 top gives)."""
+    half = top_dtype in (torch.float16, torch.bfloat16)
+    if half and want_argmax:
+        raise ValueError("16-bit tops are an inference output: want_argmax=False")
     arr = (RoiView * len(views))()
     res = []
     for k, (data, rois, scale) in enumerate(views):
@@ -320,10 +324,14 @@ def roi_pool_forward_views(views, pooled_height, pooled_width, outs=None, cold_m
         if outs is not None:
             top, am = outs[k]
         else:
-            top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.float32, device=data.device)
+            top = torch.empty((R, pooled_height, pooled_width, Cc), dtype=top_dtype if half else torch.float32, device=data.device)
             am = torch.empty((R, pooled_height, pooled_width, Cc), dtype=torch.int32, device=data.device) if want_argmax else None
         arr[k] = RoiView(data.data_ptr(), rois.data_ptr(), top.data_ptr(), am.data_ptr() if am is not None else None, float(scale), B, R, H, W, Cc)
         res.append((top, am))
+    if half:
+        check(lib().mv3d_roi_pool_forward_views_half(len(views), arr, pooled_height, pooled_width, 1 if top_dtype == torch.float16 else 2,
+                                                     1 if cold_maps else 0, _stream()), "mv3d_roi_pool_forward_views_half")
+        return res
     fn = lib().mv3d_roi_pool_forward_views_cold if cold_maps else lib().mv3d_roi_pool_forward_views
     check(fn(len(views), arr, pooled_height, pooled_width, _stream()), "mv3d_roi_pool_forward_views")
     return res

@@ -68,16 +68,19 @@ class RoiPoolViewsFunction(torch.autograd.Function):
         return tuple(ret)
 
 
-def roi_pool_views(views, pooled_height, pooled_width, spatial_scale):
-    """views: [(bottom_data NHWC device tensor, bottom_rois (R,5) device tensor), ...] -> [top, ...] (autograd-aware)."""
+def roi_pool_views(views, pooled_height, pooled_width, spatial_scale, top_dtype=None):
+    """views: [(bottom_data NHWC device tensor, bottom_rois (R,5) device tensor), ...] -> [top, ...] (autograd-aware).
+    top_dtype (inference only, torch.float16 / bfloat16, maps of 256 / 512 / 1024 channels): the pooled maps in that type -- what the
+    16-bit head would cast them to anyway -- written by the pooling launch itself."""
     flat = []
     for d, r in views:
         _check(d, r)
         flat += [d, r]
     if not (torch.is_grad_enabled() and any(d.requires_grad for d, _ in views)):
         # inference: no gradient will be asked for, so the argmax planes (as many bytes again as the pooled output) are not written
+        half = top_dtype if top_dtype in (torch.float16, torch.bfloat16) and all(d.shape[3] in (256, 512, 1024) for d, _ in views) else None
         res = ops.roi_pool_forward_views([(d.contiguous(), r.contiguous(), float(spatial_scale)) for d, r in views], int(pooled_height),
-                                         int(pooled_width), want_argmax=False)
+                                         int(pooled_width), want_argmax=False, top_dtype=half)
         return [top for top, _ in res]
     return list(RoiPoolViewsFunction.apply(int(pooled_height), int(pooled_width), float(spatial_scale), *flat))
 

@@ -218,3 +218,30 @@ def test_forward_views_without_argmax_is_the_same_top(gpu, oracle, R, cold):
         if R == 150:
             o_top, _ = oracle.roi_pool(m, r, 7, 7, 0.125)
             assert np.array_equal(b.view(np.uint32), o_top.view(np.uint32))
+
+
+@pytest.mark.parametrize("half", ["float16", "bfloat16"])
+@pytest.mark.parametrize("R,cold", [(150, False), (2000, True)])
+def test_forward_views_with_16_bit_tops(gpu, half, R, cold):
+    """mv3d_roi_pool_forward_views_half (the serving graph in 16-bit mode): the bits of the f32 `top` cast to that type, incl. NaN-free
+    maxima of NaN pixels, signed zeros and empty bins; argmax planes or other channel widths are refused"""
+    torch, ops = gpu
+    T = getattr(torch, half)
+    rs = np.random.RandomState(R + 1)
+    B = 2
+    maps = [rs.uniform(-3, 3, (B, 20, 31, 512)).astype(np.float32), rs.uniform(-1e-5, 1e5, (B, 9, 40, 512)).astype(np.float32)]
+    maps[0][0, 2:6, 3:9, ::2] = -0.0
+    maps[0][1, 5, 7, :9] = np.nan
+    rois = []
+    for m in maps:
+        h, w = m.shape[1] * 8, m.shape[2] * 8
+        x1, y1 = rs.randint(-30, w, R), rs.randint(-30, h, R)
+        rois.append(np.stack([rs.randint(0, B, R), x1, y1, x1 + rs.randint(0, w, R), y1 + rs.randint(0, h, R)], 1).astype(np.float32))
+    fv = [(dev(torch, m), dev(torch, r), 0.125) for m, r in zip(maps, rois)]
+    full = ops.roi_pool_forward_views(fv, 7, 7, cold_maps=cold, want_argmax=False)
+    got = ops.roi_pool_forward_views(fv, 7, 7, cold_maps=cold, want_argmax=False, top_dtype=T)
+    for (top, _), (top16, am) in zip(full, got):
+        assert am is None and top16.dtype == T
+        assert torch.equal(top.to(T).view(torch.int16), top16.view(torch.int16))
+    with pytest.raises(Exception):
+        ops.roi_pool_forward_views([(dev(torch, maps[0][..., :64].copy()), fv[0][1], 0.125)], 7, 7, want_argmax=False, top_dtype=T)
