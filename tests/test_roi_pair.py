@@ -145,6 +145,39 @@ def test_pair_huge_rois_ties_and_nan(gpu, oracle, no_ws):
     assert np.array_equal(bd.cpu().numpy(), oracle.roi_pool_grad(m, rois, o_am, g, 7, 7, 0.125))
 
 
+@WS
+@pytest.mark.parametrize("C", [256, 512])
+def test_pair_malformed_and_overhanging_rois(gpu, oracle, C, no_ws):
+    """The reference's backward lets a gradient through only inside the rounded ROI (roi_pooling_op.cc:401-404).  (a) A ROI whose end lies
+    before its start is pooled by the forward as a forced 1 x 1 region and gets NO gradient; (b) extents 57, 114, 121 (f32: 7 * (57 / 7) >
+    57): the last bin of the forward reaches one column / row past the ROI, what lands there is dropped; (c) a ROI of more than 2048 map
+    pixels (the tile kernel evaluates the reference's per-pixel expressions there).  Both RoiPoolGrad structures against the oracle."""
+    torch, ops = gpu
+    rs = np.random.RandomState(C)
+    B, H, W = 2, 70, 130
+    m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    # rising ramps along both axes: a bin's maximum sits in its LAST row / column, i.e. in the overhang when there is one
+    m += (np.arange(W, dtype=np.float32)[None, None, :, None] + np.arange(H, dtype=np.float32)[None, :, None, None]) * np.float32(4)
+    rois = [[0, 0, 0, 448, 100], [0, 100, 50, 40, 80], [1, 100, 50, 140, 20], [1, 40, 80, 30, 10],
+            [0, 8, 8, 8 + 113 * 8, 8 + 56 * 8], [1, 16, 0, 16 + 120 * 8, 456], [0, 0, 16, 500, 16 + 56 * 8], [1, 24, 24, 24 + 56 * 8, 24 + 56 * 8],
+            [0, -20000, -20000, 20000, 20000], [1, -100, -40000, 300, 40000]]
+    for _ in range(60):
+        x1, y1 = rs.randint(-40, W * 8), rs.randint(-40, H * 8)
+        rois.append([rs.randint(0, B), x1, y1, x1 + rs.choice([56 * 8, 113 * 8, 120 * 8, -30, 200]), y1 + rs.choice([56 * 8, -20, 90])])
+    rois = np.asarray(rois, np.float32)
+    d, r = dev(torch, m), dev(torch, rois)
+    res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
+    dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
+    o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
+    assert np.array_equal(res[0][0].cpu().numpy(), o_top) and np.array_equal(dec.cpu().numpy(), o_am)
+    # the case exists in this input: some argmax of ROI 0 names column 57 (past its end, 56)
+    assert ((o_am[0] // C) % W == 57).any()
+    g = rs.uniform(-1, 1, o_top.shape).astype(np.float32)
+    want = oracle.roi_pool_grad(m, rois, o_am, g, 7, 7, 0.125)
+    bd, = ops.roi_pool_backward_views_pair([(dev(torch, g), r, res[0][1], m.shape, 0.125)], 7, 7, workspace=False if no_ws else None)
+    assert np.array_equal(bd.cpu().numpy(), want)
+
+
 def test_autograd_views_function_uses_the_pair(gpu, oracle):
     torch, ops = gpu
     from mv3d_tf_amd.roi_pooling_layer.roi_pooling_op import roi_pool_views

@@ -47,6 +47,8 @@ def calls(bt, indexed):
                              bt.num_rois, H, W, Cc)
     ws = torch.zeros(L.mv3d_roi_pool_pair_workspace_bytes(3, bwd, 7, 7), dtype=torch.uint8, device=dev)
     wp, wn = C.c_void_p(ws.data_ptr()), ws.numel()
+    if os.environ.get("PAIR_NO_WS"):            # the one-launch tile RoiPoolGrad (what the path runs)
+        wp, wn = None, 0
     keep = (fwd, bwd, ws)
     if indexed:
         return (lambda: check(L.mv3d_roi_pool_forward_views_pair(3, fwd, 7, 7, 1, st), "fwd"),

@@ -42,7 +42,7 @@ cs = [mk(b) for b in bts]
 ws = torch.zeros(lib().mv3d_roi_pool_pair_workspace_bytes(3, cs[0][1], 7, 7), dtype=torch.uint8, device=dev)
 for fwd, arr in cs:
     check(lib().mv3d_roi_pool_forward_views_pair(3, fwd, 7, 7, 1, st), "fwd")
-bwd = lambda arr: check(lib().mv3d_roi_pool_backward_views_pair(3, arr, 7, 7, C.c_void_p(ws.data_ptr()), ws.numel(), st), "bwd")
+bwd = lambda arr: check(lib().mv3d_roi_pool_backward_views_pair(3, arr, 7, 7, None, 0, st), "bwd")
 for _ in range(2):
     for fwd, arr in cs:
         bwd(arr)
@@ -66,8 +66,14 @@ print("   last drain       :", q(t[:, 4] - t[:, 3]))
 print("   write-out        :", q(t[:, 5] - t[:, 4]))
 print("   whole wave       :", q(t[:, 5] - t[:, 0]))
 print("   end - t0         :", q(t[:, 5] - t0))
+t_issue = t[:, 6] >> 32
+t[:, 6] &= 0xffffffff
 print("   ring entries     :", q(t[:, 6]), " total", t[:, 6].sum())
 ne = t[t[:, 6] > 0]
+hot = np.argsort(-t[:, 6])[:12]
+print("the 12 fullest waves: entries, start, expand + drains, of which waiting for loads / requesting / adding (steady-state pumps), last drain")
+for i in hot:
+    print("   %4d  start %5d  exp+drain %5d  wait %5d  issue %5d  add %5d  last %4d" % (t[i, 6], t[i, 0] - t0, t[i, 3] - t[i, 1], t[i, 2], t_issue[i], t[i, 7], t[i, 4] - t[i, 3]))
 print("waves with entries: %d" % len(ne))
 print("   expand + drains  :", q(ne[:, 3] - ne[:, 1]))
 print("   last drain       :", q(ne[:, 4] - ne[:, 3]))
