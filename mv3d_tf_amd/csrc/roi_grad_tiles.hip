@@ -13,15 +13,17 @@
 //               containment test (roi_pooling_op.cc:401-404) although the forward pools a forced 1 x 1 region for it: dropped here;
 //   expansion   per surviving ROI lane = bin (ph, pw) computes the bin's rectangle exactly as the forward does, cut to the rounded ROI
 //               (f32: 7 * (57 / 7) > 57, so the last bin of a 57-wide ROI reaches one column past the ROI's end; the forward pools
-//               that column, the reference's backward drops what lands there -- same test, :401-404); bins that meet the tile are
-//               appended (ballot order = the reference's ph, pw order) to a 128-entry LDS ring of 8-byte entries
-//               {record byte offset | first pixel of (rectangle x tile) | its extent, code of that pixel | bin width};
+//               that column, the reference's backward drops what lands there -- same test, :401-404); per ROW of the tile the bins whose
+//               rectangle meets it are appended (ballot order = the reference's ph, pw order; a pixel only ever sees the bins of its own
+//               row, so row-major emission keeps every pixel's order) to a 128-entry LDS ring of 8-byte entries
+//               {record byte offset | first pixel of the row segment | its length - 1, code of that pixel};
 //   drain       a software pipeline over GROUPS of eight entries: a group's 8 code bytes + 8 top_diff slices are requested into one of
 //               FOUR register sets by inline-asm buffer loads (record offset = scalar offset; the compiler never sees a load it would
 //               wait for), three groups stay in flight across the expansion code while the fourth is added: `s_waitcnt vmcnt(32)`
-//               retires exactly the oldest group.  Per record and lane  code -> pixel of the tile  (a subtract and a compare per row
-//               of (rectangle x tile): one row for most bins) = the f32 accumulator [pixel][channel] in LDS, or a junk slot when the
-//               code names a pixel of another tile / no pixel (lane = channel: lanes never collide); read-add-write in record
+//               retires exactly the oldest group.  Per entry and lane  code -> pixel of the segment  (a subtract and a compare,
+//               branch-free) = the f32 accumulator [pixel][channel] in LDS, or a junk slot when the code names a pixel outside
+//               the segment / no pixel (lane = channel: lanes never collide); the stream is padded with null entries to whole
+//               groups; read-add-write in record
 //               order, four records per LDS round trip with the sums forwarded between records that hit the same accumulator.
 //               ROIs ascending, then ph, pw: the reference's f32 summation order, bit-identical to the per-pixel gather (a sum
 //               starts at +0 and only ever adds what the reference adds);
@@ -124,63 +126,49 @@ __device__ __forceinline__ void rgt_add4(float *acc, const int a[4], const float
     acc[a[0]] = s0; acc[a[1]] = s1; acc[a[2]] = s2; acc[a[3]] = s3;
 }
 
-// The tile pixel (slot; RGT_MAXPX = none of this tile) a value with code c of one record goes to.  Entry words: x = record offset |
-// slot of the first pixel of (rectangle x tile) [3:0] | rows - 1 [5:4] | columns - 1 [7:6] | big [8], y = code of that pixel | bin
-// width << 8 (16-bit fields for a big bin).  A code c names pixel (dh, dw) of (rectangle x tile) iff c - code0 - dh * bw = dw <= columns - 1.
-__device__ __forceinline__ int rgt_target(const int x, const int y, const int c, const int tws, const bool big, const bool live)
+// The tile pixel (slot; RGT_MAXPX = none of this tile) a value with code c goes to under one entry = one row segment of (rectangle x
+// tile).  Entry words: x = record byte offset | slot of the segment's first pixel [3:0] | pixels - 1 [5:4] | big [8], y = code of that
+// pixel.  A code c names pixel d of the segment iff c - code0 = d <= pixels - 1.  The null entry (x = 0, y = RGT_NULLCODE) names none.
+#define RGT_NULLCODE 0x1ffff
+__device__ __forceinline__ int rgt_target(const int x, const int y, const int c)
 {
-    const int slot0 = x & 15, nh = (x >> 4) & 3, nw = (x >> 6) & 3;
-    const int code0 = big ? (y & 0xffff) : (y & 0xff), bw = big ? (int)((unsigned)y >> 16) : ((y >> 8) & 0xff);
-    int slot = RGT_MAXPX;
-    const int d = c - code0;
-    if (live) {
-        slot = (unsigned)d <= (unsigned)nw ? slot0 + d : slot;
-        for (int dh = 1; dh <= nh; ++dh) {                             // (wave-uniform; most rectangles meet the tile in one row)
-            const int dr = d - dh * bw;
-            slot = (unsigned)dr <= (unsigned)nw ? slot0 + (dh << tws) + dr : slot;
-        }
-    }
-    return slot;
+    const int d = c - y;
+    return (unsigned)d <= (unsigned)((x >> 4) & 3) ? (x & 15) + d : RGT_MAXPX;
 }
 
 // entries with bins of more than 255 pixels among them (ROIs far larger than the map: rare): entry by entry, each from its own
 // plane, in the same order (compiler-tracked loads: their wait also retires every group in flight)
-__device__ __forceinline__ void rgt_drain_mixed(float *acc, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
-                                                const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt, const int lane, const int tws)
+__device__ __forceinline__ void rgt_drain_mixed(float *acc, const int2 e, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rc16,
+                                                const __amdgpu_buffer_rsrc_t rt, const int lane)
 {
-    for (int u = 0; u < m; ++u) {
+    for (int u = 0; u < RGT_G; ++u) {
         const int x = __builtin_amdgcn_readlane(e.x, u), y = __builtin_amdgcn_readlane(e.y, u);
         const int so = x & ~1023;
-        const bool big = (x & RGT_BIGBIT) != 0;
         const float td = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, lane * 4, so, 0));
-        const int c = big ? (int)__builtin_amdgcn_raw_buffer_load_b16(rc16, lane * 2, so >> 1, 0)
-                          : (int)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, so >> 2, 0);
-        const int a = rgt_target(x, y, c, tws, big, true) * 64 + lane;
+        const int c = (x & RGT_BIGBIT) ? (int)__builtin_amdgcn_raw_buffer_load_b16(rc16, lane * 2, so >> 1, 0)
+                                       : (int)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, so >> 2, 0);
+        const int a = rgt_target(x, y, c) * 64 + lane;
         acc[a] = acc[a] + td;
     }
 }
 
-// the m <= 8 live records of a landed group (entries e: entry u in lane u), in order
-__device__ __forceinline__ void rgt_consume(float *acc, const float td[RGT_G], const unsigned cd[RGT_G], const int2 e, const int m,
+// the eight entries of a landed group (entry u in lane u of e), in order
+__device__ __forceinline__ void rgt_consume(float *acc, const float td[RGT_G], const unsigned cd[RGT_G], const int2 e,
                                             const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt,
-                                            const int lane, const int tws)
+                                            const int lane)
 {
-    if (__ballot((e.x & RGT_BIGBIT) != 0 && lane < m) != 0ull) { rgt_drain_mixed(acc, e, m, rc, rc16, rt, lane, tws); return; }
+    if (__ballot((e.x & RGT_BIGBIT) != 0) != 0ull) { rgt_drain_mixed(acc, e, rc, rc16, rt, lane); return; }
 #pragma unroll
     for (int g = 0; g < RGT_G; g += 4) {
-        if (g < m) {
-            int a[4];
-            float v[4];
+        int a[4];
+        float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int u = g + j;
-                const int x = __builtin_amdgcn_readlane(e.x, u), y = __builtin_amdgcn_readlane(e.y, u);
-                const int c = (int)cd[u];
-                a[j] = rgt_target(x, y, c, tws, false, u < m) * 64 + lane;
-                v[j] = td[u];
-            }
-            rgt_add4(acc, a, v);
+        for (int j = 0; j < 4; ++j) {
+            const int u = g + j;
+            a[j] = rgt_target(__builtin_amdgcn_readlane(e.x, u), __builtin_amdgcn_readlane(e.y, u), (int)cd[u]) * 64 + lane;
+            v[j] = td[u];
         }
+        rgt_add4(acc, a, v);
     }
 }
 
@@ -188,7 +176,7 @@ __device__ __forceinline__ void rgt_consume(float *acc, const float td[RGT_G], c
 // ceil((x - start + 1) / bin), both clamped to [0, P]; an interval (the bounds grow with x).  Only for ROIs beyond RGT_EXACT_MAX.
 __device__ __forceinline__ int2 rgt_exact_span(const int lo, const int hi, const int start, const float bin, const int P, const int p)
 {
-    int a = hi + 1, b = lo - 1;
+    int a = INT_MAX, b = INT_MIN;                                      // (an empty [lo, hi] stays empty)
     for (int x = lo; x <= hi; ++x) {
         const int s = min(max((int)floorf((float)(x - start) / bin), 0), P), e = min(max((int)ceilf((float)(x - start + 1) / bin), 0), P);
         if (s <= p && p < e) { a = min(a, x); b = max(b, x); }
@@ -200,6 +188,8 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
 {
     __shared__ float acc[(RGT_MAXPX + 1) * 64];                              // the tile's accumulators [pixel][channel] + one junk row
     __shared__ int2 ring[RGT_RING];
+    __shared__ int4 geo[256];                                          // rounded geometry of the ROIs that reach the tile (of 256 rows)
+    __shared__ unsigned char ridx[256];                                // ... and their row numbers
     const int lane = threadIdx.x, lane4 = lane * 4;
     int k = 0;
 #pragma unroll
@@ -227,21 +217,20 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
     const rgt_v4i qc = rgt_rsrc(base_c), qt = rgt_rsrc(base_t);
     // ---- the drain pipeline: register sets 0..3 as a queue of groups in flight (oldest = set qh, nq of them).  Ring positions
     // (wave-uniform): done <= head <= tail -- entries before `done` are added, before `head` requested (a group's entries stay in the ring
-    // until it is added: <= 24 in flight + < 8 waiting + <= 64 appended at once <= RGT_RING); mq = live records of set i in bits [4 i + 3 : 4 i]
+    // until it is added: <= 24 in flight + < 8 waiting + <= 64 appended at once <= RGT_RING)
     int done = 0, head = 0, tail = 0;
-    int nq = 0, qh = 0, mq = 0;
+    int nq = 0, qh = 0;
     long long t_wait = 0, t_cons = 0, t_issue = 0;                     // experiment builds: ticks inside the pump's phases
-    // request the next m <= 8 entries of the ring as a group; with three groups in flight the oldest one is retired: waited for, the
+    // request the next eight entries of the ring as a group; with three groups in flight the oldest one is retired: waited for, the
     // new group requested, then added -- its adds run under the flight of the three younger groups
-    auto pump = [&](const int m) __attribute__((always_inline)) {
+    auto pump = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (ring entries written by other lanes of this wave)
         __builtin_amdgcn_wave_barrier();
-        const int2 en = ring[(head + min(lane, m - 1)) & (RGT_RING - 1)];
-        head += m;
+        const int2 en = ring[(head + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
+        head += RGT_G;
         if (nq == 3) {
-            const int mo = (mq >> (4 * qh)) & 15;
-            const int2 eo = ring[(done + min(lane, mo - 1)) & (RGT_RING - 1)];
-            done += mo;
+            const int2 eo = ring[(done + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
+            done += RGT_G;
             float td[RGT_G];
             unsigned cd[RGT_G];
             long long c0 = 0, c1 = 0;
@@ -253,10 +242,8 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
             default: RGT_LAND(32, RGT_SET3); RGT_ISSUE(RGT_SET2) break;
             }
             if (RGT_DBG(1, 1) && p.trace) c0 = (long long)wall_clock64();
-            rgt_consume(acc, td, cd, eo, mo, rc, rc16, rt, lane, tws);
+            rgt_consume(acc, td, cd, eo, rc, rc16, rt, lane);
             if (RGT_DBG(1, 1) && p.trace) { __builtin_amdgcn_s_waitcnt(0xc07f); t_cons += (long long)wall_clock64() - c0; t_issue += c0 - c1; }
-            const int ns = (qh + 3) & 3;
-            mq = (mq & ~(15 << (4 * ns))) | (m << (4 * ns));
             qh = (qh + 1) & 3;
         } else {                                                       // filling the queue: qh == 0, the new group goes to set nq
             switch (nq) {
@@ -264,7 +251,6 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
             case 1: RGT_ISSUE(RGT_SET1) break;
             default: RGT_ISSUE(RGT_SET2) break;
             }
-            mq |= m << (4 * nq);
             ++nq;
         }
     };
@@ -280,33 +266,40 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         if (base == 0) {                                               // (under the ROI rows' latency) the accumulators start at +0
             for (int i = lane; i < (RGT_MAXPX + 1) * 16; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-#pragma unroll 1
+        // ---- filter: ROI against the tile; the survivors' rounded geometry compacted (ascending) into LDS -- the expansion below keeps no
+        // per-ROI register
+        int nhit = 0;
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int roi0 = base + 64 * q;
-            if (roi0 >= R) break;
-            // ---- filter: ROI roi0 + lane against the tile
-            float r5[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) r5[u] = q == 0 ? rr[0][u] : (q == 1 ? rr[1][u] : (q == 2 ? rr[2][u] : rr[3][u]));
-            const RoiGeom g = roi_geom(r5, v.scale);
+            const RoiGeom g = roi_geom(rr[q], v.scale);
             const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);   // roi_pooling_op.cc:146-147
             // conservative bounding box of the ROI's bins (every bin's rows lie in [rsh, rsh + rh + 1]); coordinates outside the
             // range where that arithmetic is exact (NaN / inf / absurd boxes) are left to the exact per-bin test of the expansion
             const bool sane = abs(g.rsw) < (1 << 24) && abs(g.rsh) < (1 << 24) && abs(g.rew) < (1 << 24) && abs(g.reh) < (1 << 24);
             // (:401-404: h in [rsh, reh], w in [rsw, rew] -- an end before its start lets nothing through)
-            bool hit = roi0 + lane < R && (int)r5[0] == b && g.reh >= g.rsh && g.rew >= g.rsw;
+            bool hit = roi0 + lane < R && (int)rr[q][0] == b && g.reh >= g.rsh && g.rew >= g.rsw;
             if (sane) hit = hit && g.rsh < th1 && g.rsh + rh + 2 > th0 && g.rsw < tw1 && g.rsw + rw + 2 > tw0;
-            if (RGT_DBG(p.dbg, 8)) hit = false;
-            unsigned long long todo = __ballot(hit);
-            if (base == 0 && q == 0) RGT_STAMP(1);
-            if (RGT_DBG(p.dbg, 1)) todo = 0ull;
-            // ---- expansion + drain
-            while (todo != 0ull) {
-                const int j = (int)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const int r = roi0 + j, rsh = __builtin_amdgcn_readlane(g.rsh, j), rsw = __builtin_amdgcn_readlane(g.rsw, j);
-                const int reh = __builtin_amdgcn_readlane(g.reh, j), rew = __builtin_amdgcn_readlane(g.rew, j);
-                const int rhj = __builtin_amdgcn_readlane(rh, j), rwj = __builtin_amdgcn_readlane(rw, j);
+            if (RGT_DBG(p.dbg, 8 | 1)) hit = false;
+            const unsigned long long mh = __ballot(hit);
+            if (hit) {
+                const int pos = nhit + __popcll(mh & ((1ull << lane) - 1ull));
+                geo[pos] = make_int4(g.rsh, g.rsw, g.reh, g.rew);
+                ridx[pos] = (unsigned char)(64 * q + lane);
+            }
+            nhit += __popcll(mh);
+        }
+        if (base == 0) RGT_STAMP(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- expansion + drain
+        {
+            for (int i = 0; i < nhit; ++i) {
+                const int4 gg = geo[i];
+                const int r = base + (int)ridx[i];
+                const int rsh = __builtin_amdgcn_readfirstlane(gg.x), rsw = __builtin_amdgcn_readfirstlane(gg.y);
+                const int reh = __builtin_amdgcn_readfirstlane(gg.z), rew = __builtin_amdgcn_readfirstlane(gg.w);
+                const int rhj = reh - rsh + 1, rwj = rew - rsw + 1;    // (>= 1: the filter drops the others)
                 const float bh = (float)rhj / (float)PH;               // roi_pooling_op.cc:148-151 (only for hits)
                 const float bw = (float)rwj / (float)PW;
                 const bool exact = rhj > RGT_EXACT_MAX || rwj > RGT_EXACT_MAX;
@@ -325,21 +318,20 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
                         ih0 = sh.x; ih1 = sh.y; iw0 = sw.x; iw1 = sw.y;
                     }
                     const bool meets = bin < PHW && he > hs && we > ws && ih1 >= ih0 && iw1 >= iw0;
-                    const unsigned long long mb = __ballot(meets);
-                    if (mb == 0ull) continue;
-                    if (meets) {
-                        const int bwid = we - ws;
-                        const bool big = (he - hs) * bwid > 255;
-                        const int code0 = (ih0 - hs) * bwid + (iw0 - ws);
-                        int2 e;
-                        e.x = (((r * PHW + bin) * C) * 4) | (((ih0 - th0) << tws) + (iw0 - tw0)) | ((ih1 - ih0) << 4) | ((iw1 - iw0) << 6) |
-                              (big ? RGT_BIGBIT : 0);
-                        e.y = big ? (code0 | (bwid << 16)) : (code0 | (bwid << 8));
-                        ring[(tail + __popcll(mb & ((1ull << lane) - 1ull))) & (RGT_RING - 1)] = e;
+                    if (__ballot(meets) == 0ull) continue;
+                    const int bwid = we - ws;
+                    const int ex = (((r * PHW + bin) * C) * 4) | (iw0 - tw0) | ((iw1 - iw0) << 4) | ((he - hs) * bwid > 255 ? RGT_BIGBIT : 0);
+                    const int ey = (iw0 - ws) - hs * bwid;
+                    // ---- one entry per row of the tile a bin's rectangle meets, rows outermost
+                    for (int h = th0; h < th1; ++h) {
+                        const bool on = meets && ih0 <= h && h <= ih1;
+                        const unsigned long long mr = __ballot(on);
+                        if (mr == 0ull) continue;
+                        if (on) ring[(tail + __popcll(mr & ((1ull << lane) - 1ull))) & (RGT_RING - 1)] = make_int2(ex + ((h - th0) << tws), ey + h * bwid);
+                        tail += __popcll(mr);
+                        if (RGT_DBG(p.dbg, 2)) { done = head = tail; continue; }
+                        while (tail - head >= RGT_G) pump();
                     }
-                    tail += __popcll(mb);
-                    if (RGT_DBG(p.dbg, 2)) { done = head = tail; continue; }
-                    while (tail - head >= RGT_G) pump(RGT_G);
                 }
             }
         }
@@ -349,12 +341,17 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         p.trace[(long long)blockIdx.x * 8 + 6] = tail | (t_issue << 32);
         p.trace[(long long)blockIdx.x * 8 + 2] = t_wait; p.trace[(long long)blockIdx.x * 8 + 7] = t_cons;
     }
-    if (tail > head) pump(tail - head);
+    // ---- the stream padded to whole groups with null entries (no pixel, a cached record), the last group requested
+    if (tail > head) {
+        if (lane < RGT_G) ring[(tail + lane) & (RGT_RING - 1)] = make_int2(0, RGT_NULLCODE);     // (lanes past the pad write slots nobody reads)
+        tail = (tail + RGT_G - 1) & ~(RGT_G - 1);
+        // (positions: head and done only ever move by whole groups, so head is a multiple of eight here)
+        pump();
+    }
     // ---- the groups still in flight, oldest first (nothing is requested any more: one full wait)
     for (; nq > 0; --nq, qh = (qh + 1) & 3) {
-        const int mo = (mq >> (4 * qh)) & 15;
-        const int2 eo = ring[(done + min(lane, mo - 1)) & (RGT_RING - 1)];
-        done += mo;
+        const int2 eo = ring[(done + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
+        done += RGT_G;
         float td[RGT_G];
         unsigned cd[RGT_G];
         switch (qh) {
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         case 2: RGT_LAND(0, RGT_SET2); break;
         default: RGT_LAND(0, RGT_SET3); break;
         }
-        rgt_consume(acc, td, cd, eo, mo, rc, rc16, rt, lane, tws);
+        rgt_consume(acc, td, cd, eo, rc, rc16, rt, lane);
     }
     RGT_STAMP(4);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // (the accumulators: written per channel lane, read 16 B per lane)

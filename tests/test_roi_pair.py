@@ -166,6 +166,10 @@ def test_pair_malformed_and_overhanging_rois(gpu, oracle, C, no_ws):
         rois.append([rs.randint(0, B), x1, y1, x1 + rs.choice([56 * 8, 113 * 8, 120 * 8, -30, 200]), y1 + rs.choice([56 * 8, -20, 90])])
     rois = np.asarray(rois, np.float32)
     d, r = dev(torch, m), dev(torch, rois)
+    # (the pair's planes land on garbage, not on a fresh zero page: a big bin leaves its one-byte codes unwritten, a small one its 16-bit
+    # codes -- a kernel that reads the wrong one must not get away with it)
+    junk = torch.randint(0, 255, (192 << 20,), dtype=torch.uint8, device="cuda")
+    del junk
     res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
     dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
     o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)

@@ -25,7 +25,7 @@ for recipe in "$@"; do
              echo "-- no workspace (tiles)"; env ${PROBE_ENV:-} PAIR_ONLY=1 PAIR_NO_WS=1 timeout 300 python tools/roi_pair_probe.py 2>&1 | grep "pair \|differ\|rror" | tail -1
            done 2>&1 | tee $OUT/probe.txt ;;
     trace) timeout 300 python tools/roi_tiles_trace.py --lib $TUN 2>&1 | grep -v amdgpu.ids | tee $OUT/trace.txt ;;
-    ablate) for d in 0 8 1 2; do echo "-- MV3D_RGT_DBG=$d"; MV3D_RGT_DBG=$d MV3D_IDX_DBG=1 PAIR_ONLY=1 PAIR_NO_WS=1 NB=8 ROUNDS=4 timeout 300 python tools/roi_pair_probe.py --lib $TUN 2>&1 | grep "pair \|rror" | tail -1; done 2>&1 | tee $OUT/ablate.txt ;;
+    ablate) for d in 0 8 2; do echo "-- MV3D_RGT_DBG=$d"; MV3D_RGT_DBG=$d MV3D_IDX_DBG=1 PAIR_ONLY=1 PAIR_NO_WS=1 NB=8 ROUNDS=4 timeout 300 python tools/roi_pair_probe.py --lib $TUN 2>&1 | grep "pair \|rror" | tail -1; done 2>&1 | tee $OUT/ablate.txt ;;
     bench) timeout 1800 python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json; tail -2 $OUT/bench.err ;;
     bench_path) for r in 1 2 3; do timeout 600 python bench.py --steps 10 --warmup 2 --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline'].get('avg_launch_us'), d['roofline'].get('in_flight'), [k.get('avg_launch_us') for k in d.get('roofline_kernels', [])], d.get('verified'))"; done 2>&1 | tee $OUT/bench_path.txt ;;
     stats) tools/gpu_profile.sh $TAG/ks --steps 4 --warmup 1 --batches-per-step 64 --no-cpu-baseline --no-secondary > /dev/null 2>&1

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Small RoiPoolGrad cases against the oracle with a mismatch report (which channels / pixels differ)."""
+"""The one-launch RoiPoolGrad (pair without a workspace) against the oracle on the malformed / overhanging / huge ROI case of
+tests/test_roi_pair.py, with a mismatch report: differing pixels, and which single ROIs reproduce a difference."""
 import os
 import sys
 
@@ -7,49 +8,50 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from mv3d_tf_amd import build, ops, synth
+from mv3d_tf_amd import build, ops
 from oracle import oracle
 
 build.build()
-for (B, H, W, C, R, seed) in ((1, 9, 11, 64, 6, 1), (2, 13, 17, 64, 40, 2), (2, 20, 31, 128, 90, 3), (2, 24, 24, 512, 128, 4), (1, 9, 11, 64, 300, 5), (2, 12, 12, 64, 700, 6), (1, 40, 40, 256, 256, 7)):
-    rng = np.random.RandomState(seed)
-    data = synth.feature_map(seed, H, W, C, B)
-    x1 = rng.uniform(-8, W * 8 - 8, R); y1 = rng.uniform(-8, H * 8 - 8, R)
-    rois = np.stack([rng.randint(0, B, R).astype(np.float64), x1, y1, x1 + rng.uniform(0, 60, R), y1 + rng.uniform(0, 60, R)], 1).astype(np.float32)
-    top, am = oracle.roi_pool(data, rois, 7, 7, 0.125)
-    grad = rng.uniform(-1, 1, top.shape).astype(np.float32)
-    want = oracle.roi_pool_grad(data, rois, am, grad, 7, 7, 0.125)
-    got = ops.roi_pool_backward_views([(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), tuple(data.shape), 0.125)], 7, 7)[0].cpu().numpy()   # (the workspace path)
-    bad = np.argwhere(got != want)
-    print("case B%d H%d W%d C%d R%d: %d of %d elements differ" % (B, H, W, C, R, len(bad), want.size))
-    if len(bad):
-        ch = bad[:, 3]
-        print("   channels even/odd: %d / %d ; lower half (c%%64<32) %d ; first: %s" % ((ch % 2 == 0).sum(), (ch % 2 == 1).sum(), ((ch % 64) < 32).sum(), bad[:6].tolist()))
-        for b in bad[:6]:
-            print("   got %r want %r" % (got[tuple(b)], want[tuple(b)]))
-        nz = (want != 0)
-        print("   want nonzero %d, got nonzero %d, got==0 where want!=0: %d" % (nz.sum(), (got != 0).sum(), ((got == 0) & nz).sum()))
+C = int(os.environ.get("C", "256"))
+rs = np.random.RandomState(C)
+B, H, W = 2, 70, 130
+m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+m += (np.arange(W, dtype=np.float32)[None, None, :, None] + np.arange(H, dtype=np.float32)[None, :, None, None]) * np.float32(4)
+rois = [[0, 0, 0, 448, 100], [0, 100, 50, 40, 80], [1, 100, 50, 140, 20], [1, 40, 80, 30, 10],
+        [0, 8, 8, 8 + 113 * 8, 8 + 56 * 8], [1, 16, 0, 16 + 120 * 8, 456], [0, 0, 16, 500, 16 + 56 * 8], [1, 24, 24, 24 + 56 * 8, 24 + 56 * 8],
+        [0, -20000, -20000, 20000, 20000], [1, -100, -40000, 300, 40000]]
+for _ in range(60):
+    x1, y1 = rs.randint(-40, W * 8), rs.randint(-40, H * 8)
+    rois.append([rs.randint(0, B), x1, y1, x1 + rs.choice([56 * 8, 113 * 8, 120 * 8, -30, 200]), y1 + rs.choice([56 * 8, -20, 90])])
+rois = np.asarray(rois, np.float32)
+G_TEST = rs.uniform(-1, 1, (len(rois), 7, 7, C)).astype(np.float32)          # the test's top_diff (same generator position)
+dev = lambda a: torch.as_tensor(a).cuda()
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import test_roipool_pin as trp
-for name in ("roipool_bev_C512", "roipool_rgb_C512"):
-    g, data, rois, grad = trp.load_case(name)
-    top, am = oracle.roi_pool(data, rois, 7, 7, 0.125)
-    want = oracle.roi_pool_grad(data, rois, am, grad, 7, 7, 0.125)
-    got = ops.roi_pool_backward_views([(torch.as_tensor(grad).cuda(), torch.as_tensor(rois).cuda(), torch.as_tensor(am).cuda(), tuple(data.shape), 0.125)], 7, 7)[0].cpu().numpy()   # (the workspace path)
-    bad = np.argwhere(got != want)
-    print(name, data.shape, rois.shape, "differ:", len(bad), "nan in want", np.isnan(want).sum(), "nan in got", np.isnan(got).sum())
-    if len(bad):
-        px = np.unique(bad[:, :3], axis=0)
-        print("   pixels with differences:", len(px), px[:10].tolist())
-        for b in bad[:6]:
-            print("   at %s got %r want %r" % (b.tolist(), got[tuple(b)], want[tuple(b)]))
+
+def run(sel):
+    r = rois[sel]
+    d, rr = dev(m), dev(r)
+    res = ops.roi_pool_forward_views_pair([(d, rr, 0.125)], 7, 7)
+    o_top, o_am = oracle.roi_pool(m, r, 7, 7, 0.125)
+    g = G_TEST[sel] if os.environ.get("G_TEST", "1") == "1" else np.random.RandomState(1).uniform(-1, 1, o_top.shape).astype(np.float32)
+    want = oracle.roi_pool_grad(m, r, o_am, g, 7, 7, 0.125)
+    got = ops.roi_pool_backward_views_pair([(dev(g), rr, res[0][1], m.shape, 0.125)], 7, 7, workspace=False)[0].cpu().numpy()
+    return got, want
+
+
+got, want = run(np.arange(len(rois)))
+bad = np.argwhere(got != want)
+print("all ROIs: %d of %d elements differ" % (len(bad), want.size))
+if len(bad):
+    px = np.unique(bad[:, :3], axis=0)
+    print("   pixels:", len(px), px[:12].tolist(), "channels:", np.unique(bad[:, 3])[:16].tolist())
+    for b in bad[:4]:
+        print("   at %s got %r want %r" % (b.tolist(), got[tuple(b)], want[tuple(b)]))
+for i in range(len(rois)):
+    got, want = run(np.array([i]))
+    n = int((got != want).sum())
+    if n:
+        bad = np.argwhere(got != want)
+        print("ROI %d %s alone: %d differ, pixels %s" % (i, rois[i].tolist(), n, np.unique(bad[:, :3], axis=0)[:8].tolist()))
         b = bad[0]
-        n, h, w, c = b
-        cand = []
-        for r, roi in enumerate(rois):
-            for ph in range(7):
-                for pw in range(7):
-                    if am[r, ph, pw, c] == (h * data.shape[2] + w) * data.shape[3] + c and int(roi[0]) == n:
-                        cand.append((r, ph, pw, float(grad[r, ph, pw, c])))
-        print("   contributions to the first bad element:", cand)
+        print("   at %s got %r want %r" % (b.tolist(), got[tuple(b)], want[tuple(b)]))
