@@ -13,29 +13,29 @@
 //               containment test (roi_pooling_op.cc:401-404) although the forward pools a forced 1 x 1 region for it: dropped here;
 //   expansion   per surviving ROI lane = bin (ph, pw) computes the bin's rectangle exactly as the forward does, cut to the rounded ROI
 //               (f32: 7 * (57 / 7) > 57, so the last bin of a 57-wide ROI reaches one column past the ROI's end; the forward pools
-//               that column, the reference's backward drops what lands there -- same test, :401-404); per ROW of the tile the bins whose
-//               rectangle meets it are appended (ballot order = the reference's ph, pw order; a pixel only ever sees the bins of its own
-//               row, so row-major emission keeps every pixel's order) to a 128-entry LDS ring of 8-byte entries
+//               that column, the reference's backward drops what lands there -- same test, :401-404); per ROW of the tile the bins
+//               whose rectangle meets it are appended (ballot order = the reference's ph, pw order; a pixel only ever sees the bins of
+//               its own row, so row-major emission keeps every pixel's order) to a 256-entry LDS ring of 8-byte entries
 //               {record byte offset | first pixel of the row segment | its length - 1, code of that pixel};
-//   drain       a software pipeline over GROUPS of eight entries: a group's 8 code bytes + 8 top_diff slices are requested into one of
-//               FOUR register sets by inline-asm buffer loads (record offset = scalar offset; the compiler never sees a load it would
-//               wait for), three groups stay in flight across the expansion code while the fourth is added: `s_waitcnt vmcnt(32)`
-//               retires exactly the oldest group.  Per entry and lane  code -> pixel of the segment  (a subtract and a compare,
-//               branch-free) = the f32 accumulator [pixel][channel] in LDS, or a junk slot when the code names a pixel outside
-//               the segment / no pixel (lane = channel: lanes never collide); the stream is padded with null entries to whole
-//               groups; read-add-write in record
-//               order, four records per LDS round trip with the sums forwarded between records that hit the same accumulator.
+//   drain       W entries at a time, all their code bytes + top_diff slices requested at once (record offset = scalar offset of
+//               the buffer loads); per entry and lane  code -> pixel of the segment  (a subtract and a compare, branch-free) = the
+//               f32 accumulator [pixel][channel] in LDS, or a junk slot when the code names a pixel outside the segment / no
+//               pixel (lane = channel: lanes never collide); read-add-write in entry
+//               order, four entries per LDS round trip with the sums forwarded between entries that hit the same accumulator.
 //               ROIs ascending, then ph, pw: the reference's f32 summation order, bit-identical to the per-pixel gather (a sum
 //               starts at +0 and only ever adds what the reference adds);
 //   write-out   the tile's accumulators, zeros included: every pixel of bottom_diff is written exactly once -- no fill launch,
 //               no workspace, no index.
 // The reference's backward additionally asks ph in [phstart(h), phend(h)) (:423-431, f32 divides).  For every pooled size <= 15 and
 // every ROI extent <= RGT_EXACT_MAX that range contains all bins whose forward rectangle holds the pixel
-// (tests/test_roi_pair.py::test_forward_rectangles_inside_backward_ranges, exhaustive), so inside the rounded ROI the code alone decides;
-// larger ROIs evaluate the reference's expressions per pixel (rgt_exact_span).
-// (Earlier versions, git history / profiles/EXPERIMENTS.md R5.10: a strip of four tiles per 256-thread workgroup with a shared filter, 88 us;
-// accumulators in registers indexed by the wave-uniform pixel, 119 us; every group's loads waited for before its adds (16 at a time),
-// 66 us: a tile under 430 records was a chain of 27 exposed round trips.)
+// (tests/test_roi_geometry.py, exhaustive), so inside the rounded ROI the code alone decides; larger ROIs evaluate the reference's
+// expressions per pixel (rgt_exact_span).
+// (Other structures, measured and dropped, sources under tools/experiments/: a strip of four tiles per 256-thread workgroup with a
+// shared filter, 88 us; accumulators in registers indexed by the wave-uniform pixel, 119 us (profiles/r05_ad, r05_af); round 6: every
+// load pipelined through accumulation-register sets, three groups in flight across the expansion code -- the loads were never the
+// limit, a record costs ~140 ns of ONE wave's instruction stream with or without them (profiles/r06_a, r06_b); four waves sharing
+// the draining of four tiles through tickets and an in-order add token -- the token's critical section is as slow as the adds it
+// orders, 121 - 172 us (profiles/r06_c, r06_d).)
 #include "common.h"
 #include "kernels.h"
 #include "roi_geom.h"
@@ -43,9 +43,8 @@
 #include <stdlib.h>
 
 #define RGT_MAXPX 16
-#define RGT_RING 128
+#define RGT_RING 256                 // ring entries: a chunk of bins appends <= 240 (60 bins x 4 rows | 64 x 2), < 16 are left over from the last drain
 #define RGT_BIGBIT 0x100             // entry word 0: the bin has more than 255 pixels (16-bit codes in the escape plane)
-#define RGT_G 8                      // records per group = per register set
 #define RGT_EXACT_MAX 2048           // ROI extents (map pixels) up to which "forward rectangle inside backward range" is proven exhaustively
 
 struct RgtView {
@@ -72,49 +71,6 @@ struct RgtPack {
 #endif
 #define RGT_STAMP(i) do { if (RGT_DBG(1, 1) && p.trace && lane == 0) p.trace[(long long)blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
 
-typedef int rgt_v4i __attribute__((ext_vector_type(4)));
-// raw buffer resource over the whole address space above `p` (what __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000) builds),
-// as four plain words an inline-asm "s" operand takes
-__device__ __forceinline__ rgt_v4i rgt_rsrc(const void *p)
-{
-    const unsigned long long a = (unsigned long long)p;
-    const rgt_v4i r = {(int)(unsigned)a, (int)(unsigned)(a >> 32) & 0xffff, 0x7fffffff, 0x00020000};
-    return r;
-}
-
-// ---- groups in flight live in ACCUMULATION registers.  A group = eight records = 8 top_diff words + 8 code bytes per lane (two codes per
-// register: d16 / d16_hi loads); set i owns a[12 i .. 12 i + 7] (top_diff) and a[12 i + 8 .. 12 i + 11] (codes).  The compiler allocates
-// no AGPR in this kernel and is told about these by the clobber lists (they count towards the wave's register budget), so a value in
-// flight can never be copied, spilled or renamed between its request and its use -- with VGPR operands the register allocator did
-// exactly that (v_mov of a register whose load had not landed).  rgt_land = s_waitcnt + v_accvgpr_read into ordinary values.
-#define RGT_SET0 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
-#define RGT_SET1 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31
-#define RGT_SET2 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47
-#define RGT_SET3 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63
-// record J of the group `en` (entry J in lane J): one code byte and one top_diff word per lane, record byte offset = scalar offset
-// (no d16 packing of two codes per register: with SRAM ECC a d16 load clears the other half)
-#define RGT_LD2(CD, TD, J)                                                                                                          \
-    {                                                                                                                               \
-        const int so_ = __builtin_amdgcn_readlane(en.x, J) & ~1023;                                                                 \
-        asm volatile("buffer_load_ubyte a" #CD ", %0, %1, %2 offen\n\tbuffer_load_dword a" #TD ", %3, %4, %5 offen"                 \
-                     :: "v"(lane), "s"(qc), "s"(so_ >> 2), "v"(lane4), "s"(qt), "s"(so_) : "a" #CD, "a" #TD);                      \
-    }
-#define RGT_ISSUE_(T0, T1, T2, T3, T4, T5, T6, T7, C0, C1, C2, C3, C4, C5, C6, C7)                                                  \
-    RGT_LD2(C0, T0, 0) RGT_LD2(C1, T1, 1) RGT_LD2(C2, T2, 2) RGT_LD2(C3, T3, 3)                                                    \
-    RGT_LD2(C4, T4, 4) RGT_LD2(C5, T5, 5) RGT_LD2(C6, T6, 6) RGT_LD2(C7, T7, 7)
-#define RGT_ISSUE(SET) RGT_ISSUE_(SET)
-// at most N vector-memory requests outstanding: loads return in order, so with N = 16 x (groups requested after this one) the set has landed
-#define RGT_LAND_(N, T0, T1, T2, T3, T4, T5, T6, T7, C0, C1, C2, C3, C4, C5, C6, C7)                                                \
-    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_accvgpr_read_b32 %0, a" #T0 "\n\tv_accvgpr_read_b32 %1, a" #T1                       \
-                 "\n\tv_accvgpr_read_b32 %2, a" #T2 "\n\tv_accvgpr_read_b32 %3, a" #T3 "\n\tv_accvgpr_read_b32 %4, a" #T4           \
-                 "\n\tv_accvgpr_read_b32 %5, a" #T5 "\n\tv_accvgpr_read_b32 %6, a" #T6 "\n\tv_accvgpr_read_b32 %7, a" #T7           \
-                 "\n\tv_accvgpr_read_b32 %8, a" #C0 "\n\tv_accvgpr_read_b32 %9, a" #C1 "\n\tv_accvgpr_read_b32 %10, a" #C2          \
-                 "\n\tv_accvgpr_read_b32 %11, a" #C3 "\n\tv_accvgpr_read_b32 %12, a" #C4 "\n\tv_accvgpr_read_b32 %13, a" #C5        \
-                 "\n\tv_accvgpr_read_b32 %14, a" #C6 "\n\tv_accvgpr_read_b32 %15, a" #C7                                            \
-                 : "=v"(td[0]), "=v"(td[1]), "=v"(td[2]), "=v"(td[3]), "=v"(td[4]), "=v"(td[5]), "=v"(td[6]), "=v"(td[7]),          \
-                   "=v"(cd[0]), "=v"(cd[1]), "=v"(cd[2]), "=v"(cd[3]), "=v"(cd[4]), "=v"(cd[5]), "=v"(cd[6]), "=v"(cd[7]))
-#define RGT_LAND(N, SET) RGT_LAND_(N, SET)
-
 // four records, in order: acc[a[j]] += v[j]; one LDS round trip, the running sums forwarded between records on the same accumulator
 __device__ __forceinline__ void rgt_add4(float *acc, const int a[4], const float v[4])
 {
@@ -128,48 +84,98 @@ __device__ __forceinline__ void rgt_add4(float *acc, const int a[4], const float
 
 // The tile pixel (slot; RGT_MAXPX = none of this tile) a value with code c goes to under one entry = one row segment of (rectangle x
 // tile).  Entry words: x = record byte offset | slot of the segment's first pixel [3:0] | pixels - 1 [5:4] | big [8], y = code of that
-// pixel.  A code c names pixel d of the segment iff c - code0 = d <= pixels - 1.  The null entry (x = 0, y = RGT_NULLCODE) names none.
-#define RGT_NULLCODE 0x1ffff
-__device__ __forceinline__ int rgt_target(const int x, const int y, const int c)
+// pixel.  A code c names pixel d of the segment iff c - code0 = d <= pixels - 1.
+__device__ __forceinline__ int rgt_target(const int x, const int y, const int c, const bool live)
 {
     const int d = c - y;
-    return (unsigned)d <= (unsigned)((x >> 4) & 3) ? (x & 15) + d : RGT_MAXPX;
+    return live && (unsigned)d <= (unsigned)((x >> 4) & 3) ? (x & 15) + d : RGT_MAXPX;
+}
+
+// CPL channels per lane (a record's slice = 64 CPL channels, one load of CPL code bytes and one of CPL floats per record and lane).
+// Shipped: CPL = 1.  Two / four channels per lane halve / quarter the waves, filters and expansions but lengthen every wave's serial
+// record stream by as much: 98 / 155 us against 68 (profiles/r05_aj_tiles_cpl.txt; tools/experiments/roi_grad_tiles_onewave_cpl_r05.hip.txt).
+template <int CPL> struct RgtVec;
+template <> struct RgtVec<1> {
+    typedef unsigned int C; typedef float T;
+    static __device__ __forceinline__ C ldc(__amdgpu_buffer_rsrc_t r, int lane, int s) { return __builtin_amdgcn_raw_buffer_load_b8(r, lane, s, 0); }
+    static __device__ __forceinline__ T ldt(__amdgpu_buffer_rsrc_t r, int lane, int s) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, s, 0)); }
+    static __device__ __forceinline__ float el(const T &t, int) { return t; }
+};
+
+// m <= W entries of the ring (entry u in lane u of e), none of them a big bin: every load first, then the ordered adds
+template <int W, int CPL>
+__device__ __forceinline__ void rgt_drain(float *acc, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
+                                          const __amdgpu_buffer_rsrc_t rt, const int lane, const int tws, const int dbg)
+{
+    typedef RgtVec<CPL> V;
+    typename V::C cd[W];
+    typename V::T td[W];
+#pragma unroll
+    for (int g = 0; g < W; g += 4) {
+        if (g < m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int so = __builtin_amdgcn_readlane(e.x, min(g + j, m - 1)) & ~1023;
+                cd[g + j] = V::ldc(rc, lane, so >> 2);
+                td[g + j] = V::ldt(rt, lane, so);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < W; g += 4) {
+        if (g < m) {
+            int xs[4], ys[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int l = min(g + j, m - 1);
+                xs[j] = __builtin_amdgcn_readlane(e.x, l); ys[j] = __builtin_amdgcn_readlane(e.y, l);
+            }
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                int a[4];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = CPL == 1 ? (int)cd[g + j] : (int)((cd[g + j] >> (8 * k)) & 0xffu);
+                    a[j] = (rgt_target(xs[j], ys[j], c, g + j < m) * 64 + lane) * CPL + k;
+                    v[j] = V::el(td[g + j], k);
+                }
+                if (RGT_DBG(dbg, 4)) { acc[(RGT_MAXPX * 64 + lane) * CPL] += (float)(a[0] + a[1] + a[2] + a[3]) + v[0] + v[1] + v[2] + v[3]; continue; }
+                rgt_add4(acc, a, v);
+            }
+        }
+    }
 }
 
 // entries with bins of more than 255 pixels among them (ROIs far larger than the map: rare): entry by entry, each from its own
-// plane, in the same order (compiler-tracked loads: their wait also retires every group in flight)
-__device__ __forceinline__ void rgt_drain_mixed(float *acc, const int2 e, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rc16,
-                                                const __amdgpu_buffer_rsrc_t rt, const int lane)
+// plane, in the same order
+template <int CPL>
+__device__ __forceinline__ void rgt_drain_mixed(float *acc, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
+                                                const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt, const int lane, const int tws)
 {
-    for (int u = 0; u < RGT_G; ++u) {
+    for (int u = 0; u < m; ++u) {
         const int x = __builtin_amdgcn_readlane(e.x, u), y = __builtin_amdgcn_readlane(e.y, u);
         const int so = x & ~1023;
-        const float td = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, lane * 4, so, 0));
-        const int c = (x & RGT_BIGBIT) ? (int)__builtin_amdgcn_raw_buffer_load_b16(rc16, lane * 2, so >> 1, 0)
-                                       : (int)__builtin_amdgcn_raw_buffer_load_b8(rc, lane, so >> 2, 0);
-        const int a = rgt_target(x, y, c) * 64 + lane;
-        acc[a] = acc[a] + td;
+        const bool big = (x & RGT_BIGBIT) != 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int ch = lane * CPL + k;
+            const float td = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, ch * 4, so, 0));
+            const int c = big ? (int)__builtin_amdgcn_raw_buffer_load_b16(rc16, ch * 2, so >> 1, 0)
+                              : (int)__builtin_amdgcn_raw_buffer_load_b8(rc, ch, so >> 2, 0);
+            const int a = (rgt_target(x, y, c, true) * 64 + lane) * CPL + k;
+            acc[a] = acc[a] + td;
+        }
     }
 }
 
-// the eight entries of a landed group (entry u in lane u of e), in order
-__device__ __forceinline__ void rgt_consume(float *acc, const float td[RGT_G], const unsigned cd[RGT_G], const int2 e,
-                                            const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt,
-                                            const int lane)
+template <int W, int CPL>
+__device__ __forceinline__ void rgt_drain_any(float *acc, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
+                                              const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt, const int lane, const int tws,
+                                              const int dbg)
 {
-    if (__ballot((e.x & RGT_BIGBIT) != 0) != 0ull) { rgt_drain_mixed(acc, e, rc, rc16, rt, lane); return; }
-#pragma unroll
-    for (int g = 0; g < RGT_G; g += 4) {
-        int a[4];
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = g + j;
-            a[j] = rgt_target(__builtin_amdgcn_readlane(e.x, u), __builtin_amdgcn_readlane(e.y, u), (int)cd[u]) * 64 + lane;
-            v[j] = td[u];
-        }
-        rgt_add4(acc, a, v);
-    }
+    if (__ballot((e.x & RGT_BIGBIT) != 0 && lane < m) != 0ull) rgt_drain_mixed<CPL>(acc, e, m, rc, rc16, rt, lane, tws);
+    else rgt_drain<W, CPL>(acc, e, m, rc, rt, lane, tws, dbg);
 }
 
 // The pixels x of [lo, hi] that list pooled index p under the reference's backward (roi_pooling_op.cc:423-431): floor((x - start) / bin) <= p <
@@ -184,13 +190,12 @@ __device__ __forceinline__ int2 rgt_exact_span(const int lo, const int hi, const
     return make_int2(a, b);
 }
 
+template <int W, int CPL>
 __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
 {
-    __shared__ float acc[(RGT_MAXPX + 1) * 64];                              // the tile's accumulators [pixel][channel] + one junk row
+    __shared__ float acc[(RGT_MAXPX + 1) * 64 * CPL];                        // the tile's accumulators [pixel][channel] + one junk row
     __shared__ int2 ring[RGT_RING];
-    __shared__ int4 geo[256];                                          // rounded geometry of the ROIs that reach the tile (of 256 rows)
-    __shared__ unsigned char ridx[256];                                // ... and their row numbers
-    const int lane = threadIdx.x, lane4 = lane * 4;
+    const int lane = threadIdx.x;
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
@@ -209,51 +214,13 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
     const int tw0 = tx << tws, tw1 = min(tw0 + TW, Wd);
     RGT_STAMP(0);
     const unsigned char *const plane8 = v.plane8;
-    const void *const base_c = plane8 + slice * 64, *const base_t = v.top_diff + slice * 64;
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)base_c, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(plane8 + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rc16 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((const unsigned short *)(plane8 + (long long)R * PHW * C) + slice * 64), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)base_t, 0, 0x7fffffff, 0x00020000);
-    const rgt_v4i qc = rgt_rsrc(base_c), qt = rgt_rsrc(base_t);
-    // ---- the drain pipeline: register sets 0..3 as a queue of groups in flight (oldest = set qh, nq of them).  Ring positions
-    // (wave-uniform): done <= head <= tail -- entries before `done` are added, before `head` requested (a group's entries stay in the ring
-    // until it is added: <= 24 in flight + < 8 waiting + <= 64 appended at once <= RGT_RING)
-    int done = 0, head = 0, tail = 0;
-    int nq = 0, qh = 0;
-    long long t_wait = 0, t_cons = 0, t_issue = 0;                     // experiment builds: ticks inside the pump's phases
-    // request the next eight entries of the ring as a group; with three groups in flight the oldest one is retired: waited for, the
-    // new group requested, then added -- its adds run under the flight of the three younger groups
-    auto pump = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (ring entries written by other lanes of this wave)
-        __builtin_amdgcn_wave_barrier();
-        const int2 en = ring[(head + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
-        head += RGT_G;
-        if (nq == 3) {
-            const int2 eo = ring[(done + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
-            done += RGT_G;
-            float td[RGT_G];
-            unsigned cd[RGT_G];
-            long long c0 = 0, c1 = 0;
-            if (RGT_DBG(1, 1) && p.trace) { c0 = (long long)wall_clock64(); asm volatile("s_waitcnt vmcnt(32)"); c1 = (long long)wall_clock64(); t_wait += c1 - c0; }
-            switch (qh) {
-            case 0: RGT_LAND(32, RGT_SET0); RGT_ISSUE(RGT_SET3) break;
-            case 1: RGT_LAND(32, RGT_SET1); RGT_ISSUE(RGT_SET0) break;
-            case 2: RGT_LAND(32, RGT_SET2); RGT_ISSUE(RGT_SET1) break;
-            default: RGT_LAND(32, RGT_SET3); RGT_ISSUE(RGT_SET2) break;
-            }
-            if (RGT_DBG(1, 1) && p.trace) c0 = (long long)wall_clock64();
-            rgt_consume(acc, td, cd, eo, rc, rc16, rt, lane);
-            if (RGT_DBG(1, 1) && p.trace) { __builtin_amdgcn_s_waitcnt(0xc07f); t_cons += (long long)wall_clock64() - c0; t_issue += c0 - c1; }
-            qh = (qh + 1) & 3;
-        } else {                                                       // filling the queue: qh == 0, the new group goes to set nq
-            switch (nq) {
-            case 0: RGT_ISSUE(RGT_SET0) break;
-            case 1: RGT_ISSUE(RGT_SET1) break;
-            default: RGT_ISSUE(RGT_SET2) break;
-            }
-            ++nq;
-        }
-    };
+        (void *)((const unsigned short *)(plane8 + (long long)R * PHW * C) + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
+    int head = 0, tail = 0;                                            // ring positions (wave-uniform)
+    const int CH = TH > 2 ? 60 : 64;                                   // bins per expansion chunk: CH x TH + (W - 1) entries fit the ring
+    static_assert(W <= 16 && 60 * 4 + W <= RGT_RING, "ring too small for a chunk");
     for (int base = 0; base < R; base += 256) {
         // ---- the rows of 256 ROIs, requested at once (lane = ROI, four passes)
         float rr[4][5];
@@ -264,47 +231,40 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
             for (int u = 0; u < 5; ++u) rr[q][u] = v.rois[5 * (long long)roi + u];
         }
         if (base == 0) {                                               // (under the ROI rows' latency) the accumulators start at +0
-            for (int i = lane; i < (RGT_MAXPX + 1) * 16; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int i = lane; i < (RGT_MAXPX + 1) * 16 * CPL; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        // ---- filter: ROI against the tile; the survivors' rounded geometry compacted (ascending) into LDS -- the expansion below keeps no
-        // per-ROI register
-        int nhit = 0;
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const int roi0 = base + 64 * q;
-            const RoiGeom g = roi_geom(rr[q], v.scale);
+            if (roi0 >= R) break;
+            // ---- filter: ROI roi0 + lane against the tile
+            float r5[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) r5[u] = q == 0 ? rr[0][u] : (q == 1 ? rr[1][u] : (q == 2 ? rr[2][u] : rr[3][u]));
+            const RoiGeom g = roi_geom(r5, v.scale);
             const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);   // roi_pooling_op.cc:146-147
             // conservative bounding box of the ROI's bins (every bin's rows lie in [rsh, rsh + rh + 1]); coordinates outside the
             // range where that arithmetic is exact (NaN / inf / absurd boxes) are left to the exact per-bin test of the expansion
             const bool sane = abs(g.rsw) < (1 << 24) && abs(g.rsh) < (1 << 24) && abs(g.rew) < (1 << 24) && abs(g.reh) < (1 << 24);
             // (:401-404: h in [rsh, reh], w in [rsw, rew] -- an end before its start lets nothing through)
-            bool hit = roi0 + lane < R && (int)rr[q][0] == b && g.reh >= g.rsh && g.rew >= g.rsw;
+            bool hit = roi0 + lane < R && (int)r5[0] == b && g.reh >= g.rsh && g.rew >= g.rsw;
             if (sane) hit = hit && g.rsh < th1 && g.rsh + rh + 2 > th0 && g.rsw < tw1 && g.rsw + rw + 2 > tw0;
-            if (RGT_DBG(p.dbg, 8 | 1)) hit = false;
-            const unsigned long long mh = __ballot(hit);
-            if (hit) {
-                const int pos = nhit + __popcll(mh & ((1ull << lane) - 1ull));
-                geo[pos] = make_int4(g.rsh, g.rsw, g.reh, g.rew);
-                ridx[pos] = (unsigned char)(64 * q + lane);
-            }
-            nhit += __popcll(mh);
-        }
-        if (base == 0) RGT_STAMP(1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- expansion + drain
-        {
-            for (int i = 0; i < nhit; ++i) {
-                const int4 gg = geo[i];
-                const int r = base + (int)ridx[i];
-                const int rsh = __builtin_amdgcn_readfirstlane(gg.x), rsw = __builtin_amdgcn_readfirstlane(gg.y);
-                const int reh = __builtin_amdgcn_readfirstlane(gg.z), rew = __builtin_amdgcn_readfirstlane(gg.w);
+            if (RGT_DBG(p.dbg, 8)) hit = false;
+            unsigned long long todo = __ballot(hit);
+            if (base == 0 && q == 0) RGT_STAMP(1);
+            if (RGT_DBG(p.dbg, 1)) todo = 0ull;
+            // ---- expansion + drain
+            while (todo != 0ull) {
+                const int j = (int)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int r = roi0 + j, rsh = __builtin_amdgcn_readlane(g.rsh, j), rsw = __builtin_amdgcn_readlane(g.rsw, j);
+                const int reh = __builtin_amdgcn_readlane(g.reh, j), rew = __builtin_amdgcn_readlane(g.rew, j);
                 const int rhj = reh - rsh + 1, rwj = rew - rsw + 1;    // (>= 1: the filter drops the others)
                 const float bh = (float)rhj / (float)PH;               // roi_pooling_op.cc:148-151 (only for hits)
                 const float bw = (float)rwj / (float)PW;
                 const bool exact = rhj > RGT_EXACT_MAX || rwj > RGT_EXACT_MAX;
-                for (int bin0 = 0; bin0 < PHW; bin0 += 64) {
-                    const int bin = bin0 + lane;
+                for (int bin0 = 0; bin0 < PHW; bin0 += CH) {
+                    const int bin = lane < CH ? bin0 + lane : PHW;
                     const int ph = (int)(((unsigned)bin * (unsigned)p.inv_pw) >> 16), pw = bin - ph * PW;
                     // the bin's rectangle as the forward computes it (roi_pool.hip fwd_bin_rect, roi_pooling_op.cc:153-162)
                     const int hs0 = (int)floorf(__fmul_rn((float)ph, bh)), ws0 = (int)floorf(__fmul_rn((float)pw, bw));
@@ -329,52 +289,41 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
                         if (mr == 0ull) continue;
                         if (on) ring[(tail + __popcll(mr & ((1ull << lane) - 1ull))) & (RGT_RING - 1)] = make_int2(ex + ((h - th0) << tws), ey + h * bwid);
                         tail += __popcll(mr);
-                        if (RGT_DBG(p.dbg, 2)) { done = head = tail; continue; }
-                        while (tail - head >= RGT_G) pump();
+                    }
+                    if (RGT_DBG(p.dbg, 2)) { head = tail; continue; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (ring entries written by other lanes of this wave)
+                    __builtin_amdgcn_wave_barrier();
+                    while (tail - head >= W) {
+                        const int2 e = ring[(head + min(lane, W - 1)) & (RGT_RING - 1)];
+                        rgt_drain_any<W, CPL>(acc, e, W, rc, rc16, rt, lane, tws, p.dbg);
+                        head += W;
                     }
                 }
             }
         }
     }
     RGT_STAMP(3);
-    if (RGT_DBG(1, 1) && p.trace && lane == 0) {
-        p.trace[(long long)blockIdx.x * 8 + 6] = tail | (t_issue << 32);
-        p.trace[(long long)blockIdx.x * 8 + 2] = t_wait; p.trace[(long long)blockIdx.x * 8 + 7] = t_cons;
-    }
-    // ---- the stream padded to whole groups with null entries (no pixel, a cached record), the last group requested
+    if (RGT_DBG(1, 1) && p.trace && lane == 0) p.trace[(long long)blockIdx.x * 8 + 6] = tail;
     if (tail > head) {
-        if (lane < RGT_G) ring[(tail + lane) & (RGT_RING - 1)] = make_int2(0, RGT_NULLCODE);     // (lanes past the pad write slots nobody reads)
-        tail = (tail + RGT_G - 1) & ~(RGT_G - 1);
-        // (positions: head and done only ever move by whole groups, so head is a multiple of eight here)
-        pump();
-    }
-    // ---- the groups still in flight, oldest first (nothing is requested any more: one full wait)
-    for (; nq > 0; --nq, qh = (qh + 1) & 3) {
-        const int2 eo = ring[(done + (lane & (RGT_G - 1))) & (RGT_RING - 1)];
-        done += RGT_G;
-        float td[RGT_G];
-        unsigned cd[RGT_G];
-        switch (qh) {
-        case 0: RGT_LAND(0, RGT_SET0); break;
-        case 1: RGT_LAND(0, RGT_SET1); break;
-        case 2: RGT_LAND(0, RGT_SET2); break;
-        default: RGT_LAND(0, RGT_SET3); break;
-        }
-        rgt_consume(acc, td, cd, eo, rc, rc16, rt, lane);
+        const int m = tail - head;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int2 e = ring[(head + min(lane, m - 1)) & (RGT_RING - 1)];
+        rgt_drain_any<W, CPL>(acc, e, m, rc, rc16, rt, lane, tws, p.dbg);
     }
     RGT_STAMP(4);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // (the accumulators: written per channel lane, read 16 B per lane)
     __builtin_amdgcn_wave_barrier();
-    // ---- write-out: every pixel of the tile, zeros included (16 B per lane: 4 pixels x 256 bytes per store instruction)
-    constexpr int LPP = 16;                                            // lanes per pixel
-    float *const out = v.bottom_diff + (long long)b * H * Wd * C + slice * 64 + (lane & (LPP - 1)) * 4;
+    // ---- write-out: every pixel of the tile, zeros included (16 B per lane: 4 / CPL pixels x 256 CPL bytes per store instruction)
+    constexpr int LPP = 16 * CPL;                                      // lanes per pixel
+    float *const out = v.bottom_diff + (long long)b * H * Wd * C + slice * 64 * CPL + (lane & (LPP - 1)) * 4;
     const int npx = TH * TW;
     typedef float f4v __attribute__((ext_vector_type(4)));
     for (int i = 0; i < npx; i += 64 / LPP) {
         const int px = i + lane / LPP;
         const int h = th0 + (px >> tws), w = tw0 + (px & (TW - 1));
         if (px < npx && h < H && w < Wd) {
-            const float4 x = *reinterpret_cast<const float4 *>(acc + px * 64 + (lane & (LPP - 1)) * 4);
+            const float4 x = *reinterpret_cast<const float4 *>(acc + px * 64 * CPL + (lane & (LPP - 1)) * 4);
             const f4v xv = {x.x, x.y, x.z, x.w};
             __builtin_nontemporal_store(xv, reinterpret_cast<f4v *>(out + ((long long)h * Wd + w) * C));
         }
@@ -412,6 +361,7 @@ int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, i
     for (int i = 1; i < num_views; ++i)
         for (int j = i; j > 0 && key[order[j]] > key[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
     if (rgt_env("MV3D_RGT_ORDER", 0) == 1 && num_views == 3) { const int t = order[1]; order[1] = order[2]; order[2] = t; }
+    const int cpl = 1;
     const int force_px = rgt_env("MV3D_RGT_PX", 0);
     unsigned blocks = 0;
     for (int i = 0; i < num_views; ++i) {
@@ -431,7 +381,7 @@ int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, i
         v.ths = lg / 2; v.tws = lg - v.ths;                            // 1x1, 1x2, 2x2, 2x4, 4x4
         v.tiles_x = (w.width + (1 << v.tws) - 1) >> v.tws;
         v.tiles_y = (w.height + (1 << v.ths) - 1) >> v.ths;
-        v.nsl = w.channels / 64;
+        v.nsl = w.channels / (64 * cpl);
         v.first_block = blocks;
         const long long nb = (long long)w.batch_size * v.tiles_y * v.tiles_x * v.nsl;
         if (nb + blocks > 0x7fffffffLL) return MV3D_ERR_INVALID_ARG;
@@ -443,6 +393,12 @@ int mv3d_launch_roi_pair_tiles(int num_views, const mv3d_roi_grad_view *views, i
 #ifdef MV3D_TUNING
     if (getenv("MV3D_RGT_TRACE")) p.trace = (long long *)strtoull(getenv("MV3D_RGT_TRACE"), nullptr, 0);
 #endif
-    hipLaunchKernelGGL(roi_pair_tiles_kernel, dim3(blocks), dim3(64), 0, stream, p);
+    // 16 records in flight per wave (6 waves per SIMD); 32 (4 waves per SIMD) is 3 % faster alone and 4 % slower with eight batches
+    // in flight (profiles/r05_am_tiles_w32_bench_ab.txt)
+#ifdef MV3D_TUNING
+    if (rgt_env("MV3D_RGT_W", 16) == 8) { hipLaunchKernelGGL((roi_pair_tiles_kernel<8, 1>), dim3(blocks), dim3(64), 0, stream, p); return mv3d_launch_status(); }
+    if (rgt_env("MV3D_RGT_W", 16) == 12) { hipLaunchKernelGGL((roi_pair_tiles_kernel<12, 1>), dim3(blocks), dim3(64), 0, stream, p); return mv3d_launch_status(); }
+#endif
+    hipLaunchKernelGGL((roi_pair_tiles_kernel<16, 1>), dim3(blocks), dim3(64), 0, stream, p);
     return mv3d_launch_status();
 }

@@ -66,14 +66,15 @@ print("   last drain       :", q(t[:, 4] - t[:, 3]))
 print("   write-out        :", q(t[:, 5] - t[:, 4]))
 print("   whole wave       :", q(t[:, 5] - t[:, 0]))
 print("   end - t0         :", q(t[:, 5] - t0))
-t_issue = t[:, 6] >> 32
-t[:, 6] &= 0xffffffff
 print("   ring entries     :", q(t[:, 6]), " total", t[:, 6].sum())
 ne = t[t[:, 6] > 0]
+n_own, n_other = t[:, 2] & 0xffffffff, t[:, 2] >> 32
+t_room, t_turn = t[:, 7] & 0xffffffff, t[:, 7] >> 32
+print("   groups added on the own stream %d, on other waves' streams %d" % (n_own.sum(), n_other.sum()))
 hot = np.argsort(-t[:, 6])[:12]
-print("the 12 fullest waves: entries, start, expand + drains, of which waiting for loads / requesting / adding (steady-state pumps), last drain")
+print("the 12 fullest streams: entries, start, expansion phase (of which waiting for room in the ring), help phase; groups this wave added own / others, ticks waiting for turns")
 for i in hot:
-    print("   %4d  start %5d  exp+drain %5d  wait %5d  issue %5d  add %5d  last %4d" % (t[i, 6], t[i, 0] - t0, t[i, 3] - t[i, 1], t[i, 2], t_issue[i], t[i, 7], t[i, 4] - t[i, 3]))
+    print("   %4d  start %5d  expansion %5d (room %5d)  help %5d  groups own %3d other %3d  turns %5d" % (t[i, 6], t[i, 0] - t0, t[i, 3] - t[i, 1], t_room[i], t[i, 4] - t[i, 3], n_own[i], n_other[i], t_turn[i]))
 print("waves with entries: %d" % len(ne))
 print("   expand + drains  :", q(ne[:, 3] - ne[:, 1]))
 print("   last drain       :", q(ne[:, 4] - ne[:, 3]))
