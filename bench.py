@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--with-trunk", action="store_true", help="(default since r03; kept for old command lines)")
     ap.add_argument("--no-trunk", action="store_true", help="skip secondary.with_trunk (the full training step with the torch VGG16 trunks)")
     ap.add_argument("--no-fresh", action="store_true", help="skip secondary.fresh_inputs")
+    ap.add_argument("--secondary-seconds", type=float, default=1.0, help="minimum timed window of every with-trunk leg (training / serving step variants)")
     ap.add_argument("--secondary-timeout", type=int, default=1500, help="seconds the secondary legs may take before the line is printed without the rest")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one rank per GPU) | gloo (logic tests)")
     return ap.parse_args()
@@ -348,12 +349,20 @@ def events_ms(stream, fns, rounds):
     return e0.elapsed_time(e1) / (rounds * len(fns))
 
 
+def pmc_signature(workload, batch, rows, variant, launches):
+    """What a PMC pass is keyed by: the workload AND the launch set behind the timed calls -- `launches` names the kernel variant and
+    the outputs it writes (train: "pair-tiles" = forward with one-byte codes + the one-launch RoiPoolGrad; test: "top-only" /
+    "top+argmax").  A table collected for another variant of the same workload must not be quoted (the r03 pass of the
+    forward that also wrote the int32 plane was printed next to the top-only kernel)."""
+    return "%s/b%d/r%d/%s/%s" % (workload, batch, rows, variant, launches)
+
+
 def pmc_traffic(kernel, signature):
     """HBM bytes per launch from a committed PMC pass OF THIS EXACT CONFIGURATION (profiles/r0N_pmc_traffic.json: one table per
-    signature it was collected with); None otherwise -- never a stale number."""
+    signature it was collected with, pmc_signature()); None otherwise -- never a stale number."""
     try:
         table = None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):     # the newest pass that holds this configuration
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):     # the newest pass that holds this configuration
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 table = json.load(open(path))["signatures"].get(signature)
@@ -402,6 +411,59 @@ def roofline_entries(ring, workload, signature):
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("roi_pair_" if "roi_pair_" in kname else kname, signature),
                     "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(marks[fn])})
+    return out
+
+
+def nms_roofline_entries(variant="peaky", reps=30):
+    """SURVEY 8(d) for the greedy NMS: "achieved time vs the serial-chain lower bound".  One bench frame's pre-NMS boxes in processing
+    order (the product's own decode + rank: proposal_3d with a threshold nothing reaches), TRAIN cfg (12000 -> 2000 @ 0.7) and TEST cfg
+    (6000 -> 300): the call's duration from HIP events on the launch stream, and from mv3d_nms_device_trace the number of 64-box blocks
+    the chain visited and the cycles of its fastest link -- floor = blocks x fastest link: what the chain would take if every link ran
+    at the speed of its best one and nothing else (tile phase, launches of later rounds) took time."""
+    import ctypes as C
+    from mv3d_tf_amd import ops, synth
+    from mv3d_tf_amd._lib import check, lib
+    out = []
+    clk_hz = torch.cuda.get_device_properties(torch.cuda.current_device()).clock_rate * 1e3
+    prob, pred, info, calib = synth.rpn_head(1000, 76, 76, variant)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    for name, pre, post in (("TRAIN cfg 12000 -> 2000", 12000, 2000), ("TEST cfg 6000 -> 300", 6000, 300)):
+        prm = ops.proposal_params(dict(RPN_PRE_NMS_TOP_N=pre, RPN_POST_NMS_TOP_N=pre, RPN_NMS_THRESH=2.0, RPN_MIN_SIZE=5))
+        bv, _, _, num, _ = ops.proposal_3d(t(prob), t(pred), t(info), t(calib[None]), prm)
+        k = int(num[0])
+        d = torch.zeros((k, 5), dtype=torch.float32, device="cuda")
+        d[:, :4] = bv[0, :k, 1:5]
+        d[:, 4] = torch.linspace(1, 0, k, device="cuda")
+        for _ in range(3):
+            keep, cnt, _ = ops.nms_device(d, 0.7, post)
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        evs[0].record()
+        for i in range(reps):
+            ops.nms_device(d, 0.7, post)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        us = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]) * 1e3
+        nb = (k + 63) // 64
+        keep = torch.empty((k,), dtype=torch.int32, device="cuda")
+        c2 = torch.zeros((2,), dtype=torch.int32, device="cuda")
+        tr = torch.zeros((nb * 4 + 8,), dtype=torch.int64, device="cuda")
+        ws = torch.empty((lib().mv3d_nms_workspace_bytes(k),), dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            check(lib().mv3d_nms_device_trace(C.c_void_p(d.data_ptr()), k, 0.7, int(post), C.c_void_p(keep.data_ptr()), C.c_void_p(c2.data_ptr()),
+                                              C.c_void_p(c2[1:].data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), None, C.c_void_p(tr.data_ptr())), "mv3d_nms_device_trace")
+            torch.cuda.synchronize()
+        tt = tr.cpu().numpy()[:nb * 4].reshape(nb, 4)
+        tt = tt[tt[:, 2] != 0]
+        step = np.diff(tt[:, 0]) if len(tt) > 1 else np.array([0])
+        floor_us = len(tt) * float(step.min()) / clk_hz * 1e6
+        out.append({"kernel": "greedy NMS, %s @ 0.7, one frame of %d boxes (nms_tiles_kernel + nms_chain_lds_kernel + nms_round_kernel<W>)" % (name, k),
+                    "bound": "latency (serial greedy chain)", "measured_us": round(float(np.median(us)), 2), "measured_us_min": round(float(us.min()), 2),
+                    "blocks_total": int(nb), "blocks_visited": int(len(tt)), "kept": int(c2[0]),
+                    "link_cycles_min": int(step.min()), "link_cycles_median": int(np.median(step)),
+                    "chain_cycles": int(tt[-1, 2] - tt[0, 0]) if len(tt) else 0, "clock_mhz": round(clk_hz / 1e6, 1),
+                    "chain_floor_us": round(floor_us, 2), "frac": round(floor_us / float(np.median(us)), 4),
+                    "note": "floor = blocks visited x the fastest link of the chain (shader cycles / clock); frac = floor / measured call"})
     return out
 
 
@@ -704,7 +766,9 @@ def main():
         else:
             desc = ("BASELINE configs[4] per-GPU path: batch %d, TEST cfg (pre/post-NMS 6000/300, NMS 0.7) proposal_layer_3d + FV "
                     "ROIs + RoiPool 7x7 fwd on 3 views, R=%d rows; %s scores" % (batch, s0.num_rois, args.variant))
-        signature = "%s/b%d/r%d/%s" % (wl, batch, s0.num_rois, args.variant)
+        signature = pmc_signature(wl, batch, s0.num_rois, args.variant,
+                                  "pair-tiles" if wl == "train" else ("top+argmax" if getattr(args, "test_argmax", False) else "top-only"))
+        res["config"]["pmc_signature"] = signature
         res = {
             "metric": METRIC, "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
@@ -734,6 +798,11 @@ def main():
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "
                                          "configuration or null")
         res["roofline_kernels"] = entries
+        if wl == "train":
+            try:
+                res["roofline_kernels"] = entries + nms_roofline_entries(args.variant)
+            except Exception as e:                                   # (a diagnostic leg must not cost the line)
+                res["roofline_kernels"] = entries + [{"kernel": "greedy NMS", "error": "%s: %s" % (type(e).__name__, str(e)[:200])}]
         if ring.driver is not None:
             # the same two calls as the TIMED loop runs them (8 batches in flight), next to the isolated figures above
             fl = ring.driver.in_flight_us()
@@ -807,7 +876,7 @@ def main():
                                                "views (the inference call: top only%s), ring of 3 batches on the step's streams (%s launches)"
                                                % ("" if not getattr(args2, "test_argmax", False) else " + argmax", args2.launch),
                                    "frames_per_s": round(st2 * nb2 * 16 * world / dt2, 2), "timed_s": round(dt2, 3),
-                                   "roofline_kernels": roofline_entries(r2, "test", "test/b16/r4800/%s" % args.variant)}
+                                   "roofline_kernels": roofline_entries(r2, "test", pmc_signature("test", 16, 4800, args.variant, "top+argmax" if getattr(args2, "test_argmax", False) else "top-only"))}
             del r2
             torch.cuda.empty_cache()
             if not args.no_trunk:
@@ -817,27 +886,29 @@ def main():
                     sec["config1_latency"] = _tm.bench_config1_latency()
                     torch.cuda.empty_cache()
                 from mv3d_tf_amd.fast_rcnn import train_mv
-                sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4))
+                sec["with_trunk"] = train_mv.bench_train_step(rank, world, dist, seconds=args.secondary_seconds)
                 torch.cuda.empty_cache()
                 # the same step with the trunks' forward AND backward convolutions on this library's bf16 MFMA kernels (mixed precision:
                 # a lower precision than the reference's fp32 training, reported next to it)
-                mp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=torch.bfloat16, mfma=True)
+                mp = train_mv.bench_train_step(rank, world, dist, amp=torch.bfloat16, mfma=True, seconds=args.secondary_seconds)
                 torch.cuda.empty_cache()
                 # ... and in the reference's fp32 with the trunks' forward / data-gradient convolutions on the exact-f32 MFMA kernel
-                fp = train_mv.bench_train_step(rank, world, dist, steps=max(3, args.steps // 4), amp=None, mfma=True)
+                fp = train_mv.bench_train_step(rank, world, dist, amp=None, mfma=True, seconds=args.secondary_seconds)
                 torch.cuda.empty_cache()
                 if rank == 0:
                     from mv3d_tf_amd import trunk_train
                     from mv3d_tf_amd.networks.mv3d import _VGG as vgg_layers
                     sec["with_trunk"]["fp32_mfma_trunk"] = {"workload": fp["workload"], "frames_per_s": fp["frames_per_s"], "ms_per_step": fp["ms_per_step"],
+                                                             "ms_per_step_min": fp["ms_per_step_min"], "ms_per_step_median": fp["ms_per_step_median"], "steps_timed": fp["steps_timed"],
                                                              "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers, dtype=torch.float32)]}
                     sec["with_trunk"]["bf16_mfma_trunk"] = {"workload": mp["workload"], "frames_per_s": mp["frames_per_s"], "ms_per_step": mp["ms_per_step"],
+                                                             "ms_per_step_min": mp["ms_per_step_min"], "ms_per_step_median": mp["ms_per_step_median"], "steps_timed": mp["steps_timed"],
                                                              "roofline_kernels": [trunk_train.bench_wgrad_layers(vgg_layers)]}
                 if dist is not None:
                     dist.barrier()
                 torch.cuda.empty_cache()
                 from mv3d_tf_amd.fast_rcnn import test_mv
-                sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu")
+                sec["serving_with_trunk"] = test_mv.bench_serve_step(rank, world, dist, reduce_device="cuda" if args.dist_backend == "nccl" else "cpu", seconds=args.secondary_seconds)
                 torch.cuda.empty_cache()
                 if rank == 0:
                     # the hand-written MFMA convolution against the dense f16 matrix-core peak (rank 0 only: a per-kernel figure)

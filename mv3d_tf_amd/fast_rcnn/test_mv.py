@@ -8,6 +8,7 @@ session).  Returns (scores (R,K), pred_boxes_bv (R,4K) f64, pred_boxes_cnr (R,24
 pred_boxes_cnr_r (R,24K) f32) like the reference, K = 2; the geometric tail runs in
 libmv3d_hip.so (mv3d_box_detect_tail)."""
 import os
+import time
 import pickle
 
 import numpy as np
@@ -78,6 +79,7 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
     all_boxes = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]
     all_boxes_cnr = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]
     output_dir = get_output_dir(imdb, weights_filename)
+    t_detect = t_misc = 0.0                                            # the reference's _t['im_detect'] / _t['misc'] timers (:355, :433-436, :482-502)
     for i in range(num_images):
         if hasattr(imdb, "image_at"):
             im, bv = imdb.image_at(i), imdb.bv_at(i)
@@ -90,13 +92,17 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
                 from PIL import Image                               # (the reference uses cv2.imread: BGR)
                 im = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
         calib = imdb.calib_at(i)
+        t0 = time.time()
         scores, boxes_bv, boxes_cnr, boxes_cnr_r = box_detect(sess, net, im, bv, calib, None)
+        t1 = time.time()
+        t_detect += t1 - t0
         dets, dets_cnr, _ = class_detections(scores, boxes_bv, boxes_cnr, boxes_cnr_r, imdb.num_classes, 0.05)
         dets, dets_cnr = limit_detections(dets, dets_cnr, max_per_image)
         for j in range(1, imdb.num_classes):
             all_boxes[j][i] = dets[j]
             all_boxes_cnr[j][i] = dets_cnr[j]
-        print('im_detect: {:d}/{:d}'.format(i + 1, num_images))
+        t_misc += time.time() - t1
+        print('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(i + 1, num_images, t_detect / (i + 1), t_misc / (i + 1)))   # lib/fast_rcnn/test_mv.py:504-506
     with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
         pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
     with open(os.path.join(output_dir, 'detections_cnr.pkl'), 'wb') as f:
@@ -107,17 +113,78 @@ def test_net(sess, net, imdb, weights_filename, max_per_image=300, thresh=0.05, 
 
 
 
-def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp32", "fp32_mfma", "fp16", "fp16_mfma"), reduce_device="cuda", views=3):
+class ServeGraph:
+    """BASELINE configs[4]'s serving step as ONE captured hipGraph: trunks, RPN heads + softmax, proposal_layer_3d (TEST cfg), front-view
+    ROIs, RoiPool of every view, the fusion head and the box tail (lib/fast_rcnn/test_mv.py:149-264 for a batch), no host round trip
+    inside.  Shapes are fixed: every frame owns `rois_per_frame` (= RPN_POST_NMS_TOP_N) ROI rows; the rows behind a frame's num_rois are
+    zero boxes that are pooled and scored like any other and dropped by `detections()` -- the ROI counts are read ONCE, after the replay.
+    Inputs are copied into the graph's static buffers on the replay stream; outputs are the graph's static tensors (valid until the next
+    replay)."""
+
+    def __init__(self, net, feed, warmup=2):
+        self.net = net
+        dev = net.device
+        self.static = {k: (v.to(dev).clone() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, np.float32)).to(dev))
+                       for k, v in feed.items() if k != "keep_prob"}
+        self.static["keep_prob"] = 1.0
+        self.stream = torch.cuda.Stream(device=dev)
+        self.out = None
+        net.fixed_rois = True
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(warmup):                             # (weights cast / packed, workspaces allocated: nothing of that is captured)
+                    self._step()
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = self._step()
+        finally:
+            net.fixed_rois = False
+
+    def _step(self):
+        with torch.no_grad():
+            L = self.net.forward(self.static)
+            rois3 = L["rois"][2].contiguous()
+            cnr, pred_r, pred_bv, _ = ops.box_detect_tail(rois3, L["bbox_pred"].contiguous(), n_classes)
+            return {"cls_prob": L["cls_prob"], "bbox_pred": L["bbox_pred"], "rois_bv": L["rois"][0], "rois_img": L["rois"][1], "rois_3d": rois3,
+                    "corners": cnr, "pred_corners_r": pred_r, "pred_bv": pred_bv, "num_rois": L["num_rois"], "status": L["rois_status"],
+                    "rois_per_frame": L["rois_per_frame"]}
+
+    def replay(self, feed=None):
+        """enqueue one step (asynchronous); feed: new inputs for the static buffers (same shapes), or None to reuse them"""
+        with torch.cuda.stream(self.stream):
+            if feed is not None:
+                for k, v in feed.items():
+                    if k != "keep_prob":
+                        self.static[k].copy_(v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, np.float32)), non_blocking=True)
+            self.graph.replay()
+        return self.out
+
+    def detections(self):
+        """after a replay: per frame (scores, pred_bv, corners, pred_corners_r) of its num_rois rows -- the ONE host round trip of the step"""
+        self.stream.synchronize()
+        o = self.out
+        num, status, cap = o["num_rois"].cpu().numpy(), o["status"].cpu().numpy(), int(o["rois_per_frame"])
+        if int(status.max()) & 1:
+            raise ZeroDivisionError("float division")
+        host = {k: o[k].float().cpu().numpy() for k in ("cls_prob", "pred_bv", "corners", "pred_corners_r")}
+        return [tuple(host[k][b * cap:b * cap + int(num[b])] for k in ("cls_prob", "pred_bv", "corners", "pred_corners_r")) for b in range(len(num))]
+
+
+def bench_serve_step(rank, world, dist, batch=16, seconds=1.0, warmup=2, dtypes=("fp32", "fp32_mfma", "fp16", "fp16_mfma", "fp16_mfma_graph"),
+                     reduce_device="cuda", views=3, steps=None):
     """Full MV3D_test forward WITH the dense layers, for bench.py's `serving_with_trunk` key (BASELINE configs[4]: batch
     16 / GPU, TEST cfg 6000 -> 300, "fp16 VGG16"): `batch` synthetic KITTI-shaped frames per step through the trunks /
     FC head, proposal_layer_3d, RoiPool of both views and the box tail.  fp32 is the reference's precision (torch: MIOpen /
     rocBLAS); fp16 = autocast of the DENSE layers only (MIOpen / rocBLAS half kernels); fp16_mfma = the 27 3x3 convolutions
-    on this repository's MFMA kernel (mv3d_conv3x3_f16, mv3d_tf_amd.trunk), the FC head still autocast rocBLAS.  The hot-path
-    layers stay f32 in every variant; the f16 variants are a lower precision than the reference, reported next to fp32, never
-    the headline."""
-    import time
+    on this repository's MFMA kernel (mv3d_conv3x3_f16, mv3d_tf_amd.trunk), the FC head still autocast rocBLAS;
+    fp16_mfma_graph = the same step captured once as a hipGraph over fixed shapes (ServeGraph: no host sync per step, the ROI counts
+    read after the window).  The hot-path layers stay f32 in every variant; the f16 variants are a lower precision than the reference,
+    reported next to fp32, never the headline.  Every variant is timed over >= `seconds` (a fixed step count per variant, the same on
+    every rank) and reports the minimum and median step beside the mean."""
     from .. import sharding, synth
     from ..networks import get_network
+    from ..utils.timing import step_stats, timed_steps
     net = get_network("MV3D_test_3view" if views == 3 else "MV3D_test")     # configs[4] serves the full 3-view model
     rng = np.random.RandomState(200 + rank)
     bev = torch.as_tensor(((rng.random_sample((batch, 608, 608, 9)) < 0.03) * rng.uniform(0, 2.4, (batch, 608, 608, 9))).astype(np.float32)).cuda()
@@ -134,32 +201,53 @@ def bench_serve_step(rank, world, dist, batch=16, steps=4, warmup=2, dtypes=("fp
                        "RoiPool x%d + box tail: batch %d / GPU, 608x608x9 BEV + 375x1242x3 image%s"
                        % ("_3view" if views == 3 else "", views, batch, " + 64x512x3 front view" if views == 3 else "")}
     rois = [0]
+    # steps per variant for a >= `seconds` window at batch 16 on one MI355X (ms per step measured in round 5: 130 / 101 / 47 / 13.4);
+    # fixed numbers, not a calibration run, so that every rank times the same window
+    ms_guess = {"fp32": 130.0, "fp32_mfma": 101.0, "fp16": 47.0, "bf16": 47.0, "fp16_mfma": 13.4, "fp16_mfma_graph": 12.5}
 
-    def step():
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1 and dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def eager_step():
         with torch.no_grad():
             L = net.forward(feed)
             ops.box_detect_tail(L["rois"][2].contiguous(), L["bbox_pred"].contiguous(), n_classes)
             rois[0] = int(L["rois"][2].shape[0])
 
-    for name in dtypes:
-        net.amp_dtype = {"fp32": None, "fp32_mfma": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16}[name]
-        net.mfma_trunk = name.endswith("_mfma")
-        for _ in range(warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1 and dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device=reduce_device)
-        out[name] = {"frames_per_s": round(steps * batch * world / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
-                     "rois_per_step": rois[0]}
-    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
+    try:
+        for name in dtypes:
+            net.amp_dtype = {"fp32": None, "fp32_mfma": None, "fp16": torch.float16, "bf16": torch.bfloat16, "fp16_mfma": torch.float16,
+                             "fp16_mfma_graph": torch.float16}[name]
+            net.mfma_trunk = "_mfma" in name
+            n = steps or max(8, int(np.ceil(seconds * 1e3 / (ms_guess[name] * batch / 16.0))))
+            extra = {}
+            if name.endswith("_graph"):
+                sg = ServeGraph(net, feed)
+                with torch.cuda.stream(sg.stream):
+                    dt, ms = timed_steps(sg.replay, n, barrier)
+                rois[0] = int(sg.out["num_rois"].sum().item())           # (the ONE read of the counts, after the window)
+                extra = {"rows_per_step": int(sg.out["cls_prob"].shape[0]),
+                         "launch": "one hipGraph replay per step, fixed shapes (%d ROI rows per frame), no host sync inside the window" % int(sg.out["rois_per_frame"])}
+                del sg
+            else:
+                for _ in range(warmup):
+                    eager_step()
+                dt, ms = timed_steps(eager_step, n, barrier)
+            dt = sharding.max_over_ranks(dt, dist if world > 1 else None, device=reduce_device)
+            out[name] = dict({"frames_per_s": round(n * batch * world / dt, 2), "ms_per_step": round(dt / n * 1e3, 3), "timed_s": round(dt, 3),
+                              "rois_per_step": rois[0]}, **step_stats(ms), **extra)
+            torch.cuda.empty_cache()
+    finally:
+        cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
+        net.fixed_rois = False
     out["note"] = ("fp32_mfma = the reference's precision with the 3x3 convolutions on this library's exact-f32 MFMA kernel; "
                    "fp16 = autocast of the dense layers only; fp16_mfma = 3x3 convolutions on the hand-written f16 MFMA kernel "
-                   "(f32 accumulate), FC head autocast; both lower precision than the reference's fp32; the hot-path layers run in f32")
+                   "(f32 accumulate), FC head autocast; fp16_mfma_graph = that step as one captured hipGraph; all 16-bit variants are a lower "
+                   "precision than the reference's fp32; the hot-path layers run in f32.  ms_per_step = wall time of the window / steps; "
+                   "_min / _median from one HIP event per step")
     return out
 
 

@@ -313,14 +313,20 @@ def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters
     return history
 
 
-def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False, step_hook=None,
-                     cast_many=True):
+def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False, step_hook=None,
+                     cast_many=True, seconds=1.0):
     """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
     VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
     frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
     bucketed gradient all-reduce + Adam.  The VGG16 convolutions / FC layers run through torch (MIOpen / rocBLAS -- no
-    hand-written kernel is claimed for them); the hot-path layers are the HIP kernels of this repository."""
+    hand-written kernel is claimed for them); the hot-path layers are the HIP kernels of this repository.  Timed over >= `seconds`
+    (`steps` = None: a fixed count per precision from the round-5 step times, the same on every rank); the minimum and median step
+    (one HIP event per step) are reported beside the mean."""
     from .. import sharding, synth
+    from ..utils.timing import step_stats, timed_steps
+    if steps is None:
+        guess_ms = (12.0 if amp is not None else 43.0) if mfma else (53.0 if amp is None else 25.0)
+        steps = max(8, int(np.ceil(seconds * 1e3 / (guess_ms * frames_per_step / 2.0))))
     from ..networks import get_network
     np.random.seed(cfg.RNG_SEED + rank)
     net = get_network("MV3D_train_3view" if views == 3 else "MV3D_train")   # configs[2]: "full 3-view MV3D -- BEV/FV/RGB VGG16"
@@ -365,16 +371,8 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
 
     for _ in range(warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        if step_hook is not None:                                # (diagnostics: tools/train_gap_probe.py brackets steps with a profiler)
-            step_hook(i, 0)
-        step()
-        if step_hook is not None:
-            step_hook(i, 1)
-    barrier()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, device="cuda")
+    dt, ms = timed_steps(step, steps, barrier, hook=step_hook)   # (step_hook: tools/train_gap_probe.py brackets steps with a profiler)
+    dt = sharding.max_over_ranks(dt, dist if world > 1 else None, device="cuda")
     nparam = sum(p.numel() for p in params)
     dense = (("the trunks' 3x3 convolutions forward + backward on this library's bf16 MFMA kernels (mv3d_tf_amd/trunk_train.py), rpn convs / FC "
               "head through torch autocast bf16, fp32 master weights, f32 hot path") if amp is not None else
@@ -384,7 +382,8 @@ def bench_train_step(rank, world, dist, steps=5, warmup=2, frames_per_step=2, se
                                                                  % str(amp).split(".")[-1]))
     out = {"workload": "MV3D_train%s full step: %d frames / GPU / step, 608x608x9 BEV + 375x1242x3 image%s; %s; Adam (fused)"
                        % ("_3view" if views == 3 else "", frames_per_step, " + 64x512x3 front view" if views == 3 else "", dense),
-           "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 2),
+           "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "timed_s": round(dt, 3),
+           **step_stats(ms),
            "parameters": nparam, "gradient_bytes_per_step": bucketer.total_bytes(), "allreduce_buckets": len(bucketer.buckets),
            "allreduce": "RCCL, 25 MB buckets, last layer first, overlapping backward" if world > 1 else "none (1 GPU)"}
     bucketer.close()

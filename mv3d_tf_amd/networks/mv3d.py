@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from ..fast_rcnn.config import cfg
 from ..roi_pooling_layer.roi_pooling_op import roi_pool_views
-from ..rpn_msr.proposal_layer_tf import proposal_layer_3d
+from ..rpn_msr.proposal_layer_tf import proposal_layer_3d, proposal_layer_3d_fixed
 
 n_classes = 2                 # lib/networks/MV3D_train.py:4
 _feat_stride = [8, 8]         # :5
@@ -61,6 +61,7 @@ class MV3D:
         # forward only, next to amp_dtype = torch.float16).  TRAIN graph with gradients: the trunks' forward AND backward in bf16
         # with fp32 master weights (mv3d_tf_amd.trunk_train, next to amp_dtype = torch.bfloat16 for the other dense layers).
         self.mfma_trunk = False
+        self.fixed_rois = False          # TEST phase: B x capacity ROI rows, no host sync (fast_rcnn.test_mv.ServeGraph)
         self._mfma = None
         self._train_pool = None
         self._wcache = {}
@@ -361,7 +362,11 @@ class MV3D:
             L["roi_data_bv"], L["roi_data_img"] = data[0], data[1]                    # proposal_transform (network.py:292-315)
             r3, rois_fv = data[4], out["rois"]["fv"]
         else:
-            bv, img, b3 = proposal_layer_3d(prob, pred, info, cal, self.phase, [stride, ], anchor_scales)
+            if getattr(self, "fixed_rois", False):
+                # the serving step as a capturable graph (fast_rcnn.test_mv.ServeGraph): B * cap rows, no host sync; num_rois read later
+                bv, img, b3, L["num_rois"], L["rois_status"], L["rois_per_frame"] = proposal_layer_3d_fixed(prob, pred, info, cal, self.phase, stride)
+            else:
+                bv, img, b3 = proposal_layer_3d(prob, pred, info, cal, self.phase, [stride, ], anchor_scales)
             rois = (bv, img, b3, b3)
             L["rois"] = rois
             L["roi_data_bv"], L["roi_data_img"] = rois[0], rois[1]

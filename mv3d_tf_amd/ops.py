@@ -356,17 +356,24 @@ def roi_pool_backward_views(views, pooled_height, pooled_width, outs=None):
 
 
 # ---- the RoiPool pair of a training step: private compact argmax plane, index + fill and gather behind one backward call
-_PAIR_WS_FREE = {}                 # (device, bytes) -> workspaces no backward call is using
+_PAIR_WS_FREE = {}                 # (device, bytes, stream) -> workspaces whose last user was enqueued on that stream
+
+
+def _stream_key():
+    return int(torch.cuda.current_stream().cuda_stream)
 
 
 def roi_pair_workspace(nbytes, device):
-    """A workspace for mv3d_roi_pool_backward_views_pair (no initialisation needed), recycled through release_roi_pair_workspace."""
-    free = _PAIR_WS_FREE.setdefault((str(device), int(nbytes)), [])
+    """A workspace for mv3d_roi_pool_backward_views_pair (no initialisation needed), recycled through release_roi_pair_workspace.
+    The pool is per STREAM: a released workspace is handed out again only to a call enqueued on the stream its last launches
+    run on (stream order is what makes the reuse safe; another stream could start while they are still running)."""
+    free = _PAIR_WS_FREE.setdefault((str(device), int(nbytes), _stream_key()), [])
     return free.pop() if free else torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 def release_roi_pair_workspace(ws):
-    free = _PAIR_WS_FREE.setdefault((str(ws.device), int(ws.numel())), [])
+    """ws goes back to the pool of the CURRENT stream (call it on the stream the workspace's launches were enqueued on)."""
+    free = _PAIR_WS_FREE.setdefault((str(ws.device), int(ws.numel()), _stream_key()), [])
     if len(free) < 4:
         free.append(ws)
 

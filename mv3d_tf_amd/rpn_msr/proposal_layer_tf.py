@@ -57,3 +57,19 @@ def proposal_layer_3d(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, calib, cfg_k
         r = int(counts[0])
         return (bv[0, :r], img[0, :r], b3[0, :r])
     return tuple(torch.cat([t[b, :int(counts[b])] for b in range(B)], 0) for t in (bv, img, b3))
+
+
+def proposal_layer_3d_fixed(prob, pred, info, cal, cfg_key, feat_stride=8):
+    """The serving form of proposal_layer_3d for a captured graph: NO host round trip, fixed shapes.  Device tensors in; returns
+    (blob_bv (B * cap, 5), blob_img (B * cap, 5), blob_3d (B * cap, 7), num_out (B) i32, status (B) i32, cap): frame b's proposals
+    are rows [b * cap, b * cap + num_out[b]), the rows behind them are ZERO boxes of frame 0 (the kernel writes them: they are pooled
+    and scored like any row and masked by whoever reads num_out -- once, after the step).  status bit 0 = the reference's
+    ZeroDivisionError (lib/nms/cpu_nms.pyx:64), to be checked with num_out."""
+    params = ops.proposal_params(cfg[cfg_key], feat_stride=int(feat_stride))
+    B, H, W = int(prob.shape[0]), int(prob.shape[1]), int(prob.shape[2])
+    cap = lib().mv3d_proposal_3d_capacity(H, W, C.byref(params))
+    if cap < 0:
+        check(ERR_INVALID_ARG, "mv3d_proposal_3d_capacity")
+    _, out = ops.proposal_3d_outputs(B, cap, prob.device)
+    bv, img, b3, num, status = ops.proposal_3d(prob, pred, info, cal, params, out=out)
+    return bv.reshape(B * cap, 5), img.reshape(B * cap, 5), b3.reshape(B * cap, 7), num, status, cap

@@ -58,6 +58,11 @@ def test_pmc_traffic_only_for_the_profiled_configuration(bench, tmp_path, monkey
         "void roi_pool_fwd_xcd_multi_kernel<2>": {"hbm_bytes_per_launch": 7}}}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.pmc_traffic("roi_bwd_", "train/b2/r256/peaky") == 110            # RoiPoolGrad = its kernels summed
+    # the signature names the launch set: a pass of another kernel variant of the same workload is not quoted
+    sig = bench.pmc_signature("test", 16, 4800, "peaky", "top-only")
+    assert sig == "test/b16/r4800/peaky/top-only" and bench.pmc_traffic("roi_pool_fwd", sig) is None
+    (prof / "r06_pmc_traffic.json").write_text(json.dumps({"signatures": {sig: {"kernels": {"void roi_pool_fwd_xcd_multi_kernel<2>": {"hbm_bytes_per_launch": 9}}}}}))
+    assert bench.pmc_traffic("roi_pool_fwd", sig) == 9 and bench.pmc_traffic("roi_pool_fwd", bench.pmc_signature("test", 16, 4800, "peaky", "top+argmax")) is None
     assert bench.pmc_traffic("roi_pool_fwd_xcd_multi_kernel", "train/b2/r256/peaky") == 7
     assert bench.pmc_traffic("roi_bwd_", "train/b2/r128/peaky") is None            # another configuration: never a stale number
     assert bench.pmc_traffic("no_such_kernel", "train/b2/r256/peaky") is None
@@ -137,7 +142,7 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     backward pass of the 143 M-parameter graph has run (gloo here; RCCL needs one GPU per rank)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
-                          "--ring", "3", "--batches-per-step", "6", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500, env=env)
+                          "--ring", "3", "--batches-per-step", "6", "--no-cpu-baseline", "--secondary-seconds", "0.25"], capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -156,6 +161,11 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     sv = sec["serving_with_trunk"]
     assert sv["fp32"]["frames_per_s"] > 0 and sv["fp16_mfma"]["frames_per_s"] > 0 and sv["fp16_mfma"]["rois_per_step"] > 0
     assert sv["fp32_mfma"]["frames_per_s"] > 0
+    g = sv["fp16_mfma_graph"]                                        # the whole serving step as one hipGraph replay, counts read after the window
+    assert g["frames_per_s"] > 0 and g["rois_per_step"] > 0 and g["steps_timed"] >= 8 and g["ms_per_step_min"] <= g["ms_per_step_median"]
+    assert wt["steps_timed"] >= 8 and wt["ms_per_step_min"] <= wt["ms_per_step_median"]
+    nms = [e for e in d["roofline_kernels"] if "greedy NMS" in e["kernel"]]
+    assert len(nms) == 2 and all(0 < e["frac"] <= 1 and e["blocks_visited"] <= e["blocks_total"] for e in nms)
     rk = sv["roofline_kernels"][0]
     assert rk["bound"] == "mfma" and rk["peak"] == 2500.0 and 0 < rk["frac"] < 1 and abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-3
     r32 = sv["roofline_kernels"][1]

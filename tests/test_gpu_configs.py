@@ -327,3 +327,71 @@ def test_three_view_graph_forward_backward(gpu):
     Lt = t.forward({"lidar_bv_data": np.zeros((1, 608, 608, 9), np.float32), "image_data": np.zeros((1, 96, 320, 3), np.float32),
                     "lidar_fv_data": np.zeros((1, 64, 512, 3), np.float32), "im_info": info, "calib": calib})
     assert Lt["cls_prob"].shape[1] == 2 and Lt["pool_5_3"].shape[0] == Lt["cls_prob"].shape[0]
+
+
+def test_config4_serving_step_as_one_hipgraph(gpu):
+    """BASELINE configs[4] as it is stated: the WHOLE serving step -- trunks (f16 MFMA), RPN heads, proposal_layer_3d TEST cfg 6000 -> 300,
+    FV ROIs, RoiPool x3, fusion head, box tail (lib/fast_rcnn/test_mv.py:149-264 for a batch) -- captured ONCE (ServeGraph), no host
+    sync inside.  The replay equals the same fixed-shape step run eagerly, bit for bit, also after new inputs were written into the
+    graph's buffers; the rows of a frame below its num_rois carry the hot path's exact ROIs of the ordinary (host-synchronised,
+    variable-shape) forward and its scores within 16-bit GEMM tolerance (a 1200-row and an R-row GEMM may tile differently)."""
+    torch, ops = gpu
+    from mv3d_tf_amd.fast_rcnn import test_mv
+    from mv3d_tf_amd.fast_rcnn.config import cfg
+    from mv3d_tf_amd.networks import get_network
+    B = 4
+    saved = (cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N)
+    cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = 6000, 300
+    try:
+        net = get_network("MV3D_test_3view")
+        net.amp_dtype, net.mfma_trunk = torch.float16, True
+        with torch.no_grad():
+            net.params["rpn_cls_score"][0].mul_(30.0)                # (spread scores: NMS keeps a frame-dependent number of boxes)
+
+        def feed(seed):
+            rng = np.random.RandomState(seed)
+            return {"lidar_bv_data": torch.as_tensor(((rng.random_sample((B, 608, 608, 9)) < 0.03) * rng.uniform(0, 2.4, (B, 608, 608, 9))).astype(np.float32)).cuda(),
+                    "image_data": torch.as_tensor((rng.randint(0, 255, (B, 375, 1242, 3)) - cfg.PIXEL_MEANS).astype(np.float32)).cuda(),
+                    "lidar_fv_data": torch.as_tensor(rng.uniform(0, 1, (B, 64, 512, 3)).astype(np.float32)).cuda(),
+                    "im_info": np.array([[608, 608, 1]] * B, np.float32), "calib": np.stack([synth.KITTI_CALIB] * B), "keep_prob": 1.0}
+
+        f1, f2 = feed(1), feed(2)
+        sg = test_mv.ServeGraph(net, f1)
+        assert net.fixed_rois is False                               # (the flag is the graph's business only)
+        keys = ("cls_prob", "bbox_pred", "rois_bv", "rois_img", "rois_3d", "corners", "pred_corners_r", "pred_bv", "num_rois")
+        for f in (f1, f2, f1):
+            got = sg.replay(f)
+            sg.stream.synchronize()
+            got = {k: got[k].clone() for k in keys}
+            net.fixed_rois = True
+            try:
+                with torch.no_grad():
+                    L = net.forward(f)
+                    cnr, pr, pbv, _ = ops.box_detect_tail(L["rois"][2].contiguous(), L["bbox_pred"].contiguous(), 2)
+            finally:
+                net.fixed_rois = False
+            want = {"cls_prob": L["cls_prob"], "bbox_pred": L["bbox_pred"], "rois_bv": L["rois"][0], "rois_img": L["rois"][1], "rois_3d": L["rois"][2],
+                    "corners": cnr, "pred_corners_r": pr, "pred_bv": pbv, "num_rois": L["num_rois"]}
+            for k in keys:
+                assert torch.equal(got[k], want[k]), k
+            cap = 300
+            assert got["cls_prob"].shape == (B * cap, 2) and got["rois_3d"].shape == (B * cap, 7)
+            num = got["num_rois"].cpu().numpy()
+            assert (num > 0).all() and (num <= cap).all()
+            # the ordinary forward (counts to the host, variable shapes): the same ROIs in the rows a frame owns, zero rows behind them
+            with torch.no_grad():
+                V = net.forward(f)
+            off = 0
+            for b in range(B):
+                n = int(num[b])
+                for k, j in (("rois_bv", 0), ("rois_img", 1), ("rois_3d", 2)):
+                    rows = got[k][b * cap:b * cap + n]
+                    assert torch.equal(rows, V["rois"][j][off:off + n]), (k, b)
+                    assert not got[k][b * cap + n:(b + 1) * cap].any()
+                assert torch.allclose(got["cls_prob"][b * cap:b * cap + n], V["cls_prob"][off:off + n], atol=5e-3)
+                off += n
+            assert off == V["rois"][0].shape[0]
+        dets = sg.detections()
+        assert len(dets) == B and all(d[0].shape[0] == int(n) and d[1].shape == (int(n), 8) for d, n in zip(dets, sg.out["num_rois"].cpu().numpy()))
+    finally:
+        cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N = saved
