@@ -75,6 +75,72 @@ def test_data_parallel_gradients_equal_single_process_mean(tmp_path):
     assert sorted(torch.load(tmp_path / "frames.pt").tolist()) == [0, 1, 2, 3]
 
 
+def _skip_worker(rank, world, port, out_dir):
+    """rank 1's loss does not touch the LAST layer (the first bucket): its hooks never fire there, so on that rank the first bucket -- and
+    everything behind it -- is launched by finish(); rank 0 launches every bucket during backward.  The collectives must still pair up
+    bucket by bucket (sharding.GradBucketer._launch_ready: strictly in index order on every rank)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from mv3d_tf_amd import sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _tiny_model(1)
+    b = sharding.GradBucketer(params, dist, bucket_bytes=1500)
+    launched = []
+    real = dist.all_reduce
+
+    class Spy:                                                        # records which bucket goes out when (during backward / in finish)
+        ReduceOp = dist.ReduceOp
+
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            launched.append((next(i for i, x in enumerate(b.buckets) if x["flat"] is t), phase[0]))
+            return real(t, op=op, async_op=async_op)
+    b.dist = Spy
+    phase = ["backward"]
+    b.zero_grad()
+    b.reset()
+    x, y = _frame(rank)
+    if rank == 0:
+        loss = _tiny_loss(params, x, y)
+    else:
+        w1, b1, w2, b2, w3, b3 = params                               # (w3, b3 = the classifier = bucket 0: unused on this rank)
+        h = F.relu(F.conv2d(x, w1, b1, padding=1))
+        loss = F.relu(F.conv2d(h, w2, b2, padding=1)).mean()
+    loss.backward()
+    phase[0] = "finish"
+    b.finish()
+    torch.save({"grads": [p.grad.clone() for p in params], "launched": launched}, os.path.join(out_dir, "s%d.pt" % rank))
+    b.close()
+    dist.destroy_process_group()
+
+
+def test_bucket_order_when_one_rank_skips_a_parameter(tmp_path):
+    """the ordering rule of GradBucketer._launch_ready: a parameter without a gradient on ONE rank holds its bucket -- and
+    every later one -- back until finish() on that rank only; both ranks still launch the same buckets in the same order, and the reduced
+    gradients are the mean of the two ranks' (zero where a rank had none)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_skip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    order0, order1 = [i for i, _ in r0["launched"]], [i for i, _ in r1["launched"]]
+    assert order0 == order1 == list(range(len(order0))) and len(order0) >= 3
+    assert all(ph == "backward" for _, ph in r0["launched"])          # rank 0: every bucket went out under backward
+    assert all(ph == "finish" for _, ph in r1["launched"])            # rank 1: bucket 0 never completed, so nothing could go first
+    import torch.nn.functional as F
+    params = _tiny_model(1)
+    g0 = torch.autograd.grad(_tiny_loss(params, *_frame(0)), params)
+    w1, b1, w2, b2, w3, b3 = params
+    x1, _ = _frame(1)
+    l1 = F.relu(F.conv2d(F.relu(F.conv2d(x1, w1, b1, padding=1)), w2, b2, padding=1)).mean()
+    g1 = list(torch.autograd.grad(l1, [w1, b1, w2, b2])) + [torch.zeros_like(w3), torch.zeros_like(b3)]
+    for a, b_, u, v in zip(r0["grads"], r1["grads"], g0, g1):
+        assert torch.equal(a, b_) and torch.allclose(a, (u + v) / 2, rtol=1e-5, atol=1e-7)
+
+
 def test_bucketing_of_the_mv3d_parameter_list():
     """the real parameter list (shapes of networks/mv3d.py, ~143 M fp32 = 573 MB): 25 MB buckets, reverse layer order,
     gradients are views of the flat buffers"""
