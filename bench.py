@@ -768,7 +768,6 @@ def main():
                     "ROIs + RoiPool 7x7 fwd on 3 views, R=%d rows; %s scores" % (batch, s0.num_rois, args.variant))
         signature = pmc_signature(wl, batch, s0.num_rois, args.variant,
                                   "pair-tiles" if wl == "train" else ("top+argmax" if getattr(args, "test_argmax", False) else "top-only"))
-        res["config"]["pmc_signature"] = signature
         res = {
             "metric": METRIC, "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
@@ -783,6 +782,7 @@ def main():
                        "host_cores": {"usable": ncores, "note": ("%d hardware threads visible%s" % (os.cpu_count() or 0, quota_note)),
                                       "pinned": host_plan["cores"], "plan": host_plan["note"]}},
         }
+        res["config"]["pmc_signature"] = signature
         # one batch alone on one stream: the latency of the path
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -656,6 +656,25 @@ int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int hei
 int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
                         void *stream);
 
+/* ------------------------------------------------------------------ the optimizer step (csrc/adam.hip)
+ * Replaces tf.train.AdamOptimizer(lr).apply_gradients of lib/fast_rcnn/train_mv.py:138-146 (beta 0.9 / 0.999, eps 1e-8, no weight
+ * decay) for ALL parameter tensors behind one launch: per element  m = m + (g - m) (1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps), f32, in place.
+ *   tensors_dev        device array of the tensors (each: f32 param / grad / both moments, numel elements)
+ *   chunk_tensor_dev   device int32 [num_chunks]: chunk -> index into tensors_dev
+ *   chunk_first_dev    device int32 [num_chunks]: chunk -> its first element / mv3d_adam_chunk_elements() inside that tensor
+ *                      (the host cuts every tensor into chunks once; the tables change only with the parameter list)
+ *   step               1-based count of this update (the bias corrections) */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg, *exp_avg_sq;
+    long long numel;
+} mv3d_adam_tensor;
+int mv3d_adam_chunk_elements(void);
+int mv3d_adam_step(const mv3d_adam_tensor *tensors_dev, const int32_t *chunk_tensor_dev, const int32_t *chunk_first_dev, int num_chunks,
+                   double lr, double beta1, double beta2, double eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

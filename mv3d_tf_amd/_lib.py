@@ -105,6 +105,11 @@ class PackItem(C.Structure):
                 ("c_out", C.c_int32), ("c_in", C.c_int32), ("c_in_pad", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class AdamTensor(C.Structure):
+    """mv3d_adam_tensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_longlong)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "mv3d_version": (C.c_int, []),
@@ -203,6 +208,8 @@ _SIGS = {
     "mv3d_conv3x3_pack_many_f32": (C.c_int, [C.c_int, C.POINTER(PackItem), _P]),
     "mv3d_maxpool2x2_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_adam_chunk_elements": (C.c_int, []),
+    "mv3d_adam_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

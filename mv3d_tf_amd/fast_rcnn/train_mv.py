@@ -207,7 +207,8 @@ class SolverWrapper(object):
         lr = self.LEARNING_RATE
         # tf.train.AdamOptimizer(lr) defaults: beta 0.9 / 0.999, eps 1e-8.  fused: ONE launch over all parameters on the device
         # (the foreach form is seven launches and 4 ms of a step for the 214 M parameters of the 3-view graph); same update rule
-        self.optimizer = torch.optim.Adam(params, lr=lr, fused=all(p.is_cuda for p in params))
+        from ..optim import Adam                                      # (torch.optim.Adam whose step is ONE launch of mv3d_adam_step)
+        self.optimizer = Adam(params, lr=lr) if all(p.is_cuda for p in params) else torch.optim.Adam(params, lr=lr)
         if resume is not None:
             self.net.load(resume, sess, self.saver, False)
             if os.path.exists(resume + '.optim.pt'):
@@ -334,7 +335,8 @@ def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2,
     net.mfma_trunk = bool(mfma)                                  # trunks' forward + backward on the bf16 MFMA kernel (trunk_train.py)
     net.cast_many = bool(cast_many)                              # (False: autocast's per-tensor casts -- tools/train_probe.py's A / B)
     params = net.parameters()
-    opt = torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE, fused=True)
+    from ..optim import Adam
+    opt = Adam(params, lr=SolverWrapper.LEARNING_RATE)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
     rng = np.random.RandomState(100 + rank)
     frames = []
@@ -380,7 +382,7 @@ def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2,
               "kernels (v_mfma_f32_32x32x2_f32), FC head through torch (rocBLAS)")) if mfma else (
         "torch (MIOpen / rocBLAS) VGG16 trunks + FC head, " + ("fp32" if amp is None else "autocast to %s (fp32 master weights, f32 hot path)"
                                                                  % str(amp).split(".")[-1]))
-    out = {"workload": "MV3D_train%s full step: %d frames / GPU / step, 608x608x9 BEV + 375x1242x3 image%s; %s; Adam (fused)"
+    out = {"workload": "MV3D_train%s full step: %d frames / GPU / step, 608x608x9 BEV + 375x1242x3 image%s; %s; Adam (mv3d_adam_step, one launch)"
                        % ("_3view" if views == 3 else "", frames_per_step, " + 64x512x3 front view" if views == 3 else "", dense),
            "frames_per_s": round(steps * frames_per_step * world / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "timed_s": round(dt, 3),
            **step_stats(ms),

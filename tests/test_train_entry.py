@@ -453,3 +453,45 @@ def test_load_skips_a_misfitting_tensor_like_the_reference_does(tmp_path, capsys
     assert torch.equal(net.params["fc6_1"][0], torch.as_tensor(vgg["fc6_1"]["weights"]).t())
     with pytest.raises(ValueError):                                                     # without ignore_missing: raise
         MV3D.load(net, path, ignore_missing=False)
+
+
+@pytest.mark.gpu
+def test_adam_step_kernel_equals_torch_adam():
+    """mv3d_tf_amd.optim.Adam (ONE launch of mv3d_adam_step for all tensors; lib/fast_rcnn/train_mv.py:138-146's AdamOptimizer) against
+    torch.optim.Adam over several steps: tensors of odd sizes (a last partial chunk, a bias of 3), a parameter that gets its first gradient
+    later (its own step count / bias corrections), state_dict interchange in both directions."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd import build, optim
+    build.build()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(3,), (64, 9, 3, 3), (4096 * 3 + 17,), (513, 257), (1,)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    pa = [b.clone().cuda().requires_grad_(True) for b in base]
+    pb = [b.clone().cuda().requires_grad_(True) for b in base]
+    oa, ob = optim.Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    for it in range(6):
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            if k == 4 and it < 2:                                     # the last tensor joins at the third step
+                x.grad = y.grad = None
+                continue
+            gr = torch.randn(x.shape, generator=g).cuda() * (10.0 ** (k - 2))
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-8), (it, x.shape)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sb["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    ob2 = optim.Adam(pb, lr=1e-3)
+    ob2.load_state_dict(sb)                                            # torch's state continues on the kernel ...
+    oa2 = torch.optim.Adam(pa, lr=1e-3)
+    oa2.load_state_dict(sa)                                            # ... and the kernel's on torch
+    for x, y in zip(pa, pb):
+        gr = torch.randn(x.shape, generator=g).cuda()
+        x.grad, y.grad = gr.clone(), gr.clone()
+    oa2.step(); ob2.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=4e-6, atol=1e-8)
