@@ -424,7 +424,12 @@ def nms_roofline_entries(variant="peaky", reps=30):
     from mv3d_tf_amd import ops, synth
     from mv3d_tf_amd._lib import check, lib
     out = []
-    clk_hz = torch.cuda.get_device_properties(torch.cuda.current_device()).clock_rate * 1e3
+    # shader clock for cycles -> time: the device's current clock if the runtime reports one, else the part's 2.4 GHz peak engine clock
+    clk_hz, clk_src = 2.4e9, "MI355X peak engine clock (assumed)"
+    try:
+        clk_hz, clk_src = float(torch.cuda.clock_rate()) * 1e6, "torch.cuda.clock_rate()"
+    except Exception:
+        pass
     prob, pred, info, calib = synth.rpn_head(1000, 76, 76, variant)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
     for name, pre, post in (("TRAIN cfg 12000 -> 2000", 12000, 2000), ("TEST cfg 6000 -> 300", 6000, 300)):
@@ -461,7 +466,7 @@ def nms_roofline_entries(variant="peaky", reps=30):
                     "bound": "latency (serial greedy chain)", "measured_us": round(float(np.median(us)), 2), "measured_us_min": round(float(us.min()), 2),
                     "blocks_total": int(nb), "blocks_visited": int(len(tt)), "kept": int(c2[0]),
                     "link_cycles_min": int(step.min()), "link_cycles_median": int(np.median(step)),
-                    "chain_cycles": int(tt[-1, 2] - tt[0, 0]) if len(tt) else 0, "clock_mhz": round(clk_hz / 1e6, 1),
+                    "chain_cycles": int(tt[-1, 2] - tt[0, 0]) if len(tt) else 0, "clock_mhz": round(clk_hz / 1e6, 1), "clock_source": clk_src,
                     "chain_floor_us": round(floor_us, 2), "frac": round(floor_us / float(np.median(us)), 4),
                     "note": "floor = blocks visited x the fastest link of the chain (shader cycles / clock); frac = floor / measured call"})
     return out

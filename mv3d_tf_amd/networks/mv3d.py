@@ -61,6 +61,7 @@ class MV3D:
         # forward only, next to amp_dtype = torch.float16).  TRAIN graph with gradients: the trunks' forward AND backward in bf16
         # with fp32 master weights (mv3d_tf_amd.trunk_train, next to amp_dtype = torch.bfloat16 for the other dense layers).
         self.mfma_trunk = False
+        self.fused_head = True           # TRAIN phase: the fusion head as one autograd function (fused_head.py); False = op by op
         self.fixed_rois = False          # TEST phase: B x capacity ROI rows, no host sync (fast_rcnn.test_mv.ServeGraph)
         self._mfma = None
         self._train_pool = None
@@ -282,7 +283,8 @@ class MV3D:
         self._step_half = None
         if self.cast_many and self.amp_dtype is not None and self.phase == "TRAIN" and torch.is_grad_enabled():
             from ..amp_cast import cast_params
-            self._step_half = cast_params(self.params, [n for n in self._HEAD_LAYERS if n in self.params], self.amp_dtype)
+            head = ("rpn_cls_score", "rpn_bbox_pred") if self.fused_head else self._HEAD_LAYERS      # (the fused head casts its own weights)
+            self._step_half = cast_params(self.params, [n for n in head if n in self.params], self.amp_dtype)
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
@@ -384,7 +386,15 @@ class MV3D:
         # (serving in 16-bit mode: the pooled maps in the head's type straight from the pooling launch -- no f32 copy, no cast launch)
         for name, top in zip(names, roi_pool_views([(d.contiguous(), r.contiguous()) for d, r in views], 7, 7, 1.0 / 8, top_dtype=self.amp_dtype)):
             L[name] = top
-        tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)
+        if self.fused_head and self.phase == "TRAIN" and torch.is_grad_enabled():
+            # the head as ONE autograd function (mv3d_tf_amd/fused_head.py): batched GEMMs over the views, no per-op graph nodes
+            from ..fused_head import fused_head
+            sfx = ("_1", "_2", "_3")[:len(names)]
+            L["cls_score"], L["bbox_pred"], tower = fused_head([L[n] for n in names], self.params, ["fc6" + t for t in sfx], ["fc7" + t for t in sfx],
+                                                               keep_prob, self.amp_dtype or torch.float32)
+            L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
+        else:
+            tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)
         for t, x in zip(("_1", "_2", "_3"), tower):
             L["fc7" + t] = x
         self._step_half = None                                                      # (the autograd graph keeps what backward needs)

@@ -495,3 +495,49 @@ def test_adam_step_kernel_equals_torch_adam():
     oa2.step(); ob2.step()
     for x, y in zip(pa, pb):
         assert torch.allclose(x, y, rtol=4e-6, atol=1e-8)
+
+
+def test_fused_head_equals_the_op_by_op_head():
+    """mv3d_tf_amd.fused_head.FusedHead (the fusion head of MV3D_train.py:159-182 as one autograd function: stacked weights, one batched GEMM
+    per layer for all views) against the same head written op by op: outputs and every gradient (pooled maps, fc6 / fc7 of each view,
+    cls_score, bbox_pred), fp32 on CPU; with dropout, the mask statistics and the inverted scaling."""
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.fused_head import fused_head
+    torch.manual_seed(0)
+    V, R, C, N = 3, 6, 4, 8
+    pools = [torch.randn(R, 7, 7, C, requires_grad=True) for _ in range(V)]
+    params = {}
+    for t in ("_1", "_2", "_3"):
+        params["fc6" + t] = [(torch.randn(N, C * 49) * 0.1).requires_grad_(True), torch.randn(N).requires_grad_(True)]
+        params["fc7" + t] = [(torch.randn(N, N) * 0.1).requires_grad_(True), torch.randn(N).requires_grad_(True)]
+    params["cls_score"] = [torch.randn(2, V * N).requires_grad_(True), torch.randn(2).requires_grad_(True)]
+    params["bbox_pred"] = [torch.randn(48, V * N).requires_grad_(True), torch.randn(48).requires_grad_(True)]
+    leaves = pools + [q for k in params for q in params[k]]
+    n6, n7 = ["fc6_1", "fc6_2", "fc6_3"], ["fc7_1", "fc7_2", "fc7_3"]
+    cls, box, tow = fused_head(pools, params, n6, n7, 1.0, torch.float32)
+    ((cls ** 2).sum() + box.sum() * 0.3).backward()
+    got = [p.grad.clone() for p in leaves]
+    for p in leaves:
+        p.grad = None
+    tw = []
+    for v, t in enumerate(("_1", "_2", "_3")):
+        x = pools[v].permute(0, 3, 1, 2).reshape(R, -1)                # NHWC blob -> the reference's (c, h, w) flattening
+        x = F.relu(F.linear(x, *params["fc6" + t]))
+        tw.append(F.relu(F.linear(x, *params["fc7" + t])))
+    f = torch.cat(tw, 1)
+    c2, b2 = F.linear(f, *params["cls_score"]), F.linear(f, *params["bbox_pred"])
+    ((c2 ** 2).sum() + b2.sum() * 0.3).backward()
+    assert torch.allclose(cls, c2, atol=1e-5) and torch.allclose(box, b2, atol=1e-5)
+    assert all(torch.allclose(t1, t2, atol=1e-6) for t1, t2 in zip(tow, tw))
+    for a, p in zip(got, leaves):
+        assert torch.allclose(a, p.grad, atol=1e-4, rtol=1e-4)
+    # dropout: about keep_prob of a tower survives, scaled by 1 / keep_prob; the gradient flows only through the survivors
+    for p in leaves:
+        p.grad = None
+    big = [torch.randn(64, 7, 7, C, requires_grad=True) for _ in range(V)]
+    cls, box, tow = fused_head(big, params, n6, n7, 0.5, torch.float32)
+    box.sum().backward()
+    nz = torch.cat([(t != 0).float().mean().reshape(1) for t in tow])
+    assert (nz < 0.45).all() and (nz > 0.05).all()                     # ReLU zeroes about half, dropout half of the rest
+    assert all(b.grad is not None and torch.isfinite(b.grad).all() for b in big)

@@ -9,6 +9,7 @@
 #   bench          python bench.py $BENCH_ARGS -> bench.json
 #   bench_path     bench.py path-only, no secondary legs, 3 runs
 #   stats          rocprofv3 --kernel-trace --stats of a short bench run -> kernel_stats.txt
+#   overlap        kernel trace of the path mode: how many RoiPool launches run at a time (tools/rocprof_overlap.py)
 #   pmc            HBM traffic counters of the default training workload (tools/gpu_pmc.sh)
 set -u
 cd "$GRAFT_REPO_ROOT"
@@ -30,7 +31,9 @@ for recipe in "$@"; do
     bench_path) for r in 1 2 3; do timeout 600 python bench.py --steps 10 --warmup 2 --no-secondary --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline'].get('avg_launch_us'), d['roofline'].get('in_flight'), [k.get('avg_launch_us') for k in d.get('roofline_kernels', [])], d.get('verified'))"; done 2>&1 | tee $OUT/bench_path.txt ;;
     stats) tools/gpu_profile.sh $TAG/ks --steps 4 --warmup 1 --batches-per-step 64 --no-cpu-baseline --no-secondary > /dev/null 2>&1
            python tools/rocprof_summary.py $OUT/ks/r_results.db > $OUT/kernel_stats.txt 2>&1; rm -rf $OUT/ks; head -12 $OUT/kernel_stats.txt ;;
-    pmc) tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky | head -12; rm -rf $OUT/pmc_train ;;
+    overlap) tools/gpu_profile.sh $TAG/ov --steps 3 --warmup 1 --batches-per-step 128 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+           python tools/rocprof_overlap.py $OUT/ov/r_results.db 2>&1 | tee $OUT/overlap.txt; rm -rf $OUT/ov ;;
+    pmc) tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky/pair-tiles | head -12; rm -rf $OUT/pmc_train ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
