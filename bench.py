@@ -460,13 +460,18 @@ def nms_roofline_entries(variant="peaky", reps=30):
             torch.cuda.synchronize()
         tt = tr.cpu().numpy()[:nb * 4].reshape(nb, 4)
         tt = tt[tt[:, 2] != 0]
-        step = np.diff(tt[:, 0]) if len(tt) > 1 else np.array([0])
+        # links between consecutive blocks of ONE launch (later rounds are other launches on other compute units: their cycle counters
+        # are not comparable, such differences are dropped)
+        step = np.diff(tt[:, 0]) if len(tt) > 1 else np.array([1])
+        step = step[(step > 0) & (step < 200000)]
+        if len(step) == 0:
+            step = np.array([1])
         floor_us = len(tt) * float(step.min()) / clk_hz * 1e6
         out.append({"kernel": "greedy NMS, %s @ 0.7, one frame of %d boxes (nms_tiles_kernel + nms_chain_lds_kernel + nms_round_kernel<W>)" % (name, k),
                     "bound": "latency (serial greedy chain)", "measured_us": round(float(np.median(us)), 2), "measured_us_min": round(float(us.min()), 2),
                     "blocks_total": int(nb), "blocks_visited": int(len(tt)), "kept": int(c2[0]),
                     "link_cycles_min": int(step.min()), "link_cycles_median": int(np.median(step)),
-                    "chain_cycles": int(tt[-1, 2] - tt[0, 0]) if len(tt) else 0, "clock_mhz": round(clk_hz / 1e6, 1), "clock_source": clk_src,
+                    "chain_cycles": int(step.sum()), "clock_mhz": round(clk_hz / 1e6, 1), "clock_source": clk_src,
                     "chain_floor_us": round(floor_us, 2), "frac": round(floor_us / float(np.median(us)), 4),
                     "note": "floor = blocks visited x the fastest link of the chain (shader cycles / clock); frac = floor / measured call"})
     return out

@@ -315,7 +315,7 @@ def train_net(network, imdb, roidb, output_dir, pretrained_model=None, max_iters
 
 
 def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2, seed=0, amp=None, views=3, mfma=False, step_hook=None,
-                     cast_many=True, seconds=1.0):
+                     cast_many=True, seconds=1.0, fused_head=True, kernel_adam=True):
     """Full MV3D training step WITH the dense layers, for bench.py's `with_trunk` key ("also reported with
     VGG16 trunks included"; BASELINE configs[2] at one GPU, configs[3] under torch.distributed): synthetic KITTI-shaped
     frames (608x608x9 BEV, 375x1242x3 image), `frames_per_step` frames per rank and step, forward + four losses + backward +
@@ -334,9 +334,10 @@ def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2,
     net.amp_dtype = amp                                          # None = the reference's fp32; torch.bfloat16: autocast dense layers
     net.mfma_trunk = bool(mfma)                                  # trunks' forward + backward on the bf16 MFMA kernel (trunk_train.py)
     net.cast_many = bool(cast_many)                              # (False: autocast's per-tensor casts -- tools/train_probe.py's A / B)
+    net.fused_head = bool(fused_head)                            # (False: the head op by op -- tools/train_ab.py's A / B)
     params = net.parameters()
     from ..optim import Adam
-    opt = Adam(params, lr=SolverWrapper.LEARNING_RATE)
+    opt = Adam(params, lr=SolverWrapper.LEARNING_RATE) if kernel_adam else torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE, fused=True)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
     rng = np.random.RandomState(100 + rank)
     frames = []

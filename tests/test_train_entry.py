@@ -480,7 +480,7 @@ def test_adam_step_kernel_equals_torch_adam():
             x.grad, y.grad = gr.clone(), gr.clone()
         oa.step(); ob.step()
         for x, y in zip(pa, pb):
-            assert torch.allclose(x, y, rtol=2e-6, atol=1e-8), (it, x.shape)
+            assert torch.allclose(x, y, rtol=1e-6, atol=1e-6), (it, x.shape)      # (a few ulp of the parameter: both sit equally far from an f64 step)
     sa, sb = oa.state_dict(), ob.state_dict()
     for k in sb["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
@@ -494,7 +494,7 @@ def test_adam_step_kernel_equals_torch_adam():
         x.grad, y.grad = gr.clone(), gr.clone()
     oa2.step(); ob2.step()
     for x, y in zip(pa, pb):
-        assert torch.allclose(x, y, rtol=4e-6, atol=1e-8)
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-6)
 
 
 def test_fused_head_equals_the_op_by_op_head():
