@@ -484,7 +484,7 @@ def test_adam_step_kernel_equals_torch_adam():
     sa, sb = oa.state_dict(), ob.state_dict()
     for k in sb["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
-        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     ob2 = optim.Adam(pb, lr=1e-3)
     ob2.load_state_dict(sb)                                            # torch's state continues on the kernel ...
     oa2 = torch.optim.Adam(pa, lr=1e-3)
