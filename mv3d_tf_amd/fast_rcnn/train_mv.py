@@ -88,7 +88,7 @@ def total_loss(net_layers, sigma=3.0):
         return ce + box + rpn_ce + rpn_box, (ce, box, rpn_ce, rpn_box)
     B = rpn_data[0].shape[0]
     rows = L['roi_rows']
-    parts = [0.0, 0.0, 0.0, 0.0]
+    vals = []
     o = 0
     for b in range(B):
         r_ce, r_box = rpn_losses(L['rpn_cls_score_reshape'][b], (rpn_data[0][b], rpn_data[1][b]), L['rpn_bbox_pred'][b], sigma)
@@ -96,9 +96,10 @@ def total_loss(net_layers, sigma=3.0):
         o += rows[b]
         data = L['roi_data_3d']
         ce, box = rcnn_losses(L['cls_score'][sl], (None, None, data[2][sl], data[3][sl]), L['bbox_pred'][sl], sigma)
-        for k, v in enumerate((ce, box, r_ce, r_box)):
-            parts[k] = parts[k] + v / B
-    return parts[0] + parts[1] + parts[2] + parts[3], tuple(parts)
+        vals += [ce, box, r_ce, r_box]
+    # the frames' means with ONE stack + ONE reduction (4 B scalars added and divided one by one were 4 B + 4 B launches each way)
+    parts = torch.stack(vals).view(B, 4).mean(0)
+    return parts.sum(), tuple(parts.unbind(0))
 
 
 def stack_blobs(frames):

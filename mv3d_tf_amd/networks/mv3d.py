@@ -269,6 +269,52 @@ class MV3D:
             raise ValueError("ground truth for %d frames, data for %d" % (len(frames), B))
         return frames
 
+    _STAGE_BYTES = 1 << 20
+
+    def _stage_host_inputs(self, feed, L, dev, to_dev):
+        """feed -> L on the device.  Tensors go as they are.  The SMALL host arrays of a step (im_info, calib, the ground-truth lists: a
+        dozen arrays of a few hundred bytes) are packed into one pinned staging buffer and cross in ONE asynchronous copy -- each on
+        its own is a pageable, synchronous hipMemcpy (profiles/r06_train_tail: 7 copy -> copy gaps of 24 us per step).  Two staging
+        buffers alternate: the copy of step n may still be reading when step n + 1 packs."""
+        small, order = [], []
+        for k in _INPUTS:
+            if k not in feed or feed[k] is None:
+                continue
+            v = feed[k]
+            items = list(v) if isinstance(v, (list, tuple)) else [v]
+            if dev.type == "cuda" and all(not isinstance(a, torch.Tensor) and np.asarray(a).nbytes <= 65536 for a in items):
+                arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in items]
+                small += arrs
+                order.append((k, isinstance(v, (list, tuple)), [a.shape for a in arrs]))
+            else:
+                L[k] = [to_dev(a) for a in v] if isinstance(v, (list, tuple)) else to_dev(v)
+        if not small:
+            return
+        total = sum(-(-a.size // 4) * 4 for a in small)                  # (16-byte aligned pieces)
+        if total * 4 > self._STAGE_BYTES:
+            for k, is_list, shapes in order:                            # (larger than the staging buffer: the plain way)
+                v = feed[k]
+                L[k] = [to_dev(a) for a in v] if is_list else to_dev(v)
+            return
+        st = self.__dict__.setdefault("_stage", {"pin": [torch.empty(self._STAGE_BYTES // 4, dtype=torch.float32).pin_memory() for _ in range(2)], "n": 0})
+        pin = st["pin"][st["n"] & 1]
+        st["n"] += 1
+        host = pin.numpy()
+        off, offs = 0, []
+        for a in small:
+            host[off:off + a.size] = a.reshape(-1)
+            offs.append(off)
+            off += -(-a.size // 4) * 4
+        devbuf = torch.empty(total, dtype=torch.float32, device=dev)
+        devbuf.copy_(pin[:total], non_blocking=True)
+        it = iter(zip(offs, small))
+        for k, is_list, shapes in order:
+            views = []
+            for shp in shapes:
+                o, a = next(it)
+                views.append(devbuf[o:o + a.size].view(shp))
+            L[k] = views if is_list else views[0]
+
     # ---- the graph
     def forward(self, feed):
         """feed: dict with the reference's placeholder names (Appendix C of SURVEY.md); numpy or tensors."""
@@ -276,15 +322,15 @@ class MV3D:
         L.clear()
         dev = self.device
         to_dev = lambda a: a.to(dev) if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32)).to(dev)
-        for k in _INPUTS:
-            if k in feed and feed[k] is not None:
-                L[k] = [to_dev(a) for a in feed[k]] if isinstance(feed[k], (list, tuple)) else to_dev(feed[k])
+        self._stage_host_inputs(feed, L, dev, to_dev)
         keep_prob = float(feed.get("keep_prob", self.keep_prob))
         self._step_half = None
         if self.cast_many and self.amp_dtype is not None and self.phase == "TRAIN" and torch.is_grad_enabled():
             from ..amp_cast import cast_params
-            head = ("rpn_cls_score", "rpn_bbox_pred") if self.fused_head else self._HEAD_LAYERS      # (the fused head casts its own weights)
-            self._step_half = cast_params(self.params, [n for n in head if n in self.params], self.amp_dtype)
+            # (the fused head and RpnHeads cast their own weights; the torch trunks' RPN convolutions still take the step's copies)
+            head = ("rpn_cls_score", "rpn_bbox_pred") if self.fused_head else self._HEAD_LAYERS
+            if not (self.fused_head and self.mfma_trunk):
+                self._step_half = cast_params(self.params, [n for n in head if n in self.params], self.amp_dtype)
         # plain NCHW for the torch / MIOpen convolutions: measured 22.2 ms vs 29.3 ms (channels_last) for fwd + bwd of the two
         # trunks' 26 convolutions of one frame (tools/conv_layout_probe.py); the hot-path layers take NHWC, made at conv5_3
         to_nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
@@ -306,12 +352,17 @@ class MV3D:
             from ..trunk_train import conv_relu
             rpn_nhwc = conv_relu(bev_nhwc, *self.params["rpn_conv/3x3"], dtype=tdt)   # (B, H, W, 512) f32, same kernels
             L["rpn_conv/3x3"] = rpn_nhwc
-            heads = []
-            for name in ("rpn_cls_score", "rpn_bbox_pred"):                       # 1x1 convolutions = a matmul over the channel axis
-                w, b = self._half_or_master(name)
-                with self._amp():
-                    heads.append(F.linear(rpn_nhwc, w.reshape(w.shape[0], -1), b).float().contiguous())
-            score, L["rpn_bbox_pred"] = heads
+            if self.fused_head:
+                # both 1x1 heads as ONE GEMM on the stacked filters (fused_head.RpnHeads)
+                from ..fused_head import RpnHeads
+                score, L["rpn_bbox_pred"] = RpnHeads.apply(self.amp_dtype or torch.float32, rpn_nhwc, *self.params["rpn_cls_score"], *self.params["rpn_bbox_pred"])
+            else:
+                heads = []
+                for name in ("rpn_cls_score", "rpn_bbox_pred"):                   # 1x1 convolutions = a matmul over the channel axis
+                    w, b = self._half_or_master(name)
+                    with self._amp():
+                        heads.append(F.linear(rpn_nhwc, w.reshape(w.shape[0], -1), b).float().contiguous())
+                score, L["rpn_bbox_pred"] = heads
         elif self.mfma_trunk:
             score, L["rpn_bbox_pred"] = self._mfma_trunks(L)
         else:

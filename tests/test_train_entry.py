@@ -541,3 +541,25 @@ def test_fused_head_equals_the_op_by_op_head():
     nz = torch.cat([(t != 0).float().mean().reshape(1) for t in tow])
     assert (nz < 0.45).all() and (nz > 0.05).all()                     # ReLU zeroes about half, dropout half of the rest
     assert all(b.grad is not None and torch.isfinite(b.grad).all() for b in big)
+
+
+def test_rpn_heads_as_one_gemm_equal_the_two_linears():
+    """fused_head.RpnHeads (rpn_cls_score + rpn_bbox_pred of MV3D_train.py:88-97 as one GEMM on the stacked filters) against the two
+    F.linear calls: outputs and the gradients of the map, both filters and both biases (fp32, CPU)."""
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd.fused_head import RpnHeads
+    torch.manual_seed(1)
+    rpn = torch.randn(2, 5, 6, 16, requires_grad=True)
+    wc, bc = torch.randn(8, 16, 1, 1, requires_grad=True), torch.randn(8, requires_grad=True)
+    wb, bb = torch.randn(24, 16, 1, 1, requires_grad=True), torch.randn(24, requires_grad=True)
+    leaves = (rpn, wc, bc, wb, bb)
+    s, p = RpnHeads.apply(torch.float32, rpn, wc, bc, wb, bb)
+    ((s ** 2).sum() + p.sum()).backward()
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    s2, p2 = F.linear(rpn, wc.reshape(8, -1), bc), F.linear(rpn, wb.reshape(24, -1), bb)
+    ((s2 ** 2).sum() + p2.sum()).backward()
+    assert s.shape == (2, 5, 6, 8) and p.shape == (2, 5, 6, 24) and torch.allclose(s, s2, atol=1e-5) and torch.allclose(p, p2, atol=1e-5)
+    assert all(torch.allclose(a, t.grad, atol=1e-4) for a, t in zip(got, leaves))

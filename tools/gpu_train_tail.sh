@@ -12,7 +12,7 @@ import sqlite3, sys
 c = sqlite3.connect(sys.argv[1]); steps = float(sys.argv[2])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # the timed steps = the last `steps` of steps + 2 warm-up: cut at the Adam launch (multi_tensor_apply) that ends warm-up step 2
-adam = [r[1] for r in rows if "multi_tensor_apply" in r[0] and "Adam" in r[0]]        # (not the multi-tensor casts)
+adam = [r[1] for r in rows if "adam_step_kernel" in r[0] or ("multi_tensor_apply" in r[0] and "Adam" in r[0])]        # (not the multi-tensor casts)
 per = len(adam) / (steps + 2)
 cut = adam[int(round(2 * per)) - 1] if adam else rows[0][1]
 agg = {}
@@ -34,7 +34,7 @@ for (s, e, n), (ps, pe, pn) in zip(tw[1:], tw[:-1]):
         k = (pn[:60], n[:60])
         a = gaps.setdefault(k, [0, 0]); a[0] += 1; a[1] += g
 # ... and by who owns the two launches: the library's kernels (mv3d_* / roi_* / loss_* / at_* / pt_* / nms_*) or torch / rocBLAS
-own = lambda n: any(t in n for t in ("mv3d", "roi_", "loss_", "at_", "pt_", "nms_", "proposal", "rgt_"))
+own = lambda n: any(t in n for t in ("mv3d", "roi_", "loss_", "at_", "pt_", "nms_", "proposal", "rgt_", "adam_step"))
 cls = {}
 for (pn, n), v in gaps.items():
     k = ("library" if own(pn) else "torch") + " -> " + ("library" if own(n) else "torch")
