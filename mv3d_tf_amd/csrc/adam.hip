@@ -18,12 +18,13 @@ struct AdamArgs {
     float lr_over_bc1;             // lr / (1 - beta1^t)
     float inv_sqrt_bc2;            // 1 / sqrt(1 - beta2^t)
     float beta1, beta2, eps;
+    float omb1, omb2;              // 1 - beta, rounded from the DOUBLE difference as torch rounds them (1.0f - 0.999f is 1.3e-5 off)
 };
 
 __device__ __forceinline__ void adam_one(float &p, const float g, float &m, float &v, const AdamArgs &a)
 {
-    m = m + (g - m) * (1.0f - a.beta1);                                // lerp(exp_avg, grad, 1 - beta1)
-    v = a.beta2 * v + (1.0f - a.beta2) * g * g;
+    m = m + (g - m) * a.omb1;                                          // lerp(exp_avg, grad, 1 - beta1)
+    v = a.beta2 * v + a.omb2 * g * g;
     const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
     p = p - a.lr_over_bc1 * (m / denom);
 }
@@ -75,6 +76,7 @@ extern "C" int mv3d_adam_step(const mv3d_adam_tensor *tensors_dev, const int32_t
     a.lr_over_bc1 = (float)(lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)num_chunks), dim3(256), 0, (hipStream_t)stream, a);
     return mv3d_launch_status();
 }

@@ -296,7 +296,9 @@ class MV3D:
                 v = feed[k]
                 L[k] = [to_dev(a) for a in v] if is_list else to_dev(v)
             return
-        st = self.__dict__.setdefault("_stage", {"pin": [torch.empty(self._STAGE_BYTES // 4, dtype=torch.float32).pin_memory() for _ in range(2)], "n": 0})
+        st = self.__dict__.get("_stage")
+        if st is None:                                                  # (pinned allocations cost milliseconds: once per network)
+            st = self.__dict__["_stage"] = {"pin": [torch.empty(self._STAGE_BYTES // 4, dtype=torch.float32).pin_memory() for _ in range(2)], "n": 0}
         pin = st["pin"][st["n"] & 1]
         st["n"] += 1
         host = pin.numpy()
