@@ -2087,8 +2087,10 @@ extern "C" int mv3d_roi_pool_backward_views_pair(int num_views, const mv3d_roi_g
 #else
     const int tiles_env = -1;
 #endif
-    // without a workspace: ONE launch of map tiles, no index, no fill (roi_grad_tiles.hip); with one: index + gather
-    if (tiles_env == 1 || (tiles_env < 0 && !workspace))
+    // ONE launch of map tiles, no index, no fill, no scratch memory (roi_grad_tiles.hip) -- with or without a workspace: the round-5
+    // structure behind a workspace (index + zero fill, gather: three launches) is level alone and 3 - 7 % slower in the path, and a
+    // planning launch that cuts the hot tiles costs what it saves (profiles/r06_g).  (Experiment builds, MV3D_PAIR_TILES=0: index + gather.)
+    if (tiles_env != 0)
         return mv3d_launch_roi_pair_tiles(num_views, views, pooled_height, pooled_width, (hipStream_t)stream);
     if (!workspace) return MV3D_ERR_WORKSPACE;
     if (workspace_bytes < roi_pair_workspace_bytes(num_views, views, pooled_height, pooled_width)) return MV3D_ERR_WORKSPACE;

@@ -42,7 +42,7 @@ cs = [mk(b) for b in bts]
 ws = torch.zeros(lib().mv3d_roi_pool_pair_workspace_bytes(3, cs[0][1], 7, 7), dtype=torch.uint8, device=dev)
 for fwd, arr in cs:
     check(lib().mv3d_roi_pool_forward_views_pair(3, fwd, 7, 7, 1, st), "fwd")
-bwd = lambda arr: check(lib().mv3d_roi_pool_backward_views_pair(3, arr, 7, 7, None, 0, st), "bwd")
+bwd = lambda arr: check(lib().mv3d_roi_pool_backward_views_pair(3, arr, 7, 7, C.c_void_p(ws.data_ptr()) if os.environ.get("PAIR_WS") else None, ws.numel() if os.environ.get("PAIR_WS") else 0, st), "bwd")
 for _ in range(2):
     for fwd, arr in cs:
         bwd(arr)
