@@ -411,6 +411,11 @@ def roofline_entries(ring, workload, signature):
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("roi_pair_" if "roi_pair_" in kname else kname, signature),
                     "alg_bytes_per_launch": int(alg), "avg_launch_us": round(ms * 1e3, 2), "launches_timed": len(marks[fn])})
+        moved = getattr(mine[0], bytes_meth.replace("_bytes", "_moved_bytes"), None)
+        if moved is not None:
+            # (`achieved` prices the reference op's 8 B per pooled value; the pair's own minimum is 5 B -- its real bandwidth)
+            out[-1]["moved_bytes_per_launch"] = int(moved())
+            out[-1]["moved_frac"] = round(moved() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return out
 
 

@@ -293,12 +293,21 @@ class TrainPathBatch:
     def roi_backward(self):
         check(lib().mv3d_roi_pool_backward_views_pair(*self.bwd_args), "mv3d_roi_pool_backward_views_pair")
 
-    # algorithmic HBM bytes: maps once + rois + (top f32 + argmax i32) / (grad + argmax) + map write
+    # algorithmic HBM bytes (the REFERENCE op's contract): maps once + rois + (top f32 + argmax i32) / (grad + argmax) +
+    # map write -- 8 B per pooled value.  The pair itself moves 5: its argmax plane holds one-byte codes (roi_*_moved_bytes below)
     def roi_forward_bytes(self):
         return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 8 for v in self.views)
 
     def roi_backward_bytes(self):
         return sum(self.num_rois * 49 * self.maps[v].shape[3] * 8 + self.num_rois * 20 + self.maps[v].numel() * 4 for v in self.views)
+
+    def roi_forward_moved_bytes(self):
+        """what the pair's forward has to move at least: maps once + rois + top f32 + ONE code byte per pooled value"""
+        return sum(self.maps[v].numel() * 4 + self.num_rois * 20 + self.num_rois * 49 * self.maps[v].shape[3] * 5 for v in self.views)
+
+    def roi_backward_moved_bytes(self):
+        """... and its backward: top_diff f32 + one code byte per pooled value + rois + the maps written once"""
+        return sum(self.num_rois * 49 * self.maps[v].shape[3] * 5 + self.num_rois * 20 + self.maps[v].numel() * 4 for v in self.views)
 
     def snapshot(self):
         """host copies of every output of the batch (for replay == setup checks)"""

@@ -33,7 +33,9 @@ for recipe in "$@"; do
            python tools/rocprof_summary.py $OUT/ks/r_results.db > $OUT/kernel_stats.txt 2>&1; rm -rf $OUT/ks; head -12 $OUT/kernel_stats.txt ;;
     overlap) tools/gpu_profile.sh $TAG/ov --steps 3 --warmup 1 --batches-per-step 128 --no-cpu-baseline --no-secondary > /dev/null 2>&1
            python tools/rocprof_overlap.py $OUT/ov/r_results.db 2>&1 | tee $OUT/overlap.txt; rm -rf $OUT/ov ;;
-    pmc) tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky/pair-tiles | head -12; rm -rf $OUT/pmc_train ;;
+    pmc) rm -f $OUT/pmc_traffic.json $OUT/pmc_traffic.txt
+         tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky/pair-tiles | head -8; rm -rf $OUT/pmc_train
+         tools/gpu_pmc.sh $TAG/pmc_test --workload test > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_test $OUT/pmc_traffic test/b16/r4800/peaky/top-only | head -8; rm -rf $OUT/pmc_test ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
