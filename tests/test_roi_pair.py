@@ -30,7 +30,8 @@ def gpu():
     return torch, ops
 
 
-# RoiPoolGrad of the pair with a workspace (index + fill, gather) and without one (ONE launch of map tiles, csrc/roi_grad_tiles.hip)
+# RoiPoolGrad of the pair called with a workspace and without one: since round 6 the same ONE launch of map tiles either way
+# (csrc/roi_grad_tiles.hip; the entry ignores the workspace) -- both call forms stay covered, on garbage-filled scratch memory
 WS = pytest.mark.parametrize("no_ws", [False, True], ids=["workspace", "no-workspace"])
 
 
