@@ -664,16 +664,19 @@ int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int heig
  *   chunk_tensor_dev   device int32 [num_chunks]: chunk -> index into tensors_dev
  *   chunk_first_dev    device int32 [num_chunks]: chunk -> its first element / mv3d_adam_chunk_elements() inside that tensor
  *                      (the host cuts every tensor into chunks once; the tables change only with the parameter list)
- *   step               1-based count of this update (the bias corrections) */
+ *   step               1-based count of this update (the bias corrections)
+ *   lowp_dtype         the 16-bit type of the tensors' optional param_lowp copies (what the next step's GEMMs read the weights in) */
 typedef struct {
     float *param;
     const float *grad;
     float *exp_avg, *exp_avg_sq;
     long long numel;
+    void *param_lowp;            /* NULL, or `numel` 16-bit elements that receive the updated parameter rounded to lowp_dtype */
 } mv3d_adam_tensor;
 int mv3d_adam_chunk_elements(void);
 int mv3d_adam_step(const mv3d_adam_tensor *tensors_dev, const int32_t *chunk_tensor_dev, const int32_t *chunk_first_dev, int num_chunks,
-                   double lr, double beta1, double beta2, double eps, int step, void *stream);
+                   double lr, double beta1, double beta2, double eps, int step, int lowp_dtype /* of param_lowp: 0 none, 1 f16, 2 bf16 */,
+                   void *stream);
 
 #ifdef __cplusplus
 }

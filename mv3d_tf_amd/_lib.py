@@ -107,7 +107,8 @@ class PackItem(C.Structure):
 
 class AdamTensor(C.Structure):
     """mv3d_adam_tensor"""
-    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_longlong)]
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_longlong),
+                ("param_lowp", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -209,7 +210,7 @@ _SIGS = {
     "mv3d_maxpool2x2_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_adam_chunk_elements": (C.c_int, []),
-    "mv3d_adam_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _P]),
+    "mv3d_adam_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

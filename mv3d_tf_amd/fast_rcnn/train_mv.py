@@ -210,6 +210,8 @@ class SolverWrapper(object):
         # (the foreach form is seven launches and 4 ms of a step for the 214 M parameters of the 3-view graph); same update rule
         from ..optim import Adam                                      # (torch.optim.Adam whose step is ONE launch of mv3d_adam_step)
         self.optimizer = Adam(params, lr=lr) if all(p.is_cuda for p in params) else torch.optim.Adam(params, lr=lr)
+        if hasattr(self.net, "attach_optimizer"):
+            self.net.attach_optimizer(self.optimizer)
         if resume is not None:
             self.net.load(resume, sess, self.saver, False)
             if os.path.exists(resume + '.optim.pt'):
@@ -339,6 +341,7 @@ def bench_train_step(rank, world, dist, steps=None, warmup=2, frames_per_step=2,
     params = net.parameters()
     from ..optim import Adam
     opt = Adam(params, lr=SolverWrapper.LEARNING_RATE) if kernel_adam else torch.optim.Adam(params, lr=SolverWrapper.LEARNING_RATE, fused=True)
+    net.attach_optimizer(opt)                                     # (the kernel Adam also writes the head's 16-bit weight copies)
     bucketer = sharding.GradBucketer(params, dist if world > 1 else None)
     rng = np.random.RandomState(100 + rank)
     frames = []

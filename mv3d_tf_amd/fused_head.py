@@ -9,10 +9,26 @@ issued back to back with no graph nodes in between:
   * fc6 / fc7 of all views are ONE strided-batched GEMM each (bias through the GEMM's beta operand), ReLU in place, dropout by
     torch.native_dropout (output + mask in one kernel; ReLU and dropout commute, the mask scale being positive);
   * cls_score and bbox_pred are ONE GEMM on the concatenated towers (weights stacked to (2 + 48, views * 2048));
-  * backward: the same GEMMs transposed, one masked elementwise per layer, weight gradients cast to f32 by one multi-tensor copy.
+  * backward: the same GEMMs transposed, one masked elementwise per layer; the weight-gradient GEMMs write f32 directly where the
+    installed torch offers `out_dtype` (else their results are cast).
 The GEMMs themselves are the vendor library's (a dense contraction: hipBLASLt behind torch.baddbmm / addmm); the results equal the
 op-by-op graph up to GEMM batching (tests/test_train_entry.py::test_fused_head_equals_the_op_by_op_head)."""
 import torch
+
+_F32_OUT = [None]         # does this torch take bmm / mm(..., out_dtype=torch.float32) on the device?  (probed once)
+
+
+def _mm_f32(a, b, batched):
+    """a @ b with 16-bit operands and an f32 RESULT straight from the GEMM (aten::bmm.dtype / mm.dtype: the weight gradients then need
+    neither a 16-bit intermediate nor a cast launch); falls back to the product in the operands' type, cast afterwards."""
+    if a.dtype != torch.float32 and a.is_cuda and _F32_OUT[0] is not False:
+        try:
+            out = (torch.bmm if batched else torch.mm)(a, b, out_dtype=torch.float32)
+            _F32_OUT[0] = True
+            return out
+        except (TypeError, RuntimeError, NotImplementedError):
+            _F32_OUT[0] = False
+    return (torch.bmm if batched else torch.mm)(a, b).float()
 
 
 class FusedHead(torch.autograd.Function):
@@ -21,7 +37,7 @@ class FusedHead(torch.autograd.Function):
     Returns (cls_score f32 (R,2), bbox_pred f32 (R,48), fc7 towers (n_views, R, 2048) in gemm_dtype)."""
 
     @staticmethod
-    def forward(ctx, keep_prob, dt, V, *ts):
+    def forward(ctx, keep_prob, dt, V, held, *ts):
         pools, wts = ts[:V], ts[V:]
         R = pools[0].shape[0]
         dev = pools[0].device
@@ -31,13 +47,20 @@ class FusedHead(torch.autograd.Function):
         wc, bc, wb, bb = wts[4 * V:4 * V + 4]
         N6, N7 = w6[0].shape[0], w7[0].shape[0]
         nc, nb = wc.shape[0], wb.shape[0]
-        # ---- the step's copies of the master weights in the GEMM type, stacked per layer: one multi-tensor launch
-        W6 = torch.empty((V, N6, K), dtype=dt, device=dev); B6 = torch.empty((V, 1, N6), dtype=dt, device=dev)
-        W7 = torch.empty((V, N7, N6), dtype=dt, device=dev); B7 = torch.empty((V, 1, N7), dtype=dt, device=dev)
-        WH = torch.empty((nc + nb, V * N7), dtype=dt, device=dev); BH = torch.empty((nc + nb,), dtype=dt, device=dev)
-        dst = [W6[v] for v in range(V)] + [B6[v, 0] for v in range(V)] + [W7[v] for v in range(V)] + [B7[v, 0] for v in range(V)] + [WH[:nc], WH[nc:], BH[:nc], BH[nc:]]
-        src = [t.detach() for t in (w6 + b6 + w7 + b7 + [wc, wb, bc, bb])]
-        torch._foreach_copy_(dst, src)
+        # ---- the step's copies of the master weights in the GEMM type, stacked per layer.  `held` = (buffers, current): the network keeps
+        # the stacked buffers from step to step and the optimizer's launch writes the updated weights into them (optim.Adam.register_lowp);
+        # when they are current nothing is cast here, else one multi-tensor launch fills them
+        if held is not None:
+            (W6, B6, W7, B7, WH, BH), current = held
+        else:
+            W6 = torch.empty((V, N6, K), dtype=dt, device=dev); B6 = torch.empty((V, 1, N6), dtype=dt, device=dev)
+            W7 = torch.empty((V, N7, N6), dtype=dt, device=dev); B7 = torch.empty((V, 1, N7), dtype=dt, device=dev)
+            WH = torch.empty((nc + nb, V * N7), dtype=dt, device=dev); BH = torch.empty((nc + nb,), dtype=dt, device=dev)
+            current = False
+        if not current:
+            dst = [W6[v] for v in range(V)] + [B6[v, 0] for v in range(V)] + [W7[v] for v in range(V)] + [B7[v, 0] for v in range(V)] + [WH[:nc], WH[nc:], BH[:nc], BH[nc:]]
+            src = [t.detach() for t in (w6 + b6 + w7 + b7 + [wc, wb, bc, bb])]
+            torch._foreach_copy_(dst, src)
         # ---- the pooled maps, (c, h, w)-flattened, in the GEMM type
         X = torch.empty((V, R, K), dtype=dt, device=dev)
         for v in range(V):
@@ -71,7 +94,7 @@ class FusedHead(torch.autograd.Function):
             gout[:, nc:].copy_(g_box)
         else:
             gout[:, nc:].zero_()
-        gWH = gout.t().mm(F_)                                          # (nc + nb, V * N7)
+        gWH = _mm_f32(gout.t(), F_, False)                             # (nc + nb, V * N7), f32
         gBH = gout.float().sum(0)
         gF = gout.mm(WH).view(R, V, N7).permute(1, 0, 2).contiguous()  # -> (V, R, N7)
         scale = 1.0 / keep
@@ -81,10 +104,10 @@ class FusedHead(torch.autograd.Function):
                 g = torch.ops.aten.native_dropout_backward(g, M, scale)
             return torch.ops.aten.threshold_backward(g, H, 0.0)
         gH7 = through(gF, H7, M7)
-        gW7 = torch.bmm(gH7.transpose(1, 2), D6)                       # (V, N7, N6)
+        gW7 = _mm_f32(gH7.transpose(1, 2), D6, True)                   # (V, N7, N6), f32
         gB7 = gH7.float().sum(1)
         gH6 = through(torch.bmm(gH7, W7), H6, M6)
-        gW6 = torch.bmm(gH6.transpose(1, 2), X)                        # (V, N6, K)
+        gW6 = _mm_f32(gH6.transpose(1, 2), X, True)                    # (V, N6, K), f32: the masters' gradients as the GEMM writes them
         gB6 = gH6.float().sum(1)
         gpools = [None] * V
         if any(needs[:V]):
@@ -95,28 +118,41 @@ class FusedHead(torch.autograd.Function):
                     gp = torch.empty(pshapes[v], dtype=torch.float32, device=dev)
                     gp.permute(0, 3, 1, 2).copy_(gX[v].view(R_, c, h, w))
                     gpools[v] = gp
-        # ---- weight gradients back in the masters' type: one multi-tensor launch
-        srcs = [gW6[v] for v in range(V)] + [gW7[v] for v in range(V)] + [gWH[:nc], gWH[nc:]]
-        dsts = [torch.empty((N6, K), dtype=torch.float32, device=dev) for _ in range(V)] + \
-               [torch.empty((N7, N6), dtype=torch.float32, device=dev) for _ in range(V)] + \
-               [torch.empty((nc, V * N7), dtype=torch.float32, device=dev), torch.empty((nb, V * N7), dtype=torch.float32, device=dev)]
-        torch._foreach_copy_(dsts, srcs)
+        # ---- the weight gradients are f32 already (views of the batched results)
+        dsts = [gW6[v] for v in range(V)] + [gW7[v] for v in range(V)] + [gWH[:nc], gWH[nc:]]
         grads = []
         for v in range(V):
             grads += [dsts[v], gB6[v], dsts[V + v], gB7[v]]
         grads += [dsts[2 * V], gBH[:nc].contiguous(), dsts[2 * V + 1], gBH[nc:].contiguous()]
-        return (None, None, None) + tuple(gpools) + tuple(grads)
+        return (None, None, None, None) + tuple(gpools) + tuple(grads)
 
 
-def fused_head(pools, params, names6, names7, keep_prob, gemm_dtype):
-    """pools: the views' pooled maps; params: {layer: [w, b]} fp32 masters; names6 / names7: the views' fc6 / fc7 layer names.
-    Returns (cls_score, bbox_pred, [fc7 tower per view])."""
+def head_buffers(params, names6, names7, dt, device):
+    """the stacked 16-bit weight buffers of the fused head for a network to keep, and which piece of them holds which master parameter:
+    ((W6, B6, W7, B7, WH, BH), [(param, view of its copy), ...])"""
+    V = len(names6)
+    N6, K = params[names6[0]][0].shape
+    N7 = params[names7[0]][0].shape[0]
+    nc, nb = params["cls_score"][0].shape[0], params["bbox_pred"][0].shape[0]
+    W6 = torch.empty((V, N6, K), dtype=dt, device=device); B6 = torch.empty((V, 1, N6), dtype=dt, device=device)
+    W7 = torch.empty((V, N7, N6), dtype=dt, device=device); B7 = torch.empty((V, 1, N7), dtype=dt, device=device)
+    WH = torch.empty((nc + nb, V * N7), dtype=dt, device=device); BH = torch.empty((nc + nb,), dtype=dt, device=device)
+    pieces = []
+    for v, (n6, n7) in enumerate(zip(names6, names7)):
+        pieces += [(params[n6][0], W6[v]), (params[n6][1], B6[v, 0]), (params[n7][0], W7[v]), (params[n7][1], B7[v, 0])]
+    pieces += [(params["cls_score"][0], WH[:nc]), (params["bbox_pred"][0], WH[nc:]), (params["cls_score"][1], BH[:nc]), (params["bbox_pred"][1], BH[nc:])]
+    return (W6, B6, W7, B7, WH, BH), pieces
+
+
+def fused_head(pools, params, names6, names7, keep_prob, gemm_dtype, held=None):
+    """pools: the views' pooled maps; params: {layer: [w, b]} fp32 masters; names6 / names7: the views' fc6 / fc7 layer names; held:
+    None, or (head_buffers(...)[0], are the copies current?).  Returns (cls_score, bbox_pred, [fc7 tower per view])."""
     V = len(pools)
     ts = list(pools)
     for n6, n7 in zip(names6, names7):
         ts += [params[n6][0], params[n6][1], params[n7][0], params[n7][1]]
     ts += [params["cls_score"][0], params["cls_score"][1], params["bbox_pred"][0], params["bbox_pred"][1]]
-    cls, box, towers = FusedHead.apply(float(keep_prob), gemm_dtype, V, *ts)
+    cls, box, towers = FusedHead.apply(float(keep_prob), gemm_dtype, V, held, *ts)
     return cls, box, [towers[v] for v in range(V)]
 
 
@@ -153,7 +189,7 @@ class RpnHeads(torch.autograd.Function):
             g[:, nc:].copy_(g_pred.reshape(-1, nb))
         else:
             g[:, nc:].zero_()
-        gW = g.t().mm(X).float()
+        gW = _mm_f32(g.t(), X, False)
         gB = g.float().sum(0)
         gX = g.mm(Wt).float().view(B, H, W, Cin) if ctx.needs_input_grad[1] else None
         return None, gX, gW[:nc].reshape(wcs), gB[:nc].contiguous(), gW[nc:].reshape(wbs), gB[nc:].contiguous()

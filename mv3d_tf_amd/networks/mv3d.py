@@ -269,6 +269,39 @@ class MV3D:
             raise ValueError("ground truth for %d frames, data for %d" % (len(frames), B))
         return frames
 
+    # ---- the fused head's 16-bit weight copies, kept from step to step and written by the optimizer's launch
+    def _held_head(self, sfx):
+        """(stacked buffers, are they current?) for fused_head, or None outside mixed precision.  The copies are current when the last
+        writer of every head parameter was an optimizer step that also wrote its copy (attach_optimizer): the parameter's version
+        counter still is what that step saw (any in-place change through torch -- load(), a manual update -- moves it)."""
+        if self.amp_dtype is None:
+            return None
+        h = self.__dict__.get("_head_lowp")
+        if h is None or h["dtype"] != self.amp_dtype or h["sfx"] != sfx:
+            from ..fused_head import head_buffers
+            bufs, pieces = head_buffers(self.params, ["fc6" + t for t in sfx], ["fc7" + t for t in sfx], self.amp_dtype, self.device)
+            h = self.__dict__["_head_lowp"] = {"dtype": self.amp_dtype, "sfx": sfx, "bufs": bufs, "pieces": pieces, "stamp": {}}
+            opt = self.__dict__.get("_lowp_opt")
+            if opt is not None:
+                self._register_lowp(opt)
+        current = bool(h["stamp"]) and all(h["stamp"].get(id(p)) == p._version for p, _ in h["pieces"])
+        return h["bufs"], current
+
+    def _register_lowp(self, opt):
+        h = self.__dict__.get("_head_lowp")
+        if h is None:
+            return
+        stamp = h["stamp"]
+        for p, dst in h["pieces"]:
+            opt.register_lowp(p, dst, lambda q, s=stamp: s.__setitem__(id(q), q._version))
+
+    def attach_optimizer(self, opt):
+        """mv3d_tf_amd.optim.Adam only: its step also writes the 16-bit copies of the head's weights the next forward reads (no cast launch,
+        no second read of the fp32 masters).  Optional: without it the fused head casts at the top of every step."""
+        if hasattr(opt, "register_lowp"):
+            self.__dict__["_lowp_opt"] = opt
+            self._register_lowp(opt)
+
     _STAGE_BYTES = 1 << 20
 
     def _stage_host_inputs(self, feed, L, dev, to_dev):
@@ -444,7 +477,7 @@ class MV3D:
             from ..fused_head import fused_head
             sfx = ("_1", "_2", "_3")[:len(names)]
             L["cls_score"], L["bbox_pred"], tower = fused_head([L[n] for n in names], self.params, ["fc6" + t for t in sfx], ["fc7" + t for t in sfx],
-                                                               keep_prob, self.amp_dtype or torch.float32)
+                                                               keep_prob, self.amp_dtype or torch.float32, held=self._held_head(sfx))
             L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
         else:
             tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)

@@ -16,6 +16,16 @@ class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **kw):
         kw.pop("fused", None)                                        # (this class IS the fused step)
         super().__init__(params, lr=lr, betas=betas, eps=eps, **kw)
+        self.lowp = {}                                                # id(param) -> (16-bit tensor of its shape, stamp callback): see register_lowp
+
+    def register_lowp(self, param, dst, on_written=None):
+        """`dst` (float16 / bfloat16, param's number of elements, contiguous) receives the updated `param` in every step of this
+        optimizer, in the launch that updates it (the copy a cast at the top of the next step would make).  on_written(param) is called
+        after each such step (the owner records that the copy is current)."""
+        if dst.numel() != param.numel() or not dst.is_contiguous() or dst.dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("register_lowp: a contiguous float16 / bfloat16 tensor with the parameter's number of elements")
+        self.lowp[id(param)] = (dst, on_written)
+        self.__dict__.pop("_cache", None)
 
     def _plain(self, g):
         return not (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("capturable") or g.get("differentiable"))
@@ -38,11 +48,16 @@ class Adam(torch.optim.Adam):
             ent = {"ct": ct_dev, "cf": cf_dev, "n": int(ct_dev.numel()), "pin": torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
                    "dev": torch.empty(nbytes, dtype=torch.uint8, device=dev), "ptrs": None}
             cache[key] = ent
-        ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()) for p, m, v in items)
+        lp = [self.lowp.get(id(p)) for p, _, _ in items]
+        ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), l[0].data_ptr() if l else 0) for (p, m, v), l in zip(items, lp))
+        kinds = {l[0].dtype for l in lp if l}
+        if len(kinds) > 1:
+            raise ValueError("register_lowp: one 16-bit type per optimizer")
+        ent["lowp"] = 0 if not kinds else (1 if kinds.pop() == torch.float16 else 2)
         if ptrs != ent["ptrs"]:
             arr = (AdamTensor * len(items)).from_buffer(ent["pin"].numpy())
             for k, ((p, _, _), q) in enumerate(zip(items, ptrs)):
-                arr[k] = AdamTensor(q[0], q[1], q[2], q[3], p.numel())
+                arr[k] = AdamTensor(q[0], q[1], q[2], q[3], p.numel(), q[4] or None)
             ent["dev"].copy_(ent["pin"], non_blocking=True)           # (stream-ordered before the launch below)
             ent["ptrs"] = ptrs
         return ent
@@ -84,10 +99,13 @@ class Adam(torch.optim.Adam):
                 t_dev, ct_dev, cf_dev, n = ent["dev"], ent["ct"], ent["cf"], ent["n"]
                 b1, b2 = g["betas"]
                 check(lib().mv3d_adam_step(C.c_void_p(t_dev.data_ptr()), C.c_void_p(ct_dev.data_ptr()), C.c_void_p(cf_dev.data_ptr()), n,
-                                           float(g["lr"]), float(b1), float(b2), float(g["eps"]), t0 + 1,
+                                           float(g["lr"]), float(b1), float(b2), float(g["eps"]), t0 + 1, ent["lowp"],
                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "mv3d_adam_step")
                 for p, _, _ in its:
                     self.state[p]["step"] += 1
+                    l = self.lowp.get(id(p))
+                    if l and l[1]:
+                        l[1](p)
         if rest:                                                      # whatever the kernel does not cover: torch's own update for those groups
             keep = self.param_groups
             try:

@@ -497,6 +497,50 @@ def test_adam_step_kernel_equals_torch_adam():
         assert torch.allclose(x, y, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.gpu
+def test_adam_step_writes_the_16_bit_copies_and_the_head_uses_them():
+    """optim.Adam.register_lowp: the launch that updates a parameter also writes it rounded to bf16 (what a cast at the top of the next step
+    would write); the training network keeps the fused head's stacked weight buffers and finds them current after such a step, stale after
+    any other change of a head parameter."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    sys.path.insert(0, ROOT)
+    from mv3d_tf_amd import build, optim
+    build.build()
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in ((4096 * 2 + 5,), (7, 33), (3,))]
+    opt = optim.Adam(ps, lr=1e-2)
+    stamped = []
+    copies = [torch.zeros(p.numel(), dtype=torch.bfloat16, device="cuda") for p in ps[:2]]
+    for p, c in zip(ps, copies):
+        opt.register_lowp(p, c, stamped.append)
+    for it in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        opt.step()
+        for p, c in zip(ps, copies):
+            assert torch.equal(c, p.detach().reshape(-1).to(torch.bfloat16)), it
+    assert len(stamped) == 6
+    # the network: copies current after an attached optimizer's step, stale after a foreign write
+    from mv3d_tf_amd.networks import get_network
+    net = get_network("MV3D_train_3view")
+    net.amp_dtype, net.mfma_trunk = torch.bfloat16, True
+    o2 = optim.Adam(net.parameters(), lr=1e-5)
+    net.attach_optimizer(o2)
+    sfx = ("_1", "_2", "_3")
+    bufs, cur = net._held_head(sfx)
+    assert cur is False
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    o2.step()
+    bufs, cur = net._held_head(sfx)
+    assert cur is True and torch.equal(bufs[0][1], net.params["fc6_2"][0].detach().to(torch.bfloat16))
+    assert torch.equal(bufs[4][:2], net.params["cls_score"][0].detach().to(torch.bfloat16))
+    with torch.no_grad():
+        net.params["fc7_1"][1].add_(1.0)
+    assert net._held_head(sfx)[1] is False
+
+
 def test_fused_head_equals_the_op_by_op_head():
     """mv3d_tf_amd.fused_head.FusedHead (the fusion head of MV3D_train.py:159-182 as one autograd function: stacked weights, one batched GEMM
     per layer for all views) against the same head written op by op: outputs and every gradient (pooled maps, fc6 / fc7 of each view,
