@@ -167,6 +167,33 @@ class Ring:
             self.cursor += 1
 
 
+def masked_streams(n, mode):
+    """Experiment ("forward beside company"): the path's streams restricted to HALVES of the chip by
+    hipExtStreamCreateWithCUMask -- even streams one half, odd streams the other -- so that two batches' chip-filling RoiPool launches run
+    side by side on disjoint compute units instead of interleaving on all of them.  mode "words": compute units 0-127 / 128-255 of the
+    mask's numbering; "bits": even / odd compute units.  Returns None (plain streams) for any other mode.  profiles/r06_h_cu_mask_ab.txt."""
+    if mode not in ("words", "bits"):
+        return None
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    words = (ncu + 31) // 32
+    out = []
+    for i in range(n):
+        half = i & 1
+        if mode == "words":
+            m = [0xffffffff if (w < words // 2) == (half == 0) else 0 for w in range(words)]
+        else:
+            m = [0x55555555 if half == 0 else 0xaaaaaaaa for _ in range(words)]
+        arr = (ctypes.c_uint32 * words)(*m)
+        h = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), arr)
+        if rc != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out
+
+
 class PathDriver:
     """The training path as a caller drives it: `depth` batches in flight through mv3d_tf_amd.train_path.TrainPathStream (one
     submit / finish pair of the C object mv3d_train_path per batch; the library's helper thread draws on numpy's global generator,
@@ -182,7 +209,7 @@ class PathDriver:
         dev = inputs[0][0].device
         B = int(inputs[0][0].shape[0])
         self.B = B
-        self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
+        self.streams = masked_streams(self.depth, os.environ.get("MV3D_BENCH_CU_MASK", "")) or [torch.cuda.Stream() for _ in range(self.depth)]
         self.path = TrainPathStream(B, int(inputs[0][0].shape[1]), int(inputs[0][0].shape[2]), dev, depth=self.depth, streams=self.streams)
         cap = self.cap = B * self.path.roi_cap
         g = torch.Generator(device=dev).manual_seed(seed)
