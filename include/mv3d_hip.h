@@ -656,6 +656,10 @@ int mv3d_maxpool2x2_f16(const void *x_framed, void *y_framed, int batch, int hei
 int mv3d_frame_nhwc_f16(const float *x_nhwc, void *y_framed, int batch, int height, int width, int channels, int channels_out,
                         void *stream);
 
+/* softmax over `rows` rows of `classes` f32 logits (row-major, 8-byte aligned): the RPN's reshape_layer(2) + softmax
+ * (lib/networks/network.py:333-341, :399-403) and cls_prob (MV3D_train.py:178); forward only (the losses take the logits). */
+int mv3d_softmax_rows(const float *logits_dev, float *prob_dev, long long rows, int classes, void *stream);
+
 /* ------------------------------------------------------------------ the optimizer step (csrc/adam.hip)
  * Replaces tf.train.AdamOptimizer(lr).apply_gradients of lib/fast_rcnn/train_mv.py:138-146 (beta 0.9 / 0.999, eps 1e-8, no weight
  * decay) for ALL parameter tensors behind one launch: per element  m = m + (g - m) (1 - beta1);  v = beta2 v + (1 - beta2) g^2;

@@ -209,6 +209,7 @@ _SIGS = {
     "mv3d_conv3x3_pack_many_f32": (C.c_int, [C.c_int, C.POINTER(PackItem), _P]),
     "mv3d_maxpool2x2_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mv3d_frame_nhwc_f16": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mv3d_softmax_rows": (C.c_int, [_P, _P, C.c_longlong, C.c_int, _P]),
     "mv3d_adam_chunk_elements": (C.c_int, []),
     "mv3d_adam_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _P]),
 }

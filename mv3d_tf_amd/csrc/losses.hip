@@ -143,3 +143,35 @@ extern "C" int mv3d_rcnn_loss(const float *cls_score_dev, const int32_t *labels_
     d.d_cls = d_cls_score_dev; d.d_pred = d_bbox_pred_dev;
     return launch_loss(d, workspace, workspace_bytes, stream);
 }
+
+// ---- softmax over rows of K logits (K = 2: the RPN's reshape_layer(2) + softmax, lib/networks/MV3D_train.py:90-93 / network.py:399-403, and
+// cls_prob of the two-class head): max, exp of the differences, sum in class order, divide -- an elementwise pass over 92 k pairs per
+// frame, one thread per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ x, float *__restrict__ y, long long rows, int K)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *xr = x + r * K;
+    float *yr = y + r * K;
+    if (K == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(xr);
+        const float m = fmaxf(v.x, v.y);
+        const float ea = expf(v.x - m), eb = expf(v.y - m), s = ea + eb;
+        *reinterpret_cast<float2 *>(yr) = make_float2(ea / s, eb / s);
+        return;
+    }
+    float m = xr[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, xr[k]);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) { const float e = expf(xr[k] - m); yr[k] = e; s += e; }
+    for (int k = 0; k < K; ++k) yr[k] = yr[k] / s;
+}
+
+extern "C" int mv3d_softmax_rows(const float *logits_dev, float *prob_dev, long long rows, int classes, void *stream)
+{
+    if (!logits_dev || !prob_dev || rows < 0 || classes < 1 || classes > 1024) return MV3D_ERR_INVALID_ARG;
+    if (((uintptr_t)logits_dev | (uintptr_t)prob_dev) & 7) return MV3D_ERR_INVALID_ARG;
+    if (rows == 0) return MV3D_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits_dev, prob_dev, rows, classes);
+    return mv3d_launch_status();
+}

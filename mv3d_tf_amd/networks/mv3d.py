@@ -23,6 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import ops
 from ..fast_rcnn.config import cfg
 from ..roi_pooling_layer.roi_pooling_op import roi_pool_views
 from ..rpn_msr.proposal_layer_tf import proposal_layer_3d, proposal_layer_3d_fixed
@@ -220,7 +221,8 @@ class MV3D:
             tower.append(x)
         fused = torch.cat(tower, dim=1)
         cls = self._fc(fused, "cls_score", relu=False, wb=P("cls_score")).float()
-        return tower, cls, F.softmax(cls, dim=1), self._fc(fused, "bbox_pred", relu=False, wb=P("bbox_pred")).float()
+        prob = ops.softmax_rows(cls) if (cls.is_cuda and not (torch.is_grad_enabled() and cls.requires_grad)) else F.softmax(cls, dim=1)
+        return tower, cls, prob, self._fc(fused, "bbox_pred", relu=False, wb=P("bbox_pred")).float()
 
     _HEAD_LAYERS = ("rpn_cls_score", "rpn_bbox_pred", "fc6_1", "fc7_1", "fc6_2", "fc7_2", "fc6_3", "fc7_3", "cls_score", "bbox_pred")
 
@@ -413,7 +415,12 @@ class MV3D:
         L["rpn_cls_score"] = score
         n, h, w, c = score.shape
         L["rpn_cls_score_reshape"] = score.reshape(n, h, -1, 2)                       # reshape_layer(2) (network.py:333-341)
-        L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)   # :399-403
+        # :399-403 -- nothing differentiates through rpn_cls_prob (the RPN losses take the logits, the proposal layer is a py_func):
+        # on the device the library's forward-only softmax (mv3d_softmax_rows)
+        if score.is_cuda and score.dtype == torch.float32:
+            L["rpn_cls_prob"] = ops.softmax_rows(L["rpn_cls_score_reshape"]).reshape(n, h, -1, 2)
+        else:
+            L["rpn_cls_prob"] = F.softmax(L["rpn_cls_score_reshape"].reshape(-1, 2), dim=1).reshape(n, h, -1, 2)
         L["rpn_cls_prob_reshape"] = L["rpn_cls_prob"].reshape(n, h, w, c)
         stride = _feat_stride[0]
         B = int(n)
@@ -478,7 +485,7 @@ class MV3D:
             sfx = ("_1", "_2", "_3")[:len(names)]
             L["cls_score"], L["bbox_pred"], tower = fused_head([L[n] for n in names], self.params, ["fc6" + t for t in sfx], ["fc7" + t for t in sfx],
                                                                keep_prob, self.amp_dtype or torch.float32, held=self._held_head(sfx))
-            L["cls_prob"] = F.softmax(L["cls_score"], dim=1)
+            L["cls_prob"] = ops.softmax_rows(L["cls_score"]) if L["cls_score"].is_cuda else F.softmax(L["cls_score"].detach(), dim=1)   # (fetched, never differentiated: the losses take cls_score)
         else:
             tower, L["cls_score"], L["cls_prob"], L["bbox_pred"] = self._head_fn([L[n] for n in names], lambda n: None, keep_prob)
         for t, x in zip(("_1", "_2", "_3"), tower):

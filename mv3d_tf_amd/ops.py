@@ -475,6 +475,15 @@ def _loss_call(fn, name, cls, labels, pred, tgt, extra, sigma, want_grad):
     return losses, d_cls, d_pred
 
 
+def softmax_rows(logits):
+    """softmax over the last axis of an f32 device tensor (any leading shape), forward only: mv3d_softmax_rows"""
+    x = logits.detach().contiguous()
+    y = torch.empty_like(x)
+    K = int(x.shape[-1])
+    check(lib().mv3d_softmax_rows(_ptr(x), _ptr(y), x.numel() // max(K, 1), K, _stream()), "mv3d_softmax_rows")
+    return y
+
+
 def rpn_loss(rpn_cls_score, rpn_labels, rpn_bbox_pred, rpn_bbox_targets, sigma=3.0, want_grad=True):
     """(N,2) logits, (N) f32 labels in {-1,0,1}, (N,6) pred / targets -> (losses[2] = [cross-entropy, box], d_cls, d_pred)."""
     return _loss_call(lib().mv3d_rpn_loss, "mv3d_rpn_loss", rpn_cls_score, rpn_labels, rpn_bbox_pred, rpn_bbox_targets, (),

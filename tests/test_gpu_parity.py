@@ -772,3 +772,18 @@ def test_train_graph_backward_through_roi_pool(ops, torch_cuda):
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0      # gradient came through RoiPoolGrad
     g2 = net.params["rpn_bbox_pred"][0].grad
     assert g2 is not None and torch.isfinite(g2).all() and float(g2.abs().sum()) > 0   # ... and through the RPN box loss
+
+
+def test_softmax_rows_matches_torch(torch_cuda, ops):
+    """mv3d_softmax_rows (the RPN's pairwise softmax of network.py:399-403 and cls_prob): against torch's softmax, pairs and wider rows,
+    large logits, equal logits"""
+    torch = torch_cuda
+    rs = np.random.RandomState(5)
+    for shape in ((2, 76, 76 * 4, 2), (300, 2), (17, 5), (1, 2)):
+        x = rs.uniform(-30, 30, shape).astype(np.float32)
+        x.reshape(-1, shape[-1])[0] = 7.5                              # equal logits
+        t = torch.as_tensor(x).cuda()
+        got = ops.softmax_rows(t)
+        want = torch.softmax(t, dim=-1)
+        assert got.shape == want.shape and torch.allclose(got, want, rtol=2e-6, atol=1e-9)
+        assert torch.allclose(got.sum(-1), torch.ones_like(got.sum(-1)), atol=1e-6)
