@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/${1:-streams}; mkdir -p $OUT
+TUN=build_variants/libmv3d_tuning.so
+run() { echo "-- $*"; env "$@" MV3D_IDX_DBG=1 PAIR_ONLY=1 PAIR_NO_WS=1 NB=8 ROUNDS=4 timeout 300 python tools/roi_pair_probe.py --lib $TUN 2>&1 | grep "pair \|differ\|rror" | tail -1; }
+{
+timeout 900 python -m pytest tests/test_roi_pair.py tests/test_roipool_pin.py -x -q -m gpu 2>&1 | tail -3
+run MV3D_RGT_MODE=0
+for w in $STREAMS_W; do run MV3D_RGT_MODE=1 MV3D_RGT_W=$w; done
+for d in $STREAMS_DBG; do run MV3D_RGT_MODE=1 MV3D_RGT_DBG=$d; done
+for px in $STREAMS_PX; do run MV3D_RGT_MODE=1 MV3D_RGT_PX=$px; done
+echo "== trace"; MV3D_RGT_MODE=1 MV3D_RGT_DBG=16 timeout 300 python tools/roi_tiles_trace.py --lib $TUN 2>&1 | grep -v amdgpu.ids | tail -28
+} 2>&1 | tee $OUT/streams.txt

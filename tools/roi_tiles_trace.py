@@ -68,6 +68,29 @@ print("   whole wave       :", q(t[:, 5] - t[:, 0]))
 print("   end - t0         :", q(t[:, 5] - t0))
 print("   ring entries     :", q(t[:, 6]), " total", t[:, 6].sum())
 ne = t[t[:, 6] > 0]
+if int(os.environ.get("MV3D_RGT_DBG", "0")) & 16:     # the per-pixel streams kernel: 1 = pass loop done; words 2 listing, 7 adding, 3 ranges, 4 pixel loop (with flushes), 6 entries
+    whole = t[:, 5] - t[:, 0]
+    loop = t[:, 1] - t[:, 0]
+    print("   whole            :", q(whole), " total", whole.sum())
+    print("   pass loop        :", q(loop), " total", loop.sum())
+    print("   write-out        :", q(t[:, 5] - t[:, 1]), " total", (t[:, 5] - t[:, 1]).sum())
+    print("   ranges           :", q(t[:, 3]), " total", t[:, 3].sum())
+    print("   pixel loop       :", q(t[:, 4]), " total", t[:, 4].sum())
+    print("     listing        :", q(t[:, 2]), " total", t[:, 2].sum())
+    print("     adding         :", q(t[:, 7]), " total", t[:, 7].sum())
+    print("   filter (rest)    :", q(loop - t[:, 3] - t[:, 4]), " total", (loop - t[:, 3] - t[:, 4]).sum())
+    print("   entries          :", q(t[:, 6]), " total", t[:, 6].sum())
+    hot = np.argsort(-whole)[:10]
+    print("the 10 longest waves: entries, start, whole, pass loop, ranges, pixel loop, listing, adding")
+    for i in hot:
+        print("   entries %5d  start %5d  whole %5d  loop %5d ranges %5d  pixels %5d  listing %5d  adding %5d" % (t[i, 6], t[i, 0] - t0, whole[i], loop[i], t[i, 3], t[i, 4], t[i, 2], t[i, 7]))
+    span = int(t[:, 5].max() - t0)
+    alive = np.zeros(span + 1, dtype=np.int64)
+    for a_, b_ in zip(t[:, 0] - t0, t[:, 5] - t0):
+        alive[a_:b_ + 1] += 1
+    step = max(span // 20, 1)
+    print("waves alive over time (every %d ticks):" % step, alive[::step].tolist())
+    sys.exit(0)
 n_own, n_other = t[:, 2] & 0xffffffff, t[:, 2] >> 32
 t_room, t_turn = t[:, 7] & 0xffffffff, t[:, 7] >> 32
 print("   groups added on the own stream %d, on other waves' streams %d" % (n_own.sum(), n_other.sum()))
