@@ -1,4 +1,6 @@
 #!/bin/bash
+# (EXPERIMENTS R6.14; source: tools/experiments/roi_grad_tiles_regacc_static_r06.hip.txt over csrc/roi_grad_tiles.hip, tools/build_tuning.sh twice:
+#  plain, and MV3D_TUNING_OUT=libmv3d_regacc.so MV3D_EXTRA_FLAGS=-DRGT_REGACC_DEFAULT)
 # RoiPoolGrad tiles with the sums in registers (roi_pair_tiles_kernel<W, 1, true>) against the LDS read-add-write: the pair + pin tests on a
 # build that launches it by default, then timings (tuning build, MV3D_RGT_REG)
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/${1:-regacc}; mkdir -p $OUT
