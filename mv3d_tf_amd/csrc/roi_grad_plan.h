@@ -1,0 +1,138 @@
+// The RoiPool pair's tile layout and work list, shared by the pair's two launches: the FORWARD launch (roi_pool.hip) carries one planning
+// workgroup that writes the work list of the BACKWARD launch (roi_grad_tiles.hip) into bytes of the pair's private argmax buffer that
+// neither launch otherwise touches (the last quarter of view 0's buffer: one-byte codes in the first quarter, 16-bit escape codes in the
+// two behind it), so the tiles under long entry streams are cut into sub-tiles -- first in the list -- without a launch of their own.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include "roi_geom.h"
+
+#define RGT_PLAN_TILES 3072          // tiles of all views the planner's LDS heat map holds (12 KB; more tiles: the static grid)
+#define RGT_HOT_ENTRIES 250          // estimated entries from which a tile is cut
+#define RGT_HOT_MAX 128              // at most this many tiles are cut (the grid is sized for 3 extra units each)
+#define RGT_PLAN_THREADS 256         // (the forward's workgroup size)
+
+struct RgtView {
+    const float *top_diff, *rois;
+    const unsigned char *plane8;
+    float *bottom_diff;
+    float scale;
+    int B, R, H, W, C;
+    int ths, tws;                    // log2 of the tile's rows / columns
+    int tiles_x, tiles_y;
+    int nsl;                         // channel slices = C / 64
+    unsigned first_block;
+};
+struct RgtPack {
+    RgtView v[MV3D_MAX_ROI_VIEWS];
+    int n, PH, PW, inv_pw;
+    // planned mode: the launch's units come from the work list the pair's FORWARD launch wrote (rgt_plan_block) -- the tiles under long
+    // entry streams cut into four sub-tiles, first in the list; NULL = every view's tile grid as it lies
+    const int4 *work;                // unit: x = view | frame << 4 | ths << 16 | tws << 20 | skip << 24, y = first row, z = first column
+    const int *n_work;               // units in the list
+    int dbg;                         // experiment builds (MV3D_TUNING): phases switched off, 0 otherwise
+    long long *trace;                // experiment builds: 8 wall-clock stamps per wave (tools/roi_tiles_trace.py), NULL otherwise
+};
+
+// The launch layout of the views (launch order, tile shapes, grid offsets) from the SHAPES alone, and whether the pair runs planned: both
+// launches take the same decision independently.  Returns the static grid's workgroups in *blocks (0: too many), planned mode in *planned
+// with p.work / p.n_work set and the planned grid in *plan_blocks.
+bool mv3d_rgt_layout(int num_views, const mv3d_roi_grad_view *views, int PH, int PW, RgtPack &p, unsigned *blocks, bool *planned,
+                     unsigned *plan_blocks, int *hot_entries, int *hot_max);
+
+// ---- planned mode: which tiles sit under long entry streams?  ONE workgroup estimates every tile's stream from the ROIs' rounded
+// geometry (thread = ROI: rows covered x bins per row x bins across, added into an LDS heat map), cuts the tiles above RGT_HOT_ENTRIES into
+// four sub-tiles (rows first: a 4 x 4 tile becomes four 1 x 4 rows, a 2 x 2 tile four pixels -- the sub-tiles are ordinary units, every
+// one filtered, expanded and drained by a wave of its own, no communication) and writes the launch's work list: sub-tiles first (they
+// carry the longest streams and must start at once), then the other tiles in grid order.  What it buys is the makespan: one wave's
+// instruction stream is the limit of a stream (~140 ns per entry, profiles/r06_a), and a 4 x 4 tile under 465 entries is 65 us however
+// fast the other 17 k waves finish.  T threads; heat: RGT_PLAN_TILES ints of LDS, scan: 2 * T / 64 + 2 ints.
+template <int T>
+__device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int *n_work, const int hot_entries, const int hot_max, int *heat,
+                                               int *scan)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ntiles = 0;
+    for (int k = 0; k < p.n; ++k) ntiles += p.v[k].B * p.v[k].tiles_y * p.v[k].tiles_x;
+    for (int i = tid; i < ntiles; i += T) heat[i] = 0;
+    __syncthreads();
+    int tile0 = 0;
+    for (int k = 0; k < p.n; ++k) {
+        const RgtView &v = p.v[k];
+        const int TH = 1 << v.ths, TW = 1 << v.tws;
+        for (int r = tid; r < v.R; r += T) {
+            float r5[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) r5[u] = v.rois[5 * (long long)r + u];
+            const RoiGeom g = roi_geom(r5, v.scale);
+            const int b = (int)r5[0];
+            if (b < 0 || b >= v.B || g.reh < g.rsh || g.rew < g.rsw) continue;
+            const int y0 = max(g.rsh, 0), y1 = min(g.reh, v.H - 1), x0 = max(g.rsw, 0), x1 = min(g.rew, v.W - 1);
+            if (y1 < y0 || x1 < x0) continue;
+            const int ty0 = y0 >> v.ths, ty1 = y1 >> v.ths, tx0 = x0 >> v.tws, tx1 = x1 >> v.tws;
+            if ((long long)(ty1 - ty0 + 1) * (tx1 - tx0 + 1) > 64) continue;      // (a ROI over that many tiles leaves a few bins in each)
+            const float bh = (float)(g.reh - g.rsh + 1) / (float)p.PH, bw = (float)(g.rew - g.rsw + 1) / (float)p.PW;
+            const float per_row = fminf((float)p.PH, 1.0f + 1.0f / bh);            // bins whose rows hold one map row
+            for (int ty = ty0; ty <= ty1; ++ty) {
+                const int rows = min(y1, (ty << v.ths) + TH - 1) - max(y0, ty << v.ths) + 1;
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const int cols = min(x1, (tx << v.tws) + TW - 1) - max(x0, tx << v.tws) + 1;
+                    const float across = fminf((float)p.PW, 1.0f + (float)cols / bw);
+                    atomicAdd(&heat[tile0 + (b * v.tiles_y + ty) * v.tiles_x + tx], (int)(rows * per_row * across + 0.5f));
+                }
+            }
+        }
+        tile0 += v.B * v.tiles_y * v.tiles_x;
+    }
+    __syncthreads();
+    // ---- classify; positions by a block scan of (hot, cold) counts over the tiles in list order (thread t: tiles [t * per, t * per + per))
+    const int per = (ntiles + T - 1) / T;
+    const int first = tid * per, last = min(first + per, ntiles);
+    int nh = 0, nc = 0;
+    for (int i = first; i < last; ++i) { if (heat[i] >= hot_entries) ++nh; else ++nc; }
+    int ih = nh, ic = nc;                                              // inclusive scans inside the wave ...
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(ih, o), c = __shfl_up(ic, o);
+        if (lane >= o) { ih += a; ic += c; }
+    }
+    if (lane == 63) { scan[2 * wave] = ih; scan[2 * wave + 1] = ic; }
+    __syncthreads();
+    int bh_ = 0, bc_ = 0, th_ = 0, tc_ = 0;                            // ... and over the waves
+    for (int w = 0; w < T / 64; ++w) {
+        if (w < wave) { bh_ += scan[2 * w]; bc_ += scan[2 * w + 1]; }
+        th_ += scan[2 * w]; tc_ += scan[2 * w + 1];
+    }
+    int ph = bh_ + ih - nh, pc = bc_ + ic - nc;                        // exclusive positions of this thread's first hot / cold tile
+    const int cut = min(th_, hot_max);                             // hot tiles beyond the cap stay whole
+    const int cold0 = 4 * cut;                                         // the list: 4 x cut sub-tile units, then the whole tiles in grid order
+    for (int i = first; i < last; ++i) {
+        int k = 0, base = 0;                                           // the view, frame and tile coordinates of list position i
+        for (int j = 0; j < p.n; ++j) {
+            const int n = p.v[j].B * p.v[j].tiles_y * p.v[j].tiles_x;
+            if (i < base + n) { k = j; break; }
+            base += n;
+        }
+        const RgtView &v = p.v[k];
+        int t = i - base;
+        const int tx = t % v.tiles_x; t /= v.tiles_x;
+        const int ty = t % v.tiles_y, b = t / v.tiles_y;
+        const bool hot = heat[i] >= hot_entries;
+        if (hot && ph < cut) {
+            const int sy = min(v.ths, 2), sx = min(v.tws, 2 - sy);     // split bits: rows first
+            const int ths2 = v.ths - sy, tws2 = v.tws - sx;
+            for (int j = 0; j < 4; ++j) {
+                const int jy = j >> sx, jx = j & ((1 << sx) - 1);
+                const int y = (ty << v.ths) + (jy << ths2), x = (tx << v.tws) + (jx << tws2);
+                const bool skip = j >= (1 << (sy + sx)) || y >= v.H || x >= v.W;
+                work[4 * ph + j] = make_int4(k | (b << 4) | (ths2 << 16) | (tws2 << 20) | (skip ? 1 << 24 : 0), y, x, heat[i]);
+            }
+        } else {
+            const int pos = cold0 + (ph + pc) - min(ph, cut);
+            work[pos] = make_int4(k | (b << 4) | (v.ths << 16) | (v.tws << 20), ty << v.ths, tx << v.tws, heat[i]);
+        }
+        if (hot) ++ph; else ++pc;
+    }
+    if (tid == 0) *n_work = cold0 + (th_ - cut) + tc_;
+}
+

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "roi_geom.h"
+#include "roi_grad_plan.h"
 
 template <int VEC>
 struct VecT;
@@ -1464,33 +1465,54 @@ __global__ __launch_bounds__(256) void roi_pair_gather_kernel(RoiGradPack p, Roi
 }
 
 
-// the pair's forward: the multi-view pooling kernels with COMPACT argmax codes
+// the pair's forward: the multi-view pooling kernels with COMPACT argmax codes.  The first eight workgroups of the grid belong to the
+// PLAN of the pair's backward launch (roi_grad_plan.h; eight so that the workgroup -> XCD slice mapping of the pooling workgroups is kept):
+// workgroup 0 estimates every map tile's entry stream from the ROIs and writes the backward's work list -- hot tiles cut into sub-tiles,
+// first -- into the unused quarter of view 0's argmax buffer, under the pooling workgroups' shadow; the other seven return at once.
+struct RoiPlanArgs { RgtPack lay; int on, hot_entries, hot_max; };
+#define PAIR_PLAN_BLOCKS 8u
+union PairFwdLds {
+    BinGeom g[4 * 32];
+    struct { int heat[RGT_PLAN_TILES]; int scan[2 * RGT_PLAN_THREADS / 64 + 2]; } plan;
+};
 template <int FWD_PASSES>
-__global__ __launch_bounds__(256) void roi_pool_fwd_pair_kernel(RoiViewPack p)
+__global__ __launch_bounds__(256) void roi_pool_fwd_pair_kernel(RoiViewPack p, RoiPlanArgs pl)
 {
-    __shared__ BinGeom s_g[FWD_PASSES * 32];
-    int k = 0;
-#pragma unroll
-    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
-        if (j < p.n && blockIdx.x >= p.v[j].first_block) k = j;
-    const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES, true>(s_g, blockIdx.x - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
-                                             v.argmax, v.tpb_shift);
-}
-
-template <int FWD_PASSES>
-__global__ __launch_bounds__(256) void roi_pool_fwd_pair_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink)
-{
-    __shared__ BinGeom s_g[FWD_PASSES * 32];
-    __shared__ unsigned s_mask;
-    if (blockIdx.x < pf.blocks) { roi_prefetch_block(&s_mask, p, pf, blockIdx.x, sink); return; }
-    const unsigned blk = blockIdx.x - pf.blocks;
+    __shared__ PairFwdLds lds;
+    unsigned blk = blockIdx.x;
+    if (pl.on) {
+        if (blk == 0) { rgt_plan_block<RGT_PLAN_THREADS>(pl.lay, const_cast<int4 *>(pl.lay.work), const_cast<int *>(pl.lay.n_work), pl.hot_entries, pl.hot_max, lds.plan.heat, lds.plan.scan); return; }
+        if (blk < PAIR_PLAN_BLOCKS) return;
+        blk -= PAIR_PLAN_BLOCKS;
+    }
     int k = 0;
 #pragma unroll
     for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
         if (j < p.n && blk >= p.v[j].first_block) k = j;
     const RoiViewDev &v = p.v[k];
-    roi_pool_fwd_xcd_block<FWD_PASSES, true>(s_g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+    roi_pool_fwd_xcd_block<FWD_PASSES, true>(lds.g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
+                                             v.argmax, v.tpb_shift);
+}
+
+template <int FWD_PASSES>
+__global__ __launch_bounds__(256) void roi_pool_fwd_pair_cold_kernel(RoiViewPack p, RoiPrefetchPack pf, int *sink, RoiPlanArgs pl)
+{
+    __shared__ PairFwdLds lds;
+    __shared__ unsigned s_mask;
+    unsigned blk = blockIdx.x;
+    if (pl.on) {
+        if (blk == 0) { rgt_plan_block<RGT_PLAN_THREADS>(pl.lay, const_cast<int4 *>(pl.lay.work), const_cast<int *>(pl.lay.n_work), pl.hot_entries, pl.hot_max, lds.plan.heat, lds.plan.scan); return; }
+        if (blk < PAIR_PLAN_BLOCKS) return;
+        blk -= PAIR_PLAN_BLOCKS;
+    }
+    if (blk < pf.blocks) { roi_prefetch_block(&s_mask, p, pf, blk, sink); return; }
+    blk -= pf.blocks;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
+        if (j < p.n && blk >= p.v[j].first_block) k = j;
+    const RoiViewDev &v = p.v[k];
+    roi_pool_fwd_xcd_block<FWD_PASSES, true>(lds.g, blk - v.first_block, v.data, v.scale, v.B, v.R, v.H, v.W, v.C, p.PH, p.PW, v.rois, v.top,
                                              v.argmax, v.tpb_shift);
 }
 
@@ -2059,15 +2081,23 @@ extern "C" int mv3d_roi_pool_forward_views_pair(int num_views, const mv3d_roi_vi
     }
     for (int k = num_views; k < MV3D_MAX_ROI_VIEWS; ++k) p.v[k] = p.v[0];
     hipStream_t s = (hipStream_t)stream;
+    // the plan of the pair's backward launch (the decision mv3d_launch_roi_pair_tiles takes from the same shapes)
+    RoiPlanArgs pl;
+    for (int k = 0; k < num_views; ++k) g[k].argmax_data = views[k].argmax_data;
+    unsigned tile_blocks = 0, plan_blocks = 0;
+    bool planned = false;
+    if (!mv3d_rgt_layout(num_views, g, pooled_height, pooled_width, pl.lay, &tile_blocks, &planned, &plan_blocks, &pl.hot_entries, &pl.hot_max)) planned = false;
+    pl.on = planned ? 1 : 0;
+    const unsigned front = planned ? PAIR_PLAN_BLOCKS : 0u;
     RoiPrefetchPack pf;
     if (cold_maps && roi_prefetch_plan(num_views, views, pf)) {
         pf.blocks = (pf.blocks + 7u) & ~7u;
-        if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<4>, dim3(blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr);
-        else hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<2>, dim3(blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr);
+        if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<4>, dim3(front + blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr, pl);
+        else hipLaunchKernelGGL(roi_pool_fwd_pair_cold_kernel<2>, dim3(front + blocks + pf.blocks), dim3(256), 0, s, p, pf, (int *)nullptr, pl);
         return mv3d_launch_status();
     }
-    if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<4>, dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    if (passes == 4) hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<4>, dim3(front + blocks), dim3(256), 0, s, p, pl);
+    else hipLaunchKernelGGL(roi_pool_fwd_pair_kernel<2>, dim3(front + blocks), dim3(256), 0, s, p, pl);
     return mv3d_launch_status();
 }
 
