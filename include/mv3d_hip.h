@@ -194,21 +194,23 @@ int mv3d_roi_pool_backward_views(int num_views, const mv3d_roi_grad_view *views,
  *                   (h - hstart) * (wend - wstart) + (w - wstart), 0xFF for the reference's -1 -- in the first quarter of the
  *                   caller's (num_rois, PH, PW, C) int32 buffer (bins of more than 255 pixels, i.e. ROIs far larger than the
  *                   map: 16-bit codes in the two quarters behind it): 3 / 8 of the record bytes (8 -> 5 B per pooled value)
- *                   are neither written by the forward nor read by the backward.  mv3d_roi_pool_argmax_decode returns the reference's
- *                   int32 plane (tests, verification).
- *   backward        three launches: one workgroup per 16 pixels of a map row sizes (1) and then writes (2) the per-pixel candidate
- *                   lists of roi_pooling_op.cc:392-431 -- only bins whose forward rectangle contains the pixel, each with the
- *                   code the pixel has in that bin --, (2) also zero-filling the pixels without a list under its latency chain; (3) the
- *                   ordered gather: `code == pixel's code ? top_diff : +0` per record, the reference's summation order.  The
+ *                   are neither written by the forward nor read by the backward.  The LAST quarter of view 0's buffer carries the
+ *                   backward's work list (a few KB): one planning workgroup at the front of the forward launch estimates every map
+ *                   tile's entry stream from the ROIs, cuts the tiles under long streams into four sub-tiles (first in the list: a
+ *                   stream is one wave's serial work and the launch's makespan) and flags the tiles no ROI touches (written as
+ *                   zeros without a ROI filter).  Both launches decide from the shapes alone whether the list exists (<= 3072 tiles
+ *                   in all views, the list fits the quarter; otherwise the static tile grid).  mv3d_roi_pool_argmax_decode returns
+ *                   the reference's int32 plane (tests, verification).
+ *   backward        ONE launch (csrc/roi_grad_tiles.hip): a wave owns a unit of the work list -- a tile of <= 16 map pixels x 64
+ *                   channels in LDS, or a sub-tile of a cut one (a single pixel keeps its sum in a register) --, finds the ROIs that
+ *                   reach it, streams their (roi, bin) records in the reference's order (roi_pooling_op.cc:392-431) and routes every
+ *                   value to the pixel its code names; a unit is written out whole (no index, no fill, no scratch memory).  The
  *                   views must be the forward's (same order, shapes, scale, ROIs) with the argmax buffers it wrote.  (For a
  *                   foreign argmax plane use mv3d_roi_pool_backward_views: int32 argmax.)
- *   workspace       caller-owned, 256-B aligned, >= mv3d_roi_pool_pair_workspace_bytes(); needs no initialisation (every word is
- *                   written before it is read).  workspace == NULL: the backward runs WITHOUT scratch memory as ONE launch -- a wave
- *                   owns a tile of <= 16 map pixels x 64 channels in LDS, finds the ROIs that reach it, streams their (roi, bin)
- *                   records in the reference's order and routes every value to the pixel its code names (csrc/roi_grad_tiles.hip;
- *                   no index, no fill: a tile is written out whole).  Same results; on the training batch 66 us against 69 with a
- *                   workspace, and 3 - 6 % more frames/s with eight batches in flight (profiles/r05_as_*.txt, r05_at_*.txt): the mode
- *                   the library's own train graph and bench.py use.
+ *   workspace       optional and unused by the pair's own kernels since round 6 (the one-launch backward needs no scratch memory;
+ *                   measured against the round-5 index + gather structure behind a workspace: level alone, 3 - 7 % more frames/s
+ *                   with eight batches in flight); checked for alignment, handed on to mv3d_roi_pool_backward_views for shapes
+ *                   outside the pair's kernels.
  *   cold_maps       != 0: as mv3d_roi_pool_forward_views_cold.
  * Shapes outside the pair's kernels (C not in {256, 512} / not the same for all views, pooled sizes > 15, a map of more than 65534
  * pixels, an empty view) take the plain forward (int32 argmax) and mv3d_roi_pool_backward_views behind the same entries.

@@ -10,7 +10,13 @@
 #define RGT_PLAN_TILES 3072          // tiles of all views the planner's LDS heat map holds (12 KB; more tiles: the static grid)
 #define RGT_HOT_ENTRIES 250          // estimated entries from which a tile is cut
 #define RGT_HOT_MAX 128              // at most this many tiles are cut (the grid is sized for 3 extra units each)
+#define RGT_UNIT_EMPTY (1 << 25)     // work-list unit: no ROI touches the tile
+#define RGT_PLAN_CLASSES 5
+#define RGT_PLAN_SCAN(T) (RGT_PLAN_CLASSES * ((T) / 64) + MV3D_MAX_ROI_VIEWS)
 #define RGT_PLAN_THREADS 256         // (the forward's workgroup size)
+#ifndef RGT_PLAN_DEFAULT
+#define RGT_PLAN_DEFAULT 1           // (A / B builds: 0 = the static tile grid)
+#endif
 
 struct RgtView {
     const float *top_diff, *rois;
@@ -46,7 +52,7 @@ bool mv3d_rgt_layout(int num_views, const mv3d_roi_grad_view *views, int PH, int
 // one filtered, expanded and drained by a wave of its own, no communication) and writes the launch's work list: sub-tiles first (they
 // carry the longest streams and must start at once), then the other tiles in grid order.  What it buys is the makespan: one wave's
 // instruction stream is the limit of a stream (~140 ns per entry, profiles/r06_a), and a 4 x 4 tile under 465 entries is 65 us however
-// fast the other 17 k waves finish.  T threads; heat: RGT_PLAN_TILES ints of LDS, scan: 2 * T / 64 + 2 ints.
+// fast the other 17 k waves finish.  T threads; heat: RGT_PLAN_TILES ints of LDS, scan: RGT_PLAN_SCAN(T) ints.
 template <int T>
 __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int *n_work, const int hot_entries, const int hot_max, int *heat,
                                                int *scan)
@@ -55,6 +61,7 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
     int ntiles = 0;
     for (int k = 0; k < p.n; ++k) ntiles += p.v[k].B * p.v[k].tiles_y * p.v[k].tiles_x;
     for (int i = tid; i < ntiles; i += T) heat[i] = 0;
+    if (tid < MV3D_MAX_ROI_VIEWS) scan[RGT_PLAN_CLASSES * (T / 64) + tid] = 0;  // a view with a ROI the estimate does not follow: none of its tiles counts as empty
     __syncthreads();
     int tile0 = 0;
     for (int k = 0; k < p.n; ++k) {
@@ -66,11 +73,13 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
             for (int u = 0; u < 5; ++u) r5[u] = v.rois[5 * (long long)r + u];
             const RoiGeom g = roi_geom(r5, v.scale);
             const int b = (int)r5[0];
-            if (b < 0 || b >= v.B || g.reh < g.rsh || g.rew < g.rsw) continue;
+            if (b < 0 || b >= v.B || g.reh < g.rsh || g.rew < g.rsw) continue;          // (no pixel passes roi_pooling_op.cc:401-404: no entry anywhere)
             const int y0 = max(g.rsh, 0), y1 = min(g.reh, v.H - 1), x0 = max(g.rsw, 0), x1 = min(g.rew, v.W - 1);
             if (y1 < y0 || x1 < x0) continue;
             const int ty0 = y0 >> v.ths, ty1 = y1 >> v.ths, tx0 = x0 >> v.tws, tx1 = x1 >> v.tws;
-            if ((long long)(ty1 - ty0 + 1) * (tx1 - tx0 + 1) > 64) continue;      // (a ROI over that many tiles leaves a few bins in each)
+            // (a ROI over that many tiles leaves a few bins in each; coordinates outside exact integer range are left to the kernel's own tests)
+            const bool sane = abs(g.rsw) < (1 << 24) && abs(g.rsh) < (1 << 24) && abs(g.rew) < (1 << 24) && abs(g.reh) < (1 << 24);
+            if (!sane || (long long)(ty1 - ty0 + 1) * (tx1 - tx0 + 1) > 128) { scan[RGT_PLAN_CLASSES * (T / 64) + k] = 1; continue; }
             const float bh = (float)(g.reh - g.rsh + 1) / (float)p.PH, bw = (float)(g.rew - g.rsw + 1) / (float)p.PW;
             const float per_row = fminf((float)p.PH, 1.0f + 1.0f / bh);            // bins whose rows hold one map row
             for (int ty = ty0; ty <= ty1; ++ty) {
@@ -85,29 +94,49 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
         tile0 += v.B * v.tiles_y * v.tiles_x;
     }
     __syncthreads();
-    // ---- classify; positions by a block scan of (hot, cold) counts over the tiles in list order (thread t: tiles [t * per, t * per + per))
+    // ---- classify by estimate -- 0: hot (cut while the cap lasts), 1 .. 3: long, medium, short streams, 4: no ROI near -- and order the list
+    // longest first (a wave slot freed late should pick up short work: the launch ends with its last wave): positions by a block scan of the
+    // class counts over the tiles in grid order (thread t: tiles [t * per, t * per + per)), grid order kept inside a class
+    constexpr int NW = T / 64;
+    int *const flags = scan + RGT_PLAN_CLASSES * NW;
     const int per = (ntiles + T - 1) / T;
     const int first = tid * per, last = min(first + per, ntiles);
-    int nh = 0, nc = 0;
-    for (int i = first; i < last; ++i) { if (heat[i] >= hot_entries) ++nh; else ++nc; }
-    int ih = nh, ic = nc;                                              // inclusive scans inside the wave ...
+    const int lim1 = max(hot_entries / 2, 2), lim2 = max(hot_entries / 8, 1);
+    int cnt[RGT_PLAN_CLASSES], inc[RGT_PLAN_CLASSES], pos[RGT_PLAN_CLASSES], tot[RGT_PLAN_CLASSES];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int a = __shfl_up(ih, o), c = __shfl_up(ic, o);
-        if (lane >= o) { ih += a; ic += c; }
-    }
-    if (lane == 63) { scan[2 * wave] = ih; scan[2 * wave + 1] = ic; }
-    __syncthreads();
-    int bh_ = 0, bc_ = 0, th_ = 0, tc_ = 0;                            // ... and over the waves
-    for (int w = 0; w < T / 64; ++w) {
-        if (w < wave) { bh_ += scan[2 * w]; bc_ += scan[2 * w + 1]; }
-        th_ += scan[2 * w]; tc_ += scan[2 * w + 1];
-    }
-    int ph = bh_ + ih - nh, pc = bc_ + ic - nc;                        // exclusive positions of this thread's first hot / cold tile
-    const int cut = min(th_, hot_max);                             // hot tiles beyond the cap stay whole
-    const int cold0 = 4 * cut;                                         // the list: 4 x cut sub-tile units, then the whole tiles in grid order
+    for (int c = 0; c < RGT_PLAN_CLASSES; ++c) cnt[c] = 0;
     for (int i = first; i < last; ++i) {
-        int k = 0, base = 0;                                           // the view, frame and tile coordinates of list position i
+        const int e = heat[i], c = e >= hot_entries ? 0 : (e >= lim1 ? 1 : (e >= lim2 ? 2 : (e > 0 ? 3 : 4)));
+#pragma unroll
+        for (int u = 0; u < RGT_PLAN_CLASSES; ++u) cnt[u] += c == u;
+    }
+#pragma unroll
+    for (int c = 0; c < RGT_PLAN_CLASSES; ++c) {                       // inclusive scans inside the wave ...
+        int x = cnt[c];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(x, o);
+            if (lane >= o) x += a;
+        }
+        inc[c] = x;
+        if (lane == 63) scan[c * NW + wave] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RGT_PLAN_CLASSES; ++c) {                       // ... and over the waves: exclusive position inside the class, class total
+        int before = 0, all = 0;
+        for (int w = 0; w < NW; ++w) { if (w < wave) before += scan[c * NW + w]; all += scan[c * NW + w]; }
+        pos[c] = before + inc[c] - cnt[c];
+        tot[c] = all;
+    }
+    const int cut = min(tot[0], hot_max);                              // hot tiles beyond the cap stay whole (first among the whole ones)
+    int off[RGT_PLAN_CLASSES];                                         // the list: 4 x cut sub-tile units, then the classes in turn
+    off[0] = 4 * cut - cut;                                            // (a whole hot tile at hot position q >= cut sits at 4 cut + q - cut)
+    off[1] = 4 * cut + (tot[0] - cut);
+#pragma unroll
+    for (int c = 2; c < RGT_PLAN_CLASSES; ++c) off[c] = off[c - 1] + tot[c - 1];
+    for (int i = first; i < last; ++i) {
+        int k = 0, base = 0;                                           // the view, frame and tile coordinates of grid position i
         for (int j = 0; j < p.n; ++j) {
             const int n = p.v[j].B * p.v[j].tiles_y * p.v[j].tiles_x;
             if (i < base + n) { k = j; break; }
@@ -117,22 +146,30 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
         int t = i - base;
         const int tx = t % v.tiles_x; t /= v.tiles_x;
         const int ty = t % v.tiles_y, b = t / v.tiles_y;
-        const bool hot = heat[i] >= hot_entries;
-        if (hot && ph < cut) {
+        const int e = heat[i], c = e >= hot_entries ? 0 : (e >= lim1 ? 1 : (e >= lim2 ? 2 : (e > 0 ? 3 : 4)));
+        int q = 0;
+#pragma unroll
+        for (int u = 0; u < RGT_PLAN_CLASSES; ++u) { if (c == u) { q = pos[u]; pos[u] += 1; } }
+        if (c == 0 && q < cut) {
             const int sy = min(v.ths, 2), sx = min(v.tws, 2 - sy);     // split bits: rows first
             const int ths2 = v.ths - sy, tws2 = v.tws - sx;
             for (int j = 0; j < 4; ++j) {
                 const int jy = j >> sx, jx = j & ((1 << sx) - 1);
                 const int y = (ty << v.ths) + (jy << ths2), x = (tx << v.tws) + (jx << tws2);
                 const bool skip = j >= (1 << (sy + sx)) || y >= v.H || x >= v.W;
-                work[4 * ph + j] = make_int4(k | (b << 4) | (ths2 << 16) | (tws2 << 20) | (skip ? 1 << 24 : 0), y, x, heat[i]);
+                work[4 * q + j] = make_int4(k | (b << 4) | (ths2 << 16) | (tws2 << 20) | (skip ? 1 << 24 : 0), y, x, e);
             }
         } else {
-            const int pos = cold0 + (ph + pc) - min(ph, cut);
-            work[pos] = make_int4(k | (b << 4) | (v.ths << 16) | (v.tws << 20), ty << v.ths, tx << v.tws, heat[i]);
+            // a tile no ROI's rounded rectangle touches has no entry (every entry lies inside its ROI's rounded rectangle cut to the map:
+            // the expansion's ih0 .. ih1 x iw0 .. iw1): its unit is flagged EMPTY and the wave only writes the zeros
+            const bool empty = e == 0 && flags[k] == 0;
+            int o = 0;
+#pragma unroll
+            for (int u = 0; u < RGT_PLAN_CLASSES; ++u) { if (c == u) o = off[u]; }
+            work[o + q] = make_int4(k | (b << 4) | (v.ths << 16) | (v.tws << 20) | (empty ? RGT_UNIT_EMPTY : 0), ty << v.ths, tx << v.tws, e);
         }
-        if (hot) ++ph; else ++pc;
     }
-    if (tid == 0) *n_work = cold0 + (th_ - cut) + tc_;
+    if (tid == 0) *n_work = 3 * cut + ntiles;
 }
+
 

@@ -169,13 +169,37 @@ __device__ __forceinline__ void rgt_drain_mixed(float *acc, const int2 e, const 
     }
 }
 
+// A ONE-PIXEL unit (a sub-tile of a cut 2 x 2 tile: the streams of the launch's hottest pixels) keeps its sum in a register, lane =
+// channel: every entry names that pixel with code e.y, so a value is added iff its code equals it -- `s += code == y ? v : +0`, which is
+// the reference's sum bit for bit: a sum that starts at +0 and adds in the same order never becomes -0, so the +0 of a value that goes
+// elsewhere changes nothing.  Three vector instructions per entry instead of a routed LDS read-add-write.
+template <int W>
+__device__ __forceinline__ void rgt_drain1(float &s, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc, const __amdgpu_buffer_rsrc_t rt,
+                                           const int lane)
+{
+    unsigned cd[W];
+    float td[W];
+    rgt_issue<W, 1>(cd, td, e, m, rc, rt, lane);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        if (j < m) {
+            const int y = __builtin_amdgcn_readlane(e.y, j);
+            s = s + ((int)cd[j] == y ? td[j] : 0.0f);
+        }
+    }
+}
+
 template <int W, int CPL>
-__device__ __forceinline__ void rgt_drain_any(float *acc, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
+__device__ __forceinline__ void rgt_drain_any(float *acc, float &s1, const bool onepx, const int2 e, const int m, const __amdgpu_buffer_rsrc_t rc,
                                               const __amdgpu_buffer_rsrc_t rc16, const __amdgpu_buffer_rsrc_t rt, const int lane, const int tws,
                                               const int dbg)
 {
-    if (__ballot((e.x & RGT_BIGBIT) != 0 && lane < m) != 0ull) rgt_drain_mixed<CPL>(acc, e, m, rc, rc16, rt, lane, tws);
+    const bool mixed = __ballot((e.x & RGT_BIGBIT) != 0 && lane < m) != 0ull;
+    if (CPL == 1 && onepx && !mixed) { rgt_drain1<W>(s1, e, m, rc, rt, lane); return; }
+    if (CPL == 1 && onepx) acc[lane] = s1;                             // (rare: 16-bit codes in a one-pixel unit -- through the LDS slot and back)
+    if (mixed) rgt_drain_mixed<CPL>(acc, e, m, rc, rc16, rt, lane, tws);
     else rgt_drain<W, CPL>(acc, e, m, rc, rt, lane, tws, dbg);
+    if (CPL == 1 && onepx) s1 = acc[lane];
 }
 
 // The pixels x of [lo, hi] that list pooled index p under the reference's backward (roi_pooling_op.cc:423-431): floor((x - start) / bin) <= p <
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
     __shared__ int2 ring[RGT_RING];
     const int lane = threadIdx.x;
     int k = 0, slice, b, ths, tws, th0, tw0;
+    bool no_roi = false;                                               // (planned mode) no ROI touches the tile: only the zeros are written
     if (p.work) {
         const int nsl = p.v[0].nsl;                                    // (one C for all views of the pair)
         slice = (int)(blockIdx.x % (unsigned)nsl);
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         if (unit >= (unsigned)*p.n_work) return;
         const int4 d = p.work[unit];
         if (d.x & (1 << 24)) return;                                   // (a sub-tile outside the map)
+        no_roi = (d.x & RGT_UNIT_EMPTY) != 0;
         k = d.x & 15; b = (d.x >> 4) & 0xfff; ths = (d.x >> 16) & 15; tws = (d.x >> 20) & 15; th0 = d.y; tw0 = d.z;
     } else {
 #pragma unroll
@@ -230,10 +256,12 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         (void *)((const unsigned short *)(plane8 + (long long)R * PHW * C) + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)(v.top_diff + slice * 64 * CPL), 0, 0x7fffffff, 0x00020000);
     int head = 0, tail = 0;                                            // ring positions (wave-uniform)
+    const bool onepx = (ths | tws) == 0;                               // a one-pixel unit: the sum in a register (rgt_drain1)
+    float s1 = 0.0f;
     const int CH = TH > 2 ? 60 : 64;                                   // bins per expansion chunk: CH x TH + (W - 1) entries fit the ring
     static_assert(W <= 16 && 60 * 4 + W <= RGT_RING, "ring too small for a chunk");
     for (int base = 0; base < R; base += 256) {
-        if (RGT_DBG(p.dbg, 16)) {                                      // (experiment: the write-out alone -- what a tile costs whose ROI filter somebody else ran)
+        if (no_roi || RGT_DBG(p.dbg, 16)) {                            // the write-out alone (experiment builds: for every tile)
             for (int i = lane; i < (RGT_MAXPX + 1) * 16 * CPL; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             break;
         }
@@ -310,7 +338,7 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
                     __builtin_amdgcn_wave_barrier();
                     while (tail - head >= W) {
                         const int2 e = ring[(head + min(lane, W - 1)) & (RGT_RING - 1)];
-                        rgt_drain_any<W, CPL>(acc, e, W, rc, rc16, rt, lane, tws, p.dbg);
+                        rgt_drain_any<W, CPL>(acc, s1, onepx, e, W, rc, rc16, rt, lane, tws, p.dbg);
                         head += W;
                     }
                 }
@@ -324,9 +352,10 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int2 e = ring[(head + min(lane, m - 1)) & (RGT_RING - 1)];
-        rgt_drain_any<W, CPL>(acc, e, m, rc, rc16, rt, lane, tws, p.dbg);
+        rgt_drain_any<W, CPL>(acc, s1, onepx, e, m, rc, rc16, rt, lane, tws, p.dbg);
     }
     RGT_STAMP(4);
+    if (CPL == 1 && onepx && !no_roi) acc[lane] = s1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // (the accumulators: written per channel lane, read 16 B per lane)
     __builtin_amdgcn_wave_barrier();
     // ---- write-out: every pixel of the tile, zeros included (16 B per lane: 4 / CPL pixels x 256 CPL bytes per store instruction)
@@ -418,7 +447,7 @@ bool mv3d_rgt_layout(int num_views, const mv3d_roi_grad_view *views, int PH, int
     *hot_max = rgt_env("MV3D_RGT_HOT_MAX", RGT_HOT_MAX);
     if (*hot_max > 1024) *hot_max = 1024;
     const long long n0 = (long long)views[0].num_rois * PH * PW * views[0].channels;
-    if (rgt_env("MV3D_RGT_PLAN", 1) != 0 && *hot_entries > 0 && *hot_max > 0 && ntiles <= RGT_PLAN_TILES && one_c && frames_ok && views[0].argmax_data &&
+    if (rgt_env("MV3D_RGT_PLAN", RGT_PLAN_DEFAULT) != 0 && *hot_entries > 0 && *hot_max > 0 && ntiles <= RGT_PLAN_TILES && one_c && frames_ok && views[0].argmax_data &&
         (long long)MV3D_ALIGN + (ntiles + 3LL * *hot_max) * 16 <= n0) {
         char *const q = (char *)views[0].argmax_data + 3 * n0;
         p.n_work = (const int *)q;

@@ -1473,7 +1473,7 @@ struct RoiPlanArgs { RgtPack lay; int on, hot_entries, hot_max; };
 #define PAIR_PLAN_BLOCKS 8u
 union PairFwdLds {
     BinGeom g[4 * 32];
-    struct { int heat[RGT_PLAN_TILES]; int scan[2 * RGT_PLAN_THREADS / 64 + 2]; } plan;
+    struct { int heat[RGT_PLAN_TILES]; int scan[RGT_PLAN_SCAN(RGT_PLAN_THREADS)]; } plan;
 };
 template <int FWD_PASSES>
 __global__ __launch_bounds__(256) void roi_pool_fwd_pair_kernel(RoiViewPack p, RoiPlanArgs pl)

@@ -183,6 +183,82 @@ def test_pair_malformed_and_overhanging_rois(gpu, oracle, C, no_ws):
     assert np.array_equal(bd.cpu().numpy(), want)
 
 
+def _pair_against_oracle(torch, ops, oracle, m, rois, seed):
+    d, r = dev(torch, m), dev(torch, rois)
+    junk = torch.randint(0, 255, (64 << 20,), dtype=torch.uint8, device="cuda")      # (the pair's planes and work list land on garbage)
+    del junk
+    res = ops.roi_pool_forward_views_pair([(d, r, 0.125)], 7, 7)
+    dec, = ops.roi_pool_argmax_decode([(d, r, 0.125)], res, 7, 7)
+    o_top, o_am = oracle.roi_pool(m, rois, 7, 7, 0.125)
+    assert np.array_equal(res[0][0].cpu().numpy(), o_top) and np.array_equal(dec.cpu().numpy(), o_am)
+    g = np.random.RandomState(seed).uniform(-1, 1, o_top.shape).astype(np.float32)
+    want = oracle.roi_pool_grad(m, rois, o_am, g, 7, 7, 0.125)
+    for _ in range(2):                                               # (the list is read again by a second backward of the same forward)
+        bd, = ops.roi_pool_backward_views_pair([(dev(torch, g), r, res[0][1], m.shape, 0.125)], 7, 7, workspace=False)
+        assert np.array_equal(bd.cpu().numpy(), want)
+    return res
+
+
+def _work_list(torch, res, m, R, C):
+    """the backward's work list as the forward's planning workgroup wrote it (csrc/roi_grad_plan.h): last quarter of view 0's argmax buffer"""
+    raw = res[0][1].view(torch.uint8).reshape(-1)[3 * R * 49 * C:].cpu().numpy()
+    n = int(raw[:4].view(np.int32)[0])
+    return raw[256:256 + 16 * n].view(np.int32).reshape(-1, 4)
+
+
+def test_planned_backward_more_hot_tiles_than_the_cap(gpu, oracle):
+    """The pair's forward launch plans its backward (csrc/roi_grad_plan.h): tiles under long entry streams are cut into four sub-tiles, at most
+    RGT_HOT_MAX = 128 of them.  A dense view where EVERY tile is hot (256 ROIs, each over one half of a 16 x 64 map: 256 tiles of 2 x 2): 128 tiles cut into
+    one-pixel units (register sums), the others whole, no unit flagged empty; bottom_diff equal to the oracle."""
+    torch, ops = gpu
+    rs = np.random.RandomState(5)
+    B, H, W, C, R = 1, 16, 64, 256, 256
+    m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    # every ROI covers one half of the map (8 x 16 = 128 tiles: the most the estimate follows), left and right halves alternating
+    side = np.arange(R) % 2
+    x1 = side * 256 + rs.randint(0, 8, R)
+    x2 = np.where(side == 0, 247 - rs.randint(0, 8, R), 511)
+    rois = np.stack([np.zeros(R), x1, rs.randint(0, 8, R), x2, 127 - rs.randint(0, 4, R)], 1).astype(np.float32)
+    res = _pair_against_oracle(torch, ops, oracle, m, rois, 6)
+    units = _work_list(torch, res, m, R, C)
+    shapes = (units[:, 0] >> 16) & 0xff                                # ths | tws << 4
+    assert (shapes == 0).sum() == 4 * 128 and (shapes == 0x11).sum() == 256 - 128 and len(units) == 4 * 128 + 128
+    assert not (units[:, 0] & (1 << 25)).any()
+
+
+def test_planned_backward_empty_tiles_big_rois_and_16_bit_codes_in_a_hot_pixel(gpu, oracle):
+    """(a) tiles no ROI touches are flagged in the work list and only written as zeros; (b) ROIs over more than 128 tiles are not followed
+    by the estimate: their view keeps every tile unflagged; (c) one-pixel units (register sums) that meet bins of more than 255 pixels
+    (16-bit codes: the sum goes through its LDS slot and back)."""
+    torch, ops = gpu
+    rs = np.random.RandomState(9)
+    B, H, W, C = 1, 100, 112, 256
+    m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    hot = [[0, 8 * 30 + rs.randint(0, 8), 8 * 40 + rs.randint(0, 8), 8 * 36 + rs.randint(0, 16), 8 * 45 + rs.randint(0, 16)] for _ in range(380)]
+    # (a): only the small stacked ROIs -- most of the map's 2 x 2 tiles are empty, the stack's are hot
+    rois = np.asarray(hot, np.float32)
+    res = _pair_against_oracle(torch, ops, oracle, m, rois, 10)
+    units = _work_list(torch, res, m, len(rois), C)
+    assert (units[:, 0] & (1 << 25)).sum() > 2000 and (((units[:, 0] >> 16) & 0xff) == 0).sum() >= 4
+    # (b) + (c): whole-map ROIs on top (bins of 16 x 16 = 256 pixels), interleaved with the stack
+    rois = np.asarray(hot[:190] + [[0, 0, 0, W * 8 - 1, H * 8 - 1]] * 6 + hot[190:] + [[0, -40, -40, W * 8 + 40, H * 8 + 40]] * 4, np.float32)
+    res = _pair_against_oracle(torch, ops, oracle, m, rois, 11)
+    units = _work_list(torch, res, m, len(rois), C)
+    assert not (units[:, 0] & (1 << 25)).any() and (((units[:, 0] >> 16) & 0xff) == 0).sum() >= 4
+
+
+def test_backward_static_grid_when_the_planner_does_not_apply(gpu, oracle):
+    """More tiles than the planner's heat map holds (a 250 x 250 map in 4 x 4 tiles: 3969 > 3072): both launches decide for the static grid
+    from the shapes alone; same results."""
+    torch, ops = gpu
+    rs = np.random.RandomState(12)
+    B, H, W, C, R = 1, 250, 250, 256, 24
+    m = rs.uniform(-1, 1, (B, H, W, C)).astype(np.float32)
+    x1, y1 = rs.randint(-40, W * 8 - 200, R), rs.randint(-40, H * 8 - 200, R)
+    rois = np.stack([np.zeros(R), x1, y1, x1 + rs.randint(0, 900, R), y1 + rs.randint(0, 900, R)], 1).astype(np.float32)
+    _pair_against_oracle(torch, ops, oracle, m, rois, 13)
+
+
 def test_autograd_views_function_uses_the_pair(gpu, oracle):
     torch, ops = gpu
     from mv3d_tf_amd.roi_pooling_layer.roi_pooling_op import roi_pool_views
