@@ -285,13 +285,13 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
 #pragma unroll
             for (int u = 0; u < 5; ++u) r5[u] = q == 0 ? rr[0][u] : (q == 1 ? rr[1][u] : (q == 2 ? rr[2][u] : rr[3][u]));
             const RoiGeom g = roi_geom(r5, v.scale);
-            const int rw = max(g.rew - g.rsw + 1, 1), rh = max(g.reh - g.rsh + 1, 1);   // roi_pooling_op.cc:146-147
-            // conservative bounding box of the ROI's bins (every bin's rows lie in [rsh, rsh + rh + 1]); coordinates outside the
-            // range where that arithmetic is exact (NaN / inf / absurd boxes) are left to the exact per-bin test of the expansion
+            // every entry lies inside the ROI's rounded rectangle (the expansion cuts a bin's rectangle to it, :401-404), so a ROI whose
+            // rectangle misses the tile has nothing for it; coordinates outside the range where that arithmetic is exact (NaN / inf / absurd
+            // boxes) are left to the exact per-bin test of the expansion
             const bool sane = abs(g.rsw) < (1 << 24) && abs(g.rsh) < (1 << 24) && abs(g.rew) < (1 << 24) && abs(g.reh) < (1 << 24);
             // (:401-404: h in [rsh, reh], w in [rsw, rew] -- an end before its start lets nothing through)
             bool hit = roi0 + lane < R && (int)r5[0] == b && g.reh >= g.rsh && g.rew >= g.rsw;
-            if (sane) hit = hit && g.rsh < th1 && g.rsh + rh + 2 > th0 && g.rsw < tw1 && g.rsw + rw + 2 > tw0;
+            if (sane) hit = hit && g.rsh < th1 && g.reh >= th0 && g.rsw < tw1 && g.rew >= tw0;
             if (RGT_DBG(p.dbg, 8)) hit = false;
             unsigned long long todo = __ballot(hit);
             if (base == 0 && q == 0) RGT_STAMP(1);
