@@ -378,7 +378,7 @@ def events_ms(stream, fns, rounds):
 
 def pmc_signature(workload, batch, rows, variant, launches):
     """What a PMC pass is keyed by: the workload AND the launch set behind the timed calls -- `launches` names the kernel variant and
-    the outputs it writes (train: "pair-tiles" = forward with one-byte codes + the one-launch RoiPoolGrad; test: "top-only" /
+    the outputs it writes (train: "pair-tiles-planned" = forward with one-byte codes + planning workgroup, the one-launch RoiPoolGrad on its work list; test: "top-only" /
     "top+argmax").  A table collected for another variant of the same workload must not be quoted (the r03 pass of the
     forward that also wrote the int32 plane was printed next to the top-only kernel)."""
     return "%s/b%d/r%d/%s/%s" % (workload, batch, rows, variant, launches)
@@ -809,7 +809,7 @@ def main():
             desc = ("BASELINE configs[4] per-GPU path: batch %d, TEST cfg (pre/post-NMS 6000/300, NMS 0.7) proposal_layer_3d + FV "
                     "ROIs + RoiPool 7x7 fwd on 3 views, R=%d rows; %s scores" % (batch, s0.num_rois, args.variant))
         signature = pmc_signature(wl, batch, s0.num_rois, args.variant,
-                                  "pair-tiles" if wl == "train" else ("top+argmax" if getattr(args, "test_argmax", False) else "top-only"))
+                                  "pair-tiles-planned" if wl == "train" else ("top+argmax" if getattr(args, "test_argmax", False) else "top-only"))
         res = {
             "metric": METRIC, "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
@@ -834,7 +834,7 @@ def main():
         res["config"]["one_batch_latency_ms"] = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         entries = roofline_entries(ring, wl, signature)
         dom = max(entries, key=lambda e: e["avg_launch_us"]) if entries else {}
-        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = one launch of LDS map tiles, no workspace; algorithmic "
+        res["roofline"] = dict(dom, note="dominant launch of the step (RoiPoolGrad = one launch of LDS map tiles over the work list its forward launch planned, no workspace; algorithmic "
                                          "bytes as SURVEY 8(d) defines them -- 8 B per pooled value -- while the pair moves 5: its argmax plane holds one-byte codes); "
                                          "HIP event pairs on the launch stream around the call inside the batch's eager launch "
                                          "sequence, all stream-0 ring batches x 4 rounds; traffic = PMC pass of this exact "

@@ -153,7 +153,7 @@ def test_secondary_lines_and_two_gloo_ranks_with_trunk_on_one_gpu():
     c = d["config"]                                                  # the N > 1 host plan as the line states it
     assert len(c["host_cpu_s_per_step_per_rank"]) == 2 and all(x > 0 for x in c["host_cpu_s_per_step_per_rank"])
     assert c["host_cores"]["usable"] >= 1 and isinstance(c["host_cores"]["plan"], str) and c["host_cores"]["plan"]
-    assert c["parallelism"] == "frames/2" and c["launch"] in ("path", "graph") and c["pmc_signature"].endswith("/pair-tiles")
+    assert c["parallelism"] == "frames/2" and c["launch"] in ("path", "graph") and c["pmc_signature"].endswith("/pair-tiles-planned")
     sec = d["secondary"]
     fr = sec["fresh_inputs"]
     assert fr["frames_per_s"] > 0 and fr["host_draw_ms_per_frame"] > 0 and 0 < fr["fraction_of_resident_replay"]

@@ -34,8 +34,8 @@ for recipe in "$@"; do
     overlap) tools/gpu_profile.sh $TAG/ov --steps 3 --warmup 1 --batches-per-step 128 --no-cpu-baseline --no-secondary > /dev/null 2>&1
            python tools/rocprof_overlap.py $OUT/ov/r_results.db 2>&1 | tee $OUT/overlap.txt; rm -rf $OUT/ov ;;
     pmc) rm -f $OUT/pmc_traffic.json $OUT/pmc_traffic.txt
-         tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky/pair-tiles | head -8; rm -rf $OUT/pmc_train
-         tools/gpu_pmc.sh $TAG/pmc_test --workload test > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_test $OUT/pmc_traffic test/b16/r4800/peaky/top-only | head -8; rm -rf $OUT/pmc_test ;;
+         tools/gpu_pmc.sh $TAG/pmc_train > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_train $OUT/pmc_traffic train/b2/r256/peaky/pair-tiles-planned | head -8; rm -rf $OUT/pmc_train
+         [ -n "${PMC_TRAIN_ONLY:-}" ] || { tools/gpu_pmc.sh $TAG/pmc_test --workload test > /dev/null 2>&1; python tools/pmc_summary.py $OUT/pmc_test $OUT/pmc_traffic test/b16/r4800/peaky/top-only | head -8; rm -rf $OUT/pmc_test; } ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
