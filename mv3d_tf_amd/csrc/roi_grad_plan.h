@@ -80,14 +80,18 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
             // (a ROI over that many tiles leaves a few bins in each; coordinates outside exact integer range are left to the kernel's own tests)
             const bool sane = abs(g.rsw) < (1 << 24) && abs(g.rsh) < (1 << 24) && abs(g.rew) < (1 << 24) && abs(g.reh) < (1 << 24);
             if (!sane || (long long)(ty1 - ty0 + 1) * (tx1 - tx0 + 1) > 128) { scan[RGT_PLAN_CLASSES * (T / 64) + k] = 1; continue; }
-            const float bh = (float)(g.reh - g.rsh + 1) / (float)p.PH, bw = (float)(g.rew - g.rsw + 1) / (float)p.PW;
-            const float per_row = fminf((float)p.PH, 1.0f + 1.0f / bh);            // bins whose rows hold one map row
+            // (an estimate: bins per map row / column from the reciprocal bin sizes, no divide inside the loops -- this workgroup's
+            // serial work must stay well inside the pooling workgroups' shadow)
+            const float inv_bh = (float)p.PH / (float)(g.reh - g.rsh + 1), inv_bw = (float)p.PW / (float)(g.rew - g.rsw + 1);
+            const float per_row = fminf((float)p.PH, 1.0f + inv_bh);               // bins whose rows hold one map row
+            int *const hrow = heat + tile0 + b * v.tiles_y * v.tiles_x;
             for (int ty = ty0; ty <= ty1; ++ty) {
                 const int rows = min(y1, (ty << v.ths) + TH - 1) - max(y0, ty << v.ths) + 1;
+                const float down = (float)rows * per_row;
                 for (int tx = tx0; tx <= tx1; ++tx) {
                     const int cols = min(x1, (tx << v.tws) + TW - 1) - max(x0, tx << v.tws) + 1;
-                    const float across = fminf((float)p.PW, 1.0f + (float)cols / bw);
-                    atomicAdd(&heat[tile0 + (b * v.tiles_y + ty) * v.tiles_x + tx], (int)(rows * per_row * across + 0.5f));
+                    const float across = fminf((float)p.PW, 1.0f + (float)cols * inv_bw);
+                    atomicAdd(&hrow[ty * v.tiles_x + tx], max((int)(down * across + 0.5f), 1));
                 }
             }
         }
@@ -135,17 +139,21 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
     off[1] = 4 * cut + (tot[0] - cut);
 #pragma unroll
     for (int c = 2; c < RGT_PLAN_CLASSES; ++c) off[c] = off[c - 1] + tot[c - 1];
-    for (int i = first; i < last; ++i) {
-        int k = 0, base = 0;                                           // the view, frame and tile coordinates of grid position i
+    // the view, frame and tile coordinates of this thread's first tile (grid position `first`), advanced tile by tile
+    int k = 0, tx = 0, ty = 0, b = 0;
+    {
+        int base = 0;
         for (int j = 0; j < p.n; ++j) {
             const int n = p.v[j].B * p.v[j].tiles_y * p.v[j].tiles_x;
-            if (i < base + n) { k = j; break; }
+            if (first < base + n || j == p.n - 1) { k = j; break; }
             base += n;
         }
+        int t = max(first - base, 0);
+        tx = t % p.v[k].tiles_x; t /= p.v[k].tiles_x;
+        ty = t % p.v[k].tiles_y; b = t / p.v[k].tiles_y;
+    }
+    for (int i = first; i < last; ++i) {
         const RgtView &v = p.v[k];
-        int t = i - base;
-        const int tx = t % v.tiles_x; t /= v.tiles_x;
-        const int ty = t % v.tiles_y, b = t / v.tiles_y;
         const int e = heat[i], c = e >= hot_entries ? 0 : (e >= lim1 ? 1 : (e >= lim2 ? 2 : (e > 0 ? 3 : 4)));
         int q = 0;
 #pragma unroll
@@ -168,6 +176,7 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
             for (int u = 0; u < RGT_PLAN_CLASSES; ++u) { if (c == u) o = off[u]; }
             work[o + q] = make_int4(k | (b << 4) | (v.ths << 16) | (v.tws << 20) | (empty ? RGT_UNIT_EMPTY : 0), ty << v.ths, tx << v.tws, e);
         }
+        if (++tx == v.tiles_x) { tx = 0; if (++ty == v.tiles_y) { ty = 0; if (++b == v.B) { b = 0; ++k; } } }
     }
     if (tid == 0) *n_work = 3 * cut + ntiles;
 }

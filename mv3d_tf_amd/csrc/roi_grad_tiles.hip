@@ -13,9 +13,10 @@
 //               containment test (roi_pooling_op.cc:401-404) although the forward pools a forced 1 x 1 region for it: dropped here;
 //   expansion   per surviving ROI lane = bin (ph, pw) computes the bin's rectangle exactly as the forward does, cut to the rounded ROI
 //               (f32: 7 * (57 / 7) > 57, so the last bin of a 57-wide ROI reaches one column past the ROI's end; the forward pools
-//               that column, the reference's backward drops what lands there -- same test, :401-404); per ROW of the tile the bins
-//               whose rectangle meets it are appended (ballot order = the reference's ph, pw order; a pixel only ever sees the bins of
-//               its own row, so row-major emission keeps every pixel's order) to a 256-entry LDS ring of 8-byte entries
+//               that column, the reference's backward drops what lands there -- same test, :401-404); per bin (lane order = the
+//               reference's ph, pw order) one entry per ROW of the tile its rectangle meets is appended (a pixel only ever sees one row
+//               segment of a bin, so every pixel meets its bins in the reference's order; positions by one prefix sum over the lanes' row
+//               counts) to a 256-entry LDS ring of 8-byte entries
 //               {record byte offset | first pixel of the row segment | its length - 1, code of that pixel};
 //   drain       W entries at a time, all their code bytes + top_diff slices requested at once (record offset = scalar offset of
 //               the buffer loads); per entry and lane  code -> pixel of the segment  (a subtract and a compare, branch-free) = the
@@ -260,6 +261,9 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
     float s1 = 0.0f;
     const int CH = TH > 2 ? 60 : 64;                                   // bins per expansion chunk: CH x TH + (W - 1) entries fit the ring
     static_assert(W <= 16 && 60 * 4 + W <= RGT_RING, "ring too small for a chunk");
+    const int bin1 = lane < CH ? lane : PHW;                           // the first expansion chunk's bin of this lane, (ph, pw), and their float forms
+    const int ph1 = (int)(((unsigned)bin1 * (unsigned)p.inv_pw) >> 16), pw1 = bin1 - ph1 * PW;
+    const float fph0_1 = (float)ph1, fph1_1 = (float)(ph1 + 1), fpw0_1 = (float)pw1, fpw1_1 = (float)(pw1 + 1);
     for (int base = 0; base < R; base += 256) {
         if (no_roi || RGT_DBG(p.dbg, 16)) {                            // the write-out alone (experiment builds: for every tile)
             for (int i = lane; i < (RGT_MAXPX + 1) * 16 * CPL; i += 64) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -296,6 +300,13 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
             unsigned long long todo = __ballot(hit);
             if (base == 0 && q == 0) RGT_STAMP(1);
             if (RGT_DBG(p.dbg, 1)) todo = 0ull;
+            // the bin sizes of this pass's ROIs, lane = ROI (roi_pooling_op.cc:148-151): one pair of f32 divides per pass with a hit instead of
+            // one per hit ROI (a wave that got past the work list's empty flag usually has many)
+            float bhl = 0.0f, bwl = 0.0f;
+            if (todo != 0ull) {
+                bhl = (float)(g.reh - g.rsh + 1) / (float)PH;
+                bwl = (float)(g.rew - g.rsw + 1) / (float)PW;
+            }
             // ---- expansion + drain
             while (todo != 0ull) {
                 const int j = (int)__builtin_ctzll(todo);
@@ -303,15 +314,21 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
                 const int r = roi0 + j, rsh = __builtin_amdgcn_readlane(g.rsh, j), rsw = __builtin_amdgcn_readlane(g.rsw, j);
                 const int reh = __builtin_amdgcn_readlane(g.reh, j), rew = __builtin_amdgcn_readlane(g.rew, j);
                 const int rhj = reh - rsh + 1, rwj = rew - rsw + 1;    // (>= 1: the filter drops the others)
-                const float bh = (float)rhj / (float)PH;               // roi_pooling_op.cc:148-151 (only for hits)
-                const float bw = (float)rwj / (float)PW;
+                const float bh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bhl), j));
+                const float bw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bwl), j));
                 const bool exact = rhj > RGT_EXACT_MAX || rwj > RGT_EXACT_MAX;
                 for (int bin0 = 0; bin0 < PHW; bin0 += CH) {
-                    const int bin = lane < CH ? bin0 + lane : PHW;
-                    const int ph = (int)(((unsigned)bin * (unsigned)p.inv_pw) >> 16), pw = bin - ph * PW;
+                    // (the first chunk's lane -> bin map and its float forms are the wave's: bin1 .. fpw1 above; 7 x 7 bins are one chunk)
+                    int bin = bin1, ph = ph1, pw = pw1;
+                    float fph0 = fph0_1, fph1 = fph1_1, fpw0 = fpw0_1, fpw1 = fpw1_1;
+                    if (bin0 != 0) {
+                        bin = lane < CH ? bin0 + lane : PHW;
+                        ph = (int)(((unsigned)bin * (unsigned)p.inv_pw) >> 16); pw = bin - ph * PW;
+                        fph0 = (float)ph; fph1 = (float)(ph + 1); fpw0 = (float)pw; fpw1 = (float)(pw + 1);
+                    }
                     // the bin's rectangle as the forward computes it (roi_pool.hip fwd_bin_rect, roi_pooling_op.cc:153-162)
-                    const int hs0 = (int)floorf(__fmul_rn((float)ph, bh)), ws0 = (int)floorf(__fmul_rn((float)pw, bw));
-                    const int he0 = (int)ceilf(__fmul_rn((float)(ph + 1), bh)), we0 = (int)ceilf(__fmul_rn((float)(pw + 1), bw));
+                    const int hs0 = (int)floorf(__fmul_rn(fph0, bh)), ws0 = (int)floorf(__fmul_rn(fpw0, bw));
+                    const int he0 = (int)ceilf(__fmul_rn(fph1, bh)), we0 = (int)ceilf(__fmul_rn(fpw1, bw));
                     const int hs = min(max(hs0 + rsh, 0), H), he = min(max(he0 + rsh, 0), H);
                     const int ws = min(max(ws0 + rsw, 0), Wd), we = min(max(we0 + rsw, 0), Wd);
                     // (rectangle x tile), cut to the rounded ROI: hs >= rsh and ws >= rsw hold by construction
@@ -325,14 +342,25 @@ __global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
                     const int bwid = we - ws;
                     const int ex = (((r * PHW + bin) * C) * 4) | (iw0 - tw0) | ((iw1 - iw0) << 4) | ((he - hs) * bwid > 255 ? RGT_BIGBIT : 0);
                     const int ey = (iw0 - ws) - hs * bwid;
-                    // ---- one entry per row of the tile a bin's rectangle meets, rows outermost
-                    for (int h = th0; h < th1; ++h) {
-                        const bool on = meets && ih0 <= h && h <= ih1;
-                        const unsigned long long mr = __ballot(on);
-                        if (mr == 0ull) continue;
-                        if (on) ring[(tail + __popcll(mr & ((1ull << lane) - 1ull))) & (RGT_RING - 1)] = make_int2(ex + ((h - th0) << tws), ey + h * bwid);
-                        tail += __popcll(mr);
+                    // ---- one entry per row of the tile a bin's rectangle meets, bins outermost (ph, pw order), a bin's rows in turn: a pixel
+                    // meets at most one row segment of a bin, so every pixel still sees its bins in the reference's order.  Positions by ONE
+                    // prefix sum over the lanes' row counts (0 .. 4: three ballots of their bits) instead of a ballot and a branch per tile row
+                    const int nrows = meets ? ih1 - ih0 + 1 : 0;       // (ih0 .. ih1 lies inside the tile's rows)
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const unsigned long long b0 = __ballot((nrows & 1) != 0), b1 = __ballot((nrows & 2) != 0);
+                    int pre = __popcll(b0 & below) + 2 * __popcll(b1 & below), tot = __popcll(b0) + 2 * __popcll(b1);
+                    if (TH > 2) {
+                        const unsigned long long b2 = __ballot((nrows & 4) != 0);
+                        pre += 4 * __popcll(b2 & below); tot += 4 * __popcll(b2);
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < TH && i < nrows) {
+                            const int h = ih0 + i;
+                            ring[(tail + pre + i) & (RGT_RING - 1)] = make_int2(ex + ((h - th0) << tws), ey + h * bwid);
+                        }
+                    }
+                    tail += tot;
                     if (RGT_DBG(p.dbg, 2)) { head = tail; continue; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (ring entries written by other lanes of this wave)
                     __builtin_amdgcn_wave_barrier();
