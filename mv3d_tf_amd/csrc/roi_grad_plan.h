@@ -88,10 +88,15 @@ __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int
             for (int ty = ty0; ty <= ty1; ++ty) {
                 const int rows = min(y1, (ty << v.ths) + TH - 1) - max(y0, ty << v.ths) + 1;
                 const float down = (float)rows * per_row;
-                for (int tx = tx0; tx <= tx1; ++tx) {
-                    const int cols = min(x1, (tx << v.tws) + TW - 1) - max(x0, tx << v.tws) + 1;
-                    const float across = fminf((float)p.PW, 1.0f + (float)cols * inv_bw);
-                    atomicAdd(&hrow[ty * v.tiles_x + tx], max((int)(down * across + 0.5f), 1));
+                int *const hr = hrow + ty * v.tiles_x;
+                // the first and the last tile of the row may be covered in part, the ones between in full: one value for all of those
+                const int cols0 = min(x1, (tx0 << v.tws) + TW - 1) - x0 + 1;
+                atomicAdd(&hr[tx0], max((int)(down * fminf((float)p.PW, 1.0f + (float)cols0 * inv_bw) + 0.5f), 1));
+                if (tx1 > tx0) {
+                    const int cols1 = x1 - (tx1 << v.tws) + 1;
+                    atomicAdd(&hr[tx1], max((int)(down * fminf((float)p.PW, 1.0f + (float)cols1 * inv_bw) + 0.5f), 1));
+                    const int mid = max((int)(down * fminf((float)p.PW, 1.0f + (float)TW * inv_bw) + 0.5f), 1);
+                    for (int tx = tx0 + 1; tx < tx1; ++tx) atomicAdd(&hr[tx], mid);
                 }
             }
         }
