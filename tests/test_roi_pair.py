@@ -248,8 +248,8 @@ def test_planned_backward_empty_tiles_big_rois_and_16_bit_codes_in_a_hot_pixel(g
 
 
 def test_backward_static_grid_when_the_planner_does_not_apply(gpu, oracle):
-    """More tiles than the planner's heat map holds (a 250 x 250 map in 4 x 4 tiles: 3969 > 3072): both launches decide for the static grid
-    from the shapes alone; same results."""
+    """More tiles than the planner's heat map holds (a 250 x 250 map in 4 x 4 tiles: 3969 > 3072), or a work list larger than the unused
+    quarter of view 0's argmax buffer: both launches decide for the static grid from the shapes alone; same results."""
     torch, ops = gpu
     rs = np.random.RandomState(12)
     B, H, W, C, R = 1, 250, 250, 256, 24
@@ -257,6 +257,9 @@ def test_backward_static_grid_when_the_planner_does_not_apply(gpu, oracle):
     x1, y1 = rs.randint(-40, W * 8 - 200, R), rs.randint(-40, H * 8 - 200, R)
     rois = np.stack([np.zeros(R), x1, y1, x1 + rs.randint(0, 900, R), y1 + rs.randint(0, 900, R)], 1).astype(np.float32)
     _pair_against_oracle(torch, ops, oracle, m, rois, 13)
+    # and a list that does not fit the unused quarter of the argmax buffer (ONE ROI on a 100 x 100 map: 625 tiles, 12.5 KB of codes)
+    m = rs.uniform(-1, 1, (1, 100, 100, C)).astype(np.float32)
+    _pair_against_oracle(torch, ops, oracle, m, np.asarray([[0, 100, 60, 420, 333]], np.float32), 14)
 
 
 def test_autograd_views_function_uses_the_pair(gpu, oracle):
