@@ -48,7 +48,26 @@ struct Slot {
     void *a_ws[TP_MAX_BATCH], *p_ws[TP_MAX_BATCH];
     int p_cap[TP_MAX_BATCH];
     size_t p_wsz[TP_MAX_BATCH];
+    // the pinned host buffers as the device sees them (hipHostGetDevicePointer; NULL: not mapped -- the reports travel as three copies)
+    uint8_t *dv_report = nullptr;
+    int32_t *dv_pt_counts = nullptr, *dv_num_proposals = nullptr;
 };
+
+// A batch's reports -- the head of every frame's anchor report, the proposal-target counts, the proposal counts | status words -- written
+// by ONE small launch straight into the caller's pinned host buffers (16-byte stores over the host link) instead of three copy launches of
+// the runtime (17 us of queue time each with eight batches in flight, profiles/r06_s_kernel_stats.txt: __amd_rocclr_copyBuffer).
+__global__ __launch_bounds__(256) void tp_report_kernel(const uint8_t *__restrict__ report, size_t report_row, uint8_t *__restrict__ h_report,
+                                                        size_t h_row, int B, const int32_t *__restrict__ pt_counts, int32_t *__restrict__ h_pt,
+                                                        const int32_t *__restrict__ nump, int32_t *__restrict__ h_nump)
+{
+    const size_t v = h_row / 16;                                       // (h_row is a multiple of 16: slot_ok)
+    for (size_t i = threadIdx.x; i < (size_t)B * v; i += 256) {
+        const size_t b = i / v, j = i - b * v;
+        reinterpret_cast<uint4 *>(h_report + b * h_row)[j] = reinterpret_cast<const uint4 *>(report + b * report_row)[j];
+    }
+    for (int i = threadIdx.x; i < 4 * B; i += 256) h_pt[i] = pt_counts[i];
+    for (int i = threadIdx.x; i < 2 * B; i += 256) h_nump[i] = nump[i];
+}
 
 }  // namespace
 
@@ -248,6 +267,16 @@ extern "C" int mv3d_train_path_create(const mv3d_train_path_config *config, int 
         Slot &s = tp->slots[k];
         s.buf = slots[k];
         slot_tables(tp->cfg, s);
+        // the pinned report buffers as the device addresses them (one launch writes the reports); anything unmapped or unaligned: copies
+        {
+            void *d0 = nullptr, *d1 = nullptr, *d2 = nullptr;
+            const bool mapped = hipHostGetDevicePointer(&d0, s.buf.h_report, 0) == hipSuccess && hipHostGetDevicePointer(&d1, s.buf.h_pt_counts, 0) == hipSuccess &&
+                                hipHostGetDevicePointer(&d2, s.buf.h_num_proposals, 0) == hipSuccess && d0 && d1 && d2;
+            (void)hipGetLastError();                                   // (a buffer that is not pinned leaves an error behind: not ours to report)
+            if (mapped && s.buf.h_report_row % 16 == 0 && (uintptr_t)d0 % 16 == 0 && (uintptr_t)s.buf.report % 16 == 0 && !getenv("MV3D_TRAIN_PATH_COPIES")) {
+                s.dv_report = (uint8_t *)d0; s.dv_pt_counts = (int32_t *)d1; s.dv_num_proposals = (int32_t *)d2;
+            }
+        }
         // (blocking sync: the helper sleeps while it waits for a batch's reports instead of spinning on a core -- one process per GPU
         // on a node shares the host's cores with seven others; with several batches in flight the wake-up latency is hidden)
         if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) {
@@ -314,10 +343,17 @@ extern "C" int mv3d_train_path_submit(mv3d_train_path *tp, int slot, const float
     rc = mv3d_proposal_target_stage1_batch_devn(B, s.p_bv, s.p_3d, s.p_cap, s.p_num, s.gt_bv, s.gt_3d, s.G, tp->tpar, s.p_cnt, s.p_ws,
                                                 s.p_wsz, stream);
     if (rc != MV3D_OK) return rc;
-    // the reports: three device-to-host copies, no kernel
-    TP_HIP(hipMemcpy2DAsync(u.h_report, u.h_report_row, u.report, u.report_row, u.h_report_row, (size_t)B, hipMemcpyDeviceToHost, s.stream));
-    TP_HIP(hipMemcpyAsync(u.h_pt_counts, u.pt_counts, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
-    TP_HIP(hipMemcpyAsync(u.h_num_proposals, u.num_proposals, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    // the reports: one launch that writes them into the pinned host buffers (three device-to-host copies when those are not mapped)
+    if (s.dv_report) {
+        hipLaunchKernelGGL(tp_report_kernel, dim3(1), dim3(256), 0, s.stream, (const uint8_t *)u.report, (size_t)u.report_row, s.dv_report,
+                           (size_t)u.h_report_row, B, (const int32_t *)u.pt_counts, s.dv_pt_counts, (const int32_t *)u.num_proposals,
+                           s.dv_num_proposals);
+        if (mv3d_launch_status() != MV3D_OK) return MV3D_ERR_HIP;
+    } else {
+        TP_HIP(hipMemcpy2DAsync(u.h_report, u.h_report_row, u.report, u.report_row, u.h_report_row, (size_t)B, hipMemcpyDeviceToHost, s.stream));
+        TP_HIP(hipMemcpyAsync(u.h_pt_counts, u.pt_counts, (size_t)B * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+        TP_HIP(hipMemcpyAsync(u.h_num_proposals, u.num_proposals, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream));
+    }
     TP_HIP(hipEventRecord(s.ev, s.stream));
     {
         std::lock_guard<std::mutex> g(tp->m);
