@@ -7,7 +7,8 @@
 // the reference's subsampling draws between their two stages are mv3d_draw_training_subsamples (legacy_rng.hip) on numpy's own
 // generator.  Through round 4 a Python class issued these calls; its ~0.3 ms of interpreter time per batch had become the limit of
 // the path on new inputs (the device needs ~0.15 ms per batch), so the sequence lives here now:
-//   * submit(): stage 1 + three device-to-host copies of the counts + an event, all on the caller's stream -- one call;
+//   * submit(): stage 1 + one small launch that writes the batch's reports into the pinned host buffers (tp_report_kernel; three
+//     device-to-host copies when those buffers are not mapped into the device) + an event, all on the caller's stream -- one call;
 //   * a helper thread per object: waits for the event, draws (slots strictly in submission order = the reference's order of draws),
 //     uploads the lists, enqueues stage 2 on the same stream.  The caller's thread never touches the draws;
 //   * finish(): waits for "stage 2 enqueued" and reports the row counts.
@@ -52,6 +53,15 @@ struct Slot {
     uint8_t *dv_report = nullptr;
     int32_t *dv_pt_counts = nullptr, *dv_num_proposals = nullptr;
 };
+
+static bool tp_force_copies()
+{
+#ifdef MV3D_TUNING                                                     // (experiment builds: the three copy launches for an A / B)
+    return getenv("MV3D_TRAIN_PATH_COPIES") != nullptr;
+#else
+    return false;
+#endif
+}
 
 // A batch's reports -- the head of every frame's anchor report, the proposal-target counts, the proposal counts | status words -- written
 // by ONE small launch straight into the caller's pinned host buffers (16-byte stores over the host link) instead of three copy launches of
@@ -178,13 +188,15 @@ int host_stage(mv3d_train_path *tp, Slot &s)
     size_t off[5 * TP_MAX_BATCH + 1];
     off[0] = 0;
     for (int k = 0; k < 5 * B; ++k) off[k + 1] = off[k] + (size_t)s.sizes[k];
+    // (stage 2 reading the lists in place from the pinned buffer instead of this upload was measured: no gain, profiles/r06_t_path_copies.txt)
+    const int32_t *const lists = u.lists;
     if (off[5 * B]) TP_HIP(hipMemcpyAsync(u.lists, u.h_lists, off[5 * B] * sizeof(int32_t), hipMemcpyHostToDevice, s.stream));
     const int32_t *lst[5][TP_MAX_BATCH];
     int cnt[5][TP_MAX_BATCH];
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < 5; ++k) {
             cnt[k][b] = s.sizes[5 * b + k];
-            lst[k][b] = cnt[k][b] ? u.lists + off[5 * b + k] : nullptr;
+            lst[k][b] = cnt[k][b] ? lists + off[5 * b + k] : nullptr;
         }
     rc = mv3d_anchor_target_stage2_batch(B, H, W, &c.anchor, lst[0], cnt[0], lst[1], cnt[1], lst[2], cnt[2], u.rpn_labels, u.anchors,
                                          u.anchors_3d, u.n_anchors, c.anchor_cap, s.a_ws, u.anchor_ws_bytes, s.stream);
@@ -273,7 +285,7 @@ extern "C" int mv3d_train_path_create(const mv3d_train_path_config *config, int 
             const bool mapped = hipHostGetDevicePointer(&d0, s.buf.h_report, 0) == hipSuccess && hipHostGetDevicePointer(&d1, s.buf.h_pt_counts, 0) == hipSuccess &&
                                 hipHostGetDevicePointer(&d2, s.buf.h_num_proposals, 0) == hipSuccess && d0 && d1 && d2;
             (void)hipGetLastError();                                   // (a buffer that is not pinned leaves an error behind: not ours to report)
-            if (mapped && s.buf.h_report_row % 16 == 0 && (uintptr_t)d0 % 16 == 0 && (uintptr_t)s.buf.report % 16 == 0 && !getenv("MV3D_TRAIN_PATH_COPIES")) {
+            if (mapped && s.buf.h_report_row % 16 == 0 && (uintptr_t)d0 % 16 == 0 && (uintptr_t)s.buf.report % 16 == 0 && !tp_force_copies()) {
                 s.dv_report = (uint8_t *)d0; s.dv_pt_counts = (int32_t *)d1; s.dv_num_proposals = (int32_t *)d2;
             }
         }
