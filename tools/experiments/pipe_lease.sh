@@ -1,6 +1,8 @@
 #!/bin/bash
 # (EXPERIMENTS R6.15) RoiPoolGrad tiles with a group's bytes requested one group ahead of its adds, compiler-tracked (two named register
-# sets, roi_pair_tiles_kernel<W, 1, PIPE = true>): pair + pin tests on a build that launches it by default, then timings (tuning build)
+# sets, roi_pair_tiles_kernel<W, 1, PIPE = true>): pair + pin tests on a build that launches it by default, then timings (tuning build).
+# Source: tools/experiments/roi_grad_tiles_pingpong_r06.hip.txt over csrc/roi_grad_tiles.hip, tools/build_tuning.sh twice: plain, and
+# MV3D_TUNING_OUT=libmv3d_pipe8.so MV3D_EXTRA_FLAGS=-DRGT_PIPE_DEFAULT=8; PIPE_LIBS=libmv3d_pipe8.so PIPE_W="8 12 16"
 cd "$GRAFT_REPO_ROOT"; OUT=gpurun_out/${1:-pipe}; mkdir -p $OUT
 TUN=build_variants/libmv3d_tuning.so
 run() { echo "-- $*"; env "$@" MV3D_IDX_DBG=1 PAIR_ONLY=1 PAIR_NO_WS=1 NB=8 ROUNDS=4 timeout 300 python tools/roi_pair_probe.py --lib $TUN 2>&1 | grep "pair \|differ\|rror" | tail -1; }
