@@ -1,13 +1,15 @@
-"""-m gpu tests of the fast training-side RoiPool pair (VERDICT r04 #1):
+"""-m gpu tests of the fast training-side RoiPool pair:
 
-    mv3d_roi_pool_forward_views_pair     pools every view in one launch, the argmax plane kept as private 16-bit codes
-    mv3d_roi_pool_backward_views_pair    candidate index + zero fill (one launch), the ordered gather (roi_pooling_op.cc:319-452)
+    mv3d_roi_pool_forward_views_pair     pools every view in one launch, the argmax plane kept as private one-byte codes (16-bit for bins of
+                                         more than 255 pixels); one workgroup of the launch plans the backward's work list (csrc/roi_grad_plan.h)
+    mv3d_roi_pool_backward_views_pair    ONE launch of LDS map tiles over that list, the reference's summation order (roi_pooling_op.cc:319-452)
 
-top / bottom_diff bit-identical to the plain entries and to the oracle (the pair's private 16-bit argmax plane through
+top / bottom_diff bit-identical to the plain entries and to the oracle (the pair's private argmax plane through
 mv3d_roi_pool_argmax_decode) on BASELINE configs[2]'s full-size workload, on the pinned fixtures
-(tests/golden/roipool_*), across channel widths, on a workspace that is reused call after call (nothing in it has to be
-zero on entry: it is filled with garbage first).  Plus the call-compatible launcher aliases of
-roi_pooling_op_gpu.h:18-27.  All calls go through the C-ABI (ctypes, mv3d_tf_amd.ops)."""
+(tests/golden/roipool_*), across channel widths, with and without a workspace argument (filled with garbage first), on the planned
+mode's edge cases (more hot tiles than the cap, empty flags, ROIs the estimate does not follow, 16-bit codes inside one-pixel units) and on
+the static-grid fallback.  Plus the call-compatible launcher aliases of roi_pooling_op_gpu.h:18-27.  All calls go through the C-ABI
+(ctypes, mv3d_tf_amd.ops)."""
 import ctypes as C
 
 import numpy as np

@@ -37,15 +37,19 @@ for k in range(int(os.environ.get("NB", "4"))):
     raw = a.view(torch.uint8).reshape(-1)[3 * n0:].cpu().numpy()
     n_work = int(raw[:4].view(np.int32)[0])
     units = raw[256:256 + 16 * n_work].view(np.int32).reshape(-1, 4)
-    whole = units[(units[:, 0] >> 16) & 15 | ((units[:, 0] >> 20) & 15) > 0]
     heat = units[:, 3]
-    sub = 0
-    # sub-tile units come first, in fours with the same estimate
-    while sub + 4 <= n_work and len(set(heat[sub:sub + 4])) == 1 and heat[sub] >= int(os.environ.get("HOT", "250")): sub += 4
-    print(f"batch {k}: units {n_work}, sub-tile units {sub} ({sub // 4} tiles cut)")
-    h = np.concatenate([heat[:sub:4], heat[sub:]])
+    shape = (units[:, 0] >> 16) & 0xff                                  # ths | tws << 4
+    view_of = units[:, 0] & 15
+    # a view's whole tiles have its largest shape; sub-tile units (four per cut tile, first in the list) a smaller one
+    full = {v: max(shape[view_of == v], key=lambda x: (x & 15) + (x >> 4)) for v in set(view_of.tolist())}
+    is_sub = np.array([shape[i] != full[view_of[i]] for i in range(n_work)])
+    sub = int(is_sub.sum())
+    empty = int(((units[:, 0] >> 25) & 1).sum())
+    print(f"batch {k}: units {n_work}, sub-tile units {sub} ({sub // 4} tiles cut), flagged empty {empty}; estimates along the list: "
+          f"{heat[::max(n_work // 12, 1)].tolist()}")
+    h = np.concatenate([heat[is_sub][::4], heat[~is_sub]])
+    hv_view = np.concatenate([view_of[is_sub][::4], view_of[~is_sub]])
     for view in range(3):
-        sel = np.concatenate([(units[:sub:4, 0] & 15), (units[sub:, 0] & 15)]) == view
-        hv = h[sel]
+        hv = h[hv_view == view]
         print(f"   launch view {view}: tiles {hv.size}, estimate = 0: {(hv == 0).sum()}, >= 100: {(hv >= 100).sum()}, >= 160: {(hv >= 160).sum()}, >= 250: {(hv >= 250).sum()}, "
               f">= 350: {(hv >= 350).sum()}, >= 450: {(hv >= 450).sum()}, max {hv.max()}")
