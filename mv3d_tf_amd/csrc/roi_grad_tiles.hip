@@ -215,8 +215,13 @@ __device__ __forceinline__ int2 rgt_exact_span(const int lo, const int hi, const
     return make_int2(a, b);
 }
 
+#ifdef RGT_WAVES6                                                       // (experiment builds: six waves per SIMD at 80 VGPRs, three spilled)
+#define RGT_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define RGT_OCC
+#endif
 template <int W, int CPL>
-__global__ __launch_bounds__(64) void roi_pair_tiles_kernel(RgtPack p)
+__global__ __launch_bounds__(64) RGT_OCC void roi_pair_tiles_kernel(RgtPack p)
 {
     __shared__ float acc[(RGT_MAXPX + 1) * 64 * CPL];                        // the tile's accumulators [pixel][channel] + one junk row
     __shared__ int2 ring[RGT_RING];
