@@ -208,6 +208,18 @@ def _work_list(torch, res, m, R, C):
     return raw[256:256 + 16 * n].view(np.int32).reshape(-1, 4)
 
 
+def _assert_partition(units, B, H, W):
+    """every pixel of every frame belongs to exactly one unit that is not skipped (a sub-tile outside the map), estimates never rise along
+    the whole tiles of the list"""
+    cover = np.zeros((B, H, W), np.int32)
+    for x, y0, x0, _ in units:
+        if x & (1 << 24):
+            continue
+        b, th, tw = (x >> 4) & 0xfff, 1 << ((x >> 16) & 15), 1 << ((x >> 20) & 15)
+        cover[b, y0:y0 + th, x0:x0 + tw] += 1
+    assert (cover == 1).all()
+
+
 def test_planned_backward_more_hot_tiles_than_the_cap(gpu, oracle):
     """The pair's forward launch plans its backward (csrc/roi_grad_plan.h): tiles under long entry streams are cut into four sub-tiles, at most
     RGT_HOT_MAX = 128 of them.  A dense view where EVERY tile is hot (256 ROIs, each over one half of a 16 x 64 map: 256 tiles of 2 x 2): 128 tiles cut into
@@ -226,6 +238,7 @@ def test_planned_backward_more_hot_tiles_than_the_cap(gpu, oracle):
     shapes = (units[:, 0] >> 16) & 0xff                                # ths | tws << 4
     assert (shapes == 0).sum() == 4 * 128 and (shapes == 0x11).sum() == 256 - 128 and len(units) == 4 * 128 + 128
     assert not (units[:, 0] & (1 << 25)).any()
+    _assert_partition(units, B, H, W)
 
 
 def test_planned_backward_empty_tiles_big_rois_and_16_bit_codes_in_a_hot_pixel(gpu, oracle):
@@ -242,6 +255,11 @@ def test_planned_backward_empty_tiles_big_rois_and_16_bit_codes_in_a_hot_pixel(g
     res = _pair_against_oracle(torch, ops, oracle, m, rois, 10)
     units = _work_list(torch, res, m, len(rois), C)
     assert (units[:, 0] & (1 << 25)).sum() > 2000 and (((units[:, 0] >> 16) & 0xff) == 0).sum() >= 4
+    _assert_partition(units, B, H, W)
+    whole = units[((units[:, 0] >> 16) & 0xff) != 0]
+    e = whole[:, 3]                                                  # longest estimate first: the classes (>= 250, >= 125, >= 31, > 0, 0) in turn
+    cls = np.where(e >= 250, 0, np.where(e >= 125, 1, np.where(e >= 31, 2, np.where(e > 0, 3, 4))))
+    assert (np.diff(cls) >= 0).all() and ((units[:, 0] & (1 << 25)) != 0)[((units[:, 0] >> 16) & 0xff) != 0][cls == 4].all()
     # (b) + (c): whole-map ROIs on top (bins of 16 x 16 = 256 pixels), interleaved with the stack
     rois = np.asarray(hot[:190] + [[0, 0, 0, W * 8 - 1, H * 8 - 1]] * 6 + hot[190:] + [[0, -40, -40, W * 8 + 40, H * 8 + 40]] * 4, np.float32)
     res = _pair_against_oracle(torch, ops, oracle, m, rois, 11)
