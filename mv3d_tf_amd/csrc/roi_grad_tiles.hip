@@ -237,6 +237,10 @@ __global__ __launch_bounds__(64) RGT_OCC void roi_pair_tiles_kernel(RgtPack p)
         if (d.x & (1 << 24)) return;                                   // (a sub-tile outside the map)
         no_roi = (d.x & RGT_UNIT_EMPTY) != 0;
         k = d.x & 15; b = (d.x >> 4) & 0xfff; ths = (d.x >> 16) & 15; tws = (d.x >> 20) & 15; th0 = d.y; tw0 = d.z;
+        // (a list this library's forward did not write -- the caller broke the pair's contract -- must not send the wave outside the buffers)
+#ifndef RGT_NO_GUARD
+        if (k >= p.n || ths > 2 || tws > 2 || b >= p.v[k].B || (unsigned)th0 >= (unsigned)p.v[k].H || (unsigned)tw0 >= (unsigned)p.v[k].W) return;
+#endif
     } else {
 #pragma unroll
         for (int j = 1; j < MV3D_MAX_ROI_VIEWS; ++j)
