@@ -49,10 +49,11 @@ bool mv3d_rgt_layout(int num_views, const mv3d_roi_grad_view *views, int PH, int
 // ---- planned mode: which tiles sit under long entry streams?  ONE workgroup estimates every tile's stream from the ROIs' rounded
 // geometry (thread = ROI: rows covered x bins per row x bins across, added into an LDS heat map), cuts the tiles above RGT_HOT_ENTRIES into
 // four sub-tiles (rows first: a 4 x 4 tile becomes four 1 x 4 rows, a 2 x 2 tile four pixels -- the sub-tiles are ordinary units, every
-// one filtered, expanded and drained by a wave of its own, no communication) and writes the launch's work list: sub-tiles first (they
-// carry the longest streams and must start at once), then the other tiles in grid order.  What it buys is the makespan: one wave's
-// instruction stream is the limit of a stream (~140 ns per entry, profiles/r06_a), and a 4 x 4 tile under 465 entries is 65 us however
-// fast the other 17 k waves finish.  T threads; heat: RGT_PLAN_TILES ints of LDS, scan: RGT_PLAN_SCAN(T) ints.
+// one filtered, expanded and drained by a wave of its own, no communication) and writes the launch's work list LONGEST ESTIMATE FIRST: the
+// sub-tiles, the hot tiles beyond the cap, then three classes of shorter streams, the tiles no ROI touches last and flagged (their waves
+// write zeros without a ROI filter).  What it buys is the makespan: one wave's instruction stream is the limit of a stream (~100 - 140 ns per
+// entry, profiles/r06_a), a 4 x 4 tile under 465 entries is 65 us however fast the other 17 k waves finish, and a grid dispatched in order
+// should end with its shortest units (profiles/r06_p: 66 -> 44 us).  T threads; heat: RGT_PLAN_TILES ints of LDS, scan: RGT_PLAN_SCAN(T) ints.
 template <int T>
 __device__ __forceinline__ void rgt_plan_block(const RgtPack &p, int4 *work, int *n_work, const int hot_entries, const int hot_max, int *heat,
                                                int *scan)
